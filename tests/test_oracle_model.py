@@ -1,0 +1,94 @@
+"""CPU: the oracle's Qwen2.5-VL restatement against the transformers tiny-config fixture.
+
+Protocol: fp32 oracle must reproduce the reference fp32 logits (float rounding
+only) and greedy tokens; the bf16 oracle's teacher-forced logits must be as close to the reference
+fp32 logits as the reference's OWN bf16 run is (x1.5).
+"""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import npz_str, sha
+from oracle import frontend, prng, qwen25vl
+
+
+@pytest.fixture(scope="module")
+def chain(golden_npz):
+    z = golden_npz("tiny_chain.npz")
+    c = json.loads(npz_str(z["chain_json"]))
+    cfg = qwen25vl.tiny_config()
+    w = qwen25vl.synthetic_weights(cfg, seed=c["weight_seed"], std=c["std"], matrix_gain=c["matrix_gain"],
+                                   bias_std=c["bias_std"], norm_jitter=c["norm_jitter"])
+    tile = prng.synthetic_tile(c["tile_seed"], c["tile_h"], c["tile_w"])
+    return z, c, cfg, w, tile
+
+
+def _views(c, tile):
+    # reference host code restated: view = resize to <=512; crop = 512x512 box around the bbox
+    h, w, _ = tile.shape
+    s = 512 / max(w, h)
+    view = frontend.resize_bicubic(tile, int(w * s), int(h * s))
+    x1, y1, x2, y2 = (int(v) for v in c["bbox"])
+    cx, cy = (x1 + x2) // 2, (y1 + y2) // 2
+    crop = frontend.crop_zero_fill(tile, (cx - 256, cy - 256, cx + 256, cy + 256))
+    return view, crop
+
+
+def test_chain_inputs_pinned(chain):
+    z, c, cfg, w, tile = chain
+    view, crop = _views(c, tile)
+    assert sha(view) == npz_str(z["view_sha256"])
+    assert sha(crop) == npz_str(z["crop_sha256"])
+
+
+def test_fp32_oracle_matches_reference(chain):
+    z, c, cfg, w, tile = chain
+    view, crop = _views(c, tile)
+    pv_v, g_v = frontend.image_to_pixel_values(view)
+    pv_c, g_c = frontend.image_to_pixel_values(crop)
+    o = qwen25vl.Qwen25VLOracle(cfg, w, "fp32")
+    vit = o.vit_forward(pv_v, [g_v])
+    ref = z["s1_vit_fp32"]
+    assert np.abs(vit[:: max(1, vit.shape[0] // 16)][:20] - ref).max() < 2e-4
+    ids1 = z["ids1"].tolist()
+    r = qwen25vl.greedy_generate(o, ids1, pv_v, [g_v], c["n1"], c["repetition_penalty"], eos_token_ids=())
+    assert r["tokens"] == z["s1_tokens_fp32"].tolist()
+    assert np.abs(r["logits"] - z["s1_logits_fp32"]).max() < 1e-4
+    assert len(set(r["tokens"])) >= 20  # non-degenerate output
+    ids2 = z["ids2"].tolist()
+    r2 = qwen25vl.greedy_generate(o, ids2, np.concatenate([pv_v, pv_c]), [g_v, g_c], c["n2"],
+                                  c["repetition_penalty"], eos_token_ids=())
+    assert r2["tokens"] == z["s2_tokens_fp32"].tolist()
+    assert np.abs(r2["logits"] - z["s2_logits_fp32"]).max() < 1e-4
+
+
+def test_bf16_oracle_within_reference_bf16_error(chain):
+    z, c, cfg, w, tile = chain
+    view, crop = _views(c, tile)
+    pv_v, g_v = frontend.image_to_pixel_values(view)
+    o = qwen25vl.Qwen25VLOracle(cfg, w, "bf16")
+    forced = z["s1_tokens_fp32"].tolist()
+    r = qwen25vl.greedy_generate(o, z["ids1"].tolist(), pv_v, [g_v], c["n1"], c["repetition_penalty"],
+                                 eos_token_ids=(), forced_tokens=forced)
+    ref32, ref16 = z["s1_logits_fp32"], z["s1_logits_bf16"]
+    hf_err = np.abs(ref16 - ref32).max()
+    my_err = np.abs(r["logits"] - ref32).max()
+    hf_rms = np.sqrt(np.mean((ref16 - ref32) ** 2))
+    my_rms = np.sqrt(np.mean((r["logits"] - ref32) ** 2))
+    assert my_err <= 1.5 * hf_err, (my_err, hf_err)
+    assert my_rms <= 1.5 * hf_rms, (my_rms, hf_rms)
+
+
+def test_repetition_penalty_and_argmax_ties():
+    lg = np.array([1.0, -2.0, 1.0, 0.5], dtype=np.float32)
+    out = qwen25vl.apply_repetition_penalty(lg, [1, 1, 3], 2.0)
+    assert out.tolist() == [1.0, -4.0, 1.0, 0.25]
+    assert int(np.argmax(out)) == 0  # lowest index wins ties, as torch.argmax
+
+
+def test_bf16_round():
+    x = np.array([1.0, 1.00390625, 1.01171875, -3.1415927, 65504.0, np.inf], dtype=np.float32)
+    y = qwen25vl.bf16_round(x)
+    assert y.tolist() == [1.0, 1.0, 1.015625, -3.140625, 65536.0, np.inf]
+    assert np.isnan(qwen25vl.bf16_round(np.array([np.nan], dtype=np.float32)))[0]
