@@ -1,0 +1,203 @@
+/*
+ * zoomearth.h -- C ABI of libzoomearth_hip.so, the MI355X (gfx950) engine for ZoomEarth's
+ * zoom-crop-reason inference path.
+ *
+ * The reference (earth-insights/ZoomEarth) has no FFI / plugin interface: its hot path is reached
+ * through HuggingFace Python calls.  Each entry point below names the
+ * reference / transformers interface it replaces ("replaces:" lines; paths relative to
+ * /root/reference, `HF:` = site-packages/transformers).  The Python host shim in zoomearth_amd/
+ * binds exactly these symbols with ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative ze_status on error; the message is
+ *     available from ze_last_error() (per engine, or the global one when the engine is NULL);
+ *   - the caller owns every buffer it passes (device pointers normally come from torch tensors'
+ *     data_ptr()); the library owns weights, KV cache and workspaces and frees them in
+ *     ze_engine_destroy();
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - an engine is not thread-safe; distinct engines are independent (one per process / GPU);
+ *   - plain pointers and sizes only, no torch types.
+ */
+#ifndef ZOOMEARTH_H
+#define ZOOMEARTH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ze_engine ze_engine;
+
+typedef enum {
+    ZE_OK = 0,
+    ZE_ERR_INVALID = -1,   /* bad argument / shape / state                         */
+    ZE_ERR_HIP = -2,       /* a HIP runtime call failed                            */
+    ZE_ERR_NOMEM = -3,     /* capacity (max_ctx / max_seqs / workspace) exceeded   */
+    ZE_ERR_NOTFOUND = -4,  /* unknown weight name / sequence id                    */
+    ZE_ERR_MISMATCH = -5   /* image features and image tokens do not match         */
+} ze_status;
+
+typedef enum { ZE_F32 = 0, ZE_F16 = 1, ZE_BF16 = 2 } ze_dtype;
+
+#define ZE_MAX_FULLATT 16
+#define ZE_MAX_EOS 4
+
+/* Model + capacity description.  Field meaning follows the HF config.json of Qwen2.5-VL
+ * (replaces: Qwen2_5_VLConfig, HF:models/qwen2_5_vl/configuration_qwen2_5_vl.py:32-207). */
+typedef struct ze_config {
+    /* vision tower */
+    int32_t vit_depth, vit_hidden, vit_heads, vit_intermediate, vit_out_hidden;
+    int32_t patch_size, temporal_patch_size, spatial_merge_size, window_size, in_channels;
+    int32_t n_fullatt;
+    int32_t fullatt_block_indexes[ZE_MAX_FULLATT];
+    /* language model */
+    int32_t hidden, layers, heads, kv_heads, intermediate, vocab;
+    float rms_eps;
+    float rope_theta;
+    int32_t mrope_section[3];
+    int32_t tie_word_embeddings;
+    /* special tokens */
+    int32_t image_token_id, vision_start_token_id, vision_end_token_id, pad_token_id;
+    int32_t n_eos;
+    int32_t eos_token_ids[ZE_MAX_EOS];
+    /* capacities */
+    int32_t max_seqs;        /* concurrent question chains (KV slots)             */
+    int32_t max_ctx;         /* tokens per chain                                  */
+    int32_t max_patches;     /* ViT patches per ze_vit_forward call               */
+    int32_t max_tile_side;   /* largest tile edge handed to ze_op_resize_bicubic  */
+} ze_config;
+
+/* ------------------------------------------------------------------ lifecycle */
+/* replaces: Qwen2_5_VLForConditionalGeneration.from_pretrained(...).eval() + accelerator.prepare(model)
+ * (src/eval/infer.py:147-151,171; src/demo.py:128): allocates weights / KV cache / workspaces on `device_id`. */
+int ze_engine_create(const ze_config* cfg, int device_id, ze_engine** out);
+int ze_engine_destroy(ze_engine* e);
+const char* ze_last_error(const ze_engine* e);
+int ze_version(void);
+/* Blocks until all work queued on `stream` has finished (hipStreamSynchronize). */
+int ze_sync(ze_engine* e, void* stream);
+
+/* ------------------------------------------------------------------ weights */
+/* replaces: the safetensors -> nn.Parameter copy done by from_pretrained (src/eval/infer.py:147-150).
+ * `name` is an HF checkpoint key in either layout ("model.visual.*" / "model.language_model.*" (5.x) or
+ * "visual.*" / "model.layers.*" (4.49), see src/train/RL/src/open-r1-multimodal/src/open_r1/model/
+ * modeling_qwen2_vl.py:1290-1293).  `host_ptr` holds `shape` row-major elements of `dtype`; the engine converts to
+ * bf16 (round-to-nearest-even; fp16 checkpoints pass through fp32) and packs into its own layouts. */
+int ze_load_weight(ze_engine* e, const char* name, int dtype, int ndim, const int64_t* shape, const void* host_ptr);
+/* Synthetic 3B-shape (or any config) checkpoint generated on the device from the repo PRNG
+ * (oracle/prng.py is the CPU mirror): matrices N(0,(std*matrix_gain)^2), embed/lm_head N(0,std^2),
+ * norm weights 1+N(0,norm_jitter^2), biases N(0,bias_std^2). */
+int ze_weights_fill_synthetic(ze_engine* e, uint64_t seed, float std, float matrix_gain, float bias_std,
+                              float norm_jitter);
+/* Number of HF tensors still missing (0 = ready); names of missing tensors are in ze_last_error(). */
+int ze_weights_missing(ze_engine* e);
+/* The packed bf16 weight arena (one contiguous device allocation): lets the host broadcast it once over
+ * RCCL/xGMI with torch.distributed and checksum it.  Does not transfer ownership. */
+int ze_weights_arena(ze_engine* e, void** dev_ptr, size_t* bytes);
+
+/* ------------------------------------------------------------------ image front-end (K0-K2) */
+/* replaces: PIL `image.crop(box).resize((dst_w, dst_h), Image.BICUBIC)` on RGB u8 as used by cut_image /
+ * resize_image (src/eval/infer.py:41-85, src/demo.py:30-93) and by the HF image processor
+ * (HF:models/qwen2_vl/image_processing_pil_qwen2_vl.py:126-150).  Bit-exact with Pillow.
+ * src: u8 [src_h, src_w, 3] device, row stride src_w*3.  box = {x0,y0,x1,y1} may leave the image (zero fill).
+ * dst: u8 [dst_h, dst_w, 3] device.  If the box size equals the dst size this is a pure crop. */
+int ze_op_crop_resize(ze_engine* e, const uint8_t* src, int src_h, int src_w, const int32_t box[4], uint8_t* dst,
+                      int dst_h, int dst_w, void* stream);
+/* replaces: smart_resize (HF:...image_processing_pil_qwen2_vl.py:57-83). Host-only integer helper. */
+int ze_smart_resize(int height, int width, int factor, int64_t min_pixels, int64_t max_pixels, int* out_h,
+                    int* out_w);
+/* replaces: rescale + normalize + patchify (HF:...image_processing_pil_qwen2_vl.py:152-187,197-246).
+ * img: u8 [h, w, 3] device with h, w multiples of patch*merge.  out: f32 [gh*gw, C*T*P*P] device (HF row/column
+ * order).  Bit-exact. */
+int ze_op_patchify(ze_engine* e, const uint8_t* img, int h, int w, float* out_pixel_values, void* stream);
+/* replaces: Qwen2VLImageProcessor._preprocess for one image: smart_resize -> bicubic -> patchify.
+ * Writes grid_thw[3] (host) and pixel_values (device, capacity_rows rows). */
+int ze_preprocess_image(ze_engine* e, const uint8_t* img, int h, int w, int64_t min_pixels, int64_t max_pixels,
+                        float* out_pixel_values, int64_t capacity_rows, int32_t grid_thw[3], void* stream);
+
+/* ------------------------------------------------------------------ integer index builders (host) */
+/* replaces: get_vision_window_index / get_vision_cu_seqlens (HF:vision_utils.py:42-65,130-188).
+ * window_index: [sum(t*h*w)/merge^2]; cu_window: capacity cap_cu, *n_cu written. */
+int ze_vision_window_index(const ze_config* cfg, const int32_t* grid_thw, int n_images, int64_t* window_index,
+                           int32_t* cu_window, int cap_cu, int* n_cu);
+/* replaces: Qwen2_5_VLModel.get_rope_index (HF:models/qwen2_5_vl/modeling_qwen2_5_vl.py:944-1058) for ONE
+ * unpadded sequence.  position_ids: [3, len] int32; *rope_delta = max+1-len. */
+int ze_rope_index(const ze_config* cfg, const int32_t* input_ids, int len, const int32_t* grid_thw, int n_images,
+                  int32_t* position_ids, int32_t* rope_delta);
+
+/* ------------------------------------------------------------------ model */
+/* replaces: Qwen2_5_VisionTransformerPretrainedModel.forward (HF:...modeling_qwen2_5_vl.py:408-471).
+ * pixel_values: f32 [sum(t*h*w), C*T*P*P] device in HF order; grid_thw: host int32 [n_images,3];
+ * out_embeds: bf16 [sum/merge^2, vit_out_hidden] device, HF order. */
+int ze_vit_forward(ze_engine* e, const float* pixel_values, const int32_t* grid_thw, int n_images,
+                   void* out_embeds_bf16, void* stream);
+
+/* Sequence (question-chain) slots: 0 <= seq < max_seqs.  ze_seq_reset drops the KV cache of a slot and clears
+ * its repetition-penalty set; ze_seq_truncate keeps the first `keep_len` cached tokens (stage-1 prefix reuse). */
+int ze_seq_reset(ze_engine* e, int seq, void* stream);
+int ze_seq_truncate(ze_engine* e, int seq, int keep_len, void* stream);
+int ze_seq_len(ze_engine* e, int seq);
+
+/* replaces: the prefill forward of Qwen2_5_VLForConditionalGeneration (HF:...:1185-1253,1308-1400): embed,
+ * image scatter, M-RoPE, decoder layers, final norm, lm_head on the last position.
+ * input_ids: host int32 [len] = the NEW tokens appended after the `ze_seq_len` cached ones (image placeholders
+ * already expanded); image_embeds: bf16 device rows consumed in order by the image tokens of input_ids;
+ * position_ids: host int32 [3,len] (from ze_rope_index over the whole sequence); rope_delta: stored for decode.
+ * out_logits: f32 [vocab] device (values are bf16-rounded like HF's `.float()` of bf16 logits), may be NULL. */
+int ze_prefill(ze_engine* e, int seq, const int32_t* input_ids, int len, const void* image_embeds_bf16,
+               int n_image_rows, const int32_t* position_ids, int rope_delta, float* out_logits, void* stream);
+
+/* replaces: one iteration of GenerationMixin._sample in greedy mode (HF:generation/utils.py:2876-2936) for one
+ * chain: forward one token with the KV cache, fp32 logits, repetition penalty
+ * (HF:generation/logits_process.py:409-413), argmax (lowest index on ties).
+ * Feeds `token` (or, if token < 0, the chain's last sampled token); writes raw logits (may be NULL). */
+int ze_decode_step(ze_engine* e, int seq, int token, float* out_logits, void* stream);
+
+/* Generation options (replaces the kwargs of model.generate at src/eval/infer.py:109-115, src/demo.py:14-19).
+ * do_sample / temperature are accepted by the Python layer and mapped to greedy (documented deviation). */
+typedef struct ze_gen_params {
+    int32_t max_new_tokens;
+    float repetition_penalty;  /* 1.0 = off */
+    int32_t ignore_eos;        /* scripted benchmark mode: run exactly max_new_tokens steps */
+    int32_t use_graph;         /* replay the decode step as a hipGraph */
+    int32_t sync_every;        /* host EOS check interval in steps (>=1) */
+} ze_gen_params;
+
+/* replaces: GenerationMixin.generate greedy loop after prefill for one chain.  Samples the first token from the
+ * logits left by ze_prefill, then runs decode steps until EOS / max_new_tokens.  out_tokens: host int32
+ * [max_new_tokens]; *n_out = number of tokens produced (EOS included). */
+int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_t* out_tokens, int* n_out, void* stream);
+/* Marks every id in `ids` (host int32) as seen for the repetition penalty of `seq` (the prompt). */
+int ze_seq_mark_seen(ze_engine* e, int seq, const int32_t* ids, int n, void* stream);
+/* Applies penalty + argmax to f32 logits [vocab] (device) with the seen-set of `seq`; *out_token host. */
+int ze_op_sample_greedy(ze_engine* e, int seq, const float* logits, float repetition_penalty, int32_t* out_token,
+                        void* stream);
+
+/* ------------------------------------------------------------------ unit ops for parity tests (K3-K22) */
+/* C[M,N] = A[M,K] * W[N,K]^T (+bias[N]) ; bf16 in, fp32 accumulate, bf16 out (one rounding).  act: 0 none, 1 exact GELU. */
+int ze_op_linear(ze_engine* e, const void* a_bf16, const void* w_bf16, const void* bias_bf16, void* c_bf16, int M,
+                 int N, int K, int act, void* stream);
+/* y = weight * bf16(x * rsqrt(mean(x^2)+eps))  (HF:...modeling_qwen2_5_vl.py:64-79), rows x cols bf16. */
+int ze_op_rmsnorm(ze_engine* e, const void* x_bf16, const void* weight_bf16, void* y_bf16, int rows, int cols,
+                  float eps, void* stream);
+/* Varlen attention over segments: q,k,v,o bf16 [T, heads, D] (D = 80 or 128); cu_seqlens host int32 [n_seg+1];
+ * causal applies inside each segment; kv_heads divides heads (GQA). */
+int ze_op_attention(ze_engine* e, const void* q, const void* k, const void* v, void* o, int T, int heads,
+                    int kv_heads, int D, const int32_t* cu_seqlens, int n_seg, int causal, void* stream);
+
+/* ------------------------------------------------------------------ measurement */
+/* Runs the decode-path weight-streaming kernel `which` (0 qkv, 1 o_proj, 2 gate_up, 3 down, 4 lm_head) `iters`
+ * times back to back on `stream`, cycling through the layers' real weights, bracketed by HIP events on that
+ * stream; returns the average launch duration (us) and the algorithmic bytes of one launch. */
+int ze_profile_decode_kernel(ze_engine* e, int which, int iters, float* avg_us, double* bytes_per_launch,
+                             void* stream);
+/* Per-phase device time (ms) accumulated by HIP events since the last reset: [0] front-end, [1] ViT,
+ * [2] prefill, [3] decode, [4] sampling.  Only recorded while enabled. */
+int ze_phase_timers(ze_engine* e, int enable, int reset, float out_ms[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZOOMEARTH_H */

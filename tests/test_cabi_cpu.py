@@ -1,0 +1,92 @@
+"""CPU: the C-ABI library loads, exports every symbol include/zoomearth.h declares, and its host-only
+integer helpers (no GPU involved) reproduce the transformers golden vectors."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+from zoomearth_amd import _lib
+from zoomearth_amd.config import ModelConfig
+from zoomearth_amd.engine import Engine
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.lib()
+
+
+def test_exports_match_header(lib):
+    hdr = open(os.path.join(ROOT, "include", "zoomearth.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(ze_[a-z_0-9]+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 28
+    assert declared == set(_lib.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.ze_version() >= 100
+
+
+def _zcfg():
+    return Engine._make_zcfg(ModelConfig.tiny(), 2, 256, 1024, 1024)
+
+
+def test_smart_resize_host(lib, golden_json):
+    for row in golden_json("indices.json")["smart_resize"]:
+        oh, ow = C.c_int(), C.c_int()
+        assert lib.ze_smart_resize(row["h"], row["w"], 28, 3136, row["max_pixels"], C.byref(oh), C.byref(ow)) == 0
+        assert [oh.value, ow.value] == row["out"], row
+    assert lib.ze_smart_resize(10, 5000, 28, 3136, 12845056, C.byref(oh), C.byref(ow)) < 0
+    assert b"aspect ratio" in lib.ze_last_error(None)
+
+
+def test_window_index_host(lib, golden_json):
+    z = _zcfg()
+    for row in golden_json("indices.json")["vision"]:
+        g = np.asarray(row["grid"], dtype=np.int32)
+        n = int((g[:, 0] * g[:, 1] * g[:, 2]).sum()) // 4
+        wi = np.zeros(n, dtype=np.int64)
+        cu = np.zeros(n + 2, dtype=np.int32)
+        ncu = C.c_int()
+        rc = lib.ze_vision_window_index(C.byref(z), g.ctypes.data_as(C.POINTER(C.c_int32)), len(g),
+                                        wi.ctypes.data_as(C.POINTER(C.c_int64)),
+                                        cu.ctypes.data_as(C.POINTER(C.c_int32)), len(cu), C.byref(ncu))
+        assert rc == 0
+        assert wi.tolist() == row["window_index"]
+        assert cu[: ncu.value].tolist() == row["cu_window_seqlens"]
+
+
+def test_rope_index_host(lib, golden_json):
+    z = _zcfg()
+    seen = 0
+    for row in golden_json("indices.json")["rope_index"]:
+        ids = np.asarray(row["input_ids"])
+        am = np.asarray(row["attention_mask"])
+        grids = np.asarray(row["grids"], dtype=np.int32)
+        gi = 0
+        for b in range(ids.shape[0]):
+            cur = ids[b][am[b].astype(bool)].astype(np.int32)
+            n_img = int(((cur == z.image_token_id) & (np.roll(cur, 1) != z.image_token_id)).sum())
+            g = np.ascontiguousarray(grids[gi: gi + n_img])
+            gi += n_img
+            pos = np.zeros((3, len(cur)), dtype=np.int32)
+            d = C.c_int32()
+            rc = lib.ze_rope_index(C.byref(z), cur.ctypes.data_as(C.POINTER(C.c_int32)), len(cur),
+                                   g.ctypes.data_as(C.POINTER(C.c_int32)), n_img,
+                                   pos.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(d))
+            assert rc == 0
+            want = np.asarray(row["position_ids"])[:, b][:, am[b].astype(bool)]
+            assert pos.tolist() == want.tolist()
+            assert d.value == row["rope_deltas"][b][0]
+            seen += 1
+    assert seen >= 6
+    bad = np.array([5, z.image_token_id, z.image_token_id, 7], dtype=np.int32)
+    g = np.array([[1, 4, 4]], dtype=np.int32)
+    pos = np.zeros((3, 4), dtype=np.int32)
+    d = C.c_int32()
+    assert lib.ze_rope_index(C.byref(z), bad.ctypes.data_as(C.POINTER(C.c_int32)), 4, g.ctypes.data_as(C.POINTER(C.c_int32)),
+                             1, pos.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(d)) == -5

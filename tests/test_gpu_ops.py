@@ -1,0 +1,84 @@
+"""GPU: unit ops through the C ABI (GEMM / GEMV / RMSNorm / attention) vs float64 numpy on the same bf16 inputs.
+
+Tolerance: inputs are exact bf16 values, accumulation is fp32, the output is rounded once to bf16, so the result
+must be within one bf16 ulp (2^-8 relative) of the exact value plus fp32 accumulation noise.
+"""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import tiny_engine, to_dev_bf16  # noqa: F401
+from oracle import prng
+from oracle.qwen25vl import bf16_round
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(seed, shape, std=1.0):
+    n = int(np.prod(shape))
+    return bf16_round(prng.normal_ih4(seed, n, std)).reshape(shape)
+
+
+def close_bf16(got, want, scale=None, ulps=1.5):
+    scale = np.maximum(np.abs(want), scale if scale is not None else 1e-3)
+    err = np.abs(got - want) / scale
+    assert err.max() <= ulps * 2.0 ** -8 + 1e-6, (err.max(), np.unravel_index(err.argmax(), err.shape))
+
+
+@pytest.mark.parametrize("m,n,k,bias,act", [
+    (64, 64, 64, False, 0), (130, 200, 96, True, 0), (1296, 480, 160, True, 0), (24, 512, 1176, False, 0),
+    (300, 1280, 224, True, 0), (77, 640, 640, True, 1), (1, 512, 512, True, 0), (1, 2048, 1376, False, 0),
+    (1, 96, 5632, True, 0), (257, 130, 40, True, 0), (1000, 2752, 512, False, 0),
+])
+def test_linear(tiny_engine, m, n, k, bias, act):
+    a, w = rnd(1, (m, k)), rnd(2, (n, k), 0.05)
+    b = rnd(3, (n,), 0.5) if bias else None
+    got = tiny_engine.op_linear(to_dev_bf16(a), to_dev_bf16(w), to_dev_bf16(b) if bias else None, act).float().cpu().numpy()
+    want = a.astype(np.float64) @ w.astype(np.float64).T + (b.astype(np.float64) if bias else 0.0)
+    if act:
+        import math
+        want = bf16_round(want.astype(np.float32)).astype(np.float64)
+        want = 0.5 * want * (1.0 + np.vectorize(math.erf)(want / math.sqrt(2.0)))
+        close_bf16(got, want, scale=0.05, ulps=2.5)
+    else:
+        close_bf16(got, want, scale=0.05 * np.sqrt(k) * 0.05)
+
+
+@pytest.mark.parametrize("rows,cols", [(5, 160), (1296, 1280), (3, 2048), (64, 512)])
+def test_rmsnorm(tiny_engine, rows, cols):
+    x, w = rnd(4, (rows, cols), 2.0), bf16_round(1.0 + rnd(5, (cols,), 0.1))
+    got = tiny_engine.op_rmsnorm(to_dev_bf16(x), to_dev_bf16(w), 1e-6).float().cpu().numpy()
+    xf = x.astype(np.float64)
+    xn = bf16_round((xf / np.sqrt((xf * xf).mean(-1, keepdims=True) + 1e-6)).astype(np.float32))
+    want = w.astype(np.float64) * xn
+    # the intermediate bf16 rounding may flip one ulp when the fp32 rsqrt differs in the last bit
+    close_bf16(got, want, ulps=3.0)
+
+
+def ref_attention(q, k, v, cu, causal):
+    t, h, d = q.shape
+    g = h // k.shape[1]
+    out = np.zeros((t, h, d))
+    for s0, s1 in zip(cu[:-1], cu[1:]):
+        for hh in range(h):
+            s = q[s0:s1, hh].astype(np.float64) @ k[s0:s1, hh // g].astype(np.float64).T / np.sqrt(d)
+            if causal:
+                s = np.where(np.tril(np.ones_like(s)) > 0, s, -np.inf)
+            p = np.exp(s - s.max(-1, keepdims=True))
+            p /= p.sum(-1, keepdims=True)
+            out[s0:s1, hh] = p @ v[s0:s1, hh // g].astype(np.float64)
+    return out
+
+
+@pytest.mark.parametrize("d,heads,kvh,cu,causal", [
+    (80, 2, 2, [0, 64, 128, 160, 176], False), (80, 16, 16, [0, 1296], False), (80, 3, 3, [0, 4, 68, 100, 356], False),
+    (128, 4, 2, [0, 300], True), (128, 16, 2, [0, 64, 193], True), (128, 8, 1, [0, 1, 66], True),
+])
+def test_attention(tiny_engine, d, heads, kvh, cu, causal):
+    t = cu[-1]
+    q, k, v = rnd(6, (t, heads, d)), rnd(7, (t, kvh, d)), rnd(8, (t, kvh, d))
+    got = tiny_engine.op_attention(to_dev_bf16(q), to_dev_bf16(k), to_dev_bf16(v), cu, causal).float().cpu().numpy()
+    want = ref_attention(q, k, v, cu, causal)
+    # P is rounded to bf16 before the PV product (as HF eager does): allow 2^-7 of the value scale
+    assert np.abs(got - want).max() <= 2.0 ** -6 * max(1.0, np.abs(want).max()), np.abs(got - want).max()
+    assert np.sqrt(np.mean((got - want) ** 2)) <= 4e-3

@@ -1,0 +1,235 @@
+// Streaming / elementwise kernels: weight packing + synthetic fill, RMSNorm, row gathers, vision RoPE,
+// M-RoPE + KV-cache append, token embedding.  All HBM-bound; bf16 I/O is vectorised 16 B per lane,
+// reductions use 64-lane wavefront shuffles.
+#include <hip/hip_fp16.h>
+
+#include "ze_kernels.h"
+#include "ze_prng.h"
+
+// ------------------------------------------------------------------ weight packing
+__device__ __forceinline__ int map_row(int r, int mode, int offset) {
+    return mode == 0 ? offset + r : (r >> 4) * 32 + (r & 15) + offset;
+}
+
+// src: [rows, cols] of dtype (ZE_F32 / ZE_F16 / ZE_BF16), row-major, starting at logical row row0.
+__global__ void __launch_bounds__(256) k_pack_rows(const void* __restrict__ src, int dtype, int row0, int nrows,
+                                                   int cols, bf16_t* __restrict__ dst, int ld, int mode, int offset) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)nrows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    bf16_t v;
+    if (dtype == ZE_BF16) {
+        v = ((const bf16_t*)src)[i];
+    } else if (dtype == ZE_F16) {
+        v = f32_to_bf16(__half2float(((const __half*)src)[i]));
+    } else {
+        v = f32_to_bf16(((const float*)src)[i]);
+    }
+    dst[(size_t)map_row(row0 + r, mode, offset) * ld + c] = v;
+}
+
+// Synthetic tensor: value(r, c) = base + normal_ih4(seed, r*cols + c) * scale_const, rounded to bf16.
+__global__ void __launch_bounds__(256) k_fill_rows(uint64_t seed, float c_scale, float base, int rows, int cols,
+                                                   bf16_t* __restrict__ dst, int ld, int mode, int offset) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    const float v = (c_scale != 0.0f) ? base + ze_normal_ih4(seed, i, c_scale) : base;
+    dst[(size_t)map_row(r, mode, offset) * ld + c] = f32_to_bf16(v);
+}
+
+void ze_launch_pack_rows(const void* src, int dtype, int row0, int nrows, int cols, bf16_t* dst, int ld, int mode,
+                         int offset, hipStream_t s) {
+    const size_t n = (size_t)nrows * cols;
+    if (n == 0) return;
+    k_pack_rows<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(src, dtype, row0, nrows, cols, dst, ld, mode, offset);
+}
+void ze_launch_fill_rows(uint64_t seed, float c_scale, float base, int rows, int cols, bf16_t* dst, int ld, int mode,
+                         int offset, hipStream_t s) {
+    const size_t n = (size_t)rows * cols;
+    if (n == 0) return;
+    k_fill_rows<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(seed, c_scale, base, rows, cols, dst, ld, mode, offset);
+}
+
+// ------------------------------------------------------------------ RMSNorm
+// y = w * bf16(x * rsqrt(mean(x^2) + eps)); one wave per row, 16-B vector loads.
+// (HF:models/qwen2_5_vl/modeling_qwen2_5_vl.py:64-79: cast to input dtype BEFORE the weight multiply.)
+__global__ void __launch_bounds__(256) k_rmsnorm(const bf16_t* __restrict__ x, int ldx,
+                                                 const bf16_t* __restrict__ w, bf16_t* __restrict__ y, int ldy,
+                                                 int rows, int cols, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const bf16_t* xr = x + (size_t)row * ldx;
+    float ss = 0.f;
+    const int nv = cols >> 3;  // cols % 8 == 0
+    for (int v = lane; v < nv; v += 64) {
+        const uint4 q = *reinterpret_cast<const uint4*>(xr + v * 8);
+        const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = bf16lo(u[j]), b = bf16hi(u[j]);
+            ss += a * a + b * b;
+        }
+    }
+    ss = wave_sum(ss);
+    const float inv = rsqrtf(ss / (float)cols + eps);
+    bf16_t* yr = y + (size_t)row * ldy;
+    for (int v = lane; v < nv; v += 64) {
+        const uint4 q = *reinterpret_cast<const uint4*>(xr + v * 8);
+        const uint4 g = *reinterpret_cast<const uint4*>(w + v * 8);
+        const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+        const uint32_t gw[4] = {g.x, g.y, g.z, g.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = bf16_round(bf16lo(u[j]) * inv) * bf16lo(gw[j]);
+            const float b = bf16_round(bf16hi(u[j]) * inv) * bf16hi(gw[j]);
+            o[j] = pack_bf16x2(a, b);
+        }
+        *reinterpret_cast<uint4*>(yr + v * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+void ze_launch_rmsnorm(const bf16_t* x, int ldx, const bf16_t* w, bf16_t* y, int ldy, int rows, int cols, float eps,
+                       hipStream_t s) {
+    if (rows == 0) return;
+    k_rmsnorm<<<ze_cdiv(rows, 4), 256, 0, s>>>(x, ldx, w, y, ldy, rows, cols, eps);
+}
+
+// ------------------------------------------------------------------ ViT input: f32 pixel rows -> bf16, gathered, K-padded
+// dst[r][0..kp) = bf16(src[perm[r]][0..k)) with zero pad; perm may be null (identity).
+__global__ void __launch_bounds__(256) k_gather_cast_rows(const float* __restrict__ src, int k,
+                                                          const int* __restrict__ perm, bf16_t* __restrict__ dst,
+                                                          int kp, int rows) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)rows * kp) return;
+    const int r = (int)(i / kp), c = (int)(i % kp);
+    const int sr = perm ? perm[r] : r;
+    dst[i] = c < k ? f32_to_bf16(src[(size_t)sr * k + c]) : (bf16_t)0;
+}
+void ze_launch_gather_cast_rows(const float* src, int k, const int* perm, bf16_t* dst, int kp, int rows,
+                                hipStream_t s) {
+    const size_t n = (size_t)rows * kp;
+    if (n == 0) return;
+    k_gather_cast_rows<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(src, k, perm, dst, kp, rows);
+}
+
+// ------------------------------------------------------------------ vision RoPE (fp32 math, in place on q and k of the qkv buffer)
+// qkv: [N, 3, heads, D] bf16; cs: [N, D/2] float2? -> separate cos/sin f32 tables [N, D/2] where table column j
+// serves dims j and j + D/2 (emb = cat(rot, rot)); rotate_half pairs (j, j + D/2).
+// (HF:models/qwen2_5_vl/modeling_qwen2_5_vl.py:153-171)
+__global__ void __launch_bounds__(256) k_vision_rope(bf16_t* __restrict__ qkv, const float* __restrict__ cosT,
+                                                     const float* __restrict__ sinT, int n, int heads, int D) {
+    const int half = D >> 1;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)n * 2 * heads * half;
+    if (i >= total) return;
+    const int j = (int)(i % half);
+    const int hh = (int)((i / half) % heads);
+    const int which = (int)((i / ((size_t)half * heads)) % 2);  // 0 q, 1 k
+    const int row = (int)(i / ((size_t)half * heads * 2));
+    bf16_t* p = qkv + (((size_t)row * 3 + which) * heads + hh) * D;
+    const float c = cosT[(size_t)row * half + j], s = sinT[(size_t)row * half + j];
+    const float x1 = bf16_to_f32(p[j]), x2 = bf16_to_f32(p[j + half]);
+    // q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1); fp32 then one rounding
+    p[j] = f32_to_bf16(x1 * c + (-x2) * s);
+    p[j + half] = f32_to_bf16(x2 * c + x1 * s);
+}
+void ze_launch_vision_rope(bf16_t* qkv, const float* cosT, const float* sinT, int n, int heads, int D,
+                           hipStream_t s) {
+    const size_t total = (size_t)n * 2 * heads * (D / 2);
+    if (total == 0) return;
+    k_vision_rope<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(qkv, cosT, sinT, n, heads, D);
+}
+
+// ------------------------------------------------------------------ text M-RoPE + KV append (prefill)
+// qkv: [T, (heads + 2*kv_heads) * D] bf16 (q | k | v).  cos/sin tables: bf16 [max_pos, D/2] (already rounded to the
+// model dtype like HF's cos.to(x.dtype)).  pos3: int32 [3, T].  axis_of[j] in {0,1,2} for j < D/2 picks t/h/w.
+// q is rotated in place; k (rotated) and v are written to the cache rows [past + t] of their kv head.
+// bf16 arithmetic with HF's three roundings: bf16(bf16(x*cos) + bf16(rot*sin)).
+// (HF:models/qwen2_5_vl/modeling_qwen2_5_vl.py:557-599, 654-668)
+__global__ void __launch_bounds__(256) k_mrope_kv(bf16_t* __restrict__ qkv, int T, int heads, int kv_heads, int D,
+                                                  const bf16_t* __restrict__ cosT, const bf16_t* __restrict__ sinT,
+                                                  const int* __restrict__ pos3, const int* __restrict__ axis_of,
+                                                  bf16_t* __restrict__ kcache, bf16_t* __restrict__ vcache,
+                                                  int max_ctx, int past) {
+    const int half = D >> 1;
+    const int nh = heads + 2 * kv_heads;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)T * nh * half;
+    if (i >= total) return;
+    const int j = (int)(i % half);
+    const int hh = (int)((i / half) % nh);
+    const int t = (int)(i / ((size_t)half * nh));
+    bf16_t* p = qkv + (size_t)t * nh * D + (size_t)hh * D;
+    if (hh >= heads + kv_heads) {  // v: plain copy into the cache
+        const int kvh = hh - heads - kv_heads;
+        bf16_t* d = vcache + ((size_t)kvh * max_ctx + past + t) * D;
+        d[j] = p[j];
+        d[j + half] = p[j + half];
+        return;
+    }
+    const int pos = pos3[axis_of[j] * T + t];
+    const float c = bf16_to_f32(cosT[(size_t)pos * half + j]);
+    const float s = bf16_to_f32(sinT[(size_t)pos * half + j]);
+    const float x1 = bf16_to_f32(p[j]), x2 = bf16_to_f32(p[j + half]);
+    const bf16_t o1 = f32_to_bf16(bf16_round(x1 * c) + bf16_round(-x2 * s));
+    const bf16_t o2 = f32_to_bf16(bf16_round(x2 * c) + bf16_round(x1 * s));
+    if (hh < heads) {
+        p[j] = o1;
+        p[j + half] = o2;
+    } else {
+        const int kvh = hh - heads;
+        bf16_t* d = kcache + ((size_t)kvh * max_ctx + past + t) * D;
+        d[j] = o1;
+        d[j + half] = o2;
+    }
+}
+void ze_launch_mrope_kv(bf16_t* qkv, int T, int heads, int kv_heads, int D, const bf16_t* cosT, const bf16_t* sinT,
+                        const int* pos3, const int* axis_of, bf16_t* kcache, bf16_t* vcache, int max_ctx, int past,
+                        hipStream_t s) {
+    const size_t total = (size_t)T * (heads + 2 * kv_heads) * (D / 2);
+    if (total == 0) return;
+    k_mrope_kv<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(qkv, T, heads, kv_heads, D, cosT, sinT, pos3,
+                                                               axis_of, kcache, vcache, max_ctx, past);
+}
+
+// ------------------------------------------------------------------ embedding gather + image scatter (K13)
+// src[t] >= 0: embed_tokens row; src[t] < 0: image_embeds row (-1 - src[t]).
+__global__ void __launch_bounds__(256) k_embed_rows(const int* __restrict__ src, const bf16_t* __restrict__ embed,
+                                                    const bf16_t* __restrict__ image_embeds,
+                                                    bf16_t* __restrict__ out, int T, int hidden) {
+    const int nv = hidden >> 3;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)T * nv) return;
+    const int t = (int)(i / nv), v = (int)(i % nv);
+    const int sidx = src[t];
+    const bf16_t* row = sidx >= 0 ? embed + (size_t)sidx * hidden : image_embeds + (size_t)(-1 - sidx) * hidden;
+    *reinterpret_cast<uint4*>(out + (size_t)t * hidden + v * 8) = *reinterpret_cast<const uint4*>(row + v * 8);
+}
+void ze_launch_embed_rows(const int* src, const bf16_t* embed, const bf16_t* image_embeds, bf16_t* out, int T,
+                          int hidden, hipStream_t s) {
+    const size_t n = (size_t)T * (hidden / 8);
+    if (n == 0) return;
+    k_embed_rows<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(src, embed, image_embeds, out, T, hidden);
+}
+
+// rows scatter/gather of bf16 rows: dst[dst_idx[r]] = src[r] (dst_idx null = identity)
+__global__ void __launch_bounds__(256) k_scatter_rows(const bf16_t* __restrict__ src, int lds_,
+                                                      const int* __restrict__ dst_idx, bf16_t* __restrict__ dst,
+                                                      int ldd, int rows, int cols) {
+    const int nv = cols >> 3;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)rows * nv) return;
+    const int r = (int)(i / nv), v = (int)(i % nv);
+    const int d = dst_idx ? dst_idx[r] : r;
+    *reinterpret_cast<uint4*>(dst + (size_t)d * ldd + v * 8) =
+        *reinterpret_cast<const uint4*>(src + (size_t)r * lds_ + v * 8);
+}
+void ze_launch_scatter_rows(const bf16_t* src, int lds_, const int* dst_idx, bf16_t* dst, int ldd, int rows,
+                            int cols, hipStream_t s) {
+    const size_t n = (size_t)rows * (cols / 8);
+    if (n == 0) return;
+    k_scatter_rows<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(src, lds_, dst_idx, dst, ldd, rows, cols);
+}

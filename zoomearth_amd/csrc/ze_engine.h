@@ -1,0 +1,127 @@
+// ze_engine: owns the packed bf16 weight arena, the KV cache, chain state and workspaces of one GPU.
+//
+// HBM layout (3B config, sizes for max_seqs=4, max_ctx=4096):
+//   weight arena  (one hipMalloc, ~7.5 GB bf16)   all matrices [N, K] row-major, K contiguous (the MFMA / GEMV feed)
+//       ViT   : patch_embed [1280,1176]; per block qkv [3840,1280]+b, proj [1280,1280]+b,
+//               gate_up [2*3424,1280]+b (gate/up rows interleaved in blocks of 16, zero padded 3420->3424),
+//               down [1280,3424]+b (K zero padded); merger ln_q, mlp.0 [5120,5120]+b, mlp.2 [2048,5120]+b
+//       LLM   : embed_tokens [151936,2048] (= lm_head when tied); per layer qkv [2560,2048]+b (q|k|v stacked),
+//               o [2048,2048], gate_up [2*11008,2048] (interleaved), down [2048,11008]; norms
+//   KV cache      [layers][max_seqs][kv_heads][max_ctx][128] bf16, K and V separate (36,864 B per cached token)
+//   tables        text cos/sin bf16 [max_ctx + 512][64]; normalise LUT f32 [3][256]
+//   chain state   ze_seq_dev[max_seqs], seen-set u8 [max_seqs][vocab], out tokens int32 [max_seqs][max_ctx]
+//   workspaces    ViT activations for max_patches rows; prefill activations for max_ctx rows; decode vectors
+#pragma once
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "ze_host.h"
+#include "ze_kernels.h"
+
+struct ze_linear {
+    bf16_t* w = nullptr;
+    bf16_t* bias = nullptr;
+    int n = 0, k = 0, ld = 0;
+};
+struct ze_vit_block {
+    bf16_t *norm1 = nullptr, *norm2 = nullptr;
+    ze_linear qkv, proj, gate_up, down;
+};
+struct ze_text_layer {
+    bf16_t *in_norm = nullptr, *post_norm = nullptr;
+    ze_linear qkv, o, gate_up, down;
+};
+// where an HF tensor lands in the packed arena
+struct ze_dest {
+    bf16_t* dst = nullptr;
+    int rows = 0, cols = 0, ld = 0, mode = 0, offset = 0;
+    int kind = 0;  // 0 matrix, 1 norm weight, 2 bias, 3 embedding / lm_head
+};
+
+struct ze_engine {
+    ze_config cfg{};
+    int device = 0;
+    std::string err;
+    int head_dim = 128, vit_head_dim = 80, vit_ipad = 0, text_ipad = 0, max_pos = 0;
+
+    // weights
+    bf16_t* arena = nullptr;
+    size_t arena_elems = 0, arena_used = 0;
+    std::map<std::string, ze_dest> dests;
+    std::set<std::string> loaded;
+    void* staging = nullptr;
+    size_t staging_bytes = 0;
+    ze_linear patch_embed, merger0, merger2;
+    bf16_t* ln_q = nullptr;
+    std::vector<ze_vit_block> vb;
+    bf16_t *embed = nullptr, *lm_head = nullptr, *final_norm = nullptr;
+    std::vector<ze_text_layer> tl;
+
+    // tables
+    bf16_t *cosT = nullptr, *sinT = nullptr;
+    int* axis_of = nullptr;
+    float* lut = nullptr;
+    int* eos_dev = nullptr;
+
+    // KV cache + chain state
+    bf16_t *kcache = nullptr, *vcache = nullptr;
+    ze_seq_dev* st_dev = nullptr;
+    uint8_t* seen = nullptr;
+    int32_t* out_tokens = nullptr;
+    std::vector<int> ctx_host, delta_host;
+    std::vector<hipGraphExec_t> graphs;
+    std::vector<float> graph_penalty;
+    std::vector<int> graph_ignore_eos;
+
+    // front-end workspace
+    uint8_t *fe_tmp = nullptr, *fe_img = nullptr;
+    int *fe_coef = nullptr;  // device coefficient tables
+    size_t fe_tmp_bytes = 0, fe_img_bytes = 0, fe_coef_ints = 0;
+    int* fe_coef_host = nullptr;  // pinned
+
+    // ViT workspace
+    bf16_t *vx = nullptr, *vh = nullptr, *vy = nullptr, *vqkv = nullptr, *vo = nullptr, *va = nullptr, *vz = nullptr,
+           *vz2 = nullptr;
+    float *vcos = nullptr, *vsin = nullptr;
+    int *vperm = nullptr, *vinv = nullptr;
+    int4* vtiles_win = nullptr;
+    int4* vtiles_full = nullptr;
+    int* v_host_ints = nullptr;   // pinned staging for perm / tiles
+    float* v_host_f32 = nullptr;  // pinned staging for cos/sin
+    size_t v_host_ints_cap = 0, v_host_f32_cap = 0;
+
+    // prefill workspace
+    bf16_t *th = nullptr, *ty = nullptr, *tqkv = nullptr, *to = nullptr, *ta = nullptr;
+    int *tsrc = nullptr, *tpos = nullptr;
+    int4* ttiles = nullptr;
+    int* t_host_ints = nullptr;  // pinned
+    size_t t_host_ints_cap = 0;
+
+    // decode workspace
+    bf16_t *dh = nullptr, *dq = nullptr, *dattn = nullptr, *dact = nullptr;
+    float *dlogits = nullptr, *dpartial = nullptr, *dsample = nullptr;
+    int max_splits = 32;
+    int* d_host_ints = nullptr;  // pinned, small
+
+    // timers
+    bool timers_on = false;
+    struct ev_pair { int phase; hipEvent_t a, b; };
+    std::vector<ev_pair> ev_used;
+    std::vector<ev_pair> ev_free;
+    float phase_ms[5] = {0, 0, 0, 0, 0};
+
+    bf16_t* kc(int layer, int seq) const {
+        return kcache + (((size_t)layer * cfg.max_seqs + seq) * cfg.kv_heads) * (size_t)cfg.max_ctx * head_dim;
+    }
+    bf16_t* vc(int layer, int seq) const {
+        return vcache + (((size_t)layer * cfg.max_seqs + seq) * cfg.kv_heads) * (size_t)cfg.max_ctx * head_dim;
+    }
+};
+
+// engine internals used across translation units
+int ze_engine_build_layout(ze_engine* e);
+int ze_timer_begin(ze_engine* e, int phase, hipStream_t s);
+void ze_timer_end(ze_engine* e, int handle, hipStream_t s);
+int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos, hipStream_t s);

@@ -1,0 +1,784 @@
+// Forward passes of the engine: image front-end, ViT, LLM prefill, decode step (eager or hipGraph), greedy
+// generation, plus the unit ops and the measurement hooks of the C ABI.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "ze_engine.h"
+
+#define ZE_TRY(x)               \
+    do {                        \
+        int _r = (x);           \
+        if (_r != 0) return _r; \
+    } while (0)
+#define ZE_KCHECK() ZE_HIP(hipGetLastError())
+
+// ================================================================== front-end
+// dst = crop(src, box).resize((dst_w, dst_h), BICUBIC), Pillow-exact (two passes, u8 intermediate).
+static int crop_resize(ze_engine* e, const uint8_t* src, int src_h, int src_w, const int32_t box[4], uint8_t* dst,
+                       int dst_h, int dst_w, hipStream_t s) {
+    const int bx0 = box[0], by0 = box[1];
+    const int bw = box[2] - box[0], bh = box[3] - box[1];
+    if (bw <= 0 || bh <= 0 || dst_w <= 0 || dst_h <= 0) return ze_fail(e, ZE_ERR_INVALID, "empty crop box or output");
+    const bool need_h = bw != dst_w, need_v = bh != dst_h;
+    if (!need_h && !need_v) {
+        ze_launch_crop(src, src_h, src_w, bx0, by0, dst, dst_h, dst_w, s);
+        ZE_KCHECK();
+        return ZE_OK;
+    }
+    ze_coeffs ch, cv;
+    size_t ints = 0;
+    if (need_h) {
+        ze_bicubic_coeffs(bw, dst_w, &ch);
+        ints += 2 * (size_t)dst_w + ch.kk.size();
+    }
+    if (need_v) {
+        ze_bicubic_coeffs(bh, dst_h, &cv);
+        ints += 2 * (size_t)dst_h + cv.kk.size();
+    }
+    if (ints > e->fe_coef_ints) return ze_fail(e, ZE_ERR_NOMEM, "bicubic coefficient table exceeds workspace");
+    if (need_h && need_v && (size_t)bh * dst_w * 3 > e->fe_tmp_bytes)
+        return ze_fail(e, ZE_ERR_NOMEM, "resize intermediate exceeds workspace (max_tile_side)");
+    // the pinned staging buffer is reused by every call: wait until the previous upload was consumed
+    ZE_HIP(hipStreamSynchronize(s));
+    int* hp = e->fe_coef_host;
+    int* dp = e->fe_coef;
+    size_t o = 0;
+    const int *d_xmin = nullptr, *d_xcnt = nullptr, *d_xk = nullptr, *d_ymin = nullptr, *d_ycnt = nullptr,
+              *d_yk = nullptr;
+    auto put = [&](const std::vector<int>& v) {
+        memcpy(hp + o, v.data(), v.size() * sizeof(int));
+        const int* d = dp + o;
+        o += v.size();
+        return d;
+    };
+    if (need_h) {
+        d_xmin = put(ch.xmin);
+        d_xcnt = put(ch.xcnt);
+        d_xk = put(ch.kk);
+    }
+    if (need_v) {
+        d_ymin = put(cv.xmin);
+        d_ycnt = put(cv.xcnt);
+        d_yk = put(cv.kk);
+    }
+    ZE_HIP(hipMemcpyAsync(dp, hp, o * sizeof(int), hipMemcpyHostToDevice, s));
+    if (need_h) {
+        uint8_t* hout = need_v ? e->fe_tmp : dst;
+        // widest source span of a 64-column block: 64*scale + 2*support  (+ slack)
+        int max_span = 0;
+        for (int c0 = 0; c0 < dst_w; c0 += 64) {
+            const int last = std::min(dst_w, c0 + 64) - 1;
+            max_span = std::max(max_span, ch.xmin[last] + ch.xcnt[last] - ch.xmin[c0]);
+        }
+        ze_launch_resize_h(src, src_h, src_w, bx0, by0, bh, hout, dst_w, d_xmin, d_xcnt, d_xk, ch.ksize, max_span, s);
+        ZE_KCHECK();
+        if (need_v) {
+            ze_launch_resize_v(e->fe_tmp, bh, dst_w, 0, 0, dst_w * 3, dst, dst_h, d_ymin, d_ycnt, d_yk, cv.ksize, 0, s);
+            ZE_KCHECK();
+        }
+    } else {
+        ze_launch_resize_v(src, src_h, src_w, bx0, by0, dst_w * 3, dst, dst_h, d_ymin, d_ycnt, d_yk, cv.ksize, 1, s);
+        ZE_KCHECK();
+    }
+    return ZE_OK;
+}
+
+extern "C" int ze_op_crop_resize(ze_engine* e, const uint8_t* src, int src_h, int src_w, const int32_t box[4],
+                                 uint8_t* dst, int dst_h, int dst_w, void* stream) {
+    if (!e || !src || !dst || !box) return ze_fail(e, ZE_ERR_INVALID, "null argument");
+    hipSetDevice(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int h = ze_timer_begin(e, 0, s);
+    const int r = crop_resize(e, src, src_h, src_w, box, dst, dst_h, dst_w, s);
+    ze_timer_end(e, h, s);
+    return r;
+}
+
+extern "C" int ze_smart_resize(int height, int width, int factor, int64_t min_pixels, int64_t max_pixels, int* out_h,
+                               int* out_w) {
+    if (ze_smart_resize_impl(height, width, factor, min_pixels, max_pixels, out_h, out_w) != 0)
+        return ze_fail(nullptr, ZE_ERR_INVALID, "absolute aspect ratio must be smaller than 200");
+    return ZE_OK;
+}
+
+extern "C" int ze_op_patchify(ze_engine* e, const uint8_t* img, int h, int w, float* out, void* stream) {
+    if (!e || !img || !out) return ze_fail(e, ZE_ERR_INVALID, "null argument");
+    const ze_config& c = e->cfg;
+    const int f = c.patch_size * c.spatial_merge_size;
+    if (h % f || w % f) return ze_fail(e, ZE_ERR_INVALID, "image size must be a multiple of patch*merge");
+    hipSetDevice(e->device);
+    ze_launch_patchify(img, h, w, e->lut, out, c.patch_size, c.spatial_merge_size, c.temporal_patch_size,
+                       c.in_channels, (hipStream_t)stream);
+    ZE_KCHECK();
+    return ZE_OK;
+}
+
+extern "C" int ze_preprocess_image(ze_engine* e, const uint8_t* img, int h, int w, int64_t min_pixels,
+                                   int64_t max_pixels, float* out, int64_t capacity_rows, int32_t grid_thw[3],
+                                   void* stream) {
+    if (!e || !img || !out || !grid_thw) return ze_fail(e, ZE_ERR_INVALID, "null argument");
+    const ze_config& c = e->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    const int f = c.patch_size * c.spatial_merge_size;
+    int rh, rw;
+    if (ze_smart_resize_impl(h, w, f, min_pixels, max_pixels, &rh, &rw) != 0)
+        return ze_fail(e, ZE_ERR_INVALID, "absolute aspect ratio must be smaller than 200");
+    const int64_t rows = (int64_t)(rh / c.patch_size) * (rw / c.patch_size);
+    if (rows > capacity_rows) return ze_fail(e, ZE_ERR_NOMEM, "pixel_values capacity too small");
+    if ((size_t)rh * rw * 3 > e->fe_img_bytes) return ze_fail(e, ZE_ERR_NOMEM, "resized image exceeds workspace");
+    const int th = ze_timer_begin(e, 0, s);
+    const uint8_t* cur = img;
+    if (rh != h || rw != w) {
+        const int32_t box[4] = {0, 0, w, h};
+        ZE_TRY(crop_resize(e, img, h, w, box, e->fe_img, rh, rw, s));
+        cur = e->fe_img;
+    }
+    ze_launch_patchify(cur, rh, rw, e->lut, out, c.patch_size, c.spatial_merge_size, c.temporal_patch_size,
+                       c.in_channels, s);
+    ze_timer_end(e, th, s);
+    ZE_KCHECK();
+    grid_thw[0] = 1;
+    grid_thw[1] = rh / c.patch_size;
+    grid_thw[2] = rw / c.patch_size;
+    return ZE_OK;
+}
+
+// ================================================================== index helpers (C ABI wrappers)
+extern "C" int ze_vision_window_index(const ze_config* cfg, const int32_t* grid_thw, int n_images,
+                                      int64_t* window_index, int32_t* cu_window, int cap_cu, int* n_cu) {
+    if (!cfg || !grid_thw || !window_index || !cu_window || !n_cu)
+        return ze_fail(nullptr, ZE_ERR_INVALID, "null argument");
+    std::vector<int64_t> wi;
+    std::vector<int32_t> cu;
+    ze_window_index_impl(grid_thw, n_images, cfg->spatial_merge_size, cfg->window_size, cfg->patch_size, wi, cu);
+    if ((int)cu.size() > cap_cu) return ze_fail(nullptr, ZE_ERR_NOMEM, "cu_window capacity too small");
+    memcpy(window_index, wi.data(), wi.size() * sizeof(int64_t));
+    memcpy(cu_window, cu.data(), cu.size() * sizeof(int32_t));
+    *n_cu = (int)cu.size();
+    return ZE_OK;
+}
+
+extern "C" int ze_rope_index(const ze_config* cfg, const int32_t* input_ids, int len, const int32_t* grid_thw,
+                             int n_images, int32_t* position_ids, int32_t* rope_delta) {
+    if (!cfg || !input_ids || !position_ids || !rope_delta) return ze_fail(nullptr, ZE_ERR_INVALID, "null argument");
+    const int r = ze_rope_index_impl(input_ids, len, grid_thw, n_images, cfg->image_token_id, cfg->spatial_merge_size,
+                                     position_ids, rope_delta);
+    if (r != 0)
+        return ze_fail(nullptr, ZE_ERR_MISMATCH, "Image features and image tokens do not match (rope index)");
+    return ZE_OK;
+}
+
+// ================================================================== attention tile lists
+// one tile = up to 64 query rows of one segment against that segment's keys
+static int build_tiles(const int32_t* cu, int n_seg, int* out /* int4 rows */, int cap_tiles) {
+    int n = 0;
+    for (int sgi = 0; sgi < n_seg; ++sgi)
+        for (int q0 = cu[sgi]; q0 < cu[sgi + 1]; q0 += 64) {
+            if (n >= cap_tiles) return -1;
+            out[4 * n + 0] = q0;
+            out[4 * n + 1] = std::min(q0 + 64, cu[sgi + 1]);
+            out[4 * n + 2] = cu[sgi];
+            out[4 * n + 3] = cu[sgi + 1];
+            ++n;
+        }
+    return n;
+}
+
+// ================================================================== ViT
+extern "C" int ze_vit_forward(ze_engine* e, const float* pixel_values, const int32_t* grid_thw, int n_images,
+                              void* out_embeds, void* stream) {
+    if (!e || !pixel_values || !grid_thw || !out_embeds || n_images <= 0)
+        return ze_fail(e, ZE_ERR_INVALID, "null argument");
+    const ze_config& c = e->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    const int mu = c.spatial_merge_size * c.spatial_merge_size;
+    int n = 0;
+    for (int i = 0; i < n_images; ++i) {
+        const int t = grid_thw[3 * i], h = grid_thw[3 * i + 1], w = grid_thw[3 * i + 2];
+        if (t <= 0 || h <= 0 || w <= 0 || h % c.spatial_merge_size || w % c.spatial_merge_size)
+            return ze_fail(e, ZE_ERR_INVALID, "bad grid_thw");
+        n += t * h * w;
+    }
+    if (n > c.max_patches) return ze_fail(e, ZE_ERR_NOMEM, "too many patches for max_patches");
+    const int vh = c.vit_hidden, hd = e->vit_head_dim, half = hd / 2, nh = c.vit_heads;
+    const int pk = c.in_channels * c.temporal_patch_size * c.patch_size * c.patch_size;
+
+    // ---- host index prep (integer): window permutation, segment tiles, rotary tables
+    std::vector<int64_t> widx;
+    std::vector<int32_t> cu_win, cu_full(1, 0), hw;
+    ze_window_index_impl(grid_thw, n_images, c.spatial_merge_size, c.window_size, c.patch_size, widx, cu_win);
+    for (int i = 0; i < n_images; ++i)
+        for (int t = 0; t < grid_thw[3 * i]; ++t)
+            cu_full.push_back(cu_full.back() + grid_thw[3 * i + 1] * grid_thw[3 * i + 2]);
+    ze_vision_pos_ids_impl(grid_thw, n_images, c.spatial_merge_size, hw);
+    ZE_HIP(hipStreamSynchronize(s));  // pinned staging reuse
+    int* hi = e->v_host_ints;
+    int* perm = hi;              // [n]   new row r <- old row perm[r]
+    int* inv = hi + n;           // [n/mu] merged row j (window order) -> HF order row
+    int* tw = hi + 2 * n;        // window tiles
+    for (int j = 0; j < n / mu; ++j) {
+        for (int u = 0; u < mu; ++u) perm[j * mu + u] = (int)widx[j] * mu + u;
+        inv[j] = (int)widx[j];
+    }
+    const int ntw = build_tiles(cu_win.data(), (int)cu_win.size() - 1, tw, n);
+    int* tf = tw + 4 * ntw;
+    const int ntf = build_tiles(cu_full.data(), (int)cu_full.size() - 1, tf, n);
+    if (ntw < 0 || ntf < 0) return ze_fail(e, ZE_ERR_NOMEM, "attention tile list overflow");
+    // rotary: inv_freq over dim = head_dim/2 -> half/2 frequencies per axis (HF:...:125-134, 441-446)
+    const int nf = half / 2;
+    std::vector<float> invf(nf);
+    for (int i = 0; i < nf; ++i) invf[i] = 1.0f / powf(10000.0f, (float)(2 * i) / (float)half);
+    float* hc = e->v_host_f32;
+    float* hs = hc + (size_t)n * half;
+    for (int r = 0; r < n; ++r) {
+        const int old = perm[r];
+        for (int i = 0; i < nf; ++i) {
+            const float fh = (float)hw[2 * old] * invf[i], fw = (float)hw[2 * old + 1] * invf[i];
+            hc[(size_t)r * half + i] = cosf(fh);
+            hs[(size_t)r * half + i] = sinf(fh);
+            hc[(size_t)r * half + nf + i] = cosf(fw);
+            hs[(size_t)r * half + nf + i] = sinf(fw);
+        }
+    }
+    ZE_HIP(hipMemcpyAsync(e->vperm, perm, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+    ZE_HIP(hipMemcpyAsync(e->vinv, inv, (size_t)(n / mu) * sizeof(int), hipMemcpyHostToDevice, s));
+    ZE_HIP(hipMemcpyAsync(e->vtiles_win, tw, (size_t)ntw * 16, hipMemcpyHostToDevice, s));
+    ZE_HIP(hipMemcpyAsync(e->vtiles_full, tf, (size_t)ntf * 16, hipMemcpyHostToDevice, s));
+    ZE_HIP(hipMemcpyAsync(e->vcos, hc, (size_t)n * half * sizeof(float), hipMemcpyHostToDevice, s));
+    ZE_HIP(hipMemcpyAsync(e->vsin, hs, (size_t)n * half * sizeof(float), hipMemcpyHostToDevice, s));
+
+    const int th = ze_timer_begin(e, 1, s);
+    // ---- patch embed on window-ordered rows (pixel_values.type(bf16), conv3d == GEMM, no bias)
+    ze_launch_gather_cast_rows(pixel_values, pk, e->vperm, e->vx, pk, n, s);
+    ze_launch_gemm(ZE_EPI_NONE, e->vx, pk, e->patch_embed.w, e->patch_embed.ld, nullptr, nullptr, 0, e->vh, vh,
+                   nullptr, n, vh, pk, s);
+    const float scale = 1.0f / sqrtf((float)hd);
+    for (int li = 0; li < c.vit_depth; ++li) {
+        const ze_vit_block& b = e->vb[li];
+        bool full = false;
+        for (int k = 0; k < c.n_fullatt; ++k) full |= c.fullatt_block_indexes[k] == li;
+        ze_launch_rmsnorm(e->vh, vh, b.norm1, e->vy, vh, n, vh, 1e-6f, s);
+        ze_launch_gemm(ZE_EPI_NONE, e->vy, vh, b.qkv.w, b.qkv.ld, b.qkv.bias, nullptr, 0, e->vqkv, 3 * vh, nullptr, n,
+                       3 * vh, vh, s);
+        ze_launch_vision_rope(e->vqkv, e->vcos, e->vsin, n, nh, hd, s);
+        ze_launch_flash_attn(hd, 0, e->vqkv, 3 * vh, hd, e->vqkv + vh, 3 * vh, hd, e->vqkv + 2 * vh, 3 * vh, hd, e->vo,
+                             vh, hd, full ? e->vtiles_full : e->vtiles_win, full ? ntf : ntw, nh, 1, scale, 0, s);
+        ze_launch_gemm(ZE_EPI_RESIDUAL, e->vo, vh, b.proj.w, b.proj.ld, b.proj.bias, e->vh, vh, e->vh, vh, nullptr, n,
+                       vh, vh, s);
+        ze_launch_rmsnorm(e->vh, vh, b.norm2, e->vy, vh, n, vh, 1e-6f, s);
+        ze_launch_gemm(ZE_EPI_SWIGLU, e->vy, vh, b.gate_up.w, b.gate_up.ld, b.gate_up.bias, nullptr, 0, e->va,
+                       e->vit_ipad, nullptr, n, 2 * e->vit_ipad, vh, s);
+        ze_launch_gemm(ZE_EPI_RESIDUAL, e->va, e->vit_ipad, b.down.w, b.down.ld, b.down.bias, e->vh, vh, e->vh, vh,
+                       nullptr, n, vh, e->vit_ipad, s);
+    }
+    // ---- merger: RMSNorm -> [n/mu, vh*mu] -> Linear+GELU -> Linear, rows scattered back to HF order
+    ze_launch_rmsnorm(e->vh, vh, e->ln_q, e->vy, vh, n, vh, 1e-6f, s);
+    const int mh = vh * mu;
+    ze_launch_gemm(ZE_EPI_GELU, e->vy, mh, e->merger0.w, e->merger0.ld, e->merger0.bias, nullptr, 0, e->vz, mh, nullptr,
+                   n / mu, mh, mh, s);
+    ze_launch_gemm(ZE_EPI_NONE, e->vz, mh, e->merger2.w, e->merger2.ld, e->merger2.bias, nullptr, 0,
+                   (bf16_t*)out_embeds, c.vit_out_hidden, e->vinv, n / mu, c.vit_out_hidden, mh, s);
+    ze_timer_end(e, th, s);
+    ZE_KCHECK();
+    return ZE_OK;
+}
+
+// ================================================================== chains
+static int check_seq(ze_engine* e, int seq) {
+    if (!e) return ze_fail(e, ZE_ERR_INVALID, "null engine");
+    if (seq < 0 || seq >= e->cfg.max_seqs) return ze_fail(e, ZE_ERR_NOTFOUND, "sequence id out of range");
+    return ZE_OK;
+}
+
+static int push_state(ze_engine* e, int seq, hipStream_t s, int token, int n_gen, int finished) {
+    ze_seq_dev st;
+    memset(&st, 0, sizeof(st));
+    st.ctx = e->ctx_host[seq];
+    st.rope_delta = e->delta_host[seq];
+    st.token = token;
+    st.finished = finished;
+    st.n_gen = n_gen;
+    st.max_gen = e->cfg.max_ctx;
+    ZE_HIP(hipStreamSynchronize(s));
+    memcpy(e->d_host_ints, &st, sizeof(st));
+    ZE_HIP(hipMemcpyAsync(e->st_dev + seq, e->d_host_ints, sizeof(st), hipMemcpyHostToDevice, s));
+    return ZE_OK;
+}
+
+extern "C" int ze_seq_reset(ze_engine* e, int seq, void* stream) {
+    ZE_TRY(check_seq(e, seq));
+    hipSetDevice(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    e->ctx_host[seq] = 0;
+    e->delta_host[seq] = 0;
+    ZE_HIP(hipMemsetAsync(e->seen + (size_t)seq * e->cfg.vocab, 0, e->cfg.vocab, s));
+    return push_state(e, seq, s, 0, 0, 0);
+}
+
+extern "C" int ze_seq_truncate(ze_engine* e, int seq, int keep_len, void* stream) {
+    ZE_TRY(check_seq(e, seq));
+    if (keep_len < 0 || keep_len > e->ctx_host[seq]) return ze_fail(e, ZE_ERR_INVALID, "keep_len out of range");
+    hipSetDevice(e->device);
+    e->ctx_host[seq] = keep_len;
+    return push_state(e, seq, (hipStream_t)stream, 0, 0, 0);
+}
+
+extern "C" int ze_seq_len(ze_engine* e, int seq) {
+    if (check_seq(e, seq) != 0) return ZE_ERR_NOTFOUND;
+    return e->ctx_host[seq];
+}
+
+extern "C" int ze_seq_mark_seen(ze_engine* e, int seq, const int32_t* ids, int n, void* stream) {
+    ZE_TRY(check_seq(e, seq));
+    if (n < 0 || (n > 0 && !ids)) return ze_fail(e, ZE_ERR_INVALID, "bad ids");
+    if ((size_t)n > e->t_host_ints_cap) return ze_fail(e, ZE_ERR_NOMEM, "too many ids");
+    for (int i = 0; i < n; ++i)
+        if (ids[i] < 0 || ids[i] >= e->cfg.vocab) return ze_fail(e, ZE_ERR_INVALID, "token id out of range");
+    hipSetDevice(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    ZE_HIP(hipStreamSynchronize(s));
+    memcpy(e->t_host_ints, ids, (size_t)n * sizeof(int));
+    ZE_HIP(hipMemcpyAsync(e->tsrc, e->t_host_ints, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+    ze_launch_mark_seen(e->seen + (size_t)seq * e->cfg.vocab, e->tsrc, n, s);
+    ZE_KCHECK();
+    return ZE_OK;
+}
+
+// ================================================================== prefill
+extern "C" int ze_prefill(ze_engine* e, int seq, const int32_t* input_ids, int len, const void* image_embeds,
+                          int n_image_rows, const int32_t* position_ids, int rope_delta, float* out_logits,
+                          void* stream) {
+    ZE_TRY(check_seq(e, seq));
+    if (!input_ids || !position_ids || len <= 0) return ze_fail(e, ZE_ERR_INVALID, "bad prefill arguments");
+    const ze_config& c = e->cfg;
+    const int past = e->ctx_host[seq];
+    if (past + len > c.max_ctx) return ze_fail(e, ZE_ERR_NOMEM, "sequence exceeds max_ctx");
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    const int H = c.hidden, hd = e->head_dim, nq = c.heads * hd, nkv = c.kv_heads * hd, nqkv = nq + 2 * nkv;
+
+    ZE_HIP(hipStreamSynchronize(s));  // pinned staging reuse
+    int* src = e->t_host_ints;
+    int* pos = src + len;
+    int* tiles = pos + 3 * len;
+    int img = 0;
+    for (int t = 0; t < len; ++t) {
+        const int id = input_ids[t];
+        if (id < 0 || id >= c.vocab) return ze_fail(e, ZE_ERR_INVALID, "token id out of range");
+        src[t] = (id == c.image_token_id) ? -1 - img++ : id;
+        for (int a = 0; a < 3; ++a) {
+            const int p = position_ids[a * len + t];
+            if (p < 0 || p >= e->max_pos) return ze_fail(e, ZE_ERR_INVALID, "position id out of range");
+            pos[a * len + t] = p;
+        }
+    }
+    if (img != n_image_rows || (img > 0 && !image_embeds))
+        return ze_fail(e, ZE_ERR_MISMATCH, "Image features and image tokens do not match, tokens: " +
+                                               std::to_string(img) + ", features: " + std::to_string(n_image_rows));
+    int nt = 0;
+    for (int q0 = 0; q0 < len; q0 += 64, ++nt) {
+        tiles[4 * nt + 0] = q0;
+        tiles[4 * nt + 1] = std::min(q0 + 64, len);
+        tiles[4 * nt + 2] = 0;
+        tiles[4 * nt + 3] = past + len;
+    }
+    ZE_HIP(hipMemcpyAsync(e->tsrc, src, (size_t)len * sizeof(int), hipMemcpyHostToDevice, s));
+    ZE_HIP(hipMemcpyAsync(e->tpos, pos, (size_t)3 * len * sizeof(int), hipMemcpyHostToDevice, s));
+    ZE_HIP(hipMemcpyAsync(e->ttiles, tiles, (size_t)nt * 16, hipMemcpyHostToDevice, s));
+
+    const int th = ze_timer_begin(e, 2, s);
+    ze_launch_embed_rows(e->tsrc, e->embed, (const bf16_t*)image_embeds, e->th, len, H, s);
+    const float scale = 1.0f / sqrtf((float)hd);
+    for (int li = 0; li < c.layers; ++li) {
+        const ze_text_layer& L = e->tl[li];
+        ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, len, H, c.rms_eps, s);
+        ze_launch_gemm(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, nullptr, len,
+                       nqkv, H, s);
+        ze_launch_mrope_kv(e->tqkv, len, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->tpos, e->axis_of,
+                           e->kc(li, seq), e->vc(li, seq), c.max_ctx, past, s);
+        ze_launch_flash_attn(hd, 1, e->tqkv, nqkv, hd, e->kc(li, seq), hd, c.max_ctx * hd, e->vc(li, seq), hd,
+                             c.max_ctx * hd, e->to, nq, hd, e->ttiles, nt, c.heads, c.heads / c.kv_heads, scale, past,
+                             s);
+        ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, len, H, nq, s);
+        ze_launch_rmsnorm(e->th, H, L.post_norm, e->ty, H, len, H, c.rms_eps, s);
+        ze_launch_gemm(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad,
+                       nullptr, len, 2 * e->text_ipad, H, s);
+        ze_launch_gemm(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, nullptr,
+                       len, H, e->text_ipad, s);
+    }
+    // last position: final norm fused into the lm_head GEMV (logits_to_keep = 1, HF:...:1386-1387)
+    ze_gemv_args a;
+    memset(&a, 0, sizeof(a));
+    a.W = e->lm_head;
+    a.ldw = H;
+    a.N = c.vocab;
+    a.K = H;
+    a.x = e->th + (size_t)(len - 1) * H;
+    a.norm_w = e->final_norm;
+    a.eps = c.rms_eps;
+    a.out_f32 = e->dlogits;
+    a.D = hd;
+    ze_launch_gemv(ZE_GV_LOGITS, a, s);
+    ze_timer_end(e, th, s);
+    ZE_KCHECK();
+    if (out_logits)
+        ZE_HIP(hipMemcpyAsync(out_logits, e->dlogits, (size_t)c.vocab * sizeof(float), hipMemcpyDeviceToDevice, s));
+    e->ctx_host[seq] = past + len;
+    e->delta_host[seq] = rope_delta;
+    return push_state(e, seq, s, input_ids[len - 1], 0, 0);
+}
+
+// ================================================================== decode
+// One token for chain `seq`: everything is read from the device-side chain state, so the same launch
+// sequence can be captured once into a hipGraph and replayed.
+int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos, hipStream_t s) {
+    const ze_config& c = e->cfg;
+    const int H = c.hidden, hd = e->head_dim, nq = c.heads * hd, nqkv = nq + 2 * c.kv_heads * hd;
+    const ze_seq_dev* st = e->st_dev + seq;
+    const float scale = 1.0f / sqrtf((float)hd);
+    for (int li = 0; li < c.layers; ++li) {
+        const ze_text_layer& L = e->tl[li];
+        ze_gemv_args a;
+        memset(&a, 0, sizeof(a));
+        a.W = L.qkv.w;
+        a.ldw = L.qkv.ld;
+        a.N = nqkv;
+        a.K = H;
+        a.x = e->dh;
+        a.norm_w = L.in_norm;
+        a.eps = c.rms_eps;
+        a.bias = L.qkv.bias;
+        a.out_bf16 = e->dq;
+        a.st = st;
+        a.cosT = e->cosT;
+        a.sinT = e->sinT;
+        a.kcache = e->kc(li, seq);
+        a.vcache = e->vc(li, seq);
+        a.heads = c.heads;
+        a.kv_heads = c.kv_heads;
+        a.D = hd;
+        a.max_ctx = c.max_ctx;
+        if (li == 0) {
+            a.embed = e->embed;
+            a.embed_out = e->dh;
+        }
+        ze_launch_gemv(ZE_GV_QKV_ROPE, a, s);
+        ze_launch_attn_decode(e->dq, e->kc(li, seq), e->vc(li, seq), e->dattn, st, c.heads, c.kv_heads, hd, c.max_ctx,
+                              scale, e->dpartial, e->max_splits, s);
+        ze_gemv_args o;
+        memset(&o, 0, sizeof(o));
+        o.W = L.o.w;
+        o.ldw = L.o.ld;
+        o.N = H;
+        o.K = nq;
+        o.x = e->dattn;
+        o.out_bf16 = e->dh;
+        o.D = hd;
+        ze_launch_gemv(ZE_GV_RESIDUAL, o, s);
+        ze_gemv_args g;
+        memset(&g, 0, sizeof(g));
+        g.W = L.gate_up.w;
+        g.ldw = L.gate_up.ld;
+        g.N = 2 * e->text_ipad;
+        g.K = H;
+        g.x = e->dh;
+        g.norm_w = L.post_norm;
+        g.eps = c.rms_eps;
+        g.out_bf16 = e->dact;
+        g.D = hd;
+        ze_launch_gemv(ZE_GV_SWIGLU, g, s);
+        ze_gemv_args d;
+        memset(&d, 0, sizeof(d));
+        d.W = L.down.w;
+        d.ldw = L.down.ld;
+        d.N = H;
+        d.K = e->text_ipad;
+        d.x = e->dact;
+        d.out_bf16 = e->dh;
+        d.D = hd;
+        ze_launch_gemv(ZE_GV_RESIDUAL, d, s);
+    }
+    ze_gemv_args a;
+    memset(&a, 0, sizeof(a));
+    a.W = e->lm_head;
+    a.ldw = H;
+    a.N = c.vocab;
+    a.K = H;
+    a.x = e->dh;
+    a.norm_w = e->final_norm;
+    a.eps = c.rms_eps;
+    a.out_f32 = e->dlogits;
+    a.D = hd;
+    ze_launch_gemv(ZE_GV_LOGITS, a, s);
+    ze_launch_sample(e->dlogits, c.vocab, e->seen + (size_t)seq * c.vocab, penalty, e->st_dev + seq, e->eos_dev,
+                     c.n_eos, c.pad_token_id, ignore_eos, /*advance_ctx=*/1,
+                     e->out_tokens + (size_t)seq * c.max_ctx, e->dsample, s);
+    ZE_KCHECK();
+    return ZE_OK;
+}
+
+extern "C" int ze_decode_step(ze_engine* e, int seq, int token, float* out_logits, void* stream) {
+    ZE_TRY(check_seq(e, seq));
+    const ze_config& c = e->cfg;
+    if (e->ctx_host[seq] + 1 > c.max_ctx) return ze_fail(e, ZE_ERR_NOMEM, "sequence exceeds max_ctx");
+    if (token >= c.vocab) return ze_fail(e, ZE_ERR_INVALID, "token id out of range");
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    if (token >= 0) {
+        ZE_HIP(hipStreamSynchronize(s));
+        e->d_host_ints[16] = token;
+        ZE_HIP(hipMemcpyAsync(&(e->st_dev + seq)->token, e->d_host_ints + 16, sizeof(int), hipMemcpyHostToDevice, s));
+    }
+    const int th = ze_timer_begin(e, 3, s);
+    ZE_TRY(ze_enqueue_decode_step(e, seq, 1.0f, 1, s));
+    ze_timer_end(e, th, s);
+    e->ctx_host[seq] += 1;
+    if (out_logits)
+        ZE_HIP(hipMemcpyAsync(out_logits, e->dlogits, (size_t)c.vocab * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return ZE_OK;
+}
+
+extern "C" int ze_op_sample_greedy(ze_engine* e, int seq, const float* logits, float repetition_penalty,
+                                   int32_t* out_token, void* stream) {
+    ZE_TRY(check_seq(e, seq));
+    if (!logits || !out_token) return ze_fail(e, ZE_ERR_INVALID, "null argument");
+    const ze_config& c = e->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    // n_gen is rewound so the sampled token lands in out_tokens[0] of this chain's slot
+    ZE_TRY(push_state(e, seq, s, 0, 0, 0));
+    ze_launch_sample(logits, c.vocab, e->seen + (size_t)seq * c.vocab, repetition_penalty, e->st_dev + seq, e->eos_dev,
+                     c.n_eos, c.pad_token_id, 1, 0, e->out_tokens + (size_t)seq * c.max_ctx, e->dsample, s);
+    ZE_KCHECK();
+    ZE_HIP(hipMemcpyAsync(out_token, e->out_tokens + (size_t)seq * c.max_ctx, sizeof(int), hipMemcpyDeviceToHost, s));
+    ZE_HIP(hipStreamSynchronize(s));
+    return ZE_OK;
+}
+
+extern "C" int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_t* out_tokens, int* n_out,
+                           void* stream) {
+    ZE_TRY(check_seq(e, seq));
+    if (!p || !out_tokens || !n_out) return ze_fail(e, ZE_ERR_INVALID, "null argument");
+    const ze_config& c = e->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    int max_new = p->max_new_tokens;
+    if (max_new <= 0) {
+        *n_out = 0;
+        return ZE_OK;
+    }
+    // the last generated token is never fed back, so ctx grows by max_new - 1
+    if (e->ctx_host[seq] + max_new - 1 > c.max_ctx) max_new = c.max_ctx - e->ctx_host[seq] + 1;
+    if (max_new <= 0) return ze_fail(e, ZE_ERR_NOMEM, "sequence exceeds max_ctx");
+    const float pen = p->repetition_penalty > 0.f ? p->repetition_penalty : 1.0f;
+    const int ign = p->ignore_eos ? 1 : 0;
+    int32_t* dev_out = e->out_tokens + (size_t)seq * c.max_ctx;
+    ze_seq_dev* st = e->st_dev + seq;
+
+    const int t_s = ze_timer_begin(e, 4, s);
+    // first token from the prefill logits (no cache growth)
+    ze_launch_sample(e->dlogits, c.vocab, e->seen + (size_t)seq * c.vocab, pen, st, e->eos_dev, c.n_eos, c.pad_token_id,
+                     ign, 0, dev_out, e->dsample, s);
+    ze_timer_end(e, t_s, s);
+    ZE_KCHECK();
+
+    // decode-step graph for this chain (re-captured when the sampling options change)
+    hipGraphExec_t gexec = nullptr;
+    if (p->use_graph && max_new > 1) {
+        if (!e->graphs[seq] || e->graph_penalty[seq] != pen || e->graph_ignore_eos[seq] != ign) {
+            if (e->graphs[seq]) {
+                hipGraphExecDestroy(e->graphs[seq]);
+                e->graphs[seq] = nullptr;
+            }
+            hipStream_t cs;
+            ZE_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            hipGraph_t graph = nullptr;
+            int r = ZE_OK;
+            if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess)
+                r = ze_fail(e, ZE_ERR_HIP, "hipStreamBeginCapture failed");
+            if (r == ZE_OK) r = ze_enqueue_decode_step(e, seq, pen, ign, cs);
+            if (hipStreamEndCapture(cs, &graph) != hipSuccess && r == ZE_OK)
+                r = ze_fail(e, ZE_ERR_HIP, "hipStreamEndCapture failed");
+            if (r == ZE_OK && hipGraphInstantiate(&e->graphs[seq], graph, nullptr, nullptr, 0) != hipSuccess)
+                r = ze_fail(e, ZE_ERR_HIP, "hipGraphInstantiate failed");
+            if (graph) hipGraphDestroy(graph);
+            hipStreamDestroy(cs);
+            ZE_TRY(r);
+            e->graph_penalty[seq] = pen;
+            e->graph_ignore_eos[seq] = ign;
+        }
+        gexec = e->graphs[seq];
+    }
+
+    const int sync_every = std::max(1, p->sync_every);
+    int produced = 1;  // tokens sampled so far (device side)
+    int finished = 0;
+    const int t_d = ze_timer_begin(e, 3, s);
+    while (produced < max_new && !finished) {
+        const int burst = std::min(sync_every, max_new - produced);
+        for (int i = 0; i < burst; ++i) {
+            if (gexec)
+                ZE_HIP(hipGraphLaunch(gexec, s));
+            else
+                ZE_TRY(ze_enqueue_decode_step(e, seq, pen, ign, s));
+        }
+        produced += burst;
+        e->ctx_host[seq] += burst;
+        if (!ign && produced < max_new) {
+            ZE_HIP(hipMemcpyAsync(e->d_host_ints + 32, &st->finished, sizeof(int), hipMemcpyDeviceToHost, s));
+            ZE_HIP(hipStreamSynchronize(s));
+            finished = e->d_host_ints[32];
+        }
+    }
+    ze_timer_end(e, t_d, s);
+    ZE_HIP(hipMemcpyAsync(out_tokens, dev_out, (size_t)produced * sizeof(int), hipMemcpyDeviceToHost, s));
+    ZE_HIP(hipStreamSynchronize(s));
+    // trim at the first EOS (tokens after it are pad, as HF emits for finished rows)
+    int n = produced;
+    if (!ign) {
+        for (int i = 0; i < produced; ++i) {
+            bool is_eos = false;
+            for (int k = 0; k < c.n_eos; ++k) is_eos |= out_tokens[i] == c.eos_token_ids[k];
+            if (is_eos) {
+                n = i + 1;
+                break;
+            }
+        }
+    }
+    *n_out = n;
+    return ZE_OK;
+}
+
+// ================================================================== unit ops
+extern "C" int ze_op_linear(ze_engine* e, const void* a, const void* w, const void* bias, void* cmat, int M, int N,
+                            int K, int act, void* stream) {
+    if (!e || !a || !w || !cmat) return ze_fail(e, ZE_ERR_INVALID, "null argument");
+    if (K % 8) return ze_fail(e, ZE_ERR_INVALID, "K must be a multiple of 8");
+    hipSetDevice(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 1 && act == 0 && N % 2 == 0) {
+        ze_gemv_args g;
+        memset(&g, 0, sizeof(g));
+        g.W = (const bf16_t*)w;
+        g.ldw = K;
+        g.N = N;
+        g.K = K;
+        g.x = (const bf16_t*)a;
+        g.bias = (const bf16_t*)bias;
+        g.out_bf16 = (bf16_t*)cmat;
+        g.D = 128;
+        ze_launch_gemv(ZE_GV_PLAIN, g, s);
+    } else {
+        ze_launch_gemm(act ? ZE_EPI_GELU : ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias,
+                       nullptr, 0, (bf16_t*)cmat, N, nullptr, M, N, K, s);
+    }
+    ZE_KCHECK();
+    return ZE_OK;
+}
+
+extern "C" int ze_op_rmsnorm(ze_engine* e, const void* x, const void* weight, void* y, int rows, int cols, float eps,
+                             void* stream) {
+    if (!e || !x || !weight || !y) return ze_fail(e, ZE_ERR_INVALID, "null argument");
+    if (cols % 8) return ze_fail(e, ZE_ERR_INVALID, "cols must be a multiple of 8");
+    hipSetDevice(e->device);
+    ze_launch_rmsnorm((const bf16_t*)x, cols, (const bf16_t*)weight, (bf16_t*)y, cols, rows, cols, eps,
+                      (hipStream_t)stream);
+    ZE_KCHECK();
+    return ZE_OK;
+}
+
+extern "C" int ze_op_attention(ze_engine* e, const void* q, const void* k, const void* v, void* o, int T, int heads,
+                               int kv_heads, int D, const int32_t* cu, int n_seg, int causal, void* stream) {
+    if (!e || !q || !k || !v || !o || !cu) return ze_fail(e, ZE_ERR_INVALID, "null argument");
+    if (D != 80 && D != 128) return ze_fail(e, ZE_ERR_INVALID, "D must be 80 or 128");
+    if (heads % kv_heads) return ze_fail(e, ZE_ERR_INVALID, "kv_heads must divide heads");
+    hipSetDevice(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<int> tiles((size_t)4 * (T / 64 + n_seg + 2));
+    const int nt = build_tiles(cu, n_seg, tiles.data(), (int)tiles.size() / 4);
+    if (nt < 0) return ze_fail(e, ZE_ERR_NOMEM, "tile overflow");
+    int4* dt = nullptr;
+    ZE_HIP(hipMalloc((void**)&dt, (size_t)std::max(nt, 1) * 16));
+    ZE_HIP(hipMemcpyAsync(dt, tiles.data(), (size_t)nt * 16, hipMemcpyHostToDevice, s));
+    // causal inside each segment: key j visible to query i iff j <= i (absolute row indices, offset 0)
+    ze_launch_flash_attn(D, causal, (const bf16_t*)q, heads * D, D, (const bf16_t*)k, kv_heads * D, D,
+                         (const bf16_t*)v, kv_heads * D, D, (bf16_t*)o, heads * D, D, dt, nt, heads, heads / kv_heads,
+                         1.0f / sqrtf((float)D), 0, s);
+    hipError_t le = hipGetLastError();
+    hipStreamSynchronize(s);
+    hipFree(dt);
+    if (le != hipSuccess) return ze_fail(e, ZE_ERR_HIP, hipGetErrorString(le));
+    return ZE_OK;
+}
+
+// ================================================================== measurement
+extern "C" int ze_profile_decode_kernel(ze_engine* e, int which, int iters, float* avg_us, double* bytes_per_launch,
+                                        void* stream) {
+    if (!e || !avg_us || !bytes_per_launch || iters <= 0) return ze_fail(e, ZE_ERR_INVALID, "bad argument");
+    const ze_config& c = e->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    const int H = c.hidden, hd = e->head_dim, nq = c.heads * hd, nqkv = nq + 2 * c.kv_heads * hd;
+    hipEvent_t a, b;
+    ZE_HIP(hipEventCreate(&a));
+    ZE_HIP(hipEventCreate(&b));
+    ZE_HIP(hipMemsetAsync(e->dh, 0, (size_t)H * 2, s));
+    ZE_HIP(hipMemsetAsync(e->dattn, 0, (size_t)nq * 2, s));
+    ZE_HIP(hipMemsetAsync(e->dact, 0, (size_t)e->text_ipad * 2, s));
+    double bytes = 0;
+    auto launch = [&](int it) {
+        const ze_text_layer& L = e->tl[it % c.layers];
+        ze_gemv_args g;
+        memset(&g, 0, sizeof(g));
+        g.D = hd;
+        switch (which) {
+            case 0:
+                g.W = L.qkv.w; g.ldw = L.qkv.ld; g.N = nqkv; g.K = H; g.x = e->dh; g.norm_w = L.in_norm;
+                g.eps = c.rms_eps; g.bias = L.qkv.bias; g.out_bf16 = e->dq; g.st = e->st_dev; g.cosT = e->cosT;
+                g.sinT = e->sinT; g.kcache = e->kc(it % c.layers, 0); g.vcache = e->vc(it % c.layers, 0);
+                g.heads = c.heads; g.kv_heads = c.kv_heads; g.max_ctx = c.max_ctx;
+                ze_launch_gemv(ZE_GV_QKV_ROPE, g, s);
+                bytes = (double)nqkv * H * 2;
+                break;
+            case 1:
+                g.W = L.o.w; g.ldw = L.o.ld; g.N = H; g.K = nq; g.x = e->dattn; g.out_bf16 = e->dh;
+                ze_launch_gemv(ZE_GV_RESIDUAL, g, s);
+                bytes = (double)H * nq * 2;
+                break;
+            case 2:
+                g.W = L.gate_up.w; g.ldw = L.gate_up.ld; g.N = 2 * e->text_ipad; g.K = H; g.x = e->dh;
+                g.norm_w = L.post_norm; g.eps = c.rms_eps; g.out_bf16 = e->dact;
+                ze_launch_gemv(ZE_GV_SWIGLU, g, s);
+                bytes = 2.0 * c.intermediate * H * 2;
+                break;
+            case 3:
+                g.W = L.down.w; g.ldw = L.down.ld; g.N = H; g.K = e->text_ipad; g.x = e->dact; g.out_bf16 = e->dh;
+                ze_launch_gemv(ZE_GV_RESIDUAL, g, s);
+                bytes = (double)H * c.intermediate * 2;
+                break;
+            default:
+                g.W = e->lm_head; g.ldw = H; g.N = c.vocab; g.K = H; g.x = e->dh; g.norm_w = e->final_norm;
+                g.eps = c.rms_eps; g.out_f32 = e->dlogits;
+                ze_launch_gemv(ZE_GV_LOGITS, g, s);
+                bytes = (double)c.vocab * H * 2;
+                break;
+        }
+    };
+    for (int i = 0; i < std::min(iters, 4); ++i) launch(i);  // warm-up
+    ZE_HIP(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) launch(i);
+    ZE_HIP(hipEventRecord(b, s));
+    ZE_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    ZE_HIP(hipEventElapsedTime(&ms, a, b));
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    ZE_KCHECK();
+    *avg_us = ms * 1000.0f / (float)iters;
+    *bytes_per_launch = bytes;
+    return ZE_OK;
+}

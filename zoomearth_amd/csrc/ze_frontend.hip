@@ -1,0 +1,198 @@
+// Image front-end kernels: Pillow-exact bicubic crop+resize on u8 RGB and
+// LUT normalise + patchify.  Pure integer / LUT work, HBM-bound: one coalesced read of the tile
+// (75 MB for 5000x5000) dominates; coefficient tables are generated on the host in double
+// precision (identical IEEE arithmetic to Pillow's precompute_coeffs) and uploaded as int32.
+//
+// Replaces: PIL Image.crop/resize(BICUBIC) called from /root/reference/src/eval/infer.py:41-85 and the
+// HF image processor (HF:models/qwen2_vl/image_processing_pil_qwen2_vl.py:126-187).
+#include "ze_kernels.h"
+
+#define PRECISION_BITS 22
+
+__device__ __forceinline__ uint8_t clip8(int v) {
+    v >>= PRECISION_BITS;
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+// Horizontal pass over the crop box: dst[y][xx][c] for y in [0, box_h), xx in [0, out_w).
+// Source pixel (bx0 + xmin + j, by0 + y) is zero outside the image (PIL crop semantics).
+// Block = 64 output columns x 4 rows; the needed source span of a row is staged in LDS with
+// coalesced byte loads, then each thread accumulates its taps for 3 channels.
+#define HZ_COLS 64
+#define HZ_ROWS 4
+#define HZ_MAXSPAN 2816  // pixels; (64 cols * scale + 2*support) for scale <= ~40
+
+__global__ void __launch_bounds__(256) k_resize_h(const uint8_t* __restrict__ src, int src_h, int src_w, int bx0,
+                                                  int by0, int box_h, uint8_t* __restrict__ dst, int out_w,
+                                                  const int* __restrict__ xmin, const int* __restrict__ xcnt,
+                                                  const int* __restrict__ kk, int ksize) {
+    __shared__ uint8_t row_lds[HZ_ROWS][HZ_MAXSPAN * 3];
+    const int col0 = blockIdx.x * HZ_COLS;
+    const int row0 = blockIdx.y * HZ_ROWS;
+    const int ncol = min(HZ_COLS, out_w - col0);
+    const int span_lo = xmin[col0];
+    const int last = col0 + ncol - 1;
+    const int span_hi = xmin[last] + xcnt[last];  // exclusive, in box coordinates
+    const int span = span_hi - span_lo;
+    // stage: HZ_ROWS rows x span pixels x 3 bytes
+    for (int r = 0; r < HZ_ROWS; ++r) {
+        const int y = row0 + r;
+        if (y >= box_h) break;
+        const int sy = by0 + y;
+        const bool row_in = (sy >= 0 && sy < src_h);
+        const uint8_t* srow = src + (size_t)sy * src_w * 3;
+        for (int i = threadIdx.x; i < span * 3; i += 256) {
+            const int px = bx0 + span_lo + i / 3;
+            uint8_t v = 0;
+            if (row_in && px >= 0 && px < src_w) v = srow[(size_t)(bx0 + span_lo) * 3 + i];
+            row_lds[r][i] = v;
+        }
+    }
+    __syncthreads();
+    const int c = threadIdx.x & (HZ_COLS - 1);
+    const int r = threadIdx.x >> 6;
+    const int y = row0 + r;
+    if (c >= ncol || y >= box_h) return;
+    const int xx = col0 + c;
+    const int lo = xmin[xx] - span_lo;
+    const int n = xcnt[xx];
+    const int* k = kk + (size_t)xx * ksize;
+    int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+    const uint8_t* p = &row_lds[r][lo * 3];
+    for (int j = 0; j < n; ++j) {
+        const int w = k[j];
+        s0 += w * p[3 * j + 0];
+        s1 += w * p[3 * j + 1];
+        s2 += w * p[3 * j + 2];
+    }
+    uint8_t* d = dst + ((size_t)y * out_w + xx) * 3;
+    d[0] = clip8(s0);
+    d[1] = clip8(s1);
+    d[2] = clip8(s2);
+}
+
+// Fallback horizontal pass without LDS staging (span too wide for the staged kernel).
+__global__ void __launch_bounds__(256) k_resize_h_direct(const uint8_t* __restrict__ src, int src_h, int src_w,
+                                                         int bx0, int by0, int box_h, uint8_t* __restrict__ dst,
+                                                         int out_w, const int* __restrict__ xmin,
+                                                         const int* __restrict__ xcnt, const int* __restrict__ kk,
+                                                         int ksize) {
+    const int xx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (xx >= out_w || y >= box_h) return;
+    const int sy = by0 + y;
+    const bool row_in = (sy >= 0 && sy < src_h);
+    const int lo = xmin[xx], n = xcnt[xx];
+    const int* k = kk + (size_t)xx * ksize;
+    int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+    for (int j = 0; j < n; ++j) {
+        const int px = bx0 + lo + j;
+        if (row_in && px >= 0 && px < src_w) {
+            const uint8_t* p = src + ((size_t)sy * src_w + px) * 3;
+            const int w = k[j];
+            s0 += w * p[0];
+            s1 += w * p[1];
+            s2 += w * p[2];
+        }
+    }
+    uint8_t* d = dst + ((size_t)y * out_w + xx) * 3;
+    d[0] = clip8(s0);
+    d[1] = clip8(s1);
+    d[2] = clip8(s2);
+}
+
+// Vertical pass: src u8 [in_h, w, 3] (already cropped/zero-filled by the horizontal pass, or read
+// through the crop box when the horizontal pass was skipped) -> dst [out_h, w, 3].
+// One thread per output byte column element; adjacent threads read adjacent bytes (coalesced).
+__global__ void __launch_bounds__(256) k_resize_v(const uint8_t* __restrict__ src, int src_h, int src_w, int bx0,
+                                                  int by0, int row_bytes, uint8_t* __restrict__ dst, int out_h,
+                                                  const int* __restrict__ ymin, const int* __restrict__ ycnt,
+                                                  const int* __restrict__ kk, int ksize, int boxed) {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // byte index inside an output row
+    const int yy = blockIdx.y;
+    if (i >= row_bytes) return;
+    const int lo = ymin[yy], n = ycnt[yy];
+    const int* k = kk + (size_t)yy * ksize;
+    int s = 1 << (PRECISION_BITS - 1);
+    if (!boxed) {
+        const uint8_t* p = src + (size_t)lo * row_bytes + i;
+        for (int j = 0; j < n; ++j) s += k[j] * p[(size_t)j * row_bytes];
+    } else {
+        const int px = bx0 + i / 3;
+        const bool col_in = (px >= 0 && px < src_w);
+        for (int j = 0; j < n; ++j) {
+            const int sy = by0 + lo + j;
+            if (col_in && sy >= 0 && sy < src_h) s += k[j] * src[((size_t)sy * src_w + px) * 3 + (i % 3)];
+        }
+    }
+    dst[(size_t)yy * row_bytes + i] = clip8(s);
+}
+
+// Pure crop with zero fill.
+__global__ void __launch_bounds__(256) k_crop(const uint8_t* __restrict__ src, int src_h, int src_w, int bx0,
+                                              int by0, uint8_t* __restrict__ dst, int out_h, int out_w) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (i >= out_w * 3) return;
+    const int px = bx0 + i / 3, sy = by0 + y;
+    uint8_t v = 0;
+    if (px >= 0 && px < src_w && sy >= 0 && sy < src_h) v = src[((size_t)sy * src_w + px) * 3 + (i % 3)];
+    dst[(size_t)y * out_w * 3 + i] = v;
+}
+
+// LUT normalise + patchify: out[row][col] with row = ((by*gwm + bx)*m + my)*m + mx (block-major over
+// merge x merge), col = ((c*T + t)*P + py)*P + px; value = lut[c][img[y][x][c]].
+// One thread per (row, c, py) writes T*P contiguous-ish floats; consecutive threads walk px fastest.
+__global__ void __launch_bounds__(256) k_patchify(const uint8_t* __restrict__ img, int h, int w,
+                                                  const float* __restrict__ lut, float* __restrict__ out, int P,
+                                                  int M, int T, int C) {
+    const int cols = C * T * P * P;
+    const int gh = h / P, gw = w / P;
+    const size_t total = (size_t)gh * gw * cols;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int col = (int)(idx % cols);
+    const int row = (int)(idx / cols);
+    const int px = col % P;
+    const int py = (col / P) % P;
+    const int c = col / (P * P * T);
+    const int mx = row % M;
+    const int my = (row / M) % M;
+    const int blk = row / (M * M);
+    const int bx = blk % (gw / M);
+    const int by = blk / (gw / M);
+    const int y = (by * M + my) * P + py;
+    const int x = (bx * M + mx) * P + px;
+    out[idx] = lut[c * 256 + img[((size_t)y * w + x) * 3 + c]];
+}
+
+void ze_launch_resize_h(const uint8_t* src, int src_h, int src_w, int bx0, int by0, int box_h, uint8_t* dst,
+                        int out_w, const int* xmin, const int* xcnt, const int* kk, int ksize, int max_span,
+                        hipStream_t s) {
+    dim3 grid(ze_cdiv(out_w, 64), ze_cdiv(box_h, 4));
+    if (max_span <= HZ_MAXSPAN)
+        k_resize_h<<<grid, 256, 0, s>>>(src, src_h, src_w, bx0, by0, box_h, dst, out_w, xmin, xcnt, kk, ksize);
+    else
+        k_resize_h_direct<<<grid, 256, 0, s>>>(src, src_h, src_w, bx0, by0, box_h, dst, out_w, xmin, xcnt, kk,
+                                               ksize);
+}
+
+void ze_launch_resize_v(const uint8_t* src, int src_h, int src_w, int bx0, int by0, int row_bytes, uint8_t* dst,
+                        int out_h, const int* ymin, const int* ycnt, const int* kk, int ksize, int boxed,
+                        hipStream_t s) {
+    dim3 grid(ze_cdiv(row_bytes, 256), out_h);
+    k_resize_v<<<grid, 256, 0, s>>>(src, src_h, src_w, bx0, by0, row_bytes, dst, out_h, ymin, ycnt, kk, ksize,
+                                    boxed);
+}
+
+void ze_launch_crop(const uint8_t* src, int src_h, int src_w, int bx0, int by0, uint8_t* dst, int out_h, int out_w,
+                    hipStream_t s) {
+    dim3 grid(ze_cdiv(out_w * 3, 256), out_h);
+    k_crop<<<grid, 256, 0, s>>>(src, src_h, src_w, bx0, by0, dst, out_h, out_w);
+}
+
+void ze_launch_patchify(const uint8_t* img, int h, int w, const float* lut, float* out, int P, int M, int T, int C,
+                        hipStream_t s) {
+    const size_t total = (size_t)(h / P) * (w / P) * C * T * P * P;
+    k_patchify<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(img, h, w, lut, out, P, M, T, C);
+}

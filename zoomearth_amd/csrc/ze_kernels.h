@@ -1,0 +1,95 @@
+// Launcher declarations for the HIP kernels of libzoomearth_hip.so (internal C++ interface).
+#pragma once
+#include "ze_common.h"
+
+// GEMM epilogues
+enum { ZE_EPI_NONE = 0, ZE_EPI_GELU = 1, ZE_EPI_RESIDUAL = 2, ZE_EPI_SWIGLU = 3 };
+// decode GEMV epilogues
+enum { ZE_GV_QKV_ROPE = 0, ZE_GV_RESIDUAL = 1, ZE_GV_SWIGLU = 2, ZE_GV_LOGITS = 3, ZE_GV_PLAIN = 4 };
+
+// Device-resident state of one question chain; decode kernels read it so that a captured hipGraph of one
+// decode step can be replayed without host-side argument changes.
+struct ze_seq_dev {
+    int32_t ctx;        // tokens in the KV cache
+    int32_t rope_delta; // position of the next token = ctx + rope_delta
+    int32_t token;      // last sampled token (input of the next decode step)
+    int32_t finished;   // 1 after an EOS was emitted (subsequent tokens are pad)
+    int32_t n_gen;      // tokens written to out_tokens so far
+    int32_t max_gen;    // capacity of out_tokens
+    int32_t pad0, pad1;
+};
+
+// ---- front-end
+void ze_launch_resize_h(const uint8_t* src, int src_h, int src_w, int bx0, int by0, int box_h, uint8_t* dst,
+                        int out_w, const int* xmin, const int* xcnt, const int* kk, int ksize, int max_span,
+                        hipStream_t s);
+void ze_launch_resize_v(const uint8_t* src, int src_h, int src_w, int bx0, int by0, int row_bytes, uint8_t* dst,
+                        int out_h, const int* ymin, const int* ycnt, const int* kk, int ksize, int boxed,
+                        hipStream_t s);
+void ze_launch_crop(const uint8_t* src, int src_h, int src_w, int bx0, int by0, uint8_t* dst, int out_h, int out_w,
+                    hipStream_t s);
+void ze_launch_patchify(const uint8_t* img, int h, int w, const float* lut, float* out, int P, int M, int T, int C,
+                        hipStream_t s);
+
+// ---- elementwise
+void ze_launch_pack_rows(const void* src, int dtype, int row0, int nrows, int cols, bf16_t* dst, int ld, int mode,
+                         int offset, hipStream_t s);
+void ze_launch_fill_rows(uint64_t seed, float c_scale, float base, int rows, int cols, bf16_t* dst, int ld, int mode,
+                         int offset, hipStream_t s);
+void ze_launch_rmsnorm(const bf16_t* x, int ldx, const bf16_t* w, bf16_t* y, int ldy, int rows, int cols, float eps,
+                       hipStream_t s);
+void ze_launch_gather_cast_rows(const float* src, int k, const int* perm, bf16_t* dst, int kp, int rows,
+                                hipStream_t s);
+void ze_launch_vision_rope(bf16_t* qkv, const float* cosT, const float* sinT, int n, int heads, int D, hipStream_t s);
+void ze_launch_mrope_kv(bf16_t* qkv, int T, int heads, int kv_heads, int D, const bf16_t* cosT, const bf16_t* sinT,
+                        const int* pos3, const int* axis_of, bf16_t* kcache, bf16_t* vcache, int max_ctx, int past,
+                        hipStream_t s);
+void ze_launch_embed_rows(const int* src, const bf16_t* embed, const bf16_t* image_embeds, bf16_t* out, int T,
+                          int hidden, hipStream_t s);
+void ze_launch_scatter_rows(const bf16_t* src, int lds_, const int* dst_idx, bf16_t* dst, int ldd, int rows, int cols,
+                            hipStream_t s);
+
+// ---- GEMM (prefill / ViT)
+void ze_launch_gemm(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
+                    int ldr, bf16_t* C, int ldc, const int* c_rows, int M, int N, int K, hipStream_t s);
+
+// ---- decode GEMV family (batch-1 weight streaming)
+struct ze_gemv_args {
+    const bf16_t* W;      // [N, ldw] packed weight
+    int ldw, N, K;
+    const bf16_t* x;      // input vector [K] (bf16)
+    const bf16_t* norm_w; // non-null: RMSNorm prologue over x with this weight
+    float eps;
+    const bf16_t* bias;   // [N] or null
+    // epilogue targets
+    bf16_t* out_bf16;     // RESIDUAL: hidden stream (in place) ; SWIGLU: act ; PLAIN: out ; QKV: q buffer
+    float* out_f32;       // LOGITS
+    // QKV_ROPE extras
+    const ze_seq_dev* st;
+    const bf16_t* cosT;
+    const bf16_t* sinT;   // [max_pos, D/2]
+    bf16_t* kcache;
+    bf16_t* vcache;       // [kv_heads, max_ctx, D] of this layer / chain
+    int heads, kv_heads, D, max_ctx;
+    // token embedding prologue (layer 0): x = embed[st->token] copied to hidden_out first
+    const bf16_t* embed;  // non-null: x := embed row of st->token ; also written to embed_out by block 0
+    bf16_t* embed_out;
+};
+void ze_launch_gemv(int epi, const ze_gemv_args& a, hipStream_t s);
+
+// ---- attention
+// Varlen flash attention (prefill / ViT). Tiles: host-built list of (q_start, q_end, kv_start, kv_end) int4 rows.
+void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_row_stride, int q_head_stride, const bf16_t* k,
+                          int k_row_stride, int k_head_stride, const bf16_t* v, int v_row_stride, int v_head_stride,
+                          bf16_t* o, int o_row_stride, int o_head_stride, const int4* tiles, int n_tiles, int heads,
+                          int group, float scale, int q_pos_offset, hipStream_t s);
+// Decode attention for one chain: q [heads, D]; caches [kv_heads, max_ctx, D]; context = st->ctx + 1 tokens.
+void ze_launch_attn_decode(const bf16_t* q, const bf16_t* kcache, const bf16_t* vcache, bf16_t* out,
+                           const ze_seq_dev* st, int heads, int kv_heads, int D, int max_ctx, float scale,
+                           float* ws_partial, int max_splits, hipStream_t s);
+
+// ---- sampling
+void ze_launch_sample(const float* logits, int vocab, uint8_t* seen, float penalty, ze_seq_dev* st,
+                      const int* eos_ids, int n_eos, int pad_id, int ignore_eos, int advance_ctx,
+                      int32_t* out_tokens, float* ws, hipStream_t s);
+void ze_launch_mark_seen(uint8_t* seen, const int* ids, int n, hipStream_t s);

@@ -1,0 +1,278 @@
+"""Python handle on one ze_engine (one process per GPU).
+
+torch tensors are used only as device-memory containers (allocation, H2D/D2H copies, stream handles);
+every computation goes through the C ABI of libzoomearth_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import ModelConfig
+
+_NP2ZE = {np.dtype(np.float32): _lib.ZE_F32, np.dtype(np.float16): _lib.ZE_F16}
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _i32(a):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+    return a, a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class Engine:
+    def __init__(self, config: ModelConfig, device: int = 0, max_seqs: int = 4, max_ctx: int = 4096,
+                 max_patches: int = 8192, max_tile_side: int = 8192):
+        if not torch.cuda.is_available():
+            raise RuntimeError("zoomearth_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
+        self.lib = _lib.lib()
+        self.config = config
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.zcfg = self._make_zcfg(config, max_seqs, max_ctx, max_patches, max_tile_side)
+        h = C.c_void_p()
+        _lib.check(self.lib.ze_engine_create(C.byref(self.zcfg), device, C.byref(h)))
+        self.h = h
+        self.max_seqs, self.max_ctx, self.max_patches = max_seqs, max_ctx, max_patches
+        self.patch_dim = (config.vision.in_channels * config.vision.temporal_patch_size
+                          * config.vision.patch_size ** 2)
+
+    # ------------------------------------------------------------------ plumbing
+    @staticmethod
+    def _make_zcfg(c: ModelConfig, max_seqs, max_ctx, max_patches, max_tile_side) -> _lib.ZeConfig:
+        z = _lib.ZeConfig()
+        v, t = c.vision, c.text
+        z.vit_depth, z.vit_hidden, z.vit_heads = v.depth, v.hidden_size, v.num_heads
+        z.vit_intermediate, z.vit_out_hidden = v.intermediate_size, v.out_hidden_size
+        z.patch_size, z.temporal_patch_size, z.spatial_merge_size = v.patch_size, v.temporal_patch_size, v.spatial_merge_size
+        z.window_size, z.in_channels = v.window_size, v.in_channels
+        z.n_fullatt = len(v.fullatt_block_indexes)
+        for i, b in enumerate(v.fullatt_block_indexes):
+            z.fullatt_block_indexes[i] = b
+        z.hidden, z.layers, z.heads, z.kv_heads = t.hidden_size, t.num_hidden_layers, t.num_attention_heads, t.num_key_value_heads
+        z.intermediate, z.vocab = t.intermediate_size, t.vocab_size
+        z.rms_eps, z.rope_theta = t.rms_norm_eps, t.rope_theta
+        for i in range(3):
+            z.mrope_section[i] = t.mrope_section[i]
+        z.tie_word_embeddings = int(t.tie_word_embeddings)
+        z.image_token_id, z.vision_start_token_id = c.image_token_id, c.vision_start_token_id
+        z.vision_end_token_id, z.pad_token_id = c.vision_end_token_id, c.pad_token_id
+        z.n_eos = len(c.eos_token_ids)
+        for i, e in enumerate(c.eos_token_ids):
+            z.eos_token_ids[i] = e
+        z.max_seqs, z.max_ctx, z.max_patches, z.max_tile_side = max_seqs, max_ctx, max_patches, max_tile_side
+        return z
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check(self, code):
+        return _lib.check(code, self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ze_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._check(self.lib.ze_sync(self.h, self._stream()))
+
+    # ------------------------------------------------------------------ weights
+    def load_weight(self, name: str, array) -> None:
+        """array: numpy float32/float16, or a (uint16 view, 'bf16') pair for raw bf16 bits."""
+        if isinstance(array, tuple):
+            arr, dt = np.ascontiguousarray(array[0]), _lib.ZE_BF16
+        else:
+            arr = np.ascontiguousarray(array)
+            if arr.dtype not in _NP2ZE:
+                arr = arr.astype(np.float32)
+            dt = _NP2ZE[arr.dtype]
+        shape = (C.c_int64 * arr.ndim)(*arr.shape)
+        self._check(self.lib.ze_load_weight(self.h, name.encode(), dt, arr.ndim, shape,
+                                            arr.ctypes.data_as(C.c_void_p)))
+
+    def load_state_dict(self, items: Iterable) -> None:
+        for name, arr in items:
+            self.load_weight(name, arr)
+        self.assert_ready()
+
+    def fill_synthetic(self, seed: int = 0, std: float = 0.02, matrix_gain: float = 1.0, bias_std: float = 0.0,
+                       norm_jitter: float = 0.0) -> None:
+        self._check(self.lib.ze_weights_fill_synthetic(self.h, seed, std, matrix_gain, bias_std, norm_jitter))
+
+    def assert_ready(self) -> None:
+        n = self.lib.ze_weights_missing(self.h)
+        if n != 0:
+            raise RuntimeError(self.lib.ze_last_error(self.h).decode())
+
+    def weights_arena(self) -> torch.Tensor:
+        """uint8 view of the packed weight arena (no copy), e.g. for one torch.distributed.broadcast over RCCL."""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self.lib.ze_weights_arena(self.h, C.byref(p), C.byref(n)))
+
+        class _Arena:
+            __cuda_array_interface__ = {"shape": (n.value,), "typestr": "|u1", "data": (p.value, False), "version": 2}
+
+        holder = _Arena()
+        t = torch.as_tensor(holder, device=self.device)
+        t._ze_keepalive = self  # the engine owns the memory
+        return t
+
+    # ------------------------------------------------------------------ front-end
+    def crop_resize(self, tile: torch.Tensor, box: Sequence[int], out_wh: Sequence[int]) -> torch.Tensor:
+        """PIL `tile.crop(box).resize(out_wh, BICUBIC)` on a device u8 [H, W, 3] tensor."""
+        assert tile.dtype == torch.uint8 and tile.is_cuda and tile.is_contiguous() and tile.shape[-1] == 3
+        h, w = int(tile.shape[0]), int(tile.shape[1])
+        ow, oh = int(out_wh[0]), int(out_wh[1])
+        out = torch.empty((oh, ow, 3), dtype=torch.uint8, device=self.device)
+        b = (C.c_int32 * 4)(*[int(v) for v in box])
+        self._check(self.lib.ze_op_crop_resize(self.h, _ptr(tile), h, w, b, _ptr(out), oh, ow, self._stream()))
+        return out
+
+    def smart_resize(self, h: int, w: int, min_pixels: int, max_pixels: int):
+        f = self.config.vision.patch_size * self.config.vision.spatial_merge_size
+        oh, ow = C.c_int(), C.c_int()
+        _lib.check(self.lib.ze_smart_resize(h, w, f, min_pixels, max_pixels, C.byref(oh), C.byref(ow)))
+        return oh.value, ow.value
+
+    def patchify(self, img: torch.Tensor) -> torch.Tensor:
+        h, w = int(img.shape[0]), int(img.shape[1])
+        p = self.config.vision.patch_size
+        out = torch.empty(((h // p) * (w // p), self.patch_dim), dtype=torch.float32, device=self.device)
+        self._check(self.lib.ze_op_patchify(self.h, _ptr(img), h, w, _ptr(out), self._stream()))
+        return out
+
+    def preprocess_image(self, img: torch.Tensor, min_pixels: int = 3136, max_pixels: int = 128 * 128 * 28 * 28):
+        """u8 [H, W, 3] device image -> (pixel_values f32 [N, 1176] device, (1, gh, gw))."""
+        assert img.dtype == torch.uint8 and img.is_cuda and img.is_contiguous()
+        h, w = int(img.shape[0]), int(img.shape[1])
+        rh, rw = self.smart_resize(h, w, min_pixels, max_pixels)
+        p = self.config.vision.patch_size
+        rows = (rh // p) * (rw // p)
+        out = torch.empty((rows, self.patch_dim), dtype=torch.float32, device=self.device)
+        grid = (C.c_int32 * 3)()
+        self._check(self.lib.ze_preprocess_image(self.h, _ptr(img), h, w, min_pixels, max_pixels, _ptr(out), rows,
+                                                 grid, self._stream()))
+        return out, (int(grid[0]), int(grid[1]), int(grid[2]))
+
+    # ------------------------------------------------------------------ index helpers
+    def window_index(self, grids):
+        g, gp = _i32(np.asarray(grids).reshape(-1, 3))
+        n = int((g[:, 0] * g[:, 1] * g[:, 2]).sum()) // (self.config.vision.spatial_merge_size ** 2)
+        wi = np.zeros(n, dtype=np.int64)
+        cu = np.zeros(n + 2, dtype=np.int32)
+        ncu = C.c_int()
+        _lib.check(self.lib.ze_vision_window_index(C.byref(self.zcfg), gp, len(g), wi.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                   cu.ctypes.data_as(C.POINTER(C.c_int32)), len(cu), C.byref(ncu)))
+        return wi, cu[: ncu.value]
+
+    def rope_index(self, input_ids, grids):
+        ids, ip = _i32(input_ids)
+        g, gp = _i32(np.asarray(grids).reshape(-1, 3)) if len(grids) else (np.zeros((0, 3), np.int32), None)
+        pos = np.zeros((3, len(ids)), dtype=np.int32)
+        delta = C.c_int32()
+        _lib.check(self.lib.ze_rope_index(C.byref(self.zcfg), ip, len(ids), gp, len(g),
+                                          pos.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(delta)))
+        return pos, int(delta.value)
+
+    # ------------------------------------------------------------------ model
+    def vit_forward(self, pixel_values: torch.Tensor, grids) -> torch.Tensor:
+        assert pixel_values.dtype == torch.float32 and pixel_values.is_cuda and pixel_values.is_contiguous()
+        g, gp = _i32(np.asarray(grids).reshape(-1, 3))
+        n = int((g[:, 0] * g[:, 1] * g[:, 2]).sum())
+        assert pixel_values.shape[0] == n, (pixel_values.shape, n)
+        mu = self.config.vision.spatial_merge_size ** 2
+        out = torch.empty((n // mu, self.config.vision.out_hidden_size), dtype=torch.bfloat16, device=self.device)
+        self._check(self.lib.ze_vit_forward(self.h, _ptr(pixel_values), gp, len(g), _ptr(out), self._stream()))
+        return out
+
+    def seq_reset(self, seq: int):
+        self._check(self.lib.ze_seq_reset(self.h, seq, self._stream()))
+
+    def seq_truncate(self, seq: int, keep: int):
+        self._check(self.lib.ze_seq_truncate(self.h, seq, keep, self._stream()))
+
+    def seq_len(self, seq: int) -> int:
+        return self._check(self.lib.ze_seq_len(self.h, seq))
+
+    def mark_seen(self, seq: int, ids):
+        a, p = _i32(ids)
+        self._check(self.lib.ze_seq_mark_seen(self.h, seq, p, len(a), self._stream()))
+
+    def prefill(self, seq: int, new_ids, image_embeds, position_ids, rope_delta: int, want_logits: bool = True):
+        """Appends `new_ids` to chain `seq`. position_ids: int32 [3, len(new_ids)]."""
+        ids, ip = _i32(new_ids)
+        pos, pp = _i32(position_ids)
+        assert pos.shape == (3, len(ids))
+        n_img = 0 if image_embeds is None else int(image_embeds.shape[0])
+        if image_embeds is not None:
+            assert image_embeds.dtype == torch.bfloat16 and image_embeds.is_contiguous()
+        logits = torch.empty(self.config.text.vocab_size, dtype=torch.float32, device=self.device) if want_logits else None
+        self._check(self.lib.ze_prefill(self.h, seq, ip, len(ids), _ptr(image_embeds), n_img, pp, rope_delta,
+                                        _ptr(logits), self._stream()))
+        return logits
+
+    def decode_step(self, seq: int, token: int = -1, want_logits: bool = True):
+        logits = torch.empty(self.config.text.vocab_size, dtype=torch.float32, device=self.device) if want_logits else None
+        self._check(self.lib.ze_decode_step(self.h, seq, token, _ptr(logits), self._stream()))
+        return logits
+
+    def generate(self, seq: int, max_new_tokens: int, repetition_penalty: float = 1.0, ignore_eos: bool = False,
+                 use_graph: bool = True, sync_every: int = 16):
+        p = _lib.ZeGenParams(max_new_tokens, repetition_penalty, int(ignore_eos), int(use_graph), sync_every)
+        out = (C.c_int32 * max(max_new_tokens, 1))()
+        n = C.c_int()
+        self._check(self.lib.ze_generate(self.h, seq, C.byref(p), out, C.byref(n), self._stream()))
+        return [int(out[i]) for i in range(n.value)]
+
+    def sample_greedy(self, seq: int, logits: torch.Tensor, repetition_penalty: float = 1.0) -> int:
+        tok = C.c_int32()
+        self._check(self.lib.ze_op_sample_greedy(self.h, seq, _ptr(logits), repetition_penalty, C.byref(tok),
+                                                 self._stream()))
+        return int(tok.value)
+
+    # ------------------------------------------------------------------ unit ops (parity tests)
+    def op_linear(self, a, w, bias=None, act: int = 0):
+        m, k = a.shape
+        n = w.shape[0]
+        out = torch.empty((m, n), dtype=torch.bfloat16, device=self.device)
+        self._check(self.lib.ze_op_linear(self.h, _ptr(a), _ptr(w), _ptr(bias), _ptr(out), m, n, k, act, self._stream()))
+        return out
+
+    def op_rmsnorm(self, x, w, eps: float):
+        out = torch.empty_like(x)
+        self._check(self.lib.ze_op_rmsnorm(self.h, _ptr(x), _ptr(w), _ptr(out), x.shape[0], x.shape[1], eps,
+                                           self._stream()))
+        return out
+
+    def op_attention(self, q, k, v, cu_seqlens, causal: bool):
+        t, heads, d = q.shape
+        kvh = k.shape[1]
+        out = torch.empty_like(q)
+        cu, cp = _i32(cu_seqlens)
+        self._check(self.lib.ze_op_attention(self.h, _ptr(q), _ptr(k), _ptr(v), _ptr(out), t, heads, kvh, d, cp,
+                                             len(cu) - 1, int(causal), self._stream()))
+        return out
+
+    # ------------------------------------------------------------------ measurement
+    def profile_decode_kernel(self, which: int, iters: int = 72):
+        us, by = C.c_float(), C.c_double()
+        self._check(self.lib.ze_profile_decode_kernel(self.h, which, iters, C.byref(us), C.byref(by), self._stream()))
+        return float(us.value), float(by.value)
+
+    def phase_timers(self, enable: bool = True, reset: bool = False):
+        out = (C.c_float * 5)()
+        self._check(self.lib.ze_phase_timers(self.h, int(enable), int(reset), out))
+        return dict(zip(("frontend", "vit", "prefill", "decode", "sample"), [float(x) for x in out]))
