@@ -150,9 +150,9 @@ int ze_prefill(ze_engine* e, int seq, const int32_t* input_ids, int len, const v
                int n_image_rows, const int32_t* position_ids, int rope_delta, float* out_logits, void* stream);
 
 /* replaces: one iteration of GenerationMixin._sample in greedy mode (HF:generation/utils.py:2876-2936) for one
- * chain: forward one token with the KV cache, fp32 logits, repetition penalty
- * (HF:generation/logits_process.py:409-413), argmax (lowest index on ties).
- * Feeds `token` (or, if token < 0, the chain's last sampled token); writes raw logits (may be NULL). */
+ * chain WITHOUT the sampling: forward one token with the KV cache and return the raw fp32 logits (teacher forcing
+ * / host-side sampling with ze_op_sample_greedy).  Feeds `token` (or, if token < 0, the chain's last sampled
+ * token); out_logits may be NULL.  ze_generate runs the same step with the device-side sampler appended. */
 int ze_decode_step(ze_engine* e, int seq, int token, float* out_logits, void* stream);
 
 /* Generation options (replaces the kwargs of model.generate at src/eval/infer.py:109-115, src/demo.py:14-19).

@@ -58,8 +58,12 @@ def _silu(x):
 
 
 def _erf(x: np.ndarray) -> np.ndarray:
-    # float64 erf via math.erf vectorised (exact-GELU is only used on [N/4, 5120] in the merger)
-    return np.vectorize(math.erf, otypes=[np.float64])(x.astype(np.float64))
+    # float64 erf (exact-GELU is only used on [N/4, 5120] in the merger)
+    try:
+        from scipy.special import erf
+        return erf(x.astype(np.float64))
+    except ImportError:  # pragma: no cover
+        return np.vectorize(math.erf, otypes=[np.float64])(x.astype(np.float64))
 
 
 def _gelu_erf(x):

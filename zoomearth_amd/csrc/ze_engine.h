@@ -124,4 +124,4 @@ struct ze_engine {
 int ze_engine_build_layout(ze_engine* e);
 int ze_timer_begin(ze_engine* e, int phase, hipStream_t s);
 void ze_timer_end(ze_engine* e, int handle, hipStream_t s);
-int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos, hipStream_t s);
+int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos, bool sample, hipStream_t s);

@@ -435,7 +435,7 @@ extern "C" int ze_prefill(ze_engine* e, int seq, const int32_t* input_ids, int l
 // ================================================================== decode
 // One token for chain `seq`: everything is read from the device-side chain state, so the same launch
 // sequence can be captured once into a hipGraph and replayed.
-int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos, hipStream_t s) {
+int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos, bool sample, hipStream_t s) {
     const ze_config& c = e->cfg;
     const int H = c.hidden, hd = e->head_dim, nq = c.heads * hd, nqkv = nq + 2 * c.kv_heads * hd;
     const ze_seq_dev* st = e->st_dev + seq;
@@ -514,9 +514,12 @@ int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos,
     a.out_f32 = e->dlogits;
     a.D = hd;
     ze_launch_gemv(ZE_GV_LOGITS, a, s);
-    ze_launch_sample(e->dlogits, c.vocab, e->seen + (size_t)seq * c.vocab, penalty, e->st_dev + seq, e->eos_dev,
-                     c.n_eos, c.pad_token_id, ignore_eos, /*advance_ctx=*/1,
-                     e->out_tokens + (size_t)seq * c.max_ctx, e->dsample, s);
+    if (sample)
+        ze_launch_sample(e->dlogits, c.vocab, e->seen + (size_t)seq * c.vocab, penalty, e->st_dev + seq, e->eos_dev,
+                         c.n_eos, c.pad_token_id, ignore_eos, /*advance_ctx=*/1,
+                         e->out_tokens + (size_t)seq * c.max_ctx, e->dsample, s);
+    else
+        ze_launch_advance_ctx(e->st_dev + seq, s);  // teacher forcing: the caller chooses the next token
     ZE_KCHECK();
     return ZE_OK;
 }
@@ -534,7 +537,7 @@ extern "C" int ze_decode_step(ze_engine* e, int seq, int token, float* out_logit
         ZE_HIP(hipMemcpyAsync(&(e->st_dev + seq)->token, e->d_host_ints + 16, sizeof(int), hipMemcpyHostToDevice, s));
     }
     const int th = ze_timer_begin(e, 3, s);
-    ZE_TRY(ze_enqueue_decode_step(e, seq, 1.0f, 1, s));
+    ZE_TRY(ze_enqueue_decode_step(e, seq, 1.0f, 1, false, s));
     ze_timer_end(e, th, s);
     e->ctx_host[seq] += 1;
     if (out_logits)
@@ -600,7 +603,7 @@ extern "C" int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_
             int r = ZE_OK;
             if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess)
                 r = ze_fail(e, ZE_ERR_HIP, "hipStreamBeginCapture failed");
-            if (r == ZE_OK) r = ze_enqueue_decode_step(e, seq, pen, ign, cs);
+            if (r == ZE_OK) r = ze_enqueue_decode_step(e, seq, pen, ign, true, cs);
             if (hipStreamEndCapture(cs, &graph) != hipSuccess && r == ZE_OK)
                 r = ze_fail(e, ZE_ERR_HIP, "hipStreamEndCapture failed");
             if (r == ZE_OK && hipGraphInstantiate(&e->graphs[seq], graph, nullptr, nullptr, 0) != hipSuccess)
@@ -624,7 +627,7 @@ extern "C" int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_
             if (gexec)
                 ZE_HIP(hipGraphLaunch(gexec, s));
             else
-                ZE_TRY(ze_enqueue_decode_step(e, seq, pen, ign, s));
+                ZE_TRY(ze_enqueue_decode_step(e, seq, pen, ign, true, s));
         }
         produced += burst;
         e->ctx_host[seq] += burst;

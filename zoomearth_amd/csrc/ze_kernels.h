@@ -92,4 +92,5 @@ void ze_launch_attn_decode(const bf16_t* q, const bf16_t* kcache, const bf16_t* 
 void ze_launch_sample(const float* logits, int vocab, uint8_t* seen, float penalty, ze_seq_dev* st,
                       const int* eos_ids, int n_eos, int pad_id, int ignore_eos, int advance_ctx,
                       int32_t* out_tokens, float* ws, hipStream_t s);
+void ze_launch_advance_ctx(ze_seq_dev* st, hipStream_t s);
 void ze_launch_mark_seen(uint8_t* seen, const int* ids, int n, hipStream_t s);

@@ -78,6 +78,9 @@ void ze_launch_sample(const float* logits, int vocab, uint8_t* seen, float penal
     k_argmax_final<<<1, 64, 0, s>>>(ws, seen, st, eos_ids, n_eos, pad_id, ignore_eos, advance_ctx, out_tokens);
 }
 
+__global__ void k_advance_ctx(ze_seq_dev* st) { st->ctx += 1; }
+void ze_launch_advance_ctx(ze_seq_dev* st, hipStream_t s) { k_advance_ctx<<<1, 1, 0, s>>>(st); }
+
 __global__ void k_mark_seen(uint8_t* seen, const int* ids, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) seen[ids[i]] = 1;
