@@ -37,9 +37,11 @@ def test_linear(tiny_engine, m, n, k, bias, act):
     want = a.astype(np.float64) @ w.astype(np.float64).T + (b.astype(np.float64) if bias else 0.0)
     if act:
         import math
-        want = bf16_round(want.astype(np.float32)).astype(np.float64)
-        want = 0.5 * want * (1.0 + np.vectorize(math.erf)(want / math.sqrt(2.0)))
-        close_bf16(got, want, scale=0.05, ulps=2.5)
+        x = bf16_round(want.astype(np.float32)).astype(np.float64)
+        want = 0.5 * x * (1.0 + np.vectorize(math.erf)(x / math.sqrt(2.0)))
+        # one bf16 ulp of the pre-activation (|gelu'| <= 1.13) plus the output rounding
+        tol = 2.0 ** -8 * (1.2 * np.maximum(np.abs(x), 0.05) + 1.5 * np.maximum(np.abs(want), 0.05))
+        assert (np.abs(got - want) <= tol).all(), np.abs(got - want).max()
     else:
         close_bf16(got, want, scale=0.05 * np.sqrt(k) * 0.05)
 

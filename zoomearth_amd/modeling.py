@@ -1,0 +1,158 @@
+"""ZoomEarthForConditionalGeneration: the `Qwen2_5_VLForConditionalGeneration` call surface used by the
+reference entry points, on top of the HIP engine.
+
+replaces: `Qwen2_5_VLForConditionalGeneration.from_pretrained(model_name, torch_dtype=torch.float16)`, `.eval()`,
+`.device`, `.generation_config.{temperature,top_p,top_k}` and
+`model.generate(**inputs, max_new_tokens=1024, do_sample=..., num_beams=1[, temperature])`
+(/root/reference/src/eval/infer.py:109-115,147-151,160-162; src/demo.py:14-19,128).
+
+Documented deviations: arithmetic is bf16 (the reference runs fp16 weights under a bf16 autocast
+wrapper); `do_sample=True, temperature=0.01` is accepted and executed as greedy; `num_beams` must be 1.
+"""
+from __future__ import annotations
+
+import json
+import os
+from collections import OrderedDict
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import processor as _processor
+from .checkpoint import iter_checkpoint
+from .config import ModelConfig
+from .engine import Engine
+
+
+class ZoomEarthForConditionalGeneration:
+    def __init__(self, config: ModelConfig, engine: Engine, generation_config=None):
+        self.config = config
+        self.engine = engine
+        self.generation_config = generation_config or SimpleNamespace(
+            temperature=None, top_p=None, top_k=None, repetition_penalty=1.0, do_sample=False,
+            eos_token_id=list(config.eos_token_ids), pad_token_id=config.pad_token_id)
+        self._vit_cache = OrderedDict()   # image key -> bf16 features
+        self._chains = OrderedDict()      # slot -> (prompt ids tuple, image keys tuple)
+        self._next_slot = 0
+        self.reuse_prefix = True
+        _processor.set_default_engine(engine)
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def from_pretrained(cls, path: str, torch_dtype=None, device=None, max_seqs: int = 4, max_ctx: int = 4096,
+                        max_patches: int = 8192, max_tile_side: int = 8192, **kw):
+        config = ModelConfig.from_pretrained(path)
+        dev = 0 if device is None else (device.index or 0 if isinstance(device, torch.device) else int(device))
+        if device is None and "LOCAL_RANK" in os.environ:
+            dev = int(os.environ["LOCAL_RANK"])
+        engine = Engine(config, device=dev, max_seqs=max_seqs, max_ctx=max_ctx, max_patches=max_patches,
+                        max_tile_side=max_tile_side)
+        engine.load_state_dict(iter_checkpoint(path))
+        gen = SimpleNamespace(temperature=None, top_p=None, top_k=None, repetition_penalty=1.0, do_sample=False,
+                              eos_token_id=list(config.eos_token_ids), pad_token_id=config.pad_token_id)
+        gp = os.path.join(path, "generation_config.json")
+        if os.path.exists(gp):
+            with open(gp, encoding="utf-8") as f:
+                for k, v in json.load(f).items():
+                    setattr(gen, k, v)
+        return cls(config, engine, gen)
+
+    @classmethod
+    def from_synthetic(cls, config: ModelConfig, seed: int = 0, std: float = 0.02, matrix_gain: float = 1.0,
+                       bias_std: float = 0.0, norm_jitter: float = 0.0, device: int = 0, **engine_kw):
+        engine = Engine(config, device=device, **engine_kw)
+        engine.fill_synthetic(seed, std, matrix_gain, bias_std, norm_jitter)
+        return cls(config, engine)
+
+    def eval(self):
+        return self
+
+    @property
+    def device(self):
+        return self.engine.device
+
+    # ------------------------------------------------------------------ helpers
+    def _features(self, pv_rows, grid, key):
+        """ViT features of one image, cached by image identity (bit-identical to recomputation)."""
+        if key is not None and key in self._vit_cache:
+            self._vit_cache.move_to_end(key)
+            return self._vit_cache[key]
+        f = self.engine.vit_forward(pv_rows.contiguous(), [grid])
+        if key is not None:
+            self._vit_cache[key] = f
+            while len(self._vit_cache) > 8:
+                self._vit_cache.popitem(last=False)
+        return f
+
+    def _pick_slot(self, ids, keys):
+        """Returns (slot, reusable prefix length).  A cached chain is reusable when its prefilled prompt is a
+        strict prefix of `ids` and the images inside that prefix are the same objects."""
+        if self.reuse_prefix and all(k is not None for k in keys):
+            for slot, (pids, pkeys) in self._chains.items():
+                n = len(pids)
+                if 0 < n < len(ids) and tuple(ids[:n]) == pids and tuple(keys[: len(pkeys)]) == pkeys \
+                        and ids[n] != self.config.image_token_id:
+                    return slot, n
+        slot = self._next_slot
+        self._next_slot = (self._next_slot + 1) % self.engine.max_seqs
+        return slot, 0
+
+    # ------------------------------------------------------------------ generate
+    @torch.no_grad()
+    def generate(self, input_ids=None, attention_mask=None, pixel_values=None, image_grid_thw=None,
+                 mm_token_type_ids=None, image_keys=None, max_new_tokens: int = 20, do_sample: bool = False,
+                 num_beams: int = 1, temperature=None, top_p=None, top_k=None, repetition_penalty=None,
+                 ignore_eos: bool = False, **kw):
+        if num_beams != 1:
+            raise NotImplementedError("beam search is not part of the ZoomEarth path (num_beams=1 everywhere)")
+        e, cfg = self.engine, self.config
+        ids_cpu = input_ids.cpu().numpy()
+        mask = attention_mask.cpu().numpy().astype(bool) if attention_mask is not None else np.ones_like(ids_cpu, bool)
+        grids = image_grid_thw.cpu().numpy().tolist() if image_grid_thw is not None else []
+        keys = list(image_keys) if image_keys is not None else [None] * len(grids)
+        rows_per = [g[0] * g[1] * g[2] for g in grids]
+        offs = np.concatenate([[0], np.cumsum(rows_per)]).astype(int)
+        pen = repetition_penalty if repetition_penalty is not None else getattr(self.generation_config, "repetition_penalty", 1.0) or 1.0
+        gi = 0
+        outs = []
+        for b in range(ids_cpu.shape[0]):
+            ids = ids_cpu[b][mask[b]].astype(np.int64).tolist()
+            is_img = np.asarray(ids) == cfg.image_token_id
+            n_img = int((is_img & ~np.roll(is_img, 1)).sum()) if is_img.any() else 0
+            if is_img.any() and is_img[0]:
+                n_img = int((is_img[1:] & ~is_img[:-1]).sum()) + 1
+            my = list(range(gi, gi + n_img))
+            gi += n_img
+            if gi > len(grids):
+                raise ValueError("Image features and image tokens do not match")
+            my_grids = [grids[i] for i in my]
+            my_keys = [keys[i] for i in my]
+            slot, reuse = self._pick_slot(ids, my_keys)
+            n_img_reused = int(((np.asarray(ids[:reuse]) == cfg.image_token_id)
+                                & ~(np.roll(np.asarray(ids[:reuse]) == cfg.image_token_id, 1))).sum()) if reuse else 0
+            feats = [self._features(pixel_values[offs[i]:offs[i + 1]], grids[i], keys[i]) for i in my[n_img_reused:]]
+            emb = (torch.cat(feats) if len(feats) > 1 else feats[0]) if feats else None
+            pos, delta = e.rope_index(ids, my_grids)
+            if reuse:
+                e.seq_truncate(slot, reuse)
+            else:
+                e.seq_reset(slot)
+                e.mark_seen(slot, ids[:0])
+            e.prefill(slot, ids[reuse:], emb, pos[:, reuse:], delta, want_logits=False)
+            if pen != 1.0:
+                if reuse:
+                    # the seen-set of the slot still holds the previous generation: rebuild it from the prompt
+                    e.seq_truncate(slot, len(ids))
+                e.mark_seen(slot, ids)
+            self._chains[slot] = (tuple(ids), tuple(my_keys))
+            self._chains.move_to_end(slot)
+            toks = e.generate(slot, max_new_tokens, repetition_penalty=pen, ignore_eos=ignore_eos)
+            outs.append(toks)
+        width = max(len(t) for t in outs)
+        pad = cfg.pad_token_id
+        res = torch.full((ids_cpu.shape[0], ids_cpu.shape[1] + width), pad, dtype=torch.long)
+        res[:, : ids_cpu.shape[1]] = torch.from_numpy(ids_cpu)
+        for b, t in enumerate(outs):
+            res[b, ids_cpu.shape[1]: ids_cpu.shape[1] + len(t)] = torch.tensor(t, dtype=torch.long)
+        return res.to(input_ids.device)
