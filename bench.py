@@ -183,6 +183,9 @@ def main():
     cfg = ModelConfig.zoomearth_3b()
     e = Engine(cfg, device=local, max_seqs=1, max_ctx=2048, max_patches=4096, max_tile_side=max(args.tile, 1024))
     e.fill_synthetic(seed=0, std=0.02)
+    for kv in os.environ.get("ZE_TUNE", "").split(","):  # measurement-only A/B knobs, e.g. ZE_TUNE=2:64
+        if ":" in kv:
+            e.lib.ze_tune(int(kv.split(":")[0]), int(kv.split(":")[1]))
     if world > 1:
         arena = e.weights_arena()
         t0 = time.perf_counter()

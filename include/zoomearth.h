@@ -193,6 +193,9 @@ int ze_op_attention(ze_engine* e, const void* q, const void* k, const void* v, v
  * stream; returns the average launch duration (us) and the algorithmic bytes of one launch. */
 int ze_profile_decode_kernel(ze_engine* e, int which, int iters, float* avg_us, double* bytes_per_launch,
                              void* stream);
+/* Measurement-only kernel-configuration override (A/B of launch shapes inside one process): knob 0 = down-proj
+ * GEMV variant, knob 1 = gate/up GEMV variant; value 0 = shipped default. */
+int ze_tune(int knob, int value);
 /* Per-phase device time (ms) accumulated by HIP events since the last reset: [0] front-end, [1] ViT,
  * [2] prefill, [3] decode, [4] sampling.  Only recorded while enabled. */
 int ze_phase_timers(ze_engine* e, int enable, int reset, float out_ms[5]);

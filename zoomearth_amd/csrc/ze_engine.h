@@ -102,7 +102,7 @@ struct ze_engine {
     // decode workspace
     bf16_t *dh = nullptr, *dq = nullptr, *dattn = nullptr, *dact = nullptr;
     float *dlogits = nullptr, *dpartial = nullptr, *dsample = nullptr;
-    int max_splits = 32;
+    int max_splits = 64;
     int* d_host_ints = nullptr;  // pinned, small
 
     // timers

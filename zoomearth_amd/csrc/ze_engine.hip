@@ -223,6 +223,8 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     if (c.mrope_section[0] + c.mrope_section[1] + c.mrope_section[2] != e->head_dim / 2)
         return bad("mrope_section must sum to head_dim/2");
     if (c.max_seqs <= 0 || c.max_ctx <= 0 || c.max_patches <= 0) return bad("capacities must be positive");
+    // the decode GEMV stages x in LDS (<= 60 KB)
+    if (ze_pad32(c.intermediate) > 29000) return bad("intermediate > 29000 unsupported by the decode GEMV");
     e->vit_ipad = ze_pad32(c.vit_intermediate);
     e->text_ipad = ze_pad32(c.intermediate);
     e->max_pos = c.max_ctx + 512;
@@ -307,7 +309,7 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     chk(dev_alloc(e, &e->dact, e->text_ipad));
     chk(dev_alloc(e, &e->dlogits, c.vocab));
     chk(dev_alloc(e, &e->dpartial, (size_t)e->max_splits * c.heads * 132));
-    chk(dev_alloc(e, &e->dsample, 2 * 128 + 8));
+    chk(dev_alloc(e, &e->dsample, 2 * 128 + 64 + 8));
     if (r == 0 && hipHostMalloc((void**)&e->d_host_ints, 64 * sizeof(int)) != hipSuccess)
         r = ze_fail(e, ZE_ERR_HIP, "hipHostMalloc failed");
     e->staging_bytes = (size_t)64 << 20;

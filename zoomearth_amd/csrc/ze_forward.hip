@@ -13,6 +13,7 @@
         if (_r != 0) return _r; \
     } while (0)
 #define ZE_KCHECK() ZE_HIP(hipGetLastError())
+extern int ze_gemv_knobs[4];
 
 // ================================================================== front-end
 // dst = crop(src, box).resize((dst_w, dst_h), BICUBIC), Pillow-exact (two passes, u8 intermediate).
@@ -674,7 +675,9 @@ extern "C" int ze_op_linear(ze_engine* e, const void* a, const void* w, const vo
         g.bias = (const bf16_t*)bias;
         g.out_bf16 = (bf16_t*)cmat;
         g.D = 128;
-        ze_launch_gemv(ZE_GV_PLAIN, g, s);
+        if (!ze_launch_gemv(ZE_GV_PLAIN, g, s))
+            ze_launch_gemm(ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias, nullptr, 0,
+                           (bf16_t*)cmat, N, nullptr, M, N, K, s);
     } else {
         ze_launch_gemm(act ? ZE_EPI_GELU : ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias,
                        nullptr, 0, (bf16_t*)cmat, N, nullptr, M, N, K, s);
@@ -719,6 +722,11 @@ extern "C" int ze_op_attention(ze_engine* e, const void* q, const void* k, const
 }
 
 // ================================================================== measurement
+extern "C" int ze_tune(int knob, int value) {
+    if (knob < 0 || knob >= 4) return ze_fail(nullptr, ZE_ERR_INVALID, "unknown knob");
+    ze_gemv_knobs[knob] = value;
+    return ZE_OK;
+}
 extern "C" int ze_profile_decode_kernel(ze_engine* e, int which, int iters, float* avg_us, double* bytes_per_launch,
                                         void* stream) {
     if (!e || !avg_us || !bytes_per_launch || iters <= 0) return ze_fail(e, ZE_ERR_INVALID, "bad argument");

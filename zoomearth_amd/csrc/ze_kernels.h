@@ -75,7 +75,8 @@ struct ze_gemv_args {
     const bf16_t* embed;  // non-null: x := embed row of st->token ; also written to embed_out by block 0
     bf16_t* embed_out;
 };
-void ze_launch_gemv(int epi, const ze_gemv_args& a, hipStream_t s);
+// returns false when x[K] does not fit the LDS stage
+bool ze_launch_gemv(int epi, const ze_gemv_args& a, hipStream_t s);
 
 // ---- attention
 // Varlen flash attention (prefill / ViT). Tiles: host-built list of (q_start, q_end, kv_start, kv_end) int4 rows.
