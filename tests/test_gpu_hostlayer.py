@@ -1,0 +1,197 @@
+"""GPU: the Python call surface of the reference (processor(...), model.generate(...), chat_batch, zoom chain,
+from_pretrained on a safetensors checkpoint in both key layouts) on the tiny config, checked against direct
+engine calls / the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import CHAIN_W
+from oracle import frontend, prng
+from oracle import qwen25vl as Q
+from tiny_tok import make_tokenizer
+from zoomearth_amd import checkpoint
+from zoomearth_amd import hostloop as H
+from zoomearth_amd.config import ModelConfig
+from zoomearth_amd.image import DeviceImage
+from zoomearth_amd.modeling import ZoomEarthForConditionalGeneration
+from zoomearth_amd.processor import ZoomEarthProcessor
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def stack():
+    model = ZoomEarthForConditionalGeneration.from_synthetic(ModelConfig.tiny(), **CHAIN_W, max_seqs=4, max_ctx=2048,
+                                                            max_patches=4096, max_tile_side=2048)
+    proc = ZoomEarthProcessor(make_tokenizer(), min_pixels=3136, max_pixels=128 * 128 * 28 * 28)
+    proc.tokenizer.padding_side = "left"
+    tile_np = prng.synthetic_tile(77, 900, 1100)
+    tile = DeviceImage.from_numpy(tile_np, model.engine)
+    yield model, proc, tile, tile_np
+    model.engine.close()
+
+
+def words(seed, n):
+    return " ".join(f"w{int(v)}" for v in prng.uniform_ints(seed, n, 10, 1990))
+
+
+def prompt1(q):
+    return "<|im_start|> " + words(1, 4) + " <|vision_start|><|image_pad|><|vision_end|> " + q + " <|im_start|>"
+
+
+def test_device_image_matches_pil_semantics(stack):
+    model, proc, tile, tile_np = stack
+    assert tile.size == (1100, 900) and tile.width == 1100 and tile.height == 900
+    view, scale = H.resize_image(tile)
+    assert view.size == (512, 418) and scale == 1100 / 512
+    assert np.array_equal(view.numpy(), frontend.resize_bicubic(tile_np, 512, 418))
+    crop = H.cut_image(tile, [300.0, 200.0, 420.0, 330.0])
+    assert crop.size == (512, 512)
+    assert np.array_equal(crop.numpy(), frontend.crop_zero_fill(tile_np, H.zoom_box((1100, 900), [300, 200, 420, 330])))
+    big = H.cut_image(tile, [-100, -50, 700, 800])  # "large bbox" branch leaves the image: zero fill
+    assert np.array_equal(big.numpy(), frontend.crop_zero_fill(tile_np, (-100, -50, 700, 800)))
+    small, _ = H.resize_image(big)  # fused crop + resize in ONE launch on the full-res tile
+    assert np.array_equal(small.numpy(), frontend.resize_bicubic(frontend.crop_zero_fill(tile_np, (-100, -50, 700, 800)),
+                                                                  small.size[0], small.size[1]))
+    sub = big.crop((10, 20, 110, 220))  # crop of a crop composes in tile coordinates
+    assert np.array_equal(sub.numpy(), frontend.crop_zero_fill(tile_np, (-90, -30, 10, 170)))
+
+
+def test_processor_outputs(stack):
+    model, proc, tile, tile_np = stack
+    view, _ = H.resize_image(tile)
+    out = proc(text=[prompt1(words(2, 5))], images=[view], return_tensors="pt", padding="longest").to(model.device)
+    pv_ref, grid = frontend.image_to_pixel_values(frontend.resize_bicubic(tile_np, 512, 418))
+    assert out["image_grid_thw"].tolist() == [list(grid)]
+    assert np.array_equal(out["pixel_values"].cpu().numpy(), pv_ref)
+    ids = out["input_ids"][0].tolist()
+    n_img = grid[1] * grid[2] // 4
+    assert ids.count(2005) == n_img and out["mm_token_type_ids"].sum().item() == n_img
+    assert ids[ids.index(2005) - 1] == 2002 and ids[ids.index(2005) + n_img] == 2003
+    assert out["attention_mask"].shape == out["input_ids"].shape
+    with pytest.raises(ValueError):
+        proc(text=["<|image_pad|> <|image_pad|>"], images=[view])
+
+
+def test_generate_matches_engine_and_batches(stack):
+    model, proc, tile, tile_np = stack
+    e = model.engine
+    view, _ = H.resize_image(tile)
+    p_a, p_b = prompt1(words(3, 6)), prompt1(words(4, 17))
+    # single rows
+    outs = {}
+    for name, p in (("a", p_a), ("b", p_b)):
+        inp = proc(text=[p], images=[view], return_tensors="pt", padding="longest").to(model.device)
+        g = model.generate(**inp, max_new_tokens=12, do_sample=False, num_beams=1, ignore_eos=True)
+        assert g.shape == (1, inp["input_ids"].shape[1] + 12)
+        assert torch.equal(g[:, : inp["input_ids"].shape[1]].cpu(), inp["input_ids"].cpu())
+        outs[name] = g[0, inp["input_ids"].shape[1]:].tolist()
+        # direct engine path
+        ids = inp["input_ids"][0].tolist()
+        emb = e.vit_forward(inp["pixel_values"], inp["image_grid_thw"].tolist())
+        pos, delta = e.rope_index(ids, inp["image_grid_thw"].tolist())
+        e.seq_reset(3)
+        e.prefill(3, ids, emb, pos, delta, want_logits=False)
+        assert e.generate(3, 12, ignore_eos=True) == outs[name]
+    # left-padded batch of both == the single-row results; sampling flags are accepted (greedy)
+    inp = proc(text=[p_a, p_b], images=[view, view], return_tensors="pt", padding="longest").to(model.device)
+    assert (inp["attention_mask"][0] == 0).sum() == 11
+    g = model.generate(**inp, max_new_tokens=12, do_sample=True, temperature=0.01, num_beams=1, ignore_eos=True)
+    L = inp["input_ids"].shape[1]
+    assert g[0, L:].tolist() == outs["a"] and g[1, L:].tolist() == outs["b"]
+    with pytest.raises(NotImplementedError):
+        model.generate(**inp, max_new_tokens=2, num_beams=4)
+
+
+def test_two_stage_chain_with_reuse_is_identical(stack):
+    model, proc, tile, tile_np = stack
+    view, scale = H.resize_image(tile)
+    crop, _ = H.resize_image(H.cut_image(tile, [300.0, 200.0, 420.0, 330.0]))
+    p1 = prompt1(words(5, 9))
+    results = []
+    for reuse in (True, False):
+        model.reuse_prefix = reuse
+        model._chains.clear()
+        model._vit_cache.clear()
+        o1 = H.chat_batch([p1], [view], proc, model, max_new_tokens=10)
+        p2 = p1 + " " + o1[0] + " <|vision_start|><|image_pad|><|vision_end|>"
+        o2 = H.chat_batch([p2], [[view, crop]], proc, model, max_new_tokens=10)
+        results.append((o1, o2))
+    model.reuse_prefix = True
+    assert results[0] == results[1]
+    assert len(results[0][0][0].split()) >= 5
+
+
+def test_zoom_chain_scripted(stack):
+    """Control flow of the chain with a scripted stage-1 text (random weights never emit a bbox)."""
+    model, proc, tile, tile_np = stack
+    seen = []
+
+    def chat(prompts, images):
+        seen.append(images)
+        out = H.chat_batch(prompts, images, proc, model, max_new_tokens=6)
+        if len(seen) == 1:
+            return ['w5 [{"bbox_2d": [140, 93, 195, 153], "label": "w9"}] <answer>w1</answer>']
+        return out
+
+    r = H.zoom_chain("w11 w12 w13", tile, chat)
+    assert not r["error"] and r["bbox"] == [v * (1100 / 512) for v in (140, 93, 195, 153)]
+    assert seen[1][0][1].size == (512, 512) and isinstance(r["output2"], str)
+
+
+def test_from_pretrained_both_key_layouts(stack, tmp_path):
+    model, proc, tile, tile_np = stack
+    cfg = Q.tiny_config()
+    w = Q.synthetic_weights(cfg, **CHAIN_W)
+    hf_cfg = {"vision_config": dict(depth=4, hidden_size=160, num_heads=2, intermediate_size=220, out_hidden_size=512,
+                                    fullatt_block_indexes=[1, 3]),
+              "hidden_size": 512, "num_hidden_layers": 3, "num_attention_heads": 4, "num_key_value_heads": 2,
+              "intermediate_size": 1376, "vocab_size": 2048, "rms_norm_eps": 1e-6, "rope_theta": 1000000.0,
+              "rope_scaling": {"type": "mrope", "mrope_section": [16, 24, 24]}, "tie_word_embeddings": True,
+              "image_token_id": 2005, "vision_start_token_id": 2002, "vision_end_token_id": 2003,
+              "eos_token_id": [2045, 2043], "pad_token_id": 2043}
+    view, _ = H.resize_image(tile)
+    inp = proc(text=[prompt1(words(6, 5))], images=[view], return_tensors="pt", padding="longest")
+    ref = model.generate(**inp, max_new_tokens=8, ignore_eos=True)
+
+    def rename_449(k):  # 4.49-era layout
+        if k.startswith("model.visual."):
+            return k[len("model."):]
+        if k.startswith("model.language_model."):
+            return "model." + k[len("model.language_model."):]
+        return k
+
+    for tag, rename, bf16 in (("v5_f32", lambda k: k, False), ("v449_bf16", rename_449, True)):
+        d = tmp_path / tag
+        os.makedirs(d)
+        with open(d / "config.json", "w") as f:
+            json.dump(hf_cfg, f)
+        with open(d / "generation_config.json", "w") as f:
+            json.dump({"eos_token_id": [2045, 2043], "pad_token_id": 2043, "repetition_penalty": 1.0}, f)
+        tensors = {rename(k): v for k, v in w.items()}
+        if tag == "v449_bf16":
+            tensors["lm_head.weight"] = w["model.language_model.embed_tokens.weight"]  # tied copy present in the file
+        checkpoint.write_safetensors(str(d / "model.safetensors"), tensors, bf16=bf16)
+        m2 = ZoomEarthForConditionalGeneration.from_pretrained(str(d), max_seqs=1, max_ctx=1024, max_patches=2048,
+                                                               max_tile_side=1024)
+        try:
+            inp2 = proc(text=[prompt1(words(6, 5))], images=[DeviceImage.from_numpy(view.numpy(), m2.engine)],
+                        return_tensors="pt", padding="longest")
+            got = m2.generate(**inp2, max_new_tokens=8, ignore_eos=True)
+            assert torch.equal(got.cpu(), ref.cpu()), tag
+        finally:
+            m2.engine.close()
+    from zoomearth_amd import processor as P
+    P.set_default_engine(model.engine)
+    # a checkpoint with a missing tensor fails loudly
+    d = tmp_path / "broken"
+    os.makedirs(d)
+    with open(d / "config.json", "w") as f:
+        json.dump(hf_cfg, f)
+    checkpoint.write_safetensors(str(d / "model.safetensors"), {k: v for k, v in w.items() if "layers.1.mlp.up_proj" not in k})
+    with pytest.raises(RuntimeError, match="missing weights"):
+        ZoomEarthForConditionalGeneration.from_pretrained(str(d), max_seqs=1, max_ctx=256, max_patches=1024, max_tile_side=1024)
+    P.set_default_engine(model.engine)

@@ -1,0 +1,143 @@
+"""CPU: checkpoint reader/writer, tokenizer shim, config parsing, question sharding (incl. a 2-process gloo run)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from zoomearth_amd import accel, checkpoint
+from zoomearth_amd.config import ModelConfig
+
+
+def test_safetensors_roundtrip(tmp_path):
+    rng = np.random.default_rng(0)
+    t = {"a.weight": rng.standard_normal((5, 7)).astype(np.float32), "b.bias": rng.standard_normal(9).astype(np.float16)}
+    p = str(tmp_path / "m.safetensors")
+    checkpoint.write_safetensors(p, t)
+    got = dict(checkpoint.iter_safetensors(p))
+    assert np.array_equal(got["a.weight"], t["a.weight"]) and np.array_equal(got["b.bias"], t["b.bias"])
+    # interoperable with the `safetensors` package
+    from safetensors.numpy import load_file, save_file
+    assert np.array_equal(load_file(p)["a.weight"], t["a.weight"])
+    save_file({"c": t["a.weight"]}, str(tmp_path / "n.safetensors"))
+    assert np.array_equal(dict(checkpoint.iter_safetensors(str(tmp_path / "n.safetensors")))["c"], t["a.weight"])
+    # bf16 storage comes back as raw bits
+    checkpoint.write_safetensors(str(tmp_path / "h.safetensors"), {"a": t["a.weight"]}, bf16=True)
+    arr, tag = dict(checkpoint.iter_safetensors(str(tmp_path / "h.safetensors")))["a"]
+    assert tag == "bf16" and arr.dtype == np.uint16 and arr.shape == (5, 7)
+    back = (arr.astype(np.uint32) << 16).view(np.float32)
+    assert np.abs(back - t["a.weight"]).max() <= np.abs(t["a.weight"]).max() * 2.0 ** -8
+
+
+def test_checkpoint_index(tmp_path):
+    checkpoint.write_safetensors(str(tmp_path / "model-00001-of-00002.safetensors"), {"x": np.zeros(3, np.float32)})
+    checkpoint.write_safetensors(str(tmp_path / "model-00002-of-00002.safetensors"), {"y": np.ones(2, np.float32)})
+    with open(tmp_path / "model.safetensors.index.json", "w") as f:
+        json.dump({"weight_map": {"x": "model-00001-of-00002.safetensors", "y": "model-00002-of-00002.safetensors"}}, f)
+    assert sorted(k for k, _ in checkpoint.iter_checkpoint(str(tmp_path))) == ["x", "y"]
+    with pytest.raises(FileNotFoundError):
+        checkpoint.checkpoint_files(str(tmp_path / "nope"))
+
+
+def test_config_from_hf_json_both_layouts():
+    flat = {"hidden_size": 2048, "num_hidden_layers": 36, "num_attention_heads": 16, "num_key_value_heads": 2,
+            "intermediate_size": 11008, "vocab_size": 151936, "rms_norm_eps": 1e-6, "rope_theta": 1000000.0,
+            "rope_scaling": {"type": "mrope", "mrope_section": [16, 24, 24]}, "tie_word_embeddings": True,
+            "image_token_id": 151655, "eos_token_id": 151645,
+            "vision_config": {"depth": 32, "hidden_size": 1280, "num_heads": 16, "intermediate_size": 3420,
+                              "out_hidden_size": 2048, "fullatt_block_indexes": [7, 15, 23, 31]}}
+    a = ModelConfig.from_hf_dict(flat)
+    nested = {"text_config": {k: v for k, v in flat.items() if k not in ("vision_config", "rope_scaling", "image_token_id")},
+              "vision_config": flat["vision_config"], "tie_word_embeddings": True, "image_token_id": 151655}
+    nested["text_config"]["rope_parameters"] = {"rope_type": "default", "rope_theta": 1000000.0, "mrope_section": [16, 24, 24]}
+    b = ModelConfig.from_hf_dict(nested)
+    ref = ModelConfig.zoomearth_3b()
+    for c in (a, b):
+        assert c.text == ref.text and c.vision == ref.vision and c.image_token_id == 151655
+
+
+def test_tokenizer_shim():
+    from tiny_tok import make_tokenizer
+    tok = make_tokenizer()
+    ids = tok.encode("w1 w2<|vision_start|><|image_pad|><|image_pad|><|vision_end|> w7")
+    assert ids == [1, 2, 2002, 2005, 2005, 2003, 7]
+    tok.padding_side = "left"
+    enc = tok(["w1 w2 w3", "w9"], padding="longest", return_tensors="pt")
+    assert enc["input_ids"].tolist() == [[1, 2, 3], [2043, 2043, 9]]
+    assert enc["attention_mask"].tolist() == [[1, 1, 1], [0, 0, 1]]
+    assert tok.decode([1, 2045, 2, 2043], skip_special_tokens=True) == "w1 w2"
+    assert "<|im_end|>" in tok.decode([1, 2045], skip_special_tokens=False)
+
+
+def test_sharding_covers_every_question_once():
+    names = [f"t{(i * 7) % 13}.tif" for i in range(200)]
+    for world in (1, 2, 4, 8):
+        parts = [accel.shard_by_tile(names, r, world) for r in range(world)]
+        assert sorted(sum(parts, [])) == list(range(200))
+        owners = {}
+        for r, p in enumerate(parts):
+            for i in p:
+                assert owners.setdefault(names[i], r) == r  # a tile never splits across ranks
+        sizes = [len(p) for p in parts]
+        assert max(sizes) - min(sizes) <= 16
+        rr = [accel.shard_round_robin(200, r, world) for r in range(world)]
+        assert sorted(sum(rr, [])) == list(range(200))
+
+
+def test_merge_results(tmp_path):
+    for r, ids in enumerate(([3, 1], [2, 0])):
+        with open(tmp_path / f"exp{r}.jsonl", "w") as f:
+            for i in ids:
+                f.write(json.dumps({"question_id": i, "answer1": "é"}, ensure_ascii=False) + "\n")
+    n = accel.merge_results(str(tmp_path / "exp"), 2, str(tmp_path / "exp.jsonl"))
+    rows = [json.loads(l) for l in open(tmp_path / "exp.jsonl", encoding="utf-8")]
+    assert n == 4 and [r["question_id"] for r in rows] == [0, 1, 2, 3]
+
+
+WORKER = r"""
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from zoomearth_amd import accel
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+acc = accel.Accelerator()
+assert acc.process_index == rank and acc.num_processes == world
+dist.init_process_group("gloo", rank=rank, world_size=world)
+# the path's only collective: one-time broadcast of the packed weight arena (here a CPU stand-in buffer)
+arena = torch.arange(4096, dtype=torch.uint8) if rank == 0 else torch.zeros(4096, dtype=torch.uint8)
+acc.broadcast_weights(arena, src=0)
+chk = torch.tensor([int(arena.to(torch.int64).sum())])
+gathered = [torch.zeros_like(chk) for _ in range(world)]
+dist.all_gather(gathered, chk)
+assert all(int(g) == int(gathered[0]) for g in gathered) and int(chk) == int(torch.arange(4096, dtype=torch.uint8).to(torch.int64).sum())
+names = [f"t{(i * 5) % 11}.tif" for i in range(97)]
+class DS(list):
+    pass
+ds = DS({"image_name": n, "question_id": i} for i, n in enumerate(names))
+class DL:
+    dataset, batch_size, collate_fn = ds, 1, staticmethod(lambda x: x)
+_, dl = acc.prepare(object(), DL())
+mine = [b[0]["question_id"] for b in dl]
+out = [None] * world
+dist.all_gather_object(out, mine)
+if rank == 0:
+    assert sorted(sum(out, [])) == list(range(97)), out
+    print("OK", [len(o) for o in out])
+dist.destroy_process_group()
+"""
+
+
+def test_two_process_gloo_sharding_and_broadcast(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = 29600 + os.getpid() % 200
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "OK" in outs[0]

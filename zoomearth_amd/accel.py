@@ -1,0 +1,129 @@
+"""Minimal stand-in for the slice of `accelerate.Accelerator` the reference's inference entry point uses
+(/root/reference/src/eval/infer.py:158,165,171,109,250): `.device`, `.process_index`, `.num_processes`,
+`.is_main_process`, `.prepare(model, dataloader)`, `.unwrap_model(model)`.
+
+One process per GPU (torchrun / torch.distributed.run sets RANK, LOCAL_RANK, WORLD_SIZE).  The question stream
+shards with NO collective on the data path; `broadcast_weights` is the path's only collective: a
+one-time broadcast of the packed weight arena from rank 0 over RCCL/xGMI so the checkpoint is read from disk once.
+"""
+from __future__ import annotations
+
+import os
+from collections import defaultdict
+
+
+def shard_round_robin(n_items: int, rank: int, world: int):
+    """accelerate-style batch sharding: item i goes to rank i % world."""
+    return list(range(rank, n_items, world))
+
+
+def shard_by_tile(image_names, rank: int, world: int):
+    """Tile-level longest-processing-time packing: all questions of one tile go to one rank so each
+    75-MB tile is decoded/uploaded once; tiles are sorted by question count and greedily assigned to the least
+    loaded rank.  Returns the question indices of `rank`, grouped by tile, in dataset order inside a tile.
+    Deterministic on every rank (no communication needed)."""
+    groups = defaultdict(list)
+    for i, name in enumerate(image_names):
+        groups[name].append(i)
+    order = sorted(groups.items(), key=lambda kv: (-len(kv[1]), kv[0]))
+    load = [0] * world
+    mine = []
+    for name, idx in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        load[r] += len(idx)
+        if r == rank:
+            mine.extend(idx)
+    return mine
+
+
+class Accelerator:
+    def __init__(self, mixed_precision=None, project_dir=None, log_with=None, **kw):
+        self.process_index = int(os.environ.get("RANK", "0"))
+        self.local_process_index = int(os.environ.get("LOCAL_RANK", "0"))
+        self.num_processes = int(os.environ.get("WORLD_SIZE", "1"))
+        self.mixed_precision = mixed_precision
+        import torch
+        self.device = torch.device("cuda", self.local_process_index)
+        self._pg = False
+
+    @property
+    def is_main_process(self) -> bool:
+        return self.process_index == 0
+
+    def unwrap_model(self, model):
+        return model
+
+    def prepare(self, model, dataloader):
+        """Model: already on its GPU (the engine owns the weights).  Dataloader: sharded by tile."""
+        return model, ShardedLoader(dataloader, self.process_index, self.num_processes)
+
+    # ---- the one collective of the path
+    def init_process_group(self, backend="nccl"):
+        import torch.distributed as dist
+        if self.num_processes > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            dist.init_process_group(backend, rank=self.process_index, world_size=self.num_processes)
+            self._pg = True
+
+    def broadcast_weights(self, arena, src: int = 0):
+        """arena: uint8 tensor view of the engine's packed weights (Engine.weights_arena())."""
+        if self.num_processes <= 1:
+            return
+        import torch.distributed as dist
+        self.init_process_group("nccl" if arena.is_cuda else "gloo")
+        dist.broadcast(arena, src=src)
+
+    def wait_for_everyone(self):
+        if self.num_processes > 1:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.barrier()
+
+
+class ShardedLoader:
+    """Iterates the batches of this rank.  `dataset` rows need `image_name`; batches are lists of rows."""
+
+    def __init__(self, dataloader, rank: int, world: int, by_tile: bool = True):
+        self.dl, self.rank, self.world, self.by_tile = dataloader, rank, world, by_tile
+
+    def _indices(self):
+        ds = self.dl.dataset
+        n = len(ds)
+        if self.world <= 1:
+            return list(range(n))
+        if self.by_tile:
+            try:
+                names = ds["image_name"] if not isinstance(ds, list) else [r["image_name"] for r in ds]
+                return shard_by_tile(list(names), self.rank, self.world)
+            except Exception:
+                pass
+        return shard_round_robin(n, self.rank, self.world)
+
+    def __len__(self):
+        bs = getattr(self.dl, "batch_size", 1) or 1
+        return (len(self._indices()) + bs - 1) // bs
+
+    def __iter__(self):
+        ds = self.dl.dataset
+        bs = getattr(self.dl, "batch_size", 1) or 1
+        collate = getattr(self.dl, "collate_fn", None) or (lambda x: x)
+        idx = self._indices()
+        for i in range(0, len(idx), bs):
+            yield collate([ds[j] for j in idx[i: i + bs]])
+
+
+def merge_results(pattern_prefix: str, world: int, out_path: str) -> int:
+    """Concatenate results/{exp}{rank}.jsonl of all ranks sorted by question_id into one file for eval.sh."""
+    import json
+    rows = []
+    for r in range(world):
+        p = f"{pattern_prefix}{r}.jsonl"
+        if os.path.exists(p):
+            with open(p, encoding="utf-8") as f:
+                rows.extend(json.loads(line) for line in f if line.strip())
+    rows.sort(key=lambda d: (str(type(d["question_id"])), d["question_id"]))
+    with open(out_path, "w", encoding="utf-8") as f:
+        for d in rows:
+            f.write(json.dumps(d, ensure_ascii=False) + "\n")
+    return len(rows)
