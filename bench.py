@@ -230,6 +230,12 @@ def main():
         for which, name in ((0, "qkv"), (1, "o_proj"), (3, "down"), (4, "lm_head")):
             u, b = e.profile_decode_kernel(which, iters=72)
             others[name] = {"us": round(u, 2), "GBps": round(b / (u * 1e-6) / 1e9, 1)}
+        traffic, traffic_src = None, None
+        tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tp):  # PMC passes cannot run inside this process: the latest committed measurement
+            with open(tp) as f:
+                tj = json.load(f)
+            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/traffic_latest.json (rocprofv3 --pmc, round %d)" % tj["round"]
         line = {
             "metric": "questions/sec end-to-end, ZoomEarth-3B on 5000px tiles", "value": world * args.steps / dt,
             "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -242,7 +248,7 @@ def main():
                        "reuse": "stage-1 prompt KV and view features reused in stage 2 (bit-identical)",
                        "parallelism": f"dp{world}", "weight_broadcast_s": round(bcast_s, 4)},
             "roofline": {"bound": "hbm", "kernel": "k_gemv<SWIGLU> (decode gate/up weight stream)", "achieved": ach,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_us": us, "bytes_per_launch": by, "other_decode_kernels": others},
             "phase_ms_per_question": {k: round(v / args.steps, 3) for k, v in phases.items()},
         }
