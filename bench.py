@@ -247,7 +247,7 @@ def main():
                        "repetition_penalty": PENALTY, "hip_graph": not args.no_graph,
                        "reuse": "stage-1 prompt KV and view features reused in stage 2 (bit-identical)",
                        "parallelism": f"dp{world}", "weight_broadcast_s": round(bcast_s, 4)},
-            "roofline": {"bound": "hbm", "kernel": "k_gemv<SWIGLU> (decode gate/up weight stream)", "achieved": ach,
+            "roofline": {"bound": "hbm", "kernel": "k_gemv<EPI=SWIGLU,PAIRS=1,KSPLIT=1,CH=4> = k_gemv<2, 1, 1, 4> (decode gate/up weight stream, 36 launches per token)", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_us": us, "bytes_per_launch": by, "other_decode_kernels": others},
             "phase_ms_per_question": {k: round(v / args.steps, 3) for k, v in phases.items()},

@@ -141,3 +141,23 @@ def test_two_process_gloo_sharding_and_broadcast(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "OK" in outs[0]
+
+
+def test_scorer(tmp_path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ze_eval", os.path.join(ROOT, "src", "eval", "eval.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    recs = [
+        {"ground_truth": "Yes", "answer1": " yes ", "answer2": "no", "type": "region"},      # broken by stage 2
+        {"ground_truth": "bridge", "answer1": "road", "answer2": "Bridge", "type": "object"},  # fixed by stage 2
+        {"ground_truth": "3", "answer1": "3", "answer2": None, "type": "global"},             # answer2 None -> answer1
+        {"ground_truth": "car", "answer1": None, "answer2": None, "type": "object"},
+    ]
+    r = ev.score_records(recs)
+    assert (r["total"], r["correct1"], r["correct2"]) == (4, 2, 2)
+    assert r["by_type"]["object"] == (2, 0, 1) and r["by_type"]["global"] == (1, 1, 1)
+    assert len(r["fixed"]) == 1 and len(r["broken"]) == 1
+    p = tmp_path / "r.jsonl"
+    p.write_text("\n".join(json.dumps(x) for x in recs) + "\n")
+    assert ev.evaluation_metrics(str(p))["total"] == 4

@@ -9,6 +9,7 @@
 // LDS as bf16.  Issue order follows the in-order vmcnt retirement: activation vector + norm weight first, then the
 // first trip of the weight stream (so the prologue only waits for two L2-resident vectors while the HBM latency
 // of the first weight loads hides behind it), then the epilogue operands (bias / residual / cos-sin).
+#include <algorithm>
 #include <type_traits>
 
 #include "ze_kernels.h"
@@ -273,6 +274,8 @@ __global__ void __launch_bounds__(256) k_gemv(const ze_gemv_args a) {
     }
 }
 
+extern int ze_gemv_knobs[4];
+
 template <int EPI, int PAIRS, int KSPLIT, int CH>
 static void launch_gemv_cfg(const ze_gemv_args& a, hipStream_t s) {
     const int P = a.N / 2;
@@ -280,10 +283,23 @@ static void launch_gemv_cfg(const ze_gemv_args& a, hipStream_t s) {
     const size_t lds = (size_t)nch * 512 * 2 + 4 * 2 * PAIRS * sizeof(float) + 64;
     int grid = (KSPLIT == 1) ? ze_cdiv(P, 4 * PAIRS) : ze_cdiv(P, PAIRS);
     if (grid > 2048) grid = 2048;
+    // One resident round: with more blocks than the chip holds at once the tail of the grid waits for slots and
+    // pays the x-staging prologue a second time (measured: gate_up 18.5 us -> 15.8 us at 3 blocks/CU, down
+    // 13.2 -> 11.1 at 2 blocks/CU; one block more per CU is a cliff).  Long streams (lm_head) keep 2048 blocks.
+    int dev = 0, cus = 256, occ = 0;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_gemv<EPI, PAIRS, KSPLIT, CH>, 256, lds) == hipSuccess &&
+        occ > 0) {
+        const int resident = occ * cus;
+        const int natural = (KSPLIT == 1) ? ze_cdiv(P, 4 * PAIRS) : ze_cdiv(P, PAIRS);
+        if (natural <= 4 * resident && grid > resident) grid = resident;
+    }
+    if (ze_gemv_knobs[2] > 0) grid = std::min(ze_cdiv(P, PAIRS * (KSPLIT == 1 ? 4 : 1)), ze_gemv_knobs[2]);
     hipLaunchKernelGGL((k_gemv<EPI, PAIRS, KSPLIT, CH>), dim3(grid), dim3(256), lds, s, a);
 }
 
-int ze_gemv_knobs[4] = {0, 0, 0, 0};  // measurement-only overrides set through ze_tune(): [0] down, [1] gate_up
+int ze_gemv_knobs[4] = {0, 0, 0, 0};  // measurement-only overrides set through ze_tune(): [0] down, [1] gate_up, [2] grid cap
 
 bool ze_launch_gemv(int epi, const ze_gemv_args& a, hipStream_t s) {
     // shape policy: long-K / few-row matrices split K over the 4 waves of a block (each wave streams its K/4 share
