@@ -85,7 +85,7 @@ class Chain:
         pos2, delta2 = e.rope_index(ids2, [g_v, g_c])
         e.seq_truncate(0, len(ids1))
         e.prefill(0, ids2[len(ids1):], emb_c, pos2[:, len(ids1):], delta2, want_logits=False)
-        e.mark_seen(0, ids2[len(ids1):])
+        e.mark_seen(0, ids2)
         out2 = e.generate(0, N2, repetition_penalty=PENALTY, ignore_eos=True, use_graph=self.use_graph, sync_every=N2)
         return out1, out2, len(ids1), len(ids2)
 

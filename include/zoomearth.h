@@ -135,7 +135,8 @@ int ze_vit_forward(ze_engine* e, const float* pixel_values, const int32_t* grid_
                    void* out_embeds_bf16, void* stream);
 
 /* Sequence (question-chain) slots: 0 <= seq < max_seqs.  ze_seq_reset drops the KV cache of a slot and clears
- * its repetition-penalty set; ze_seq_truncate keeps the first `keep_len` cached tokens (stage-1 prefix reuse). */
+ * its repetition-penalty set; ze_seq_truncate keeps the first `keep_len` cached tokens (stage-1 prefix reuse) and
+ * also clears the repetition-penalty set (the caller re-marks the new prompt with ze_seq_mark_seen). */
 int ze_seq_reset(ze_engine* e, int seq, void* stream);
 int ze_seq_truncate(ze_engine* e, int seq, int keep_len, void* stream);
 int ze_seq_len(ze_engine* e, int seq);
@@ -169,6 +170,15 @@ typedef struct ze_gen_params {
  * logits left by ze_prefill, then runs decode steps until EOS / max_new_tokens.  out_tokens: host int32
  * [max_new_tokens]; *n_out = number of tokens produced (EOS included). */
 int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_t* out_tokens, int* n_out, void* stream);
+/* Batched decode (BASELINE configs[2]: many question chains per GPU).  One token for each of the n distinct chains
+ * `seqs[i]`: the weights are streamed once for the whole batch (MFMA path, rows = chains); each chain keeps its own
+ * KV cache, position and repetition-penalty set, and its results do not depend on the batch composition.
+ * ze_decode_batch: teacher forcing / raw logits (tokens[i] < 0 or tokens == NULL feeds the chain's last token);
+ * out_logits: f32 [n, vocab] device or NULL.  ze_generate_batch: greedy loop for all chains after their prefills
+ * (continuous batching: chains that hit EOS leave the batch); out_tokens host int32 [n, max_new_tokens], n_out [n]. */
+int ze_decode_batch(ze_engine* e, const int32_t* seqs, int n, const int32_t* tokens, float* out_logits, void* stream);
+int ze_generate_batch(ze_engine* e, const int32_t* seqs, int n, const ze_gen_params* p, int32_t* out_tokens,
+                      int32_t* n_out, void* stream);
 /* Marks every id in `ids` (host int32) as seen for the repetition penalty of `seq` (the prompt). */
 int ze_seq_mark_seen(ze_engine* e, int seq, const int32_t* ids, int n, void* stream);
 /* Applies penalty + argmax to f32 logits [vocab] (device) with the seen-set of `seq`; *out_token host. */

@@ -1,0 +1,116 @@
+"""GPU: batched decode (BASELINE configs[2]): many chains per step through the MFMA path, via the C ABI.
+
+Properties checked: (1) batch invariance -- a chain's logits / tokens are bit-identical whatever other chains share
+its steps; (2) agreement with the single-chain GEMV path within bf16 rounding of the logits; (3) ragged lengths and
+chains leaving the batch at their EOS."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import CHAIN_W, tiny_engine  # noqa: F401
+from oracle import prng
+from oracle import qwen25vl as Q
+
+pytestmark = pytest.mark.gpu
+
+
+def text_ids(seed, n):
+    return prng.uniform_ints(seed, n, 10, 1990).tolist()
+
+
+def prefill_text(e, seq, ids):
+    pos, delta = e.rope_index(ids, [])
+    e.seq_reset(seq)
+    e.prefill(seq, ids, None, pos, delta, want_logits=False)
+
+
+@pytest.fixture(scope="module")
+def eng(tiny_engine):
+    tiny_engine.fill_synthetic(**CHAIN_W)
+    return tiny_engine
+
+
+PROMPTS = [text_ids(11, 70), text_ids(12, 5), text_ids(13, 131)]
+
+
+def test_decode_batch_invariance_and_agreement(eng):
+    e = eng
+    for s, ids in enumerate(PROMPTS):
+        prefill_text(e, s, ids)
+    forced = [[int(t) for t in text_ids(20 + s, 6)] for s in range(3)]
+    batch_logits = []
+    for step in range(6):
+        lg = e.decode_batch([0, 1, 2], [forced[s][step] for s in range(3)])
+        batch_logits.append(lg.cpu().numpy())
+    # the same chains alone through the batched path: bit-identical rows
+    for s, ids in enumerate(PROMPTS):
+        prefill_text(e, s, ids)
+    for step in range(6):
+        for s in (2, 0, 1):
+            lg = e.decode_batch([s], [forced[s][step]]).cpu().numpy()
+            assert np.array_equal(lg[0], batch_logits[step][s]), (step, s)
+    # the single-chain GEMV path: same arithmetic up to accumulation order
+    for s, ids in enumerate(PROMPTS):
+        prefill_text(e, s, ids)
+    worst = 0.0
+    for step in range(6):
+        for s in range(3):
+            lg = e.decode_step(s, forced[s][step]).cpu().numpy()
+            worst = max(worst, float(np.abs(lg - batch_logits[step][s]).max()))
+    scale = float(np.abs(batch_logits[0]).max())
+    assert worst <= 0.05 * max(scale, 1.0), (worst, scale)
+    # and the fp32 oracle, with the bf16-oracle's own error as the yardstick (x2)
+    cfg = Q.tiny_config()
+    w = Q.synthetic_weights(cfg, **CHAIN_W)
+    o32, o16 = Q.Qwen25VLOracle(cfg, w, "fp32"), Q.Qwen25VLOracle(cfg, w, "bf16")
+    ref32, ref16 = o32.prefill(PROMPTS[1]), o16.prefill(PROMPTS[1])
+    errs, yard = [], []
+    for step in range(6):
+        ref32, ref16 = o32.decode_step(forced[1][step]), o16.decode_step(forced[1][step])
+        errs.append(np.abs(batch_logits[step][1] - ref32).max())
+        yard.append(np.abs(ref16 - ref32).max())
+    assert max(errs) <= 2.0 * max(yard), (errs, yard)
+
+
+def test_generate_batch_ragged_and_eos(eng):
+    e = eng
+    for s, ids in enumerate(PROMPTS):
+        prefill_text(e, s, ids)
+        e.mark_seen(s, ids)
+    free = e.generate_batch([0, 1, 2], 14, repetition_penalty=1.3, ignore_eos=True)
+    assert [len(t) for t in free] == [14, 14, 14]
+    assert [e.seq_len(s) for s in range(3)] == [len(p) + 13 for p in PROMPTS]
+    # each chain alone reproduces its tokens exactly (batch invariance of the whole loop)
+    for s, ids in enumerate(PROMPTS):
+        prefill_text(e, s, ids)
+        e.mark_seen(s, ids)
+        assert e.generate_batch([s], 14, repetition_penalty=1.3, ignore_eos=True)[0] == free[s]
+    assert len(set(sum(free, []))) >= 20
+    # EOS: make chain 1's 4th and chain 2's 9th token an EOS via a second engine with those ids as EOS
+    from zoomearth_amd.config import ModelConfig
+    from zoomearth_amd.engine import Engine
+    cfg = ModelConfig.tiny()
+    cfg.eos_token_ids = (free[1][3], free[2][8])
+    e2 = Engine(cfg, max_seqs=3, max_ctx=512, max_patches=1024, max_tile_side=1024)
+    try:
+        e2.fill_synthetic(**CHAIN_W)
+        want = []
+        for s in range(3):
+            cut = next((i for i, t in enumerate(free[s]) if t in cfg.eos_token_ids), None)
+            want.append(free[s] if cut is None else free[s][: cut + 1])
+        for sync_every in (1, 5):
+            for s, ids in enumerate(PROMPTS):
+                prefill_text(e2, s, ids)
+                e2.mark_seen(s, ids)
+            got = e2.generate_batch([0, 1, 2], 14, repetition_penalty=1.3, ignore_eos=False, sync_every=sync_every)
+            assert got == want, (sync_every, got, want)
+    finally:
+        e2.close()
+
+
+def test_batch_errors(eng):
+    from zoomearth_amd._lib import ZoomEarthError
+    with pytest.raises(ZoomEarthError):
+        eng.decode_batch([0, 0])
+    with pytest.raises(ZoomEarthError):
+        eng.decode_batch([0, 7])

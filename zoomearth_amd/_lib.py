@@ -85,6 +85,9 @@ _SIGS = {
                              _P, _P]),
     "ze_decode_step": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "ze_generate": (C.c_int, [_P, C.c_int, C.POINTER(ZeGenParams), C.POINTER(C.c_int32), C.POINTER(C.c_int), _P]),
+    "ze_decode_batch": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), _P, _P]),
+    "ze_generate_batch": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.POINTER(ZeGenParams), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_int32), _P]),
     "ze_seq_mark_seen": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.c_int, _P]),
     "ze_op_sample_greedy": (C.c_int, [_P, C.c_int, _P, C.c_float, C.POINTER(C.c_int32), _P]),
     "ze_op_linear": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

@@ -215,13 +215,23 @@ __device__ __forceinline__ void split_geometry(int ctx, int max_splits, int& chu
     nsplit = (ctx + chunk - 1) / chunk;
 }
 
-__global__ void __launch_bounds__(256) k_attn_decode_split(const bf16_t* __restrict__ q,
+__global__ void __launch_bounds__(256) k_attn_decode_split(const bf16_t* __restrict__ q, int q_row_stride,
                                                            const bf16_t* __restrict__ kcache,
-                                                           const bf16_t* __restrict__ vcache,
-                                                           const ze_seq_dev* __restrict__ st, int heads, int kv_heads,
+                                                           const bf16_t* __restrict__ vcache, size_t cache_seq_stride,
+                                                           const ze_seq_dev* __restrict__ st_base,
+                                                           const int* __restrict__ seq_ids, int heads, int kv_heads,
                                                            int max_ctx, float scale_log2e, float* __restrict__ ws,
                                                            int max_splits) {
     constexpr int D = 128;
+    // chain of this block (grid.z): batched decode indexes the chain table, single-chain decode passes its state
+    const int bz = blockIdx.z;
+    const ze_seq_dev* st = seq_ids ? st_base + seq_ids[bz] : st_base;
+    if (seq_ids) {
+        kcache += (size_t)seq_ids[bz] * cache_seq_stride;
+        vcache += (size_t)seq_ids[bz] * cache_seq_stride;
+    }
+    q += (size_t)bz * q_row_stride;
+    ws += (size_t)bz * max_splits * heads * AD_STRIDE;
     __shared__ __attribute__((aligned(16))) bf16_t sV[AD_TOK][D];  // 16 KB
     __shared__ float sS[AD_TOK][AD_GMAX];                            // scores, then probabilities
     __shared__ float sM[AD_GMAX], sL[AD_GMAX];
@@ -366,9 +376,15 @@ __global__ void __launch_bounds__(256) k_attn_decode_split(const bf16_t* __restr
 
 // grid = heads, 128 threads (one per output dim): split weights are computed lane-parallel by the first wave.
 __global__ void __launch_bounds__(128) k_attn_decode_combine(const float* __restrict__ ws,
-                                                             const ze_seq_dev* __restrict__ st, int heads,
-                                                             int max_splits, bf16_t* __restrict__ out) {
+                                                             const ze_seq_dev* __restrict__ st_base,
+                                                             const int* __restrict__ seq_ids, int heads,
+                                                             int max_splits, bf16_t* __restrict__ out,
+                                                             int out_row_stride) {
     constexpr int D = 128;
+    const int bz = blockIdx.y;
+    const ze_seq_dev* st = seq_ids ? st_base + seq_ids[bz] : st_base;
+    ws += (size_t)bz * max_splits * heads * AD_STRIDE;
+    out += (size_t)bz * out_row_stride;
     __shared__ float sW[64];
     __shared__ float sInv;
     const int ctx = st->ctx + 1;
@@ -404,12 +420,15 @@ __global__ void __launch_bounds__(128) k_attn_decode_combine(const float* __rest
     out[(size_t)h * D + d] = f32_to_bf16(acc * sInv);
 }
 
-void ze_launch_attn_decode(const bf16_t* q, const bf16_t* kcache, const bf16_t* vcache, bf16_t* out,
-                           const ze_seq_dev* st, int heads, int kv_heads, int D, int max_ctx, float scale,
+void ze_launch_attn_decode(const bf16_t* q, int q_row_stride, const bf16_t* kcache, const bf16_t* vcache,
+                           size_t cache_seq_stride, bf16_t* out, int out_row_stride, const ze_seq_dev* st,
+                           const int* seq_ids, int n, int heads, int kv_heads, int D, int max_ctx, float scale,
                            float* ws_partial, int max_splits, hipStream_t s) {
     (void)D;
     const float sl = scale * 1.4426950408889634f;
-    k_attn_decode_split<<<dim3(kv_heads, max_splits), 256, 0, s>>>(q, kcache, vcache, st, heads, kv_heads, max_ctx,
-                                                                    sl, ws_partial, max_splits);
-    k_attn_decode_combine<<<heads, 128, 0, s>>>(ws_partial, st, heads, max_splits, out);
+    k_attn_decode_split<<<dim3(kv_heads, max_splits, n), 256, 0, s>>>(q, q_row_stride, kcache, vcache, cache_seq_stride,
+                                                                       st, seq_ids, heads, kv_heads, max_ctx, sl,
+                                                                       ws_partial, max_splits);
+    k_attn_decode_combine<<<dim3(heads, n), 128, 0, s>>>(ws_partial, st, seq_ids, heads, max_splits, out,
+                                                         out_row_stride);
 }

@@ -233,3 +233,70 @@ void ze_launch_scatter_rows(const bf16_t* src, int lds_, const int* dst_idx, bf1
     if (n == 0) return;
     k_scatter_rows<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(src, lds_, dst_idx, dst, ldd, rows, cols);
 }
+
+// ------------------------------------------------------------------ batched decode: one token per chain
+__global__ void __launch_bounds__(256) k_embed_tokens_batch(const ze_seq_dev* __restrict__ st,
+                                                            const int* __restrict__ seq_ids, int n,
+                                                            const bf16_t* __restrict__ embed, bf16_t* __restrict__ out,
+                                                            int hidden) {
+    const int nv = hidden >> 3;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)n * nv) return;
+    const int b = (int)(i / nv), v = (int)(i % nv);
+    const int tok = st[seq_ids[b]].token;
+    *reinterpret_cast<uint4*>(out + (size_t)b * hidden + v * 8) =
+        *reinterpret_cast<const uint4*>(embed + (size_t)tok * hidden + v * 8);
+}
+void ze_launch_embed_tokens_batch(const ze_seq_dev* st, const int* seq_ids, int n, const bf16_t* embed, bf16_t* out,
+                                  int hidden, hipStream_t s) {
+    const size_t tot = (size_t)n * (hidden / 8);
+    if (tot == 0) return;
+    k_embed_tokens_batch<<<(unsigned)((tot + 255) / 256), 256, 0, s>>>(st, seq_ids, n, embed, out, hidden);
+}
+
+// qkv: [n, (heads + 2 kv_heads) * D]; row b belongs to chain seq_ids[b] at position ctx + rope_delta (all three
+// M-RoPE axes equal during decode).  Same bf16 arithmetic as k_mrope_kv.
+__global__ void __launch_bounds__(256) k_rope_kv_batch(bf16_t* __restrict__ qkv, int n, int heads, int kv_heads, int D,
+                                                       const bf16_t* __restrict__ cosT, const bf16_t* __restrict__ sinT,
+                                                       const ze_seq_dev* __restrict__ st,
+                                                       const int* __restrict__ seq_ids, bf16_t* __restrict__ kcache,
+                                                       bf16_t* __restrict__ vcache, size_t cache_seq_stride,
+                                                       int max_ctx) {
+    const int half = D >> 1;
+    const int nh = heads + 2 * kv_heads;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)n * nh * half) return;
+    const int j = (int)(i % half);
+    const int hh = (int)((i / half) % nh);
+    const int b = (int)(i / ((size_t)half * nh));
+    const int seq = seq_ids[b];
+    const int ctx = st[seq].ctx, pos = ctx + st[seq].rope_delta;
+    bf16_t* p = qkv + (size_t)b * nh * D + (size_t)hh * D;
+    if (hh >= heads + kv_heads) {
+        bf16_t* d = vcache + seq * cache_seq_stride + ((size_t)(hh - heads - kv_heads) * max_ctx + ctx) * D;
+        d[j] = p[j];
+        d[j + half] = p[j + half];
+        return;
+    }
+    const float c = bf16_to_f32(cosT[(size_t)pos * half + j]);
+    const float sn = bf16_to_f32(sinT[(size_t)pos * half + j]);
+    const float x1 = bf16_to_f32(p[j]), x2 = bf16_to_f32(p[j + half]);
+    const bf16_t o1 = f32_to_bf16(bf16_round(x1 * c) + bf16_round(-x2 * sn));
+    const bf16_t o2 = f32_to_bf16(bf16_round(x2 * c) + bf16_round(x1 * sn));
+    if (hh < heads) {
+        p[j] = o1;
+        p[j + half] = o2;
+    } else {
+        bf16_t* d = kcache + seq * cache_seq_stride + ((size_t)(hh - heads) * max_ctx + ctx) * D;
+        d[j] = o1;
+        d[j + half] = o2;
+    }
+}
+void ze_launch_rope_kv_batch(bf16_t* qkv, int n, int heads, int kv_heads, int D, const bf16_t* cosT, const bf16_t* sinT,
+                             const ze_seq_dev* st, const int* seq_ids, bf16_t* kcache, bf16_t* vcache,
+                             size_t cache_seq_stride, int max_ctx, hipStream_t s) {
+    const size_t tot = (size_t)n * (heads + 2 * kv_heads) * (D / 2);
+    if (tot == 0) return;
+    k_rope_kv_batch<<<(unsigned)((tot + 255) / 256), 256, 0, s>>>(qkv, n, heads, kv_heads, D, cosT, sinT, st, seq_ids,
+                                                                  kcache, vcache, cache_seq_stride, max_ctx);
+}

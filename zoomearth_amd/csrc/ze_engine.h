@@ -104,6 +104,10 @@ struct ze_engine {
     float *dlogits = nullptr, *dpartial = nullptr, *dsample = nullptr;
     int max_splits = 64;
     int* d_host_ints = nullptr;  // pinned, small
+    // batched decode
+    int* bseq = nullptr;
+    float *blogits = nullptr, *bpartial = nullptr, *bsample = nullptr;
+    ze_seq_dev* bstate_host = nullptr;  // pinned
 
     // timers
     bool timers_on = false;

@@ -223,6 +223,7 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     if (c.mrope_section[0] + c.mrope_section[1] + c.mrope_section[2] != e->head_dim / 2)
         return bad("mrope_section must sum to head_dim/2");
     if (c.max_seqs <= 0 || c.max_ctx <= 0 || c.max_patches <= 0) return bad("capacities must be positive");
+    if (c.max_seqs > c.max_ctx) return bad("max_seqs must not exceed max_ctx");
     // the decode GEMV stages x in LDS (<= 60 KB)
     if (ze_pad32(c.intermediate) > 29000) return bad("intermediate > 29000 unsupported by the decode GEMV");
     e->vit_ipad = ze_pad32(c.vit_intermediate);
@@ -307,10 +308,16 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     chk(dev_alloc(e, &e->dq, (size_t)c.heads * e->head_dim));
     chk(dev_alloc(e, &e->dattn, (size_t)c.heads * e->head_dim));
     chk(dev_alloc(e, &e->dact, e->text_ipad));
-    chk(dev_alloc(e, &e->dlogits, c.vocab));
+    chk(dev_alloc(e, &e->dlogits, (size_t)c.max_seqs * c.vocab));
+    chk(dev_alloc(e, &e->bseq, c.max_seqs));
+    chk(dev_alloc(e, &e->blogits, (size_t)c.max_seqs * c.vocab));
+    chk(dev_alloc(e, &e->bpartial, (size_t)c.max_seqs * e->max_splits * c.heads * 132));
+    chk(dev_alloc(e, &e->bsample, (size_t)c.max_seqs * 2 * 128 + 8));
+    if (r == 0 && hipHostMalloc((void**)&e->bstate_host, sizeof(ze_seq_dev) * c.max_seqs) != hipSuccess)
+        r = ze_fail(e, ZE_ERR_HIP, "hipHostMalloc failed");
     chk(dev_alloc(e, &e->dpartial, (size_t)e->max_splits * c.heads * 132));
     chk(dev_alloc(e, &e->dsample, 2 * 128 + 64 + 8));
-    if (r == 0 && hipHostMalloc((void**)&e->d_host_ints, 64 * sizeof(int)) != hipSuccess)
+    if (r == 0 && hipHostMalloc((void**)&e->d_host_ints, (64 + c.max_seqs) * sizeof(int)) != hipSuccess)
         r = ze_fail(e, ZE_ERR_HIP, "hipHostMalloc failed");
     e->staging_bytes = (size_t)64 << 20;
     if (r == 0 && hipMalloc(&e->staging, e->staging_bytes) != hipSuccess) r = ze_fail(e, ZE_ERR_HIP, "hipMalloc staging");
@@ -342,10 +349,10 @@ extern "C" int ze_engine_destroy(ze_engine* e) {
                    e->st_dev, e->seen, e->out_tokens, e->fe_tmp, e->fe_img, e->fe_coef, e->vx, e->vh, e->vy, e->vqkv,
                    e->vo, e->va, e->vz, e->vz2, e->vcos, e->vsin, e->vperm, e->vinv, e->vtiles_win, e->vtiles_full,
                    e->th, e->ty, e->tqkv, e->to, e->ta, e->tsrc, e->tpos, e->ttiles, e->dh, e->dq, e->dattn, e->dact,
-                   e->dlogits, e->dpartial, e->dsample};
+                   e->dlogits, e->dpartial, e->dsample, e->bseq, e->blogits, e->bpartial, e->bsample};
     for (void* p : dev)
         if (p) hipFree(p);
-    void* host[] = {e->fe_coef_host, e->v_host_ints, e->v_host_f32, e->t_host_ints, e->d_host_ints};
+    void* host[] = {e->fe_coef_host, e->v_host_ints, e->v_host_f32, e->t_host_ints, e->d_host_ints, e->bstate_host};
     for (void* p : host)
         if (p) hipHostFree(p);
     delete e;

@@ -325,6 +325,8 @@ extern "C" int ze_seq_truncate(ze_engine* e, int seq, int keep_len, void* stream
     if (keep_len < 0 || keep_len > e->ctx_host[seq]) return ze_fail(e, ZE_ERR_INVALID, "keep_len out of range");
     hipSetDevice(e->device);
     e->ctx_host[seq] = keep_len;
+    // the seen-set belongs to the dropped continuation: the caller re-marks the (new) prompt
+    ZE_HIP(hipMemsetAsync(e->seen + (size_t)seq * e->cfg.vocab, 0, e->cfg.vocab, (hipStream_t)stream));
     return push_state(e, seq, (hipStream_t)stream, 0, 0, 0);
 }
 
@@ -421,13 +423,14 @@ extern "C" int ze_prefill(ze_engine* e, int seq, const int32_t* input_ids, int l
     a.x = e->th + (size_t)(len - 1) * H;
     a.norm_w = e->final_norm;
     a.eps = c.rms_eps;
-    a.out_f32 = e->dlogits;
+    a.out_f32 = e->dlogits + (size_t)seq * c.vocab;
     a.D = hd;
     ze_launch_gemv(ZE_GV_LOGITS, a, s);
     ze_timer_end(e, th, s);
     ZE_KCHECK();
     if (out_logits)
-        ZE_HIP(hipMemcpyAsync(out_logits, e->dlogits, (size_t)c.vocab * sizeof(float), hipMemcpyDeviceToDevice, s));
+        ZE_HIP(hipMemcpyAsync(out_logits, e->dlogits + (size_t)seq * c.vocab, (size_t)c.vocab * sizeof(float),
+                              hipMemcpyDeviceToDevice, s));
     e->ctx_host[seq] = past + len;
     e->delta_host[seq] = rope_delta;
     return push_state(e, seq, s, input_ids[len - 1], 0, 0);
@@ -468,8 +471,8 @@ int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos,
             a.embed_out = e->dh;
         }
         ze_launch_gemv(ZE_GV_QKV_ROPE, a, s);
-        ze_launch_attn_decode(e->dq, e->kc(li, seq), e->vc(li, seq), e->dattn, st, c.heads, c.kv_heads, hd, c.max_ctx,
-                              scale, e->dpartial, e->max_splits, s);
+        ze_launch_attn_decode(e->dq, 0, e->kc(li, seq), e->vc(li, seq), 0, e->dattn, 0, st, nullptr, 1, c.heads,
+                              c.kv_heads, hd, c.max_ctx, scale, e->dpartial, e->max_splits, s);
         ze_gemv_args o;
         memset(&o, 0, sizeof(o));
         o.W = L.o.w;
@@ -512,11 +515,11 @@ int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos,
     a.x = e->dh;
     a.norm_w = e->final_norm;
     a.eps = c.rms_eps;
-    a.out_f32 = e->dlogits;
+    a.out_f32 = e->dlogits + (size_t)seq * c.vocab;
     a.D = hd;
     ze_launch_gemv(ZE_GV_LOGITS, a, s);
     if (sample)
-        ze_launch_sample(e->dlogits, c.vocab, e->seen + (size_t)seq * c.vocab, penalty, e->st_dev + seq, e->eos_dev,
+        ze_launch_sample(e->dlogits + (size_t)seq * c.vocab, c.vocab, e->seen + (size_t)seq * c.vocab, penalty, e->st_dev + seq, e->eos_dev,
                          c.n_eos, c.pad_token_id, ignore_eos, /*advance_ctx=*/1,
                          e->out_tokens + (size_t)seq * c.max_ctx, e->dsample, s);
     else
@@ -542,7 +545,8 @@ extern "C" int ze_decode_step(ze_engine* e, int seq, int token, float* out_logit
     ze_timer_end(e, th, s);
     e->ctx_host[seq] += 1;
     if (out_logits)
-        ZE_HIP(hipMemcpyAsync(out_logits, e->dlogits, (size_t)c.vocab * sizeof(float), hipMemcpyDeviceToDevice, s));
+        ZE_HIP(hipMemcpyAsync(out_logits, e->dlogits + (size_t)seq * c.vocab, (size_t)c.vocab * sizeof(float),
+                              hipMemcpyDeviceToDevice, s));
     return ZE_OK;
 }
 
@@ -585,8 +589,8 @@ extern "C" int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_
 
     const int t_s = ze_timer_begin(e, 4, s);
     // first token from the prefill logits (no cache growth)
-    ze_launch_sample(e->dlogits, c.vocab, e->seen + (size_t)seq * c.vocab, pen, st, e->eos_dev, c.n_eos, c.pad_token_id,
-                     ign, 0, dev_out, e->dsample, s);
+    ze_launch_sample(e->dlogits + (size_t)seq * c.vocab, c.vocab, e->seen + (size_t)seq * c.vocab, pen, st, e->eos_dev,
+                     c.n_eos, c.pad_token_id, ign, 0, dev_out, e->dsample, s);
     ze_timer_end(e, t_s, s);
     ZE_KCHECK();
 
@@ -654,6 +658,150 @@ extern "C" int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_
         }
     }
     *n_out = n;
+    return ZE_OK;
+}
+
+// ================================================================== batched decode (BASELINE configs[2])
+// One token for each of n chains per step: the weights are streamed ONCE for the whole batch through the MFMA GEMM
+// path (rows = chains), each chain keeps its own KV cache / position / seen-set.  Rows are computed independently of
+// the batch composition (same per-element accumulation order for every tile shape), so a chain's tokens do not
+// depend on which other chains share its steps.
+static int upload_batch(ze_engine* e, const int32_t* seqs, int n, hipStream_t s) {
+    if (n <= 0 || n > e->cfg.max_seqs) return ze_fail(e, ZE_ERR_INVALID, "batch size out of range");
+    for (int i = 0; i < n; ++i) {
+        if (seqs[i] < 0 || seqs[i] >= e->cfg.max_seqs) return ze_fail(e, ZE_ERR_NOTFOUND, "sequence id out of range");
+        for (int j = 0; j < i; ++j)
+            if (seqs[j] == seqs[i]) return ze_fail(e, ZE_ERR_INVALID, "duplicate sequence id in a batch");
+        if (e->ctx_host[seqs[i]] + 1 > e->cfg.max_ctx) return ze_fail(e, ZE_ERR_NOMEM, "sequence exceeds max_ctx");
+    }
+    ZE_HIP(hipStreamSynchronize(s));
+    memcpy(e->d_host_ints + 64, seqs, (size_t)n * sizeof(int));
+    ZE_HIP(hipMemcpyAsync(e->bseq, e->d_host_ints + 64, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+    return ZE_OK;
+}
+
+static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_eos, int sample, hipStream_t s) {
+    const ze_config& c = e->cfg;
+    const int H = c.hidden, hd = e->head_dim, nq = c.heads * hd, nkv = c.kv_heads * hd, nqkv = nq + 2 * nkv;
+    const size_t seq_stride = (size_t)c.kv_heads * c.max_ctx * hd;
+    const float scale = 1.0f / sqrtf((float)hd);
+    ze_launch_embed_tokens_batch(e->st_dev, e->bseq, n, e->embed, e->th, H, s);
+    for (int li = 0; li < c.layers; ++li) {
+        const ze_text_layer& L = e->tl[li];
+        ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, n, H, c.rms_eps, s);
+        ze_launch_gemm(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, nullptr, n, nqkv,
+                       H, s);
+        ze_launch_rope_kv_batch(e->tqkv, n, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(li, 0),
+                                e->vc(li, 0), seq_stride, c.max_ctx, s);
+        ze_launch_attn_decode(e->tqkv, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, e->to, nq, e->st_dev, e->bseq, n,
+                              c.heads, c.kv_heads, hd, c.max_ctx, scale, e->bpartial, e->max_splits, s);
+        ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, n, H, nq, s);
+        ze_launch_rmsnorm(e->th, H, L.post_norm, e->ty, H, n, H, c.rms_eps, s);
+        ze_launch_gemm(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad,
+                       nullptr, n, 2 * e->text_ipad, H, s);
+        ze_launch_gemm(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, nullptr, n,
+                       H, e->text_ipad, s);
+    }
+    ze_launch_rmsnorm(e->th, H, e->final_norm, e->ty, H, n, H, c.rms_eps, s);
+    ze_launch_gemm(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, nullptr, n,
+                   c.vocab, H, s);
+    ze_launch_sample_batch(e->blogits, c.vocab, e->seen, penalty, e->st_dev, e->bseq, n, e->eos_dev, c.n_eos,
+                           c.pad_token_id, ignore_eos, 1, sample, e->out_tokens, c.max_ctx, e->bsample, s);
+    ZE_KCHECK();
+    return ZE_OK;
+}
+
+extern "C" int ze_decode_batch(ze_engine* e, const int32_t* seqs, int n, const int32_t* tokens, float* out_logits,
+                               void* stream) {
+    if (!e || !seqs) return ze_fail(e, ZE_ERR_INVALID, "null argument");
+    const ze_config& c = e->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    ZE_TRY(upload_batch(e, seqs, n, s));
+    if (tokens) {
+        for (int i = 0; i < n; ++i) {
+            if (tokens[i] >= c.vocab) return ze_fail(e, ZE_ERR_INVALID, "token id out of range");
+            if (tokens[i] >= 0) {
+                e->d_host_ints[16] = tokens[i];
+                ZE_HIP(hipMemcpyAsync(&(e->st_dev + seqs[i])->token, e->d_host_ints + 16, sizeof(int),
+                                      hipMemcpyHostToDevice, s));
+                ZE_HIP(hipStreamSynchronize(s));
+            }
+        }
+    }
+    const int th = ze_timer_begin(e, 3, s);
+    ZE_TRY(enqueue_decode_batch(e, n, 1.0f, 1, 0, s));
+    ze_timer_end(e, th, s);
+    for (int i = 0; i < n; ++i) e->ctx_host[seqs[i]] += 1;
+    if (out_logits)
+        ZE_HIP(hipMemcpyAsync(out_logits, e->blogits, (size_t)n * c.vocab * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return ZE_OK;
+}
+
+extern "C" int ze_generate_batch(ze_engine* e, const int32_t* seqs, int n, const ze_gen_params* p, int32_t* out_tokens,
+                                 int32_t* n_out, void* stream) {
+    if (!e || !seqs || !p || !out_tokens || !n_out) return ze_fail(e, ZE_ERR_INVALID, "null argument");
+    const ze_config& c = e->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    const int max_new = p->max_new_tokens;
+    if (max_new <= 0 || n <= 0) return ze_fail(e, ZE_ERR_INVALID, "max_new_tokens and n must be positive");
+    for (int i = 0; i < n; ++i) {
+        if (seqs[i] < 0 || seqs[i] >= c.max_seqs) return ze_fail(e, ZE_ERR_NOTFOUND, "sequence id out of range");
+        if (e->ctx_host[seqs[i]] + max_new - 1 > c.max_ctx) return ze_fail(e, ZE_ERR_NOMEM, "sequence exceeds max_ctx");
+    }
+    const float pen = p->repetition_penalty > 0.f ? p->repetition_penalty : 1.0f;
+    const int ign = p->ignore_eos ? 1 : 0;
+    // first token of every chain from the logits its prefill left behind
+    for (int i = 0; i < n; ++i) {
+        const int q = seqs[i];
+        ze_launch_sample(e->dlogits + (size_t)q * c.vocab, c.vocab, e->seen + (size_t)q * c.vocab, pen, e->st_dev + q,
+                         e->eos_dev, c.n_eos, c.pad_token_id, ign, 0, e->out_tokens + (size_t)q * c.max_ctx, e->dsample, s);
+    }
+    ZE_KCHECK();
+    std::vector<int> active(seqs, seqs + n);
+    std::vector<int> produced(c.max_seqs, 0);
+    for (int q : active) produced[q] = 1;
+    const int sync_every = std::max(1, p->sync_every);
+    const int td = ze_timer_begin(e, 3, s);
+    int steps = 1;
+    while (steps < max_new && !active.empty()) {
+        ZE_TRY(upload_batch(e, active.data(), (int)active.size(), s));
+        const int burst = std::min(sync_every, max_new - steps);
+        for (int i = 0; i < burst; ++i) ZE_TRY(enqueue_decode_batch(e, (int)active.size(), pen, ign, 1, s));
+        steps += burst;
+        for (int q : active) {
+            produced[q] += burst;
+            e->ctx_host[q] += burst;
+        }
+        if (!ign && steps < max_new) {  // drop the chains that emitted an EOS (continuous batching: others go on)
+            ZE_HIP(hipMemcpyAsync(e->bstate_host, e->st_dev, sizeof(ze_seq_dev) * c.max_seqs, hipMemcpyDeviceToHost, s));
+            ZE_HIP(hipStreamSynchronize(s));
+            std::vector<int> still;
+            for (int q : active)
+                if (!e->bstate_host[q].finished) still.push_back(q);
+            active.swap(still);
+        }
+    }
+    ze_timer_end(e, td, s);
+    ZE_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < n; ++i) {
+        const int q = seqs[i];
+        int32_t* dst = out_tokens + (size_t)i * max_new;
+        ZE_HIP(hipMemcpy(dst, e->out_tokens + (size_t)q * c.max_ctx, (size_t)produced[q] * sizeof(int), hipMemcpyDeviceToHost));
+        int cnt = produced[q];
+        if (!ign) {
+            for (int t = 0; t < produced[q]; ++t) {
+                bool is_eos = false;
+                for (int k = 0; k < c.n_eos; ++k) is_eos |= dst[t] == c.eos_token_ids[k];
+                if (is_eos) {
+                    cnt = t + 1;
+                    break;
+                }
+            }
+        }
+        n_out[i] = cnt;
+    }
     return ZE_OK;
 }
 

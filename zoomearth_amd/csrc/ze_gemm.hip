@@ -152,7 +152,10 @@ __global__ void __launch_bounds__(256) k_gemm_tn(const bf16_t* __restrict__ A, i
                 if (EPI == ZE_EPI_GELU) v = gelu_erf(v);
                 if (EPI == ZE_EPI_RESIDUAL) v = bf16_to_f32(R[(size_t)row * ldr + col]) + v;
                 const int orow = c_rows ? c_rows[row] : row;
-                C[(size_t)orow * ldc + col] = f32_to_bf16(v);
+                if (EPI == ZE_EPI_F32)  // fp32 copy of the bf16-rounded value (HF: logits.float())
+                    reinterpret_cast<float*>(C)[(size_t)orow * ldc + col] = v;
+                else
+                    C[(size_t)orow * ldc + col] = f32_to_bf16(v);
             }
         }
 }
@@ -171,6 +174,7 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
         case ZE_EPI_GELU: ZE_GEMM_LAUNCH(ZE_EPI_GELU); break;
         case ZE_EPI_RESIDUAL: ZE_GEMM_LAUNCH(ZE_EPI_RESIDUAL); break;
         case ZE_EPI_SWIGLU: ZE_GEMM_LAUNCH(ZE_EPI_SWIGLU); break;
+        case ZE_EPI_F32: ZE_GEMM_LAUNCH(ZE_EPI_F32); break;
     }
 #undef ZE_GEMM_LAUNCH
 }

@@ -3,7 +3,7 @@
 #include "ze_common.h"
 
 // GEMM epilogues
-enum { ZE_EPI_NONE = 0, ZE_EPI_GELU = 1, ZE_EPI_RESIDUAL = 2, ZE_EPI_SWIGLU = 3 };
+enum { ZE_EPI_NONE = 0, ZE_EPI_GELU = 1, ZE_EPI_RESIDUAL = 2, ZE_EPI_SWIGLU = 3, ZE_EPI_F32 = 4 };
 // decode GEMV epilogues
 enum { ZE_GV_QKV_ROPE = 0, ZE_GV_RESIDUAL = 1, ZE_GV_SWIGLU = 2, ZE_GV_LOGITS = 3, ZE_GV_PLAIN = 4 };
 
@@ -85,8 +85,11 @@ void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_row_stride, 
                           bf16_t* o, int o_row_stride, int o_head_stride, const int4* tiles, int n_tiles, int heads,
                           int group, float scale, int q_pos_offset, hipStream_t s);
 // Decode attention for one chain: q [heads, D]; caches [kv_heads, max_ctx, D]; context = st->ctx + 1 tokens.
-void ze_launch_attn_decode(const bf16_t* q, const bf16_t* kcache, const bf16_t* vcache, bf16_t* out,
-                           const ze_seq_dev* st, int heads, int kv_heads, int D, int max_ctx, float scale,
+// Batched form: n chains; chain b = seq_ids[b] (null: chain 0 is `st` itself), q/out rows b, caches offset by
+// seq * cache_seq_stride elements, partials offset by b * max_splits * heads * 132 floats.
+void ze_launch_attn_decode(const bf16_t* q, int q_row_stride, const bf16_t* kcache, const bf16_t* vcache,
+                           size_t cache_seq_stride, bf16_t* out, int out_row_stride, const ze_seq_dev* st,
+                           const int* seq_ids, int n, int heads, int kv_heads, int D, int max_ctx, float scale,
                            float* ws_partial, int max_splits, hipStream_t s);
 
 // ---- sampling
@@ -94,4 +97,13 @@ void ze_launch_sample(const float* logits, int vocab, uint8_t* seen, float penal
                       const int* eos_ids, int n_eos, int pad_id, int ignore_eos, int advance_ctx,
                       int32_t* out_tokens, float* ws, hipStream_t s);
 void ze_launch_advance_ctx(ze_seq_dev* st, hipStream_t s);
+// batched decode helpers (one token for each of n chains)
+void ze_launch_embed_tokens_batch(const ze_seq_dev* st, const int* seq_ids, int n, const bf16_t* embed, bf16_t* out,
+                                  int hidden, hipStream_t s);
+void ze_launch_rope_kv_batch(bf16_t* qkv, int n, int heads, int kv_heads, int D, const bf16_t* cosT, const bf16_t* sinT,
+                             const ze_seq_dev* st, const int* seq_ids, bf16_t* kcache, bf16_t* vcache,
+                             size_t cache_seq_stride, int max_ctx, hipStream_t s);
+void ze_launch_sample_batch(const float* logits, int vocab, uint8_t* seen_base, float penalty, ze_seq_dev* st,
+                            const int* seq_ids, int n, const int* eos_ids, int n_eos, int pad_id, int ignore_eos,
+                            int advance_ctx, int sample, int32_t* out_tokens_base, int max_gen, float* ws, hipStream_t s);
 void ze_launch_mark_seen(uint8_t* seen, const int* ids, int n, hipStream_t s);

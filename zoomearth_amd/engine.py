@@ -237,6 +237,23 @@ class Engine:
         self._check(self.lib.ze_generate(self.h, seq, C.byref(p), out, C.byref(n), self._stream()))
         return [int(out[i]) for i in range(n.value)]
 
+    def decode_batch(self, seqs, tokens=None, want_logits: bool = True):
+        sq, sp = _i32(seqs)
+        tk, tp = _i32(tokens) if tokens is not None else (None, None)
+        logits = torch.empty((len(sq), self.config.text.vocab_size), dtype=torch.float32, device=self.device) if want_logits else None
+        self._check(self.lib.ze_decode_batch(self.h, sp, len(sq), tp, _ptr(logits), self._stream()))
+        return logits
+
+    def generate_batch(self, seqs, max_new_tokens: int, repetition_penalty: float = 1.0, ignore_eos: bool = False,
+                       sync_every: int = 16):
+        """Greedy generation for several prefilled chains at once; returns one token list per chain."""
+        sq, sp = _i32(seqs)
+        p = _lib.ZeGenParams(max_new_tokens, repetition_penalty, int(ignore_eos), 0, sync_every)
+        out = (C.c_int32 * (len(sq) * max_new_tokens))()
+        n_out = (C.c_int32 * len(sq))()
+        self._check(self.lib.ze_generate_batch(self.h, sp, len(sq), C.byref(p), out, n_out, self._stream()))
+        return [[int(out[i * max_new_tokens + t]) for t in range(n_out[i])] for i in range(len(sq))]
+
     def sample_greedy(self, seq: int, logits: torch.Tensor, repetition_penalty: float = 1.0) -> int:
         tok = C.c_int32()
         self._check(self.lib.ze_op_sample_greedy(self.h, seq, _ptr(logits), repetition_penalty, C.byref(tok),

@@ -116,39 +116,45 @@ class ZoomEarthForConditionalGeneration:
         pen = repetition_penalty if repetition_penalty is not None else getattr(self.generation_config, "repetition_penalty", 1.0) or 1.0
         gi = 0
         outs = []
-        for b in range(ids_cpu.shape[0]):
+        nrows = ids_cpu.shape[0]
+        batched = nrows > 1
+        if batched and nrows > e.max_seqs:
+            raise ValueError(f"batch of {nrows} rows needs max_seqs >= {nrows} (engine has {e.max_seqs})")
+        if batched:  # every row gets its own chain slot; the decode steps then run as one batch
+            self._chains.clear()
+            self._next_slot = 0
+        slots = []
+        for b in range(nrows):
             ids = ids_cpu[b][mask[b]].astype(np.int64).tolist()
             is_img = np.asarray(ids) == cfg.image_token_id
-            n_img = int((is_img & ~np.roll(is_img, 1)).sum()) if is_img.any() else 0
-            if is_img.any() and is_img[0]:
-                n_img = int((is_img[1:] & ~is_img[:-1]).sum()) + 1
+            starts = is_img & ~np.concatenate([[False], is_img[:-1]])
+            n_img = int(starts.sum())
             my = list(range(gi, gi + n_img))
             gi += n_img
             if gi > len(grids):
                 raise ValueError("Image features and image tokens do not match")
             my_grids = [grids[i] for i in my]
             my_keys = [keys[i] for i in my]
-            slot, reuse = self._pick_slot(ids, my_keys)
-            n_img_reused = int(((np.asarray(ids[:reuse]) == cfg.image_token_id)
-                                & ~(np.roll(np.asarray(ids[:reuse]) == cfg.image_token_id, 1))).sum()) if reuse else 0
+            slot, reuse = (b, 0) if batched else self._pick_slot(ids, my_keys)
+            pre = np.asarray(ids[:reuse]) == cfg.image_token_id
+            n_img_reused = int((pre & ~np.concatenate([[False], pre[:-1]])).sum()) if reuse else 0
             feats = [self._features(pixel_values[offs[i]:offs[i + 1]], grids[i], keys[i]) for i in my[n_img_reused:]]
             emb = (torch.cat(feats) if len(feats) > 1 else feats[0]) if feats else None
             pos, delta = e.rope_index(ids, my_grids)
             if reuse:
-                e.seq_truncate(slot, reuse)
+                e.seq_truncate(slot, reuse)  # also clears the chain's seen-set
             else:
                 e.seq_reset(slot)
-                e.mark_seen(slot, ids[:0])
             e.prefill(slot, ids[reuse:], emb, pos[:, reuse:], delta, want_logits=False)
             if pen != 1.0:
-                if reuse:
-                    # the seen-set of the slot still holds the previous generation: rebuild it from the prompt
-                    e.seq_truncate(slot, len(ids))
                 e.mark_seen(slot, ids)
-            self._chains[slot] = (tuple(ids), tuple(my_keys))
-            self._chains.move_to_end(slot)
-            toks = e.generate(slot, max_new_tokens, repetition_penalty=pen, ignore_eos=ignore_eos)
-            outs.append(toks)
+            if not batched:
+                self._chains[slot] = (tuple(ids), tuple(my_keys))
+                self._chains.move_to_end(slot)
+                outs.append(e.generate(slot, max_new_tokens, repetition_penalty=pen, ignore_eos=ignore_eos))
+            slots.append(slot)
+        if batched:
+            outs = e.generate_batch(slots, max_new_tokens, repetition_penalty=pen, ignore_eos=ignore_eos)
         width = max(len(t) for t in outs)
         pad = cfg.pad_token_id
         res = torch.full((ids_cpu.shape[0], ids_cpu.shape[1] + width), pad, dtype=torch.long)
