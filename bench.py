@@ -171,8 +171,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("ZE_BENCH_FORCE_DIST") == "1"  # the env flag exercises RCCL at N=1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
 
@@ -186,7 +188,7 @@ def main():
     for kv in os.environ.get("ZE_TUNE", "").split(","):  # measurement-only A/B knobs, e.g. ZE_TUNE=2:64
         if ":" in kv:
             e.lib.ze_tune(int(kv.split(":")[0]), int(kv.split(":")[1]))
-    if world > 1:
+    if use_dist:
         arena = e.weights_arena()
         t0 = time.perf_counter()
         dist.broadcast(arena, src=0)  # the path's only collective: one-time weight broadcast over RCCL/xGMI
@@ -199,7 +201,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -216,7 +218,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     phases = e.phase_timers(enable=False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -252,7 +254,7 @@ def main():
                          "avg_us": us, "bytes_per_launch": by, "other_decode_kernels": others},
             "phase_ms_per_question": {k: round(v / args.steps, 3) for k, v in phases.items()},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             try:
                 line["cpu_baseline"] = cpu_baseline()
             except Exception as ex:  # pragma: no cover
@@ -260,7 +262,7 @@ def main():
                                         "sample": f"failed: {ex}"}
         print(json.dumps(line), flush=True)
     e.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

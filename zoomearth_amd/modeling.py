@@ -48,7 +48,11 @@ class ZoomEarthForConditionalGeneration:
             dev = int(os.environ["LOCAL_RANK"])
         engine = Engine(config, device=dev, max_seqs=max_seqs, max_ctx=max_ctx, max_patches=max_patches,
                         max_tile_side=max_tile_side)
-        engine.load_state_dict(iter_checkpoint(path))
+        try:
+            engine.load_state_dict(iter_checkpoint(path))
+        except Exception:
+            engine.close()
+            raise
         gen = SimpleNamespace(temperature=None, top_p=None, top_k=None, repetition_penalty=1.0, do_sample=False,
                               eos_token_id=list(config.eos_token_ids), pad_token_id=config.pad_token_id)
         gp = os.path.join(path, "generation_config.json")
