@@ -104,6 +104,9 @@ struct ze_engine {
     float *dlogits = nullptr, *dpartial = nullptr, *dsample = nullptr;
     int max_splits = 64;
     int* d_host_ints = nullptr;  // pinned, small
+    // split-K GEMM workspace
+    float* gslab = nullptr;
+    unsigned* gtickets = nullptr;
     // batched decode
     int* bseq = nullptr;
     float *blogits = nullptr, *bpartial = nullptr, *bsample = nullptr;

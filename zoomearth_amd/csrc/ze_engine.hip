@@ -309,6 +309,12 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     chk(dev_alloc(e, &e->dattn, (size_t)c.heads * e->head_dim));
     chk(dev_alloc(e, &e->dact, e->text_ipad));
     chk(dev_alloc(e, &e->dlogits, (size_t)c.max_seqs * c.vocab));
+    {
+        const size_t slab_floats = (size_t)16 << 20;  // 64 MB of fp32 split-K slabs
+        chk(dev_alloc(e, &e->gslab, slab_floats, false));
+        chk(dev_alloc(e, &e->gtickets, 4096, true));
+        if (r == 0) ze_gemm_set_workspace(e->gslab, slab_floats, e->gtickets, 4096);
+    }
     chk(dev_alloc(e, &e->bseq, c.max_seqs));
     chk(dev_alloc(e, &e->blogits, (size_t)c.max_seqs * c.vocab));
     chk(dev_alloc(e, &e->bpartial, (size_t)c.max_seqs * e->max_splits * c.heads * 132));
@@ -349,7 +355,7 @@ extern "C" int ze_engine_destroy(ze_engine* e) {
                    e->st_dev, e->seen, e->out_tokens, e->fe_tmp, e->fe_img, e->fe_coef, e->vx, e->vh, e->vy, e->vqkv,
                    e->vo, e->va, e->vz, e->vz2, e->vcos, e->vsin, e->vperm, e->vinv, e->vtiles_win, e->vtiles_full,
                    e->th, e->ty, e->tqkv, e->to, e->ta, e->tsrc, e->tpos, e->ttiles, e->dh, e->dq, e->dattn, e->dact,
-                   e->dlogits, e->dpartial, e->dsample, e->bseq, e->blogits, e->bpartial, e->bsample};
+                   e->dlogits, e->dpartial, e->dsample, e->gslab, e->gtickets, e->bseq, e->blogits, e->bpartial, e->bsample};
     for (void* p : dev)
         if (p) hipFree(p);
     void* host[] = {e->fe_coef_host, e->v_host_ints, e->v_host_f32, e->t_host_ints, e->d_host_ints, e->bstate_host};

@@ -22,7 +22,8 @@ template <int BM, int BN, int EPI>
 __global__ void __launch_bounds__(256) k_gemm_tn(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
                                                  int ldw, const bf16_t* __restrict__ bias,
                                                  const bf16_t* __restrict__ R, int ldr, bf16_t* __restrict__ C,
-                                                 int ldc, const int* __restrict__ c_rows, int M, int N, int K) {
+                                                 int ldc, const int* __restrict__ c_rows, int M, int N, int K,
+                                                 int ksplit, float* __restrict__ slab, unsigned* __restrict__ tickets) {
     constexpr int TM = BM / 32, TN = BN / 32;        // MFMA tiles per wave
     constexpr int A_LOADS = BM * 8 / 256;            // uint4 per thread per K-tile
     constexpr int B_LOADS = BN * 8 / 256;
@@ -33,7 +34,8 @@ __global__ void __launch_bounds__(256) k_gemm_tn(const bf16_t* __restrict__ A, i
     // XCD-aware block remap: consecutive remapped ids (sharing the A row panel) land on one XCD's L2
     const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
     const int nwg = nbx * nby;
-    int bid = blockIdx.x;
+    const int ks = blockIdx.x / nwg;  // split-K slice of this block (all slices of a tile share its output)
+    int bid = blockIdx.x % nwg;
     {
         const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -80,14 +82,17 @@ __global__ void __launch_bounds__(256) k_gemm_tn(const bf16_t* __restrict__ A, i
         }
     };
 
-    const int nk = (K + GEMM_BK - 1) / GEMM_BK;
-    load_tiles(0);
+    const int nk_all = (K + GEMM_BK - 1) / GEMM_BK;
+    const int nk_per = (nk_all + ksplit - 1) / ksplit;
+    const int kt0 = ks * nk_per;
+    const int nk = max(0, min(nk_all - kt0, nk_per));
+    load_tiles(kt0 * GEMM_BK);
     store_tiles(0);
     __syncthreads();
     const int fr = lane & 15, fq = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles((kt + 1) * GEMM_BK);
+        if (kt + 1 < nk) load_tiles((kt0 + kt + 1) * GEMM_BK);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int chunk = ks * 4 + fq;
@@ -112,6 +117,53 @@ __global__ void __launch_bounds__(256) k_gemm_tn(const bf16_t* __restrict__ A, i
         }
         if (kt + 1 < nk) store_tiles(buf ^ 1);
         __syncthreads();
+    }
+
+    // ---------------- split-K: deterministic reduction by the last-arriving slice of the tile.
+    // Every slice parks its fp32 accumulators in a slab (one float4 per thread per MFMA tile), publishes them with an
+    // agent-scope release + ticket; the block that draws the last ticket acquires, adds the slabs IN SLICE ORDER
+    // (bit-reproducible, independent of arrival order) and runs the epilogue.  (cdna_hip_programming.md, Projection
+    // GEMM item 2: one release + one acquire per tile episode, never __threadfence per call.)
+    if (ksplit > 1) {
+        float4* my = reinterpret_cast<float4*>(slab) + ((size_t)(ks * nwg + bid) * 256 + tid) * (TM * TN);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) my[i * TN + j] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* flag = reinterpret_cast<unsigned*>(smem);  // the staging buffers are dead now
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned old = __hip_atomic_fetch_add(&tickets[bid], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned last = (old == (unsigned)ksplit - 1u) ? 1u : 0u;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&tickets[bid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            }
+            *flag = last;
+        }
+        __syncthreads();
+        if (*flag == 0u) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < ksplit; ++q) {
+            const float4* src = reinterpret_cast<const float4*>(slab) + ((size_t)(q * nwg + bid) * 256 + tid) * (TM * TN);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float4 v = src[i * TN + j];
+                    acc[i][j][0] += v.x;
+                    acc[i][j][1] += v.y;
+                    acc[i][j][2] += v.z;
+                    acc[i][j][3] += v.w;
+                }
+        }
     }
 
     // ---------------- epilogue: acc[i][j][r] -> row = wm0 + i*16 + fq*4 + r, col = wn0 + j*16 + fr
@@ -160,15 +212,38 @@ __global__ void __launch_bounds__(256) k_gemm_tn(const bf16_t* __restrict__ A, i
         }
 }
 
+// split-K workspace (fp32 slabs + per-tile tickets), owned by the engine and passed once
+static float* g_slab = nullptr;
+static unsigned* g_tickets = nullptr;
+static size_t g_slab_floats = 0;
+static int g_ticket_cap = 0;
+void ze_gemm_set_workspace(float* slab, size_t slab_floats, unsigned* tickets, int ticket_cap) {
+    g_slab = slab;
+    g_slab_floats = slab_floats;
+    g_tickets = tickets;
+    g_ticket_cap = ticket_cap;
+}
+
 template <int BM, int BN>
 static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,
                        const bf16_t* R, int ldr, bf16_t* C, int ldc, const int* c_rows, int M, int N, int K,
-                       hipStream_t s) {
-    const int grid = ze_cdiv(M, BM) * ze_cdiv(N, BN);
+                       hipStream_t s, bool stream_mode) {
+    const int nwg = ze_cdiv(M, BM) * ze_cdiv(N, BN);
+    // Split K only in weight-streaming mode (batched decode, few rows): the slice count is a function of (N, K)
+    // alone -- computed for ONE row tile -- so a chain's result never depends on how many chains share the step.
+    // Prefill / ViT never split: their accumulation order must not depend on M (prefix-KV reuse is bit-exact).
+    int ksplit = 1;
+    if (stream_mode) {
+        const int nk = ze_cdiv(K, GEMM_BK);
+        const int tiles_n = ze_cdiv(N, BN);
+        while (tiles_n * ksplit < 200 && ksplit < 8 && nk / (ksplit * 2) >= 4) ksplit *= 2;
+    }
+    if (ksplit > 1 && (!g_slab || (size_t)ksplit * nwg * BM * BN > g_slab_floats || nwg > g_ticket_cap)) ksplit = 1;
+    const int grid = nwg * ksplit;
     const size_t lds = (size_t)2 * (BM + BN) * 8 * 16;
 #define ZE_GEMM_LAUNCH(E)                                                                                          \
     hipLaunchKernelGGL((k_gemm_tn<BM, BN, E>), dim3(grid), dim3(256), lds, s, A, lda, W, ldw, bias, R, ldr, C, ldc, \
-                       c_rows, M, N, K)
+                       c_rows, M, N, K, ksplit, g_slab, g_tickets)
     switch (epi) {
         case ZE_EPI_NONE: ZE_GEMM_LAUNCH(ZE_EPI_NONE); break;
         case ZE_EPI_GELU: ZE_GEMM_LAUNCH(ZE_EPI_GELU); break;
@@ -179,16 +254,22 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
 #undef ZE_GEMM_LAUNCH
 }
 
+void ze_launch_gemm_stream(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,
+                           const bf16_t* R, int ldr, bf16_t* C, int ldc, int M, int N, int K, hipStream_t s) {
+    if (M <= 0 || N <= 0) return;
+    launch_cfg<64, 64>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s, true);
+}
+
 void ze_launch_gemm(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
                     int ldr, bf16_t* C, int ldc, const int* c_rows, int M, int N, int K, hipStream_t s) {
     if (M <= 0 || N <= 0) return;
-    // pick the largest tile that still gives the 256 CUs about one block each
+    // pick the largest tile that still gives the 256 CUs about one block each (split-K covers the rest)
     const long b128 = (long)ze_cdiv(M, 128) * ze_cdiv(N, 128);
     const long b64x128 = (long)ze_cdiv(M, 64) * ze_cdiv(N, 128);
     if (b128 >= 200)
-        launch_cfg<128, 128>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s);
+        launch_cfg<128, 128>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, false);
     else if (b64x128 >= 160)
-        launch_cfg<64, 128>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s);
+        launch_cfg<64, 128>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, false);
     else
-        launch_cfg<64, 64>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s);
+        launch_cfg<64, 64>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, false);
 }

@@ -53,6 +53,12 @@ void ze_launch_scatter_rows(const bf16_t* src, int lds_, const int* dst_idx, bf1
 void ze_launch_gemm(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
                     int ldr, bf16_t* C, int ldc, const int* c_rows, int M, int N, int K, hipStream_t s);
 
+// Weight-streaming form for batched decode (few rows): 64x64 tiles, deterministic split-K chosen from (N, K) only.
+void ze_launch_gemm_stream(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,
+                           const bf16_t* R, int ldr, bf16_t* C, int ldc, int M, int N, int K, hipStream_t s);
+// split-K workspace: fp32 slabs (>= ksplit * tiles * BM * BN floats) and zero-initialised per-tile tickets
+void ze_gemm_set_workspace(float* slab, size_t slab_floats, unsigned* tickets, int ticket_cap);
+
 // ---- decode GEMV family (batch-1 weight streaming)
 struct ze_gemv_args {
     const bf16_t* W;      // [N, ldw] packed weight
