@@ -90,6 +90,50 @@ class Chain:
         return out1, out2, len(ids1), len(ids2)
 
 
+class BatchChain(Chain):
+    """B question chains advanced together (BASELINE configs[2]): one multi-image ViT call per stage, per-chain
+    prefill, batched decode where the weights are streamed once per step for all chains."""
+
+    def questions(self, q0: int, B: int):
+        e, cfg, H = self.e, self.e.config, self.H
+        side = self.side
+        s = 512 / side
+        view = e.crop_resize(self.tile, (0, 0, side, side), (int(side * s), int(side * s)))
+        pv_v, g_v = e.preprocess_image(view)
+        emb_v = e.vit_forward(pv_v, [g_v])  # the B questions of this step are about the same tile: one view
+        n_img = g_v[1] * g_v[2] // 4
+        ids1 = [question_ids(cfg, q0 + b, n_img) for b in range(B)]
+        for b in range(B):
+            pos, delta = e.rope_index(ids1[b], [g_v])
+            e.seq_reset(b)
+            e.prefill(b, ids1[b], emb_v, pos, delta, want_logits=False)
+            e.mark_seen(b, ids1[b])
+        out1 = e.generate_batch(list(range(B)), N1, repetition_penalty=PENALTY, ignore_eos=True, sync_every=N1)
+        # zoom crops (different sizes -> dynamic-resolution ViT batch)
+        pvs, grids = [], []
+        for b in range(B):
+            box = H.zoom_box((side, side), scripted_bbox(q0 + b, side))
+            bw, bh = box[2] - box[0], box[3] - box[1]
+            sc = min(1.0, 512 / max(bw, bh))
+            crop = e.crop_resize(self.tile, box, (int(bw * sc), int(bh * sc)) if sc < 1 else (bw, bh))
+            pv, g = e.preprocess_image(crop)
+            pvs.append(pv)
+            grids.append(g)
+        import torch
+        emb_c = e.vit_forward(torch.cat(pvs), grids)
+        off = 0
+        for b in range(B):
+            n_c = grids[b][1] * grids[b][2] // 4
+            ids2 = ids1[b] + out1[b] + [cfg.vision_start_token_id] + [cfg.image_token_id] * n_c + [cfg.vision_end_token_id]
+            pos2, delta2 = e.rope_index(ids2, [g_v, grids[b]])
+            e.seq_truncate(b, len(ids1[b]))
+            e.prefill(b, ids2[len(ids1[b]):], emb_c[off:off + n_c].contiguous(), pos2[:, len(ids1[b]):], delta2, want_logits=False)
+            e.mark_seen(b, ids2)
+            off += n_c
+        out2 = e.generate_batch(list(range(B)), N2, repetition_penalty=PENALTY, ignore_eos=True, sync_every=N2)
+        return out1, out2, len(ids1[0]), len(ids1[0]) + N1 + 326
+
+
 def cpu_baseline(budget_s: float = 45.0):
     """The oracle (numpy port of the reference arithmetic, fp32 BLAS on all host cores) on a bounded sample,
     extrapolated by layer count to the question AS THE REFERENCE EXECUTES IT (no reuse: 3 view encodes, 802- and
@@ -163,6 +207,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tile", type=int, default=5000)
+    ap.add_argument("--batch", type=int, default=1, help="question chains advanced together (1 = BASELINE configs[1]; >1 = configs[2])")
     args = ap.parse_args()
 
     import torch
@@ -183,7 +228,8 @@ def main():
     from zoomearth_amd.engine import Engine
 
     cfg = ModelConfig.zoomearth_3b()
-    e = Engine(cfg, device=local, max_seqs=1, max_ctx=2048, max_patches=4096, max_tile_side=max(args.tile, 1024))
+    e = Engine(cfg, device=local, max_seqs=max(1, args.batch), max_ctx=2048, max_patches=max(4096, 1400 * args.batch),
+               max_tile_side=max(args.tile, 1024))
     e.fill_synthetic(seed=0, std=0.02)
     for kv in os.environ.get("ZE_TUNE", "").split(","):  # measurement-only A/B knobs, e.g. ZE_TUNE=2:64
         if ":" in kv:
@@ -197,7 +243,7 @@ def main():
     else:
         bcast_s = 0.0
     tile = torch.from_numpy(synthetic_tile(1000 + rank, args.tile, args.tile)).to(f"cuda:{local}")
-    chain = Chain(e, tile, use_graph=not args.no_graph)
+    chain = Chain(e, tile, use_graph=not args.no_graph) if args.batch <= 1 else BatchChain(e, tile)
 
     def barrier():
         torch.cuda.synchronize()
@@ -206,14 +252,22 @@ def main():
             torch.cuda.synchronize()
 
     q0 = rank * 100000
+    B = max(1, args.batch)
+
+    def run_step(q):
+        if B == 1:
+            return chain.question(q)
+        o1, o2, l1, l2 = chain.questions(q * B, B)
+        return o1[0], o2[0], l1, l2
+
     for i in range(args.warmup):
-        chain.question(q0 + i)
+        run_step(q0 + i)
     e.phase_timers(enable=True, reset=True)
     barrier()
     t0 = time.perf_counter()
     lens = None
     for i in range(args.steps):
-        out1, out2, l1, l2 = chain.question(q0 + args.warmup + i)
+        out1, out2, l1, l2 = run_step(q0 + args.warmup + i)
         lens = (l1, l2, len(out1), len(out2))
     barrier()
     dt = time.perf_counter() - t0
@@ -239,12 +293,15 @@ def main():
                 tj = json.load(f)
             traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/traffic_latest.json (rocprofv3 --pmc, round %d)" % tj["round"]
         line = {
-            "metric": "questions/sec end-to-end, ZoomEarth-3B on 5000px tiles", "value": world * args.steps / dt,
+            "metric": "questions/sec end-to-end, ZoomEarth-3B on 5000px tiles", "value": world * args.steps * B / dt,
             "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: ZoomEarth-3B shape, one 5000x5000 tile per GPU, full two-stage "
-                                   "zoom chain per question, greedy, batch 1",
+            "config": {"workload": ("BASELINE configs[1]: ZoomEarth-3B shape, one 5000x5000 tile per GPU, full two-stage "
+                                    "zoom chain per question, greedy, batch 1") if B == 1 else
+                                   (f"BASELINE configs[2]: ZoomEarth-3B shape, {B} question chains advanced together per GPU "
+                                    "(batched decode, dynamic-resolution ViT batch), one step = %d questions" % B),
+                       "batch": B,
                        "tile": [args.tile, args.tile], "L1": lens[0], "L2": lens[1], "N1": lens[2], "N2": lens[3],
                        "repetition_penalty": PENALTY, "hip_graph": not args.no_graph,
                        "reuse": "stage-1 prompt KV and view features reused in stage 2 (bit-identical)",

@@ -13,6 +13,7 @@
 //   workspaces    ViT activations for max_patches rows; prefill activations for max_ctx rows; decode vectors
 #pragma once
 #include <map>
+#include <tuple>
 #include <set>
 #include <string>
 #include <vector>
@@ -111,6 +112,7 @@ struct ze_engine {
     int* bseq = nullptr;
     float *blogits = nullptr, *bpartial = nullptr, *bsample = nullptr;
     ze_seq_dev* bstate_host = nullptr;  // pinned
+    std::map<std::tuple<int, float, int>, hipGraphExec_t> bgraphs;  // captured batched decode step per batch size
 
     // timers
     bool timers_on = false;

@@ -343,6 +343,8 @@ extern "C" int ze_engine_destroy(ze_engine* e) {
     hipDeviceSynchronize();
     for (auto g : e->graphs)
         if (g) hipGraphExecDestroy(g);
+    for (auto& kv : e->bgraphs)
+        if (kv.second) hipGraphExecDestroy(kv.second);
     for (auto& p : e->ev_used) {
         hipEventDestroy(p.a);
         hipEventDestroy(p.b);

@@ -767,7 +767,37 @@ extern "C" int ze_generate_batch(ze_engine* e, const int32_t* seqs, int n, const
     while (steps < max_new && !active.empty()) {
         ZE_TRY(upload_batch(e, active.data(), (int)active.size(), s));
         const int burst = std::min(sync_every, max_new - steps);
-        for (int i = 0; i < burst; ++i) ZE_TRY(enqueue_decode_batch(e, (int)active.size(), pen, ign, 1, s));
+        const int na = (int)active.size();
+        hipGraphExec_t gx = nullptr;
+        if (p->use_graph) {  // one captured step per batch size (chain ids / positions live in device memory)
+            auto key = std::make_tuple(na, pen, ign);
+            auto it = e->bgraphs.find(key);
+            if (it == e->bgraphs.end()) {
+                hipStream_t cs;
+                ZE_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+                hipGraph_t graph = nullptr;
+                int r = ZE_OK;
+                if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess)
+                    r = ze_fail(e, ZE_ERR_HIP, "hipStreamBeginCapture failed");
+                if (r == ZE_OK) r = enqueue_decode_batch(e, na, pen, ign, 1, cs);
+                if (hipStreamEndCapture(cs, &graph) != hipSuccess && r == ZE_OK)
+                    r = ze_fail(e, ZE_ERR_HIP, "hipStreamEndCapture failed");
+                hipGraphExec_t ex = nullptr;
+                if (r == ZE_OK && hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0) != hipSuccess)
+                    r = ze_fail(e, ZE_ERR_HIP, "hipGraphInstantiate failed");
+                if (graph) hipGraphDestroy(graph);
+                hipStreamDestroy(cs);
+                ZE_TRY(r);
+                it = e->bgraphs.emplace(key, ex).first;
+            }
+            gx = it->second;
+        }
+        for (int i = 0; i < burst; ++i) {
+            if (gx)
+                ZE_HIP(hipGraphLaunch(gx, s));
+            else
+                ZE_TRY(enqueue_decode_batch(e, na, pen, ign, 1, s));
+        }
         steps += burst;
         for (int q : active) {
             produced[q] += burst;

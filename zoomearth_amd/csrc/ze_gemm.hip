@@ -13,6 +13,7 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define GEMM_BK 64
 
@@ -125,17 +126,28 @@ __global__ void __launch_bounds__(256) k_gemm_tn(const bf16_t* __restrict__ A, i
     // (bit-reproducible, independent of arrival order) and runs the epilogue.  (cdna_hip_programming.md, Projection
     // GEMM item 2: one release + one acquire per tile episode, never __threadfence per call.)
     if (ksplit > 1) {
-        float4* my = reinterpret_cast<float4*>(slab) + ((size_t)(ks * nwg + bid) * 256 + tid) * (TM * TN);
+        // slabs go out WRITE-THROUGH (sc1 buffer stores): no L2 write-back fence is needed before the ticket
+        // (publish-large: 3.0 us vs 8.2 us for plain stores + release fence at 64 KB per workgroup)
+        {
+            const size_t slab_bytes = (size_t)ksplit * nwg * 256 * (TM * TN) * 16;
+            auto rsrc = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)min(slab_bytes, (size_t)0x7fffffff), 0x00020000);
+            const unsigned base = (unsigned)((((size_t)(ks * nwg + bid) * 256 + tid) * (TM * TN)) * 16);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) my[i * TN + j] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (int j = 0; j < TN; ++j) {
+                    u32x4 v;
+                    v.x = __float_as_uint(acc[i][j][0]);
+                    v.y = __float_as_uint(acc[i][j][1]);
+                    v.z = __float_as_uint(acc[i][j][2]);
+                    v.w = __float_as_uint(acc[i][j][3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, base + (unsigned)(i * TN + j) * 16, 0, 16 /* sc1 */);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the ticket
         __syncthreads();
         unsigned* flag = reinterpret_cast<unsigned*>(smem);  // the staging buffers are dead now
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned old = __hip_atomic_fetch_add(&tickets[bid], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned last = (old == (unsigned)ksplit - 1u) ? 1u : 0u;
             if (last) {

@@ -245,10 +245,10 @@ class Engine:
         return logits
 
     def generate_batch(self, seqs, max_new_tokens: int, repetition_penalty: float = 1.0, ignore_eos: bool = False,
-                       sync_every: int = 16):
+                       sync_every: int = 16, use_graph: bool = True):
         """Greedy generation for several prefilled chains at once; returns one token list per chain."""
         sq, sp = _i32(seqs)
-        p = _lib.ZeGenParams(max_new_tokens, repetition_penalty, int(ignore_eos), 0, sync_every)
+        p = _lib.ZeGenParams(max_new_tokens, repetition_penalty, int(ignore_eos), int(use_graph), sync_every)
         out = (C.c_int32 * (len(sq) * max_new_tokens))()
         n_out = (C.c_int32 * len(sq))()
         self._check(self.lib.ze_generate_batch(self.h, sp, len(sq), C.byref(p), out, n_out, self._stream()))
