@@ -205,6 +205,9 @@ void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_rs, int q_hs
 //   B  softmax statistics per head over the 64 scores (one wave handles two heads, wavefront max / sum).
 //   C  thread (head, 4-dim slice) accumulates sum_t p[t] * V[t] from LDS: no cross-thread reduction at the end.
 // Partials (m, l, o[128]) per (split, head) go to a workspace; k_attn_decode_combine merges the splits.
+// (Measured alternative, rejected: merging in the last-arriving slice block -- sc1 partial stores + ticket + agent
+//  acquire, as the split-K GEMM does -- removed the combine launch but cost 30 ms more per question: the acquire
+//  and the re-read of 90 KB of partials through memory are slower than the 4.8-us combine kernel.)
 #define AD_GMAX 8
 #define AD_STRIDE 132  // floats per (split, head) partial: m, l, pad, pad, o[128]
 #define AD_TOK 64
