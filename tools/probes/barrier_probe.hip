@@ -52,6 +52,46 @@ __device__ __forceinline__ bool bar_xcd(hbar* b, u32 xcc, u32 per_xcd, u32 nxcd,
     return ok;
 }
 
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+// fence-free hierarchical barrier: the payload is published write-through (sc1) and read with sc1 loads, so the
+// barrier itself is only atomics + polls (no buffer_wbl2 / buffer_inv)
+template <int SLEEP>
+__device__ __forceinline__ bool bar_xcd_nofence(hbar* b, u32 xcc, u32 per_xcd, u32 nxcd, u32 epoch, u32* timeout) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's sc1 stores have left
+    __syncthreads();
+    bool ok = true;
+    if (threadIdx.x == 0) {
+        const u32 old = __hip_atomic_fetch_add(&b->xcd_cnt[xcc * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u32 spins = 0;
+        if (old == epoch * per_xcd - 1) {
+            __hip_atomic_fetch_add(&b->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (ld_relaxed(&b->top[0]) < epoch * nxcd) { if (SLEEP) __builtin_amdgcn_s_sleep(SLEEP); if (++spins > 4000000u) { *timeout = 2; ok = false; break; } }
+            __hip_atomic_store(&b->xcd_gen[xcc * 32], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (ld_relaxed(&b->xcd_gen[xcc * 32]) < epoch) { if (SLEEP) __builtin_amdgcn_s_sleep(SLEEP); if (++spins > 4000000u) { *timeout = 3; ok = false; break; } }
+        }
+    }
+    __syncthreads();
+    return ok;
+}
+template <int SLEEP>
+__global__ void __launch_bounds__(256) k_xcd_nf(hbar* b, const u32* census, int iters, u32* timeout, float* data, u32* mism) {
+    const u32 xcc = xcc_id();
+    const u32 per = census[xcc];
+    u32 nx = 0;
+    for (int i = 0; i < 8; ++i) nx += census[i] > 0;
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(data, 0, 256 * 256 * 4, 0x00020000);
+    for (int i = 0; i < iters; ++i) {
+        // publish 4 B per thread with an sc1 dword store
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)(i + 1)), rsrc, (blockIdx.x * 256 + threadIdx.x) * 4, 0, 16);
+        if (!bar_xcd_nofence<SLEEP>(b, xcc, per, nx, (u32)(2 * i + 1), timeout)) return;
+        const int other = (blockIdx.x * 37 + 11 + i) % gridDim.x;
+        const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (other * 256 + threadIdx.x) * 4, 0, 16));
+        if (v < (float)(i + 1)) atomicAdd(mism, 1u);
+        if (!bar_xcd_nofence<SLEEP>(b, xcc, per, nx, (u32)(2 * i + 2), timeout)) return;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_flat(u32* ctr, int iters, u32* timeout, float* data) {
     for (int i = 0; i < iters; ++i) {
         data[blockIdx.x * 256 + threadIdx.x] += 1.0f;  // something to publish
@@ -97,6 +137,18 @@ int main() {
         CHECK(hipEventRecord(a)); k_xcd<<<nb, 256>>>(hb, census, iters, timeout, data, mism); CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
         float ms; CHECK(hipEventElapsedTime(&ms, a, b)); u32 to, mm; CHECK(hipMemcpy(&to, timeout, 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(&mm, mism, 4, hipMemcpyDeviceToHost));
         printf("xcd-hierarchical barrier: %.2f us per barrier (2 per iter; timeout flag %u, stale reads %u)\n", ms * 1000 / (2 * iters), to, mm);
+    }
+    for (int rep = 0; rep < 3; ++rep) {
+        CHECK(hipMemset(hb, 0, sizeof(hbar))); CHECK(hipMemset(timeout, 0, 4)); CHECK(hipMemset(mism, 0, 4)); CHECK(hipMemset(data, 0, nb * 256 * 4));
+        CHECK(hipEventRecord(a)); k_xcd_nf<1><<<nb, 256>>>(hb, census, iters, timeout, data, mism); CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+        float ms; CHECK(hipEventElapsedTime(&ms, a, b)); u32 to, mm; CHECK(hipMemcpy(&to, timeout, 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(&mm, mism, 4, hipMemcpyDeviceToHost));
+        printf("xcd barrier, no fences, sc1 payload, sleep1: %.2f us per barrier (timeout %u, stale reads %u)\n", ms * 1000 / (2 * iters), to, mm);
+    }
+    for (int rep = 0; rep < 3; ++rep) {
+        CHECK(hipMemset(hb, 0, sizeof(hbar))); CHECK(hipMemset(timeout, 0, 4)); CHECK(hipMemset(mism, 0, 4)); CHECK(hipMemset(data, 0, nb * 256 * 4));
+        CHECK(hipEventRecord(a)); k_xcd_nf<0><<<nb, 256>>>(hb, census, iters, timeout, data, mism); CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+        float ms; CHECK(hipEventElapsedTime(&ms, a, b)); u32 to, mm; CHECK(hipMemcpy(&to, timeout, 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(&mm, mism, 4, hipMemcpyDeviceToHost));
+        printf("xcd barrier, no fences, sc1 payload, no sleep: %.2f us per barrier (timeout %u, stale reads %u)\n", ms * 1000 / (2 * iters), to, mm);
     }
     return 0;
 }

@@ -208,15 +208,7 @@ void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_rs, int q_hs
 // (Measured alternative, rejected: merging in the last-arriving slice block -- sc1 partial stores + ticket + agent
 //  acquire, as the split-K GEMM does -- removed the combine launch but cost 30 ms more per question: the acquire
 //  and the re-read of 90 KB of partials through memory are slower than the 4.8-us combine kernel.)
-#define AD_GMAX 8
-#define AD_STRIDE 132  // floats per (split, head) partial: m, l, pad, pad, o[128]
-#define AD_TOK 64
-
-__device__ __forceinline__ void split_geometry(int ctx, int max_splits, int& chunk, int& nsplit) {
-    chunk = (ctx + max_splits - 1) / max_splits;
-    chunk = (chunk + AD_TOK - 1) / AD_TOK * AD_TOK;
-    nsplit = (ctx + chunk - 1) / chunk;
-}
+#include "ze_attn_decode.h"
 
 __global__ void __launch_bounds__(256) k_attn_decode_split(const bf16_t* __restrict__ q, int q_row_stride,
                                                            const bf16_t* __restrict__ kcache,
@@ -225,7 +217,6 @@ __global__ void __launch_bounds__(256) k_attn_decode_split(const bf16_t* __restr
                                                            const int* __restrict__ seq_ids, int heads, int kv_heads,
                                                            int max_ctx, float scale_log2e, float* __restrict__ ws,
                                                            int max_splits) {
-    constexpr int D = 128;
     // chain of this block (grid.z): batched decode indexes the chain table, single-chain decode passes its state
     const int bz = blockIdx.z;
     const ze_seq_dev* st = seq_ids ? st_base + seq_ids[bz] : st_base;
@@ -233,194 +224,23 @@ __global__ void __launch_bounds__(256) k_attn_decode_split(const bf16_t* __restr
         kcache += (size_t)seq_ids[bz] * cache_seq_stride;
         vcache += (size_t)seq_ids[bz] * cache_seq_stride;
     }
-    q += (size_t)bz * q_row_stride;
-    ws += (size_t)bz * max_splits * heads * AD_STRIDE;
-    __shared__ __attribute__((aligned(16))) bf16_t sV[AD_TOK][D];  // 16 KB
-    __shared__ float sS[AD_TOK][AD_GMAX];                            // scores, then probabilities
-    __shared__ float sM[AD_GMAX], sL[AD_GMAX];
-    const int G = heads / kv_heads;
-    const int ctx = st->ctx + 1;
-    int chunk, nsplit;
-    split_geometry(ctx, max_splits, chunk, nsplit);
-    const int split = blockIdx.y, kvh = blockIdx.x;
-    if (split >= nsplit) return;
-    const int t0 = split * chunk, t1 = min(ctx, t0 + chunk);
-    const int tid = threadIdx.x, gid = tid >> 4, li = tid & 15, lane = tid & 63, wid = tid >> 6;
-
-    // q of the (up to) 8 heads of this kv head, this lane's 8 dims, pre-scaled by scale*log2(e)
-    float qv[AD_GMAX][8];
-#pragma unroll
-    for (int g = 0; g < AD_GMAX; ++g) {
-        uint4 u = make_uint4(0, 0, 0, 0);
-        if (g < G) u = *reinterpret_cast<const uint4*>(q + (size_t)(kvh * G + g) * D + li * 8);
-        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            qv[g][2 * j] = bf16lo(w[j]) * scale_log2e;
-            qv[g][2 * j + 1] = bf16hi(w[j]) * scale_log2e;
-        }
-    }
-    const bf16_t* kb = kcache + (size_t)kvh * max_ctx * D + li * 8;
-    const bf16_t* vb = vcache + (size_t)kvh * max_ctx * D + li * 8;
-    // phase-C ownership: head og, dims od..od+3
-    const int og = tid >> 5, od = (tid & 31) * 4;
-    float m_run = -INFINITY, l_run = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-
-    for (int base = t0; base < t1; base += AD_TOK) {
-        // ---------------- phase A: loads first
-        uint4 ku[4], vu[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int t = base + gid + 16 * i;
-            const bool ok = t < t1;
-            ku[i] = ok ? *reinterpret_cast<const uint4*>(kb + (size_t)t * D) : make_uint4(0, 0, 0, 0);
-            vu[i] = ok ? *reinterpret_cast<const uint4*>(vb + (size_t)t * D) : make_uint4(0, 0, 0, 0);
-        }
-        float v[32];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t kw[4] = {ku[i].x, ku[i].y, ku[i].z, ku[i].w};
-            float kf[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                kf[2 * j] = bf16lo(kw[j]);
-                kf[2 * j + 1] = bf16hi(kw[j]);
-            }
-#pragma unroll
-            for (int g = 0; g < AD_GMAX; ++g) {
-                float s = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) s = fmaf(qv[g][j], kf[j], s);
-                v[i * 8 + g] = s;
-            }
-            *reinterpret_cast<uint4*>(&sV[gid + 16 * i][li * 8]) = vu[i];
-        }
-        // halving butterfly over the 16 lanes of the group: lane li ends with the totals of idx 2*li, 2*li+1
-        {
-            const bool b8 = li & 8, b4 = li & 4, b2 = li & 2, b1 = li & 1;
-            float w16[16], w8[8], w4[4], w2[2];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float keep = b8 ? v[16 + k] : v[k], send = b8 ? v[k] : v[16 + k];
-                w16[k] = keep + __shfl_xor(send, 8, 64);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float keep = b4 ? w16[8 + k] : w16[k], send = b4 ? w16[k] : w16[8 + k];
-                w8[k] = keep + __shfl_xor(send, 4, 64);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float keep = b2 ? w8[4 + k] : w8[k], send = b2 ? w8[k] : w8[4 + k];
-                w4[k] = keep + __shfl_xor(send, 2, 64);
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const float keep = b1 ? w4[2 + k] : w4[k], send = b1 ? w4[k] : w4[2 + k];
-                w2[k] = keep + __shfl_xor(send, 1, 64);
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int idx = 2 * li + k, i = idx >> 3, g = idx & 7;
-                const int tl = gid + 16 * i;
-                sS[tl][g] = (base + tl < t1) ? w2[k] : -INFINITY;
-            }
-        }
-        __syncthreads();
-        // ---------------- phase B: per-head max / sum over the 64 scores; wave w handles heads 2w, 2w+1
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int g = wid * 2 + hh;
-            const float s = sS[lane][g];
-            const float mx = wave_max(s);
-            const float p = (mx == -INFINITY) ? 0.f : exp2f(s - mx);
-            const float sum = wave_sum(p);
-            sS[lane][g] = p;
-            if (lane == 0) {
-                sM[g] = mx;
-                sL[g] = sum;
-            }
-        }
-        __syncthreads();
-        // ---------------- phase C: o[og][od..od+3] += sum_t p[t][og] * V[t][od..]
-        {
-            const float mr = sM[og], lr = sL[og];
-            const float mn = fmaxf(m_run, mr);
-            const float mu = (mn == -INFINITY) ? 0.f : mn;
-            const float a_old = exp2f(m_run - mu), a_new = exp2f(mr - mu);
-            float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-#pragma unroll 16
-            for (int t = 0; t < AD_TOK; ++t) {
-                const float p = sS[t][og];
-                const uint2 vv = *reinterpret_cast<const uint2*>(&sV[t][od]);
-                c0 = fmaf(p, bf16lo(vv.x), c0);
-                c1 = fmaf(p, bf16hi(vv.x), c1);
-                c2 = fmaf(p, bf16lo(vv.y), c2);
-                c3 = fmaf(p, bf16hi(vv.y), c3);
-            }
-            o0 = o0 * a_old + c0 * a_new;
-            o1 = o1 * a_old + c1 * a_new;
-            o2 = o2 * a_old + c2 * a_new;
-            o3 = o3 * a_old + c3 * a_new;
-            l_run = l_run * a_old + lr * a_new;
-            m_run = mn;
-        }
-        __syncthreads();  // sS / sV are rewritten by the next round
-    }
-    if (og < G) {
-        float* dst = ws + ((size_t)(split * heads + kvh * G + og)) * AD_STRIDE;
-        if ((tid & 31) == 0) {
-            dst[0] = m_run;
-            dst[1] = l_run;
-        }
-        *reinterpret_cast<float4*>(dst + 4 + od) = make_float4(o0, o1, o2, o3);
-    }
+    __shared__ ad_split_lds L;
+    attn_split_body<false>(L, q + (size_t)bz * q_row_stride, kcache, vcache, st->ctx + 1, blockIdx.x, blockIdx.y, heads,
+                           kv_heads, max_ctx, scale_log2e, ws + (size_t)bz * max_splits * heads * AD_STRIDE, max_splits);
 }
 
-// grid = heads, 128 threads (one per output dim): split weights are computed lane-parallel by the first wave.
+// grid = (heads, chains), 128 threads (one per output dim)
 __global__ void __launch_bounds__(128) k_attn_decode_combine(const float* __restrict__ ws,
                                                              const ze_seq_dev* __restrict__ st_base,
                                                              const int* __restrict__ seq_ids, int heads,
                                                              int max_splits, bf16_t* __restrict__ out,
                                                              int out_row_stride) {
-    constexpr int D = 128;
     const int bz = blockIdx.y;
     const ze_seq_dev* st = seq_ids ? st_base + seq_ids[bz] : st_base;
-    ws += (size_t)bz * max_splits * heads * AD_STRIDE;
-    out += (size_t)bz * out_row_stride;
     __shared__ float sW[64];
     __shared__ float sInv;
-    const int ctx = st->ctx + 1;
-    int chunk, nsplit;
-    split_geometry(ctx, max_splits, chunk, nsplit);
-    const int h = blockIdx.x, d = threadIdx.x;
-    if (d < 64) {
-        float m = -INFINITY, l = 0.f;
-        if (d < nsplit) {
-            const float2 ml = *reinterpret_cast<const float2*>(ws + ((size_t)(d * heads + h)) * AD_STRIDE);
-            m = ml.x;
-            l = ml.y;
-        }
-        const float mx = wave_max(m);
-        const float w = (m == -INFINITY) ? 0.f : exp2f(m - mx);
-        const float tot = wave_sum(w * l);
-        sW[d] = w;
-        if (d == 0) sInv = tot > 0.f ? 1.0f / tot : 0.f;
-    }
-    __syncthreads();
-    float acc = 0.f;
-    const float* p = ws + (size_t)h * AD_STRIDE + 4 + d;
-    const size_t step = (size_t)heads * AD_STRIDE;
-    int s = 0;
-    for (; s + 8 <= nsplit; s += 8) {
-        float x[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = p[(size_t)(s + u) * step];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc = fmaf(sW[s + u], x[u], acc);
-    }
-    for (; s < nsplit; ++s) acc = fmaf(sW[s], p[(size_t)s * step], acc);
-    out[(size_t)h * D + d] = f32_to_bf16(acc * sInv);
+    attn_combine_body<false>(sW, &sInv, ws + (size_t)bz * max_splits * heads * AD_STRIDE, st->ctx + 1, blockIdx.x,
+                             threadIdx.x, heads, max_splits, out + (size_t)bz * out_row_stride);
 }
 
 void ze_launch_attn_decode(const bf16_t* q, int q_row_stride, const bf16_t* kcache, const bf16_t* vcache,
