@@ -23,32 +23,35 @@ struct ad_split_lds {
 
 // FRESH: q / K / V / partials cross workgroups INSIDE the running launch (fused layer kernel): every such access
 // is a write-through (sc1) store or an L1-bypassing (sc1) load.  Arithmetic is identical in both forms.
+// Addresses are (wave-uniform base, per-lane byte offset): the buffer descriptor of the sc1 forms must live in
+// SGPRs -- a per-lane base pointer makes hipcc wrap every access in a 64-trip readfirstlane waterfall loop
+// (measured: the fused kernel 4x slower than the four launches it replaces).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ad_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
 template <bool FRESH>
-__device__ __forceinline__ uint4 ad_load16(const void* p) {
+__device__ __forceinline__ uint4 ad_load16(const void* base, uint32_t off) {
     if (FRESH) {
         typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 16, 0x00020000), 0, 0, 16);
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(ad_rsrc(base), off, 0, 16);
         return make_uint4(v.x, v.y, v.z, v.w);
     }
-    return *reinterpret_cast<const uint4*>(p);
+    return *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(base) + off);
 }
 template <bool FRESH>
-__device__ __forceinline__ float ad_load4(const float* p) {
-    if (FRESH)
-        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 4, 0x00020000), 0, 0, 16));
-    return *p;
+__device__ __forceinline__ float ad_load4(const void* base, uint32_t off) {
+    if (FRESH) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ad_rsrc(base), off, 0, 16));
+    return *reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(base) + off);
 }
 template <bool FRESH>
-__device__ __forceinline__ void ad_store2(bf16_t* p, bf16_t v) {
+__device__ __forceinline__ void ad_store2(void* base, uint32_t off, bf16_t v) {
     if (FRESH)
-        __builtin_amdgcn_raw_buffer_store_b16(v, __builtin_amdgcn_make_buffer_rsrc(p, 0, 2, 0x00020000), 0, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b16(v, ad_rsrc(base), off, 0, 16);
     else
-        *p = v;
+        *reinterpret_cast<bf16_t*>(reinterpret_cast<uint8_t*>(base) + off) = v;
 }
 template <bool FRESH>
-__device__ __forceinline__ void ad_store16(void* p, float a, float b, float c, float d) {
+__device__ __forceinline__ void ad_store16(void* base, uint32_t off, float a, float b, float c, float d) {
     if (FRESH) {
         typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
         u32x4_t v;
@@ -56,9 +59,9 @@ __device__ __forceinline__ void ad_store16(void* p, float a, float b, float c, f
         v.y = __float_as_uint(b);
         v.z = __float_as_uint(c);
         v.w = __float_as_uint(d);
-        __builtin_amdgcn_raw_buffer_store_b128(v, __builtin_amdgcn_make_buffer_rsrc(p, 0, 16, 0x00020000), 0, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, ad_rsrc(base), off, 0, 16);
     } else {
-        *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+        *reinterpret_cast<float4*>(reinterpret_cast<uint8_t*>(base) + off) = make_float4(a, b, c, d);
     }
 }
 
@@ -84,7 +87,7 @@ __device__ __forceinline__ void attn_split_body(ad_split_lds& L, const bf16_t* _
 #pragma unroll
     for (int g = 0; g < AD_GMAX; ++g) {
         uint4 u = make_uint4(0, 0, 0, 0);
-        if (g < G) u = ad_load16<FRESH>(q + (size_t)(kvh * G + g) * D + li * 8);
+        if (g < G) u = ad_load16<FRESH>(q, (uint32_t)(((kvh * G + g) * D + li * 8) * 2));
         const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -92,8 +95,8 @@ __device__ __forceinline__ void attn_split_body(ad_split_lds& L, const bf16_t* _
             qv[g][2 * j + 1] = bf16hi(w[j]) * scale_log2e;
         }
     }
-    const bf16_t* kb = kcache + (size_t)kvh * max_ctx * D + li * 8;
-    const bf16_t* vb = vcache + (size_t)kvh * max_ctx * D + li * 8;
+    const bf16_t* kb = kcache + (size_t)kvh * max_ctx * D;  // wave-uniform bases, per-lane byte offsets
+    const bf16_t* vb = vcache + (size_t)kvh * max_ctx * D;
     // phase-C ownership: head og, dims od..od+3
     const int og = tid >> 5, od = (tid & 31) * 4;
     float m_run = -INFINITY, l_run = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
@@ -108,8 +111,9 @@ __device__ __forceinline__ void attn_split_body(ad_split_lds& L, const bf16_t* _
             ku[i] = make_uint4(0, 0, 0, 0);
             vu[i] = make_uint4(0, 0, 0, 0);
             if (ok) {
-                ku[i] = ad_load16<FRESH>(kb + (size_t)t * D);
-                vu[i] = ad_load16<FRESH>(vb + (size_t)t * D);
+                const uint32_t off = (uint32_t)((t * D + li * 8) * 2);
+                ku[i] = ad_load16<FRESH>(kb, off);
+                vu[i] = ad_load16<FRESH>(vb, off);
             }
         }
         float v[32];
@@ -204,9 +208,9 @@ __device__ __forceinline__ void attn_split_body(ad_split_lds& L, const bf16_t* _
         __syncthreads();  // sS / sV are rewritten by the next round
     }
     if (og < G) {
-        float* dst = ws + ((size_t)(split * heads + kvh * G + og)) * AD_STRIDE;
-        if ((tid & 31) == 0) ad_store16<FRESH>(dst, m_run, l_run, 0.f, 0.f);
-        ad_store16<FRESH>(dst + 4 + od, o0, o1, o2, o3);
+        const uint32_t dst = (uint32_t)((split * heads + kvh * G + og) * AD_STRIDE * 4);
+        if ((tid & 31) == 0) ad_store16<FRESH>(ws, dst, m_run, l_run, 0.f, 0.f);
+        ad_store16<FRESH>(ws, dst + (4 + od) * 4, o0, o1, o2, o3);
     }
 }
 
@@ -222,7 +226,7 @@ __device__ __forceinline__ void attn_combine_body(float* sW, float* sInvp, const
     if (d < 64) {
         float m = -INFINITY, l = 0.f;
         if (d < nsplit) {
-            const uint4 ml = ad_load16<FRESH>(ws + ((size_t)(d * heads + h)) * AD_STRIDE);
+            const uint4 ml = ad_load16<FRESH>(ws, (uint32_t)((d * heads + h) * AD_STRIDE * 4));
             m = __uint_as_float(ml.x);
             l = __uint_as_float(ml.y);
         }
@@ -234,17 +238,17 @@ __device__ __forceinline__ void attn_combine_body(float* sW, float* sInvp, const
     }
     __syncthreads();
     float acc = 0.f;
-    const float* p = ws + (size_t)h * AD_STRIDE + 4 + d;
-    const size_t step = (size_t)heads * AD_STRIDE;
+    const uint32_t p = (uint32_t)((h * AD_STRIDE + 4 + d) * 4);
+    const uint32_t step = (uint32_t)(heads * AD_STRIDE * 4);
     int s = 0;
     for (; s + 8 <= nsplit; s += 8) {
         float x[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = ad_load4<FRESH>(p + (size_t)(s + u) * step);
+        for (int u = 0; u < 8; ++u) x[u] = ad_load4<FRESH>(ws, p + (s + u) * step);
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc = fmaf(sW[s + u], x[u], acc);
     }
-    for (; s < nsplit; ++s) acc = fmaf(sW[s], ad_load4<FRESH>(p + (size_t)s * step), acc);
-    ad_store2<FRESH>(out + (size_t)h * D + d, f32_to_bf16(acc * sInv));
+    for (; s < nsplit; ++s) acc = fmaf(sW[s], ad_load4<FRESH>(ws, p + s * step), acc);
+    ad_store2<FRESH>(out, (uint32_t)((h * D + d) * 2), f32_to_bf16(acc * sInv));
 }
 

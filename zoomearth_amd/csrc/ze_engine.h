@@ -105,6 +105,10 @@ struct ze_engine {
     float *dlogits = nullptr, *dpartial = nullptr, *dsample = nullptr;
     int max_splits = 64;
     int* d_host_ints = nullptr;  // pinned, small
+    // fused decode attention block (ze_mega.hip)
+    ze_grid_barrier* gbar = nullptr;
+    int attn_blocks = 0;  // 0: shape unsupported, the four stand-alone kernels run instead
+    std::vector<int> graph_variant;
     // split-K GEMM workspace
     float* gslab = nullptr;
     unsigned* gtickets = nullptr;

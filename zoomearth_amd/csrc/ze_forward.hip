@@ -13,7 +13,7 @@
         if (_r != 0) return _r; \
     } while (0)
 #define ZE_KCHECK() ZE_HIP(hipGetLastError())
-extern int ze_gemv_knobs[4];
+extern int ze_gemv_knobs[8];
 
 // ================================================================== front-end
 // dst = crop(src, box).resize((dst_w, dst_h), BICUBIC), Pillow-exact (two passes, u8 intermediate).
@@ -439,13 +439,61 @@ extern "C" int ze_prefill(ze_engine* e, int seq, const int32_t* input_ids, int l
 // ================================================================== decode
 // One token for chain `seq`: everything is read from the device-side chain state, so the same launch
 // sequence can be captured once into a hipGraph and replayed.
+// 1: the fused attention block (ze_mega.hip) replaces QKV GEMV + slices + merge + O-proj; 0: the stand-alone kernels
+static int ze_decode_variant(const ze_engine* e) { return (ze_gemv_knobs[3] > 0 && e->attn_blocks > 0) ? 1 : 0; }
+// the fused kernel's bounded spins gave up somewhere in the work enqueued so far (stream must be idle)
+static int ze_check_grid_timeout(ze_engine* e, hipStream_t s) {
+    unsigned flag = 0;
+    ZE_HIP(hipMemcpyAsync(&flag, e->gbar->timeout, sizeof(flag), hipMemcpyDeviceToHost, s));
+    ZE_HIP(hipStreamSynchronize(s));
+    if (!flag) return ZE_OK;
+    ZE_HIP(hipMemsetAsync(e->gbar->timeout, 0, sizeof(unsigned), s));
+    return ze_fail(e, ZE_ERR_HIP, "grid barrier timed out in the fused decode kernel (workgroups not co-resident?)");
+}
+
 int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos, bool sample, hipStream_t s) {
     const ze_config& c = e->cfg;
     const int H = c.hidden, hd = e->head_dim, nq = c.heads * hd, nqkv = nq + 2 * c.kv_heads * hd;
     const ze_seq_dev* st = e->st_dev + seq;
     const float scale = 1.0f / sqrtf((float)hd);
+    const int fused = ze_decode_variant(e);
+    if (fused) {
+        if (hipMemsetAsync(e->gbar, 0, offsetof(ze_grid_barrier, timeout), s) != hipSuccess)
+            return ze_fail(e, ZE_ERR_HIP, "hipMemsetAsync failed");
+    }
     for (int li = 0; li < c.layers; ++li) {
         const ze_text_layer& L = e->tl[li];
+        if (fused) {
+            ze_layer_attn_args f;
+            memset(&f, 0, sizeof(f));
+            f.wqkv = L.qkv.w;
+            f.ldqkv = L.qkv.ld;
+            f.bqkv = L.qkv.bias;
+            f.wo = L.o.w;
+            f.ldo = L.o.ld;
+            f.bo = L.o.bias;
+            f.in_norm = L.in_norm;
+            f.eps = c.rms_eps;
+            f.h = e->dh;
+            f.embed = li == 0 ? e->embed : nullptr;
+            f.st = st;
+            f.cosT = e->cosT;
+            f.sinT = e->sinT;
+            f.kcache = e->kc(li, seq);
+            f.vcache = e->vc(li, seq);
+            f.q = e->dq;
+            f.attn = e->dattn;
+            f.partial = e->dpartial;
+            f.max_splits = e->max_splits;
+            f.hidden = H;
+            f.heads = c.heads;
+            f.kv_heads = c.kv_heads;
+            f.max_ctx = c.max_ctx;
+            f.scale_log2e = scale * 1.4426950408889634f;
+            f.bar = e->gbar;
+            f.epoch0 = (unsigned)li * 3u;
+            ze_launch_layer_attn(f, e->attn_blocks, s);
+        } else {
         ze_gemv_args a;
         memset(&a, 0, sizeof(a));
         a.W = L.qkv.w;
@@ -483,6 +531,7 @@ int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos,
         o.out_bf16 = e->dh;
         o.D = hd;
         ze_launch_gemv(ZE_GV_RESIDUAL, o, s);
+        }
         ze_gemv_args g;
         memset(&g, 0, sizeof(g));
         g.W = L.gate_up.w;
@@ -597,7 +646,8 @@ extern "C" int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_
     // decode-step graph for this chain (re-captured when the sampling options change)
     hipGraphExec_t gexec = nullptr;
     if (p->use_graph && max_new > 1) {
-        if (!e->graphs[seq] || e->graph_penalty[seq] != pen || e->graph_ignore_eos[seq] != ign) {
+        if (!e->graphs[seq] || e->graph_penalty[seq] != pen || e->graph_ignore_eos[seq] != ign ||
+            e->graph_variant[seq] != ze_decode_variant(e)) {
             if (e->graphs[seq]) {
                 hipGraphExecDestroy(e->graphs[seq]);
                 e->graphs[seq] = nullptr;
@@ -618,6 +668,7 @@ extern "C" int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_
             ZE_TRY(r);
             e->graph_penalty[seq] = pen;
             e->graph_ignore_eos[seq] = ign;
+            e->graph_variant[seq] = ze_decode_variant(e);
         }
         gexec = e->graphs[seq];
     }
@@ -645,6 +696,7 @@ extern "C" int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_
     ze_timer_end(e, t_d, s);
     ZE_HIP(hipMemcpyAsync(out_tokens, dev_out, (size_t)produced * sizeof(int), hipMemcpyDeviceToHost, s));
     ZE_HIP(hipStreamSynchronize(s));
+    if (ze_decode_variant(e)) ZE_TRY(ze_check_grid_timeout(e, s));
     // trim at the first EOS (tokens after it are pad, as HF emits for finished rows)
     int n = produced;
     if (!ign) {
@@ -900,7 +952,7 @@ extern "C" int ze_op_attention(ze_engine* e, const void* q, const void* k, const
 
 // ================================================================== measurement
 extern "C" int ze_tune(int knob, int value) {
-    if (knob < 0 || knob >= 4) return ze_fail(nullptr, ZE_ERR_INVALID, "unknown knob");
+    if (knob < 0 || knob >= 8) return ze_fail(nullptr, ZE_ERR_INVALID, "unknown knob");
     ze_gemv_knobs[knob] = value;
     return ZE_OK;
 }

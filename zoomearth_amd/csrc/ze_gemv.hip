@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256) k_gemv(const ze_gemv_args a) {
     }
 }
 
-extern int ze_gemv_knobs[4];
+extern int ze_gemv_knobs[8];
 
 template <int EPI, int PAIRS, int KSPLIT, int CH>
 static void launch_gemv_cfg(const ze_gemv_args& a, hipStream_t s) {
@@ -299,7 +299,8 @@ static void launch_gemv_cfg(const ze_gemv_args& a, hipStream_t s) {
     hipLaunchKernelGGL((k_gemv<EPI, PAIRS, KSPLIT, CH>), dim3(grid), dim3(256), lds, s, a);
 }
 
-int ze_gemv_knobs[4] = {0, 0, 0, 0};  // measurement-only overrides set through ze_tune(): [0] down, [1] gate_up, [2] grid cap
+// overrides set through ze_tune(): [0] down variant, [1] gate_up variant, [2] grid cap, [3] fused attention block
+int ze_gemv_knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 bool ze_launch_gemv(int epi, const ze_gemv_args& a, hipStream_t s) {
     // shape policy: long-K / few-row matrices split K over the 4 waves of a block (each wave streams its K/4 share

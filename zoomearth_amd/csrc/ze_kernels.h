@@ -84,6 +84,32 @@ struct ze_gemv_args {
 // returns false when x[K] does not fit the LDS stage
 bool ze_launch_gemv(int epi, const ze_gemv_args& a, hipStream_t s);
 
+// ---- fused decode attention block of one layer (ze_mega.hip): QKV GEMV -> slices -> merge -> O-proj in one launch
+struct ze_grid_barrier {  // zeroed at the start of every decode step; every word on its own 128-B line
+    unsigned cnt[8 * 32];  // arrivals per group (group = blockIdx % 8, up to 64 workgroups each)
+    unsigned gen[8 * 32];  // last completed epoch, published to the group by its last arriver
+    unsigned top[32];      // group completions
+    unsigned timeout[32];  // set when a bounded spin gave up: the step's output is invalid and the host reports it
+};
+struct ze_layer_attn_args {
+    const bf16_t* wqkv; int ldqkv; const bf16_t* bqkv;  // [(heads + 2 kv_heads) * 128, hidden]
+    const bf16_t* wo; int ldo; const bf16_t* bo;        // [hidden, heads * 128]
+    const bf16_t* in_norm; float eps;
+    bf16_t* h;            // hidden stream [hidden], updated in place
+    const bf16_t* embed;  // non-null (layer 0): the stream starts as embed[st->token]
+    const ze_seq_dev* st;
+    const bf16_t* cosT; const bf16_t* sinT;
+    bf16_t* kcache; bf16_t* vcache;  // [kv_heads, max_ctx, 128] of this layer / chain
+    bf16_t* q; bf16_t* attn;         // scratch [heads * 128]
+    float* partial; int max_splits;
+    int hidden, heads, kv_heads, max_ctx;
+    float scale_log2e;
+    ze_grid_barrier* bar; unsigned epoch0;  // this launch uses epochs epoch0 + 1 .. epoch0 + 3
+};
+// workgroups the fused kernel may be launched with (all co-resident, multiple of 8), 0 when the shape is unsupported
+int ze_layer_attn_blocks(int hidden, int heads, int kv_heads, int head_dim);
+void ze_launch_layer_attn(const ze_layer_attn_args& a, int blocks, hipStream_t s);
+
 // ---- attention
 // Varlen flash attention (prefill / ViT). Tiles: host-built list of (q_start, q_end, kv_start, kv_end) int4 rows.
 void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_row_stride, int q_head_stride, const bf16_t* k,
