@@ -1,4 +1,4 @@
-"""GPU: the fused per-layer decode attention block (ze_mega.hip, ze_tune knob 3) against the four stand-alone
+"""GPU: the fused per-layer decode attention block (ze_mega.hip; ze_tune knob 3, off by default) against the four stand-alone
 kernels it replaces (QKV GEMV + flash-decoding slices + merge + O-proj), through the C ABI.
 
 The fused launch keeps the stand-alone arithmetic (same row ownership, same accumulation order), so the bar is
@@ -48,10 +48,32 @@ def check_engine(e, prompt_len, n_forced, n_gen, vocab_hi):
         prefill_text(e, 0, ids)
         got_tok_eager = e.generate(0, n_gen, repetition_penalty=1.3, ignore_eos=True, use_graph=False)
     finally:
-        fused(e, False)
+        fused(e, False)  # the shipped default
     for i, (a, b) in enumerate(zip(ref, got)):
         assert np.array_equal(a, b), f"step {i}: max |diff| {np.abs(a - b).max()}"
     assert list(ref_tok) == list(got_tok) == list(got_tok_eager)
+
+
+def test_fused_chain_slot_reuse_with_different_prompts(tiny_engine):
+    """Regression: captured decode steps replayed on a chain slot that held a DIFFERENT chain before (the first fused
+    version zeroed its barrier counters with a memset node that ran unordered inside the graph; identical prompts
+    hid it because stale data and fresh data were equal)."""
+    e = tiny_engine
+    e.fill_synthetic(**CHAIN_W)
+    prompts = {k: text_ids(40 + i, n) for i, (k, n) in enumerate((("a", 284), ("b", 295), ("c", 308)))}
+
+    def gen(seq, name, on, graph=True, sync_every=16):
+        fused(e, on)
+        prefill_text(e, seq, prompts[name])
+        return e.generate(seq, 12, ignore_eos=True, use_graph=graph, sync_every=sync_every)
+
+    try:
+        ref = {k: gen(0, k, False) for k in prompts}
+        for seq, graph, sync_every in ((1, True, 16), (2, True, 1), (1, False, 16), (2, True, 3)):
+            for name in "abcab":
+                assert gen(seq, name, True, graph, sync_every) == ref[name], (seq, graph, sync_every, name)
+    finally:
+        fused(e, False)
 
 
 def test_fused_attention_block_tiny(tiny_engine):

@@ -103,6 +103,17 @@ __device__ __forceinline__ void attn_split_body(ad_split_lds& L, const bf16_t* _
 
     for (int base = t0; base < t1; base += AD_TOK) {
         // ---------------- phase A: loads first
+        // Only the newest row was written inside this launch (sc1 stores of the fused QKV phase) and is read with
+        // sc1 loads; every older row comes from earlier launches and is read the way the stand-alone kernel reads
+        // it.  The newest row is fetched once per lane up front (workgroup-uniform branch) and selected in, so the
+        // eight row loads below stay free of per-lane control flow.
+        uint4 kn = make_uint4(0, 0, 0, 0), vn = make_uint4(0, 0, 0, 0);
+        const int tn = ctx - 1;
+        if (FRESH && tn >= base && tn < base + AD_TOK) {
+            const uint32_t off = (uint32_t)((tn * D + li * 8) * 2);
+            kn = ad_load16<true>(kb, off);
+            vn = ad_load16<true>(vb, off);
+        }
         uint4 ku[4], vu[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -112,8 +123,12 @@ __device__ __forceinline__ void attn_split_body(ad_split_lds& L, const bf16_t* _
             vu[i] = make_uint4(0, 0, 0, 0);
             if (ok) {
                 const uint32_t off = (uint32_t)((t * D + li * 8) * 2);
-                ku[i] = ad_load16<FRESH>(kb, off);
-                vu[i] = ad_load16<FRESH>(vb, off);
+                ku[i] = ad_load16<false>(kb, off);
+                vu[i] = ad_load16<false>(vb, off);
+            }
+            if (FRESH && t == tn) {
+                ku[i] = kn;
+                vu[i] = vn;
             }
         }
         float v[32];

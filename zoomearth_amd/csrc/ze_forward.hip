@@ -447,7 +447,8 @@ static int ze_check_grid_timeout(ze_engine* e, hipStream_t s) {
     ZE_HIP(hipMemcpyAsync(&flag, e->gbar->timeout, sizeof(flag), hipMemcpyDeviceToHost, s));
     ZE_HIP(hipStreamSynchronize(s));
     if (!flag) return ZE_OK;
-    ZE_HIP(hipMemsetAsync(e->gbar->timeout, 0, sizeof(unsigned), s));
+    ZE_HIP(hipMemsetAsync(e->gbar, 0, sizeof(ze_grid_barrier), s));  // counters may have been left mid-barrier
+    ZE_HIP(hipStreamSynchronize(s));
     return ze_fail(e, ZE_ERR_HIP, "grid barrier timed out in the fused decode kernel (workgroups not co-resident?)");
 }
 
@@ -457,10 +458,6 @@ int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos,
     const ze_seq_dev* st = e->st_dev + seq;
     const float scale = 1.0f / sqrtf((float)hd);
     const int fused = ze_decode_variant(e);
-    if (fused) {
-        if (hipMemsetAsync(e->gbar, 0, offsetof(ze_grid_barrier, timeout), s) != hipSuccess)
-            return ze_fail(e, ZE_ERR_HIP, "hipMemsetAsync failed");
-    }
     for (int li = 0; li < c.layers; ++li) {
         const ze_text_layer& L = e->tl[li];
         if (fused) {
@@ -491,7 +488,6 @@ int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos,
             f.max_ctx = c.max_ctx;
             f.scale_log2e = scale * 1.4426950408889634f;
             f.bar = e->gbar;
-            f.epoch0 = (unsigned)li * 3u;
             ze_launch_layer_attn(f, e->attn_blocks, s);
         } else {
         ze_gemv_args a;

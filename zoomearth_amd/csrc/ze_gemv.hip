@@ -33,6 +33,10 @@ struct epi_in {
 // (Measured alternative, rejected: keeping each lane's x slices in registers with a per-wave RMSNorm removes the
 //  LDS staging and all barriers but makes every wave re-read x and the norm weight from L2 -- 8 KB per 8-16 KB of
 //  weight rows -- and ran 10-30 % slower on every decode shape.)
+// (Measured, rejected: one-shot forms of the down projection that request the whole 45-MB matrix at t = 0 -- one
+//  pair set per workgroup, 12 / 24 / 48 loads in flight per lane, every workgroup resident -- ran 10.8-12.9 us
+//  against 10.4: across this family a launch costs about 2.5 us + bytes / 7 TB/s inside the kernel plus 1.3 us at
+//  the boundary whatever the issue structure, so the remaining lever is hiding the fixed part across launches.)
 template <int EPI, int PAIRS, int KSPLIT, int CH>
 __global__ void __launch_bounds__(256) k_gemv(const ze_gemv_args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -40,7 +44,7 @@ __global__ void __launch_bounds__(256) k_gemv(const ze_gemv_args a) {
     const int K = a.K;
     const int nch = (K + 511) >> 9;  // 512-element chunks (64 lanes x 8); the last one may be partial
     const int Kp = nch << 9;
-    float* red = reinterpret_cast<float*>(smem + (size_t)Kp * 2);  // [4][2*PAIRS] partials
+    float* red = reinterpret_cast<float*>(smem + (size_t)(Kp + 512) * 2);  // [4][2*PAIRS] partials, behind the zero chunk
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> scalar branches below
 
@@ -107,12 +111,24 @@ __global__ void __launch_bounds__(256) k_gemv(const ze_gemv_args a) {
     // ---------------- early issue: x, norm weight, first weight trip, first epilogue operands
     const bf16_t* xin = a.x;
     if (a.embed) xin = a.embed + (size_t)a.st->token * K;
+    // every x vector of this thread is requested before the first weight trip: loads retire in issue order, so an
+    // x load issued later (the staging loop used to fetch vectors 2..6 of the 22-KB down-projection input one per
+    // iteration) returns only after the wave's 8-12 HBM weight loads AND then pays one L2 round trip per iteration
+    // (measured: down-projection 11.1 -> 10.4 us).  Addresses are clamped, not branched on.
+    constexpr int XV = (KSPLIT > 1) ? 6 : 1;
     const bool v0_in = tid * 8 < K;
-    uint4 xq0 = make_uint4(0, 0, 0, 0), g0 = make_uint4(0, 0, 0, 0);
-    if (v0_in) xq0 = *reinterpret_cast<const uint4*>(xin + tid * 8);
+    uint4 xq[XV];
+    uint4 g0 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+        const int v = min(tid + i * 256, (K >> 3) - 1);
+        xq[i] = *reinterpret_cast<const uint4*>(xin + v * 8);
+    }
     if (a.norm_w && v0_in) g0 = *reinterpret_cast<const uint4*>(a.norm_w + tid * 8);
     const int p_first = unit * PAIRS;
-    const bool pre = (p_first < P) && (c_begin + (CH - 1) * c_step < nch);  // wave-uniform
+    // (the first trip may run past the last chunk: those loads re-read the row's last 16 B and meet the all-zero
+    //  chunk kept behind x in LDS, so every wave -- not only those with a full first trip -- streams from t = 0)
+    const bool pre = p_first < P;  // wave-uniform
     uint4 wpre[CH][2 * PAIRS];
     const bf16_t* wrow0[2 * PAIRS];
     int r10[PAIRS], r20[PAIRS];
@@ -125,15 +141,21 @@ __global__ void __launch_bounds__(256) k_gemv(const ze_gemv_args a) {
 
     // ---------------- prologue: x -> LDS as bf16, zero padded to Kp (optionally embed fetch and/or RMSNorm)
     float ss = 0.f;
-    for (int v = tid; v < (Kp >> 3); v += 256) {
-        uint4 q = make_uint4(0, 0, 0, 0);
-        if (v == tid) q = xq0;
-        else if (v * 8 < K) q = *reinterpret_cast<const uint4*>(xin + v * 8);
+    auto stage_x = [&](int v, uint4 q) {
+        if (v * 8 >= K) q = make_uint4(0, 0, 0, 0);
         if (a.embed && blockIdx.x == 0 && v * 8 < K) *reinterpret_cast<uint4*>(a.embed_out + v * 8) = q;
         *reinterpret_cast<uint4*>(xs + v * 8) = q;
         const uint32_t u[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) ss += bf16lo(u[j]) * bf16lo(u[j]) + bf16hi(u[j]) * bf16hi(u[j]);
+    };
+#pragma unroll
+    for (int i = 0; i < XV; ++i)
+        if (tid + i * 256 < ((Kp + 512) >> 3)) stage_x(tid + i * 256, xq[i]);
+    for (int v = tid + XV * 256; v < ((Kp + 512) >> 3); v += 256) {
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (v * 8 < K) q = *reinterpret_cast<const uint4*>(xin + v * 8);
+        stage_x(v, q);
     }
     if (a.norm_w) {
         ss = wave_sum(ss);
@@ -162,6 +184,7 @@ __global__ void __launch_bounds__(256) k_gemv(const ze_gemv_args a) {
 #pragma unroll
         for (int i = 0; i < 2 * PAIRS; ++i) acc[i] = 0.f;
         auto fma_chunk = [&](int c, const uint4 (&wc)[2 * PAIRS]) {
+            c = min(c, nch);  // chunk nch is the zero chunk
             const uint4 xq = *reinterpret_cast<const uint4*>(xs + (c << 9) + lane_off);
             const uint32_t xu[4] = {xq.x, xq.y, xq.z, xq.w};
 #pragma unroll
@@ -259,12 +282,7 @@ __global__ void __launch_bounds__(256) k_gemv(const ze_gemv_args a) {
         }
     };
 
-    if (pre) {
-        pair_set(p_first, wrow0, r10, r20, std::true_type{}, wpre, e0);
-    } else if (p_first < P) {
-        rows_of(p_first, wrow0, r10, r20);
-        pair_set(p_first, wrow0, r10, r20, std::false_type{}, wpre, e0);
-    }
+    if (pre) pair_set(p_first, wrow0, r10, r20, std::true_type{}, wpre, e0);
     for (int p0 = p_first + nunits * PAIRS; p0 < P; p0 += nunits * PAIRS) {
         const bf16_t* wrow[2 * PAIRS];
         int r1[PAIRS], r2[PAIRS];
@@ -280,7 +298,7 @@ template <int EPI, int PAIRS, int KSPLIT, int CH>
 static void launch_gemv_cfg(const ze_gemv_args& a, hipStream_t s) {
     const int P = a.N / 2;
     const int nch = (a.K + 511) / 512;
-    const size_t lds = (size_t)nch * 512 * 2 + 4 * 2 * PAIRS * sizeof(float) + 64;
+    const size_t lds = (size_t)(nch + 1) * 512 * 2 + 4 * 2 * PAIRS * sizeof(float) + 64;
     int grid = (KSPLIT == 1) ? ze_cdiv(P, 4 * PAIRS) : ze_cdiv(P, PAIRS);
     if (grid > 2048) grid = 2048;
     // One resident round: with more blocks than the chip holds at once the tail of the grid waits for slots and
@@ -294,6 +312,9 @@ static void launch_gemv_cfg(const ze_gemv_args& a, hipStream_t s) {
         const int resident = occ * cus;
         const int natural = (KSPLIT == 1) ? ze_cdiv(P, 4 * PAIRS) : ze_cdiv(P, PAIRS);
         if (natural <= 4 * resident && grid > resident) grid = resident;
+        // K-split units (down projection): two workgroups per CU taking two pair sets each beat 1024 resident
+        // one-set workgroups and 768 + 256 (10.4 vs 10.9 us)
+        if (KSPLIT > 1 && natural > 2 * cus && natural <= 4 * cus) grid = ze_cdiv(natural, 2);
     }
     if (ze_gemv_knobs[2] > 0) grid = std::min(ze_cdiv(P, PAIRS * (KSPLIT == 1 ? 4 : 1)), ze_gemv_knobs[2]);
     hipLaunchKernelGGL((k_gemv<EPI, PAIRS, KSPLIT, CH>), dim3(grid), dim3(256), lds, s, a);
@@ -306,7 +327,7 @@ bool ze_launch_gemv(int epi, const ze_gemv_args& a, hipStream_t s) {
     // shape policy: long-K / few-row matrices split K over the 4 waves of a block (each wave streams its K/4 share
     // in ONE trip of 6 chunks: 12 loads in flight per lane, no second latency-exposed phase); many-row matrices give
     // each wave two row pairs (16 loads in flight per lane).
-    if ((size_t)((a.K + 511) / 512) * 1024 > 60000) return false;  // x must fit the LDS stage
+    if ((size_t)((a.K + 511) / 512 + 1) * 1024 > 60000) return false;  // x must fit the LDS stage
     const bool long_k = a.K > 4096;
     const bool many_rows = a.N >= 8192;
     switch (epi) {

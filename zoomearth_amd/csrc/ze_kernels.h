@@ -85,10 +85,10 @@ struct ze_gemv_args {
 bool ze_launch_gemv(int epi, const ze_gemv_args& a, hipStream_t s);
 
 // ---- fused decode attention block of one layer (ze_mega.hip): QKV GEMV -> slices -> merge -> O-proj in one launch
-struct ze_grid_barrier {  // zeroed at the start of every decode step; every word on its own 128-B line
-    unsigned cnt[8 * 32];  // arrivals per group (group = blockIdx % 8, up to 64 workgroups each)
-    unsigned gen[8 * 32];  // last completed epoch, published to the group by its last arriver
-    unsigned top[32];      // group completions
+struct ze_grid_barrier {  // zeroed once at engine creation; every word on its own 128-B line
+    unsigned cnt[8 * 32];  // arrivals per group (group = blockIdx % 8, up to 64 workgroups each); back to 0 per barrier
+    unsigned gen[8 * 32];  // barriers completed so far (monotonic, wraps), one copy per group
+    unsigned top[32];      // groups completed; back to 0 per barrier
     unsigned timeout[32];  // set when a bounded spin gave up: the step's output is invalid and the host reports it
 };
 struct ze_layer_attn_args {
@@ -104,7 +104,7 @@ struct ze_layer_attn_args {
     float* partial; int max_splits;
     int hidden, heads, kv_heads, max_ctx;
     float scale_log2e;
-    ze_grid_barrier* bar; unsigned epoch0;  // this launch uses epochs epoch0 + 1 .. epoch0 + 3
+    ze_grid_barrier* bar;
 };
 // workgroups the fused kernel may be launched with (all co-resident, multiple of 8), 0 when the shape is unsupported
 int ze_layer_attn_blocks(int hidden, int heads, int kv_heads, int head_dim);

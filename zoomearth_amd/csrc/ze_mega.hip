@@ -1,17 +1,24 @@
-// Fused decode "attention block" of one layer in ONE persistent launch (256 workgroups, one per CU):
+// Fused decode "attention block" of one layer in ONE launch (one row pair per wave, every workgroup resident):
 //     RMSNorm + QKV GEMV + M-RoPE + KV append  ->  flash-decoding slices  ->  slice merge  ->  O-proj + residual
-// The four stand-alone kernels it replaces are latency-bound (23.9 us per layer for 19 MB of weights); here their
-// three all-to-all dependencies are in-launch grid barriers instead of kernel boundaries.
+// with the three all-to-all dependencies as in-launch grid barriers instead of kernel boundaries, and the O-proj
+// weights of every wave requested at the start of the launch so that they arrive while the attention phases run.
 //
-// Barrier: two-level (32 workgroups of a group label blockIdx % 8 -> group leader -> top counter -> per-group
-// generation word), relaxed agent-scope atomics and polls only.  NO release / acquire fences: every byte that
-// crosses workgroups inside the launch is stored write-through (sc1) and loaded with sc1 (L1-bypassing) loads, each
-// storing wave drains (s_waitcnt vmcnt(0)) and the workgroup barriers before its lane 0 arrives.  Measured on
-// MI355X (tools/probes/barrier_probe.hip): 2.46 us per barrier INCLUDING the payload hop, against 7.6 us with
-// release/acquire fences and 12 us for a flat counter; 0 stale reads.  Correctness never depends on placement
-// (blockIdx % 8 is only a label that happens to be the XCD under round-robin dispatch: it makes the polls L2-local).
-// Every spin is bounded: on a timeout the launch sets *timeout and exits; the host then reports an error.
-// Counters are zeroed by a memset node at the start of every decode step; epochs count up inside the step.
+// STATUS (round 1, measured on MI355X, 3B shape, ctx 800-1400): bit-identical to the four stand-alone kernels and
+// break-even with them -- 590 +- 5 ms per question either way.  A barrier costs 2.5 us against 1.3 us for a kernel
+// boundary inside a captured graph; what the launch wins back is the O-proj preload and three x-staging prologues.
+// (An earlier reading of -30 ms came from a broken barrier: see mg_barrier.)  It is therefore OFF by default
+// (ze_tune knob 3) and kept, with its parity tests, as the base for the step that can win: streaming the next
+// gate/up weights into LDS while the attention phases leave HBM idle ("next").
+//
+// Barrier: two-level (the workgroups of a group label blockIdx % 8 -> last arriver of the group -> top counter ->
+// the last group's last arriver publishes a generation word per group), relaxed agent-scope atomics and polls only.
+// NO release / acquire fences: every byte that crosses workgroups inside the launch is stored write-through (sc1)
+// and loaded with sc1 (L1-bypassing) loads, each storing wave drains (s_waitcnt vmcnt(0)) and the workgroup
+// barriers before its lane 0 arrives.  Measured on MI355X (tools/probes/barrier_probe.hip): 2.46 us per barrier
+// INCLUDING the payload hop, against 7.6 us with release/acquire fences and 12 us for a flat counter; 0 stale
+// reads.  Correctness never depends on placement (blockIdx % 8 is only a label that happens to be the XCD under
+// round-robin dispatch: it makes the polls L2-local).  Every spin is bounded: on a timeout the launch sets
+// *timeout and exits; the host then reports an error and re-zeroes the counters.
 //
 // Arithmetic is bit-identical to the stand-alone kernels (same row-pair ownership, same per-lane accumulation
 // order, same reductions); the test-suite compares the two paths token for token and logit for logit.
@@ -25,8 +32,12 @@ __device__ __forceinline__ unsigned mg_ld(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// returns false on timeout
-__device__ __forceinline__ bool mg_barrier(ze_grid_barrier* b, unsigned epoch, unsigned groups, unsigned per_group) {
+// Self-resetting, so a launch needs neither a zeroing memset in front of it (a memset NODE in a captured decode step
+// was observed to run unordered with the step's first kernel: stale counts, barriers that pass early) nor an epoch
+// from the host: arrival counters return to 0 inside every barrier, the generation words only grow, and a launch
+// counts its barriers from the generation it finds at its start (all launches of a stream are serialised, so that
+// value is final).  returns false on timeout
+__device__ __forceinline__ bool mg_barrier(ze_grid_barrier* b, unsigned target, unsigned groups, unsigned per_group) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's sc1 stores have left the CU
     __syncthreads();
     __shared__ unsigned s_ok;
@@ -34,19 +45,21 @@ __device__ __forceinline__ bool mg_barrier(ze_grid_barrier* b, unsigned epoch, u
         unsigned ok = 1;
         const unsigned g = blockIdx.x % groups;
         const unsigned old = __hip_atomic_fetch_add(&b->cnt[g * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == per_group - 1) {  // last of its group: nobody of the group adds again before gen[g] moves
+            __hip_atomic_store(&b->cnt[g * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned t = __hip_atomic_fetch_add(&b->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == groups - 1) {  // last group: release everybody
+                __hip_atomic_store(&b->top[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (unsigned k = 0; k < groups; ++k)
+                    __hip_atomic_store(&b->gen[k * 32], target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         unsigned spins = 0;
-        if (old == epoch * per_group - 1) {  // last of its group: leader
-            __hip_atomic_fetch_add(&b->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (mg_ld(&b->top[0]) < epoch * groups) {
-                if (++spins > 2000000u) { ok = 0; break; }
+        while ((int)(mg_ld(&b->gen[g * 32]) - target) < 0) {
+            if (++spins > 2000000u) {
+                ok = 0;
+                break;
             }
-            __hip_atomic_store(&b->gen[g * 32], ok ? epoch : 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            unsigned v;
-            while ((v = mg_ld(&b->gen[g * 32])) < epoch) {
-                if (++spins > 2000000u) { ok = 0; break; }
-            }
-            if (v == 0xffffffffu) ok = 0;
         }
         if (!ok) __hip_atomic_store(&b->timeout[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_ok = ok;
@@ -98,7 +111,8 @@ __global__ void __launch_bounds__(256) k_layer_attn(const ze_layer_attn_args a) 
     float* red = reinterpret_cast<float*>(smem + 8192);     // 16 floats
     ad_split_lds& AL = *reinterpret_cast<ad_split_lds*>(smem + 8192 + 64);
     float* sW = reinterpret_cast<float*>(smem + 8192 + 64); // the merge phase reuses the slice LDS
-    if (mg_ld(&a.bar->timeout[0])) return;                  // an earlier launch of this step gave up: do not spin again
+    if (mg_ld(&a.bar->timeout[0])) return;                  // an earlier launch gave up: do not spin again
+    const unsigned gen0 = mg_ld(&a.bar->gen[(blockIdx.x % 8) * 32]);  // barriers of this launch: gen0 + 1, + 2, + 3
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = a.hidden;                                              // <= 2048 (host-checked)
@@ -210,7 +224,7 @@ __global__ void __launch_bounds__(256) k_layer_attn(const ze_layer_attn_args a) 
         load_rows(a.wqkv, a.ldqkv, r1, r2, K, nch, w);
         qkv_pair(p, w);
     }
-    if (!mg_barrier(a.bar, a.epoch0 + 1, groups, per_group)) return;
+    if (!mg_barrier(a.bar, gen0 + 1, groups, per_group)) return;
 
     // ---------------- phase B: flash-decoding slices (workgroup -> (kv head, slice))
     {
@@ -222,8 +236,11 @@ __global__ void __launch_bounds__(256) k_layer_attn(const ze_layer_attn_args a) 
                                   a.kv_heads, a.max_ctx, a.scale_log2e, a.partial, a.max_splits);
             __syncthreads();
         }
+        // (Measured, rejected: letting the workgroups without a slice touch the next gate/up weights -- one word per
+        //  128-B line, 8-90 MB -- so that they sit in L2 / MALL when the MLP kernel starts: the question got 10-89 ms
+        //  SLOWER, about 1 ms per prefetched MB; the later nt stream gains nothing from it.)
     }
-    if (!mg_barrier(a.bar, a.epoch0 + 2, groups, per_group)) return;
+    if (!mg_barrier(a.bar, gen0 + 2, groups, per_group)) return;
 
     // ---------------- phase C: merge the slices (workgroup -> two heads, 128 threads each)
     for (int hp = blockIdx.x; hp * 2 < a.heads; hp += gridDim.x) {
@@ -232,7 +249,7 @@ __global__ void __launch_bounds__(256) k_layer_attn(const ze_layer_attn_args a) 
         attn_combine_body<true>(w, w + 64, a.partial, ctx + 1, h, d, a.heads, a.max_splits, a.attn);
         __syncthreads();
     }
-    if (!mg_barrier(a.bar, a.epoch0 + 3, groups, per_group)) return;
+    if (!mg_barrier(a.bar, gen0 + 3, groups, per_group)) return;
 
     // ---------------- phase D: O-proj + residual; x = attention output (fresh, sc1)
     {
