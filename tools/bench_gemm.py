@@ -11,7 +11,9 @@ shapes = [("llm qkv", 802, 2560, 2048), ("llm o", 802, 2048, 2048), ("llm gate_u
           ("vit qkv", 1296, 3840, 1280), ("vit proj", 1296, 1280, 1280), ("vit gate_up", 1296, 6848, 1280), ("vit down", 1296, 1280, 3424),
           ("merger0", 324, 5120, 5120), ("merger2", 324, 2048, 5120), ("patch", 1296, 1280, 1176), ("big", 4096, 4096, 4096)]
 tot = 0.0
-for name, m, n, k in shapes:
+import itertools
+for (name, m, n, k), old in itertools.product(shapes, (1, 2, 0)):
+    e.lib.ze_tune(6, old)
     a = (torch.randn(m, k, device="cuda") * 0.5).to(torch.bfloat16)
     w = (torch.randn(n, k, device="cuda") * 0.05).to(torch.bfloat16)
     for _ in range(3):
@@ -23,5 +25,5 @@ for name, m, n, k in shapes:
         e.op_linear(a, w)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / it
-    print(f"{name:14s} M={m:5d} N={n:6d} K={k:6d}  {dt * 1e6:8.1f} us  {2 * m * n * k / dt / 1e12:7.1f} TFLOP/s", flush=True)
+    print(f"{('policy  ', 'regstage', 'ring    ')[old]} {name:14s} M={m:5d} N={n:6d} K={k:6d}  {dt * 1e6:8.1f} us  {2 * m * n * k / dt / 1e12:7.1f} TFLOP/s", flush=True)
 e.close()

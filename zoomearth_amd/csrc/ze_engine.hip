@@ -226,8 +226,10 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     if (c.max_seqs > c.max_ctx) return bad("max_seqs must not exceed max_ctx");
     // the decode GEMV stages x in LDS (<= 60 KB)
     if (ze_pad32(c.intermediate) > 29000) return bad("intermediate > 29000 unsupported by the decode GEMV");
-    e->vit_ipad = ze_pad32(c.vit_intermediate);
-    e->text_ipad = ze_pad32(c.intermediate);
+    // MLP width padded to the GEMM K-step (64): zero rows / columns in the packed weights, so the down projection
+    // takes the LDS-DMA ring kernel (K % 64 == 0) for the ViT too (3420 -> 3456)
+    e->vit_ipad = (c.vit_intermediate + 63) / 64 * 64;
+    e->text_ipad = (c.intermediate + 63) / 64 * 64;
     e->max_pos = c.max_ctx + 512;
 
     if (hipSetDevice(device_id) != hipSuccess) return bad("hipSetDevice failed");

@@ -17,109 +17,22 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define GEMM_BK 64
 
+extern int ze_gemv_knobs[8];  // [6]: 0 = shipped policy, 1 = register-staged kernel everywhere, 2 = ring wherever it applies
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// Tail shared by the GEMM kernels: optional split-K reduction (deterministic, by the last-arriving slice of the tile)
+// and the epilogue.  acc[i][j][r] -> row = wm0 + i*16 + fq*4 + r, col = wn0 + j*16 + fr.
 template <int BM, int BN, int EPI>
-__global__ void __launch_bounds__(256) k_gemm_tn(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
-                                                 int ldw, const bf16_t* __restrict__ bias,
-                                                 const bf16_t* __restrict__ R, int ldr, bf16_t* __restrict__ C,
-                                                 int ldc, const int* __restrict__ c_rows, int M, int N, int K,
-                                                 int ksplit, float* __restrict__ slab, unsigned* __restrict__ tickets) {
-    constexpr int TM = BM / 32, TN = BN / 32;        // MFMA tiles per wave
-    constexpr int A_LOADS = BM * 8 / 256;            // uint4 per thread per K-tile
-    constexpr int B_LOADS = BN * 8 / 256;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint4* const sA0 = reinterpret_cast<uint4*>(smem);                // 2 x [8 chunks][BM rows]
-    uint4* const sB0 = reinterpret_cast<uint4*>(smem) + 2 * BM * 8;   // 2 x [8 chunks][BN rows]
-
-    // XCD-aware block remap: consecutive remapped ids (sharing the A row panel) land on one XCD's L2
-    const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
-    const int nwg = nbx * nby;
-    const int ks = blockIdx.x / nwg;  // split-K slice of this block (all slices of a tile share its output)
-    int bid = blockIdx.x % nwg;
-    {
-        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int bm0 = (bid / nbx) * BM, bn0 = (bid % nbx) * BN;
-
+__device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / 32][BN / 32], uint8_t* smem, const bf16_t* __restrict__ bias,
+                                            const bf16_t* __restrict__ R, int ldr, bf16_t* __restrict__ C, int ldc,
+                                            const int* __restrict__ c_rows, int M, int N, int ksplit, int ks, int bid,
+                                            int nwg, int bm0, int bn0, float* __restrict__ slab,
+                                            unsigned* __restrict__ tickets) {
+    constexpr int TM = BM / 32, TN = BN / 32;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm0 = (wid >> 1) * (BM / 2), wn0 = (wid & 1) * (BN / 2);
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    uint4 ra[A_LOADS], rb[B_LOADS];
-    const int ld_chunk = tid & 7;   // 16-B chunk along K
-    const int ld_row = tid >> 3;    // 0..31
-
-    auto load_tiles = [&](int k0) {
-        const int kc = k0 + ld_chunk * 8;
-        const bool kin = kc < K;
-#pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) {
-            const int row = bm0 + ld_row + i * 32;
-            ra[i] = (kin && row < M) ? *reinterpret_cast<const uint4*>(A + (size_t)row * lda + kc) : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) {
-            const int row = bn0 + ld_row + i * 32;
-            rb[i] = (kin && row < N) ? *reinterpret_cast<const uint4*>(W + (size_t)row * ldw + kc) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) {
-            const int row = ld_row + i * 32;
-            sA0[buf * BM * 8 + ld_chunk * BM + (row ^ ld_chunk)] = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) {
-            const int row = ld_row + i * 32;
-            sB0[buf * BN * 8 + ld_chunk * BN + (row ^ ld_chunk)] = rb[i];
-        }
-    };
-
-    const int nk_all = (K + GEMM_BK - 1) / GEMM_BK;
-    const int nk_per = (nk_all + ksplit - 1) / ksplit;
-    const int kt0 = ks * nk_per;
-    const int nk = max(0, min(nk_all - kt0, nk_per));
-    load_tiles(kt0 * GEMM_BK);
-    store_tiles(0);
-    __syncthreads();
     const int fr = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles((kt0 + kt + 1) * GEMM_BK);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int chunk = ks * 4 + fq;
-            bf16x8 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm0 + i * 16 + fr;
-                const uint4 v = sA0[buf * BM * 8 + chunk * BM + (row ^ chunk)];
-                fa[i] = *reinterpret_cast<const bf16x8*>(&v);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = wn0 + j * 16 + fr;
-                const uint4 v = sB0[buf * BN * 8 + chunk * BN + (row ^ chunk)];
-                fb[j] = *reinterpret_cast<const bf16x8*>(&v);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
-        __syncthreads();
-    }
-
     // ---------------- split-K: deterministic reduction by the last-arriving slice of the tile.
     // Every slice parks its fp32 accumulators in a slab (one float4 per thread per MFMA tile), publishes them with an
     // agent-scope release + ticket; the block that draws the last ticket acquires, adds the slabs IN SLICE ORDER
@@ -224,6 +137,256 @@ __global__ void __launch_bounds__(256) k_gemm_tn(const bf16_t* __restrict__ A, i
         }
 }
 
+template <int BM, int BN, int EPI>
+__global__ void __launch_bounds__(256) k_gemm_tn(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
+                                                 int ldw, const bf16_t* __restrict__ bias,
+                                                 const bf16_t* __restrict__ R, int ldr, bf16_t* __restrict__ C,
+                                                 int ldc, const int* __restrict__ c_rows, int M, int N, int K,
+                                                 int ksplit, float* __restrict__ slab, unsigned* __restrict__ tickets) {
+    constexpr int TM = BM / 32, TN = BN / 32;        // MFMA tiles per wave
+    constexpr int A_LOADS = BM * 8 / 256;            // uint4 per thread per K-tile
+    constexpr int B_LOADS = BN * 8 / 256;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint4* const sA0 = reinterpret_cast<uint4*>(smem);                // 2 x [8 chunks][BM rows]
+    uint4* const sB0 = reinterpret_cast<uint4*>(smem) + 2 * BM * 8;   // 2 x [8 chunks][BN rows]
+
+    // XCD-aware block remap: consecutive remapped ids land on one XCD's L2
+    const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
+    const int nwg = nbx * nby;
+    const int ks = blockIdx.x / nwg;  // split-K slice of this block (all slices of a tile share its output)
+    int bid = blockIdx.x % nwg;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    // Workgroups with consecutive remapped ids share an XCD (its L2).  Walk the tile grid so that they share the
+    // panel of the LARGER operand: with N > M (weights larger than activations: every GEMM of this path) ids run
+    // down a column of tiles, an XCD then streams 1/8 of W once and re-reads the small A from L2 / MALL; the other
+    // order makes all eight XCDs pull the whole of W through the fabric (gate/up at M = 802: 723 MB against 117 MB).
+    const bool col_major = N > M;
+    const int bm0 = (col_major ? bid % nby : bid / nbx) * BM, bn0 = (col_major ? bid / nby : bid % nbx) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm0 = (wid >> 1) * (BM / 2), wn0 = (wid & 1) * (BN / 2);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[A_LOADS], rb[B_LOADS];
+    const int ld_chunk = tid & 7;   // 16-B chunk along K
+    const int ld_row = tid >> 3;    // 0..31
+
+    auto load_tiles = [&](int k0) {
+        const int kc = k0 + ld_chunk * 8;
+        const bool kin = kc < K;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int row = bm0 + ld_row + i * 32;
+            ra[i] = (kin && row < M) ? *reinterpret_cast<const uint4*>(A + (size_t)row * lda + kc) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int row = bn0 + ld_row + i * 32;
+            rb[i] = (kin && row < N) ? *reinterpret_cast<const uint4*>(W + (size_t)row * ldw + kc) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int row = ld_row + i * 32;
+            sA0[buf * BM * 8 + ld_chunk * BM + (row ^ ld_chunk)] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int row = ld_row + i * 32;
+            sB0[buf * BN * 8 + ld_chunk * BN + (row ^ ld_chunk)] = rb[i];
+        }
+    };
+
+    const int nk_all = (K + GEMM_BK - 1) / GEMM_BK;
+    const int nk_per = (nk_all + ksplit - 1) / ksplit;
+    const int kt0 = ks * nk_per;
+    const int nk = max(0, min(nk_all - kt0, nk_per));
+    load_tiles(kt0 * GEMM_BK);
+    store_tiles(0);
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles((kt0 + kt + 1) * GEMM_BK);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = ks * 4 + fq;
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm0 + i * 16 + fr;
+                const uint4 v = sA0[buf * BM * 8 + chunk * BM + (row ^ chunk)];
+                fa[i] = *reinterpret_cast<const bf16x8*>(&v);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn0 + j * 16 + fr;
+                const uint4 v = sB0[buf * BN * 8 + chunk * BN + (row ^ chunk)];
+                fb[j] = *reinterpret_cast<const bf16x8*>(&v);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    gemm_finish<BM, BN, EPI>(acc, smem, bias, R, ldr, C, ldc, c_rows, M, N, ksplit, ks, bid, nwg, bm0, bn0, slab, tickets);
+}
+
+// ------------------------------------------------------------------ LDS-DMA ring kernel (K % 64 == 0)
+// The prefill / ViT GEMMs have 300-1300 rows: a launch is one or two rounds of workgroups whose K loops are only
+// 20-170 steps long, so the register-staged kernel above (one tile of prefetch, ~0.1 us of MFMA per step against
+// 1-2 us of load latency) is latency-bound at 200-500 TFLOP/s.  This kernel keeps STAGES - 1 K-tiles in flight per
+// workgroup with `global_load_lds` (no VGPR cost):
+//   * stage image per operand: [rows][128 B], the 16-B chunk index XOR-ed with (row >> 1) & 7.  One wave-instruction
+//     moves 8 full 128-B rows (lanes l -> row l >> 3, LDS chunk l & 7); LDS-DMA writes lane-linearly, so the swizzle
+//     lives on the SOURCE address and, as the same involution, on the fragment read: 16 rows x one chunk by
+//     ds_read_b128 then touch 16 distinct 16-B slots of the 256-B bank row (conflict-free).
+//   * K loop: counted s_waitcnt vmcnt(N) (this wave's DMAs of the stage about to be read have landed), ONE raw
+//     s_barrier (everybody's have, and everybody is done reading the stage about to be refilled), issue the DMAs of
+//     stage kt + STAGES - 1, fragment reads + MFMA of stage kt.  No __syncthreads() and no ordinary global load inside
+//     the loop (either would drain the DMA queue), all LDS in one array.
+// Rows past M / N re-read the last valid row (their outputs are never stored).  Accumulation order per output
+// element is that of the kernel above (same MFMA, same K order), so the two produce identical results.
+template <int ROWS, int NT>
+__device__ __forceinline__ void ring_issue(const bf16_t* __restrict__ G, int ld, int row0, int row_max, int k0,
+                                           unsigned lds_img, int wid, int lane) {
+    // ROWS / 8 wave-instructions per image, NT / 64 waves share them
+#pragma unroll
+    for (int g = 0; g < ROWS / 8 / (NT / 64); ++g) {
+        const int grp = wid + g * (NT / 64);
+        const int row = grp * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const bf16_t* src = G + (size_t)min(row0 + row, row_max) * ld + k0 + c * 8;
+        // Issued from inline asm on purpose: for a DMA it knows about (__builtin_amdgcn_global_load_lds) hipcc puts
+        // s_waitcnt vmcnt(0) in front of the next ds_read of the array, which drains the ring every K-step.  The
+        // ordering DMA -> ds_read is provided by ring_wait + the barrier in the K loop instead.
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(src), "s"(lds_img + grp * 1024)
+            : "memory");
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void ring_wait() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else static_assert(N == 0, "add the literal");
+}
+
+template <int BM, int BN, int STAGES, int EPI>
+__global__ void __launch_bounds__(256) k_gemm_ring(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
+                                                   int ldw, const bf16_t* __restrict__ bias,
+                                                   const bf16_t* __restrict__ R, int ldr, bf16_t* __restrict__ C,
+                                                   int ldc, const int* __restrict__ c_rows, int M, int N, int K,
+                                                   int ksplit, float* __restrict__ slab,
+                                                   unsigned* __restrict__ tickets) {
+    constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    constexpr int LPW = (BM + BN) / 32;  // DMA instructions per wave per stage
+    static_assert(STAGES == 3 || STAGES == 4, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
+    const int nwg = nbx * nby;
+    const int ks = blockIdx.x / nwg;
+    int bid = blockIdx.x % nwg;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    // Workgroups with consecutive remapped ids share an XCD (its L2).  Walk the tile grid so that they share the
+    // panel of the LARGER operand: with N > M (weights larger than activations: every GEMM of this path) ids run
+    // down a column of tiles, an XCD then streams 1/8 of W once and re-reads the small A from L2 / MALL; the other
+    // order makes all eight XCDs pull the whole of W through the fabric (gate/up at M = 802: 723 MB against 117 MB).
+    const bool col_major = N > M;
+    const int bm0 = (col_major ? bid % nby : bid / nbx) * BM, bn0 = (col_major ? bid / nby : bid % nbx) * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wid >> 1) * (BM / 2), wn0 = (wid & 1) * (BN / 2);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk_all = K / GEMM_BK;
+    const int nk_per = (nk_all + ksplit - 1) / ksplit;
+    const int kt0 = ks * nk_per;
+    const int nk = max(0, min(nk_all - kt0, nk_per));
+
+    // LDS byte address of the staging array (wave-uniform: it goes to M0)
+    const unsigned smem_lds = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem);
+    auto issue = [&](int kt) {
+        const unsigned img = smem_lds + (kt % STAGES) * STAGE_BYTES;
+        const int k0 = (kt0 + kt) * GEMM_BK;
+        ring_issue<BM, 256>(A, lda, bm0, M - 1, k0, img, wid, lane);
+        ring_issue<BN, 256>(W, ldw, bn0, N - 1, k0, img + BM * 128, wid, lane);
+    };
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) issue(s);
+
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        // stages still allowed in flight behind stage kt: min(STAGES - 2, nk - 1 - kt)
+        const int ahead = min(STAGES - 2, nk - 1 - kt);
+        if (ahead >= 2) ring_wait<2 * LPW>();
+        else if (ahead == 1) ring_wait<LPW>();
+        else ring_wait<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+        const uint8_t* imgA = smem + (kt % STAGES) * STAGE_BYTES;
+        const uint8_t* imgB = imgA + BM * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int chunk = kk * 4 + fq;
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm0 + i * 16 + fr;
+                fa[i] = *reinterpret_cast<const bf16x8*>(imgA + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn0 + j * 16 + fr;
+                fb[j] = *reinterpret_cast<const bf16x8*>(imgB + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // the tail reuses the staging LDS
+    gemm_finish<BM, BN, EPI>(acc, smem, bias, R, ldr, C, ldc, c_rows, M, N, ksplit, ks, bid, nwg, bm0, bn0, slab, tickets);
+}
+
 // split-K workspace (fp32 slabs + per-tile tickets), owned by the engine and passed once
 static float* g_slab = nullptr;
 static unsigned* g_tickets = nullptr;
@@ -252,6 +415,41 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
     }
     if (ksplit > 1 && (!g_slab || (size_t)ksplit * nwg * BM * BN > g_slab_floats || nwg > g_ticket_cap)) ksplit = 1;
     const int grid = nwg * ksplit;
+    // The ring wins where a launch is at most one round of workgroups (few tiles, long K: o / down / merger / ViT
+    // proj, 1.3-1.9x) and loses 15-25 % to the register-staged kernel on grids of many rounds, which hide latency
+    // with 2-3 co-resident workgroups per CU instead (qkv, gate/up): measured per shape, tools/bench_gemm.py.
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    const bool ring = ze_gemv_knobs[6] == 2 || (ze_gemv_knobs[6] == 0 && grid <= cus);
+    if (K % GEMM_BK == 0 && K / GEMM_BK / ksplit >= 4 && ring) {
+        // LDS-DMA ring: four stages when they fit beside nothing else (one workgroup per CU), else three
+        constexpr int STAGES = ((BM + BN) * 128 * 4 <= 128 * 1024) ? 4 : 3;
+        const size_t lds_ring = (size_t)(BM + BN) * 128 * STAGES;
+#define ZE_RING_LAUNCH(E)                                                                                              \
+    do {                                                                                                               \
+        static bool attr_set = false;                                                                                  \
+        if (!attr_set) {                                                                                               \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<BM, BN, STAGES, E>),                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ring);                            \
+            attr_set = true;                                                                                           \
+        }                                                                                                              \
+        hipLaunchKernelGGL((k_gemm_ring<BM, BN, STAGES, E>), dim3(grid), dim3(256), lds_ring, s, A, lda, W, ldw, bias, \
+                           R, ldr, C, ldc, c_rows, M, N, K, ksplit, g_slab, g_tickets);                                \
+    } while (0)
+        switch (epi) {
+            case ZE_EPI_NONE: ZE_RING_LAUNCH(ZE_EPI_NONE); break;
+            case ZE_EPI_GELU: ZE_RING_LAUNCH(ZE_EPI_GELU); break;
+            case ZE_EPI_RESIDUAL: ZE_RING_LAUNCH(ZE_EPI_RESIDUAL); break;
+            case ZE_EPI_SWIGLU: ZE_RING_LAUNCH(ZE_EPI_SWIGLU); break;
+            case ZE_EPI_F32: ZE_RING_LAUNCH(ZE_EPI_F32); break;
+        }
+#undef ZE_RING_LAUNCH
+        return;
+    }
     const size_t lds = (size_t)2 * (BM + BN) * 8 * 16;
 #define ZE_GEMM_LAUNCH(E)                                                                                          \
     hipLaunchKernelGGL((k_gemm_tn<BM, BN, E>), dim3(grid), dim3(256), lds, s, A, lda, W, ldw, bias, R, ldr, C, ldc, \
@@ -275,12 +473,16 @@ void ze_launch_gemm_stream(int epi, const bf16_t* A, int lda, const bf16_t* W, i
 void ze_launch_gemm(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
                     int ldr, bf16_t* C, int ldc, const int* c_rows, int M, int N, int K, hipStream_t s) {
     if (M <= 0 || N <= 0) return;
-    // pick the largest tile that still gives the 256 CUs about one block each (split-K covers the rest)
+    // Many tiles: the largest tile (the register-staged kernel hides latency with several workgroups per CU).
+    // Otherwise the largest tile whose grid is one round of at least half the CUs, which then runs on the LDS-DMA
+    // ring kernel when K % 64 == 0 (launch_cfg); 64 x 64 tiles for what is left.
     const long b128 = (long)ze_cdiv(M, 128) * ze_cdiv(N, 128);
     const long b64x128 = (long)ze_cdiv(M, 64) * ze_cdiv(N, 128);
+    const long b64 = (long)ze_cdiv(M, 64) * ze_cdiv(N, 64);
+    const bool ringable = K % GEMM_BK == 0;
     if (b128 >= 200)
         launch_cfg<128, 128>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, false);
-    else if (b64x128 >= 160)
+    else if (b64x128 >= 160 || (ringable && (b64x128 >= 128 || b64 > 256)))
         launch_cfg<64, 128>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, false);
     else
         launch_cfg<64, 64>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, false);
