@@ -216,7 +216,8 @@ __global__ void __launch_bounds__(256) k_attn_decode_split(const bf16_t* __restr
                                                            const ze_seq_dev* __restrict__ st_base,
                                                            const int* __restrict__ seq_ids, int heads, int kv_heads,
                                                            int max_ctx, float scale_log2e, float* __restrict__ ws,
-                                                           int max_splits) {
+                                                           int max_splits, unsigned* __restrict__ tickets,
+                                                           bf16_t* __restrict__ out, int out_row_stride) {
     // chain of this block (grid.z): batched decode indexes the chain table, single-chain decode passes its state
     const int bz = blockIdx.z;
     const ze_seq_dev* st = seq_ids ? st_base + seq_ids[bz] : st_base;
@@ -225,33 +226,45 @@ __global__ void __launch_bounds__(256) k_attn_decode_split(const bf16_t* __restr
         vcache += (size_t)seq_ids[bz] * cache_seq_stride;
     }
     __shared__ ad_split_lds L;
-    attn_split_body<false>(L, q + (size_t)bz * q_row_stride, kcache, vcache, st->ctx + 1, blockIdx.x, blockIdx.y, heads,
-                           kv_heads, max_ctx, scale_log2e, ws + (size_t)bz * max_splits * heads * AD_STRIDE, max_splits);
-}
-
-// grid = (heads, chains), 128 threads (one per output dim)
-__global__ void __launch_bounds__(128) k_attn_decode_combine(const float* __restrict__ ws,
-                                                             const ze_seq_dev* __restrict__ st_base,
-                                                             const int* __restrict__ seq_ids, int heads,
-                                                             int max_splits, bf16_t* __restrict__ out,
-                                                             int out_row_stride) {
-    const int bz = blockIdx.y;
-    const ze_seq_dev* st = seq_ids ? st_base + seq_ids[bz] : st_base;
-    __shared__ float sW[64];
-    __shared__ float sInv;
-    attn_combine_body<false>(sW, &sInv, ws + (size_t)bz * max_splits * heads * AD_STRIDE, st->ctx + 1, blockIdx.x,
-                             threadIdx.x, heads, max_splits, out + (size_t)bz * out_row_stride);
+    const int ctx = st->ctx + 1, kvh = blockIdx.x;
+    int chunk, nsplit;
+    split_geometry(ctx, max_splits, chunk, nsplit);
+    if ((int)blockIdx.y >= nsplit) return;  // workgroup-uniform: no slice, no ticket
+    float* wsb = ws + (size_t)bz * max_splits * heads * AD_STRIDE;
+    attn_split_body<false, true>(L, q + (size_t)bz * q_row_stride, kcache, vcache, ctx, kvh, blockIdx.y, heads, kv_heads,
+                                 max_ctx, scale_log2e, wsb, max_splits);
+    // ---- merge by the last-arriving slice of this (chain, kv head).  Hand-off without fences: the partials above
+    // went out write-through (sc1), every storing wave drains, the workgroup barriers, ONE lane takes a ticket
+    // (relaxed agent-scope add on one unsharded counter); the workgroup whose add came last reads every partial
+    // with sc1 loads, in slice order, so the result does not depend on who is last.  The ticket returns to 0 for
+    // the next launch.  (With an agent-scope acquire fence + plain loads in place of the sc1 pair this merge cost
+    // 30 ms per question MORE than a separate merge launch; in this form it replaces that 4.8-us launch.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned* flag = reinterpret_cast<unsigned*>(&L.sM[0]);  // the slice LDS is dead now
+    if (threadIdx.x == 0) {
+        unsigned* t = tickets + (size_t)bz * kv_heads + kvh;
+        const unsigned old = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned last = old == (unsigned)nsplit - 1u;
+        if (last) __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = last;
+    }
+    __syncthreads();
+    if (*flag == 0u) return;
+    __syncthreads();  // everybody has read the flag before the merge reuses the LDS
+    float* sW = reinterpret_cast<float*>(&L.sV[0][0]);
+    attn_merge_group(sW, sW + AD_GMAX * 64, wsb, ctx, kvh, heads, kv_heads, max_splits,
+                     out + (size_t)bz * out_row_stride);
 }
 
 void ze_launch_attn_decode(const bf16_t* q, int q_row_stride, const bf16_t* kcache, const bf16_t* vcache,
                            size_t cache_seq_stride, bf16_t* out, int out_row_stride, const ze_seq_dev* st,
                            const int* seq_ids, int n, int heads, int kv_heads, int D, int max_ctx, float scale,
-                           float* ws_partial, int max_splits, hipStream_t s) {
+                           float* ws_partial, int max_splits, unsigned* tickets, hipStream_t s) {
     (void)D;
     const float sl = scale * 1.4426950408889634f;
     k_attn_decode_split<<<dim3(kv_heads, max_splits, n), 256, 0, s>>>(q, q_row_stride, kcache, vcache, cache_seq_stride,
                                                                        st, seq_ids, heads, kv_heads, max_ctx, sl,
-                                                                       ws_partial, max_splits);
-    k_attn_decode_combine<<<dim3(heads, n), 128, 0, s>>>(ws_partial, st, seq_ids, heads, max_splits, out,
-                                                         out_row_stride);
+                                                                       ws_partial, max_splits, tickets, out,
+                                                                       out_row_stride);
 }

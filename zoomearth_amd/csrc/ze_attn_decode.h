@@ -65,7 +65,10 @@ __device__ __forceinline__ void ad_store16(void* base, uint32_t off, float a, fl
     }
 }
 
-template <bool FRESH>
+// FRESH: q and the newest K/V row were written inside this launch (fused layer kernel).  PUB: the partials are
+// published write-through (sc1) because they are merged inside this launch (by the fused kernel's merge phase or by
+// the last-arriving slice workgroup of the stand-alone kernel).
+template <bool FRESH, bool PUB = FRESH>
 __device__ __forceinline__ void attn_split_body(ad_split_lds& L, const bf16_t* __restrict__ q,
                                                 const bf16_t* __restrict__ kcache, const bf16_t* __restrict__ vcache,
                                                 int ctx, int kvh, int split, int heads, int kv_heads, int max_ctx,
@@ -224,8 +227,8 @@ __device__ __forceinline__ void attn_split_body(ad_split_lds& L, const bf16_t* _
     }
     if (og < G) {
         const uint32_t dst = (uint32_t)((split * heads + kvh * G + og) * AD_STRIDE * 4);
-        if ((tid & 31) == 0) ad_store16<FRESH>(ws, dst, m_run, l_run, 0.f, 0.f);
-        ad_store16<FRESH>(ws, dst + (4 + od) * 4, o0, o1, o2, o3);
+        if ((tid & 31) == 0) ad_store16<PUB>(ws, dst, m_run, l_run, 0.f, 0.f);
+        ad_store16<PUB>(ws, dst + (4 + od) * 4, o0, o1, o2, o3);
     }
 }
 
@@ -267,3 +270,83 @@ __device__ __forceinline__ void attn_combine_body(float* sW, float* sInvp, const
     ad_store2<FRESH>(out, (uint32_t)((h * D + d) * 2), f32_to_bf16(acc * sInv));
 }
 
+// Merge of the slices of ALL q heads of one kv head by one 256-thread workgroup (the last-arriving slice workgroup):
+// wave w computes the slice weights of heads 2w, 2w+1 (lane = slice), then thread (head og, dims od..od+3)
+// accumulates in slice order -- per output element the arithmetic of attn_combine_body.  Partials are read with
+// sc1 loads (they were published sc1 inside this launch).  sW: [AD_GMAX][64] floats, sInv: [AD_GMAX].
+__device__ __forceinline__ void attn_merge_group(float* sW, float* sInv, const float* __restrict__ ws, int ctx, int kvh,
+                                                 int heads, int kv_heads, int max_splits, bf16_t* __restrict__ out) {
+    constexpr int D = 128;
+    const int G = heads / kv_heads;
+    int chunk, nsplit;
+    split_geometry(ctx, max_splits, chunk, nsplit);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int og = tid >> 5, od = (tid & 31) * 4;
+    const int hc = kvh * G + min(og, G - 1);  // idle threads (og >= G) shadow the last head: no branch around loads
+    const uint32_t p = (uint32_t)((hc * AD_STRIDE + 4 + od) * 4), step = (uint32_t)(heads * AD_STRIDE * 4);
+    // Everything the merge needs is requested at once -- the (m, l) pairs and the first 16 slices of this thread's
+    // four output dims -- so the last arriver pays one memory round trip, not one per dependent step.
+    uint4 ml[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int g = min(wid * 2 + hh, G - 1);
+        ml[hh] = ad_load16<true>(ws, (uint32_t)((min(lane, nsplit - 1) * heads + kvh * G + g) * AD_STRIDE * 4));
+    }
+    uint4 x0[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) x0[u] = ad_load16<true>(ws, p + min(u, nsplit - 1) * step);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int g = wid * 2 + hh;
+        if (g < G) {  // wave-uniform
+            const float m = lane < nsplit ? __uint_as_float(ml[hh].x) : -INFINITY;
+            const float l = lane < nsplit ? __uint_as_float(ml[hh].y) : 0.f;
+            const float mx = wave_max(m);
+            const float w = (m == -INFINITY) ? 0.f : exp2f(m - mx);
+            const float tot = wave_sum(w * l);
+            sW[g * 64 + lane] = w;
+            if (lane == 0) sInv[g] = tot > 0.f ? 1.0f / tot : 0.f;
+        }
+    }
+    __syncthreads();
+    if (og >= G) return;
+    const int h = kvh * G + og;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        if (u < nsplit) {
+            const float w = sW[og * 64 + u];
+            a0 = fmaf(w, __uint_as_float(x0[u].x), a0);
+            a1 = fmaf(w, __uint_as_float(x0[u].y), a1);
+            a2 = fmaf(w, __uint_as_float(x0[u].z), a2);
+            a3 = fmaf(w, __uint_as_float(x0[u].w), a3);
+        }
+    }
+    int s = 16;
+    for (; s + 8 <= nsplit; s += 8) {
+        uint4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = ad_load16<true>(ws, p + (s + u) * step);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float w = sW[og * 64 + s + u];
+            a0 = fmaf(w, __uint_as_float(x[u].x), a0);
+            a1 = fmaf(w, __uint_as_float(x[u].y), a1);
+            a2 = fmaf(w, __uint_as_float(x[u].z), a2);
+            a3 = fmaf(w, __uint_as_float(x[u].w), a3);
+        }
+    }
+    for (; s < nsplit; ++s) {
+        const uint4 x = ad_load16<true>(ws, p + s * step);
+        const float w = sW[og * 64 + s];
+        a0 = fmaf(w, __uint_as_float(x.x), a0);
+        a1 = fmaf(w, __uint_as_float(x.y), a1);
+        a2 = fmaf(w, __uint_as_float(x.z), a2);
+        a3 = fmaf(w, __uint_as_float(x.w), a3);
+    }
+    const float inv = sInv[og];
+    uint2 o;
+    o.x = pack_bf16x2(a0 * inv, a1 * inv);
+    o.y = pack_bf16x2(a2 * inv, a3 * inv);
+    *reinterpret_cast<uint2*>(out + (size_t)h * D + od) = o;
+}

@@ -106,6 +106,7 @@ struct ze_engine {
     int max_splits = 64;
     int* d_host_ints = nullptr;  // pinned, small
     // fused decode attention block (ze_mega.hip)
+    unsigned* atickets = nullptr;  // decode attention: one arrival ticket per (chain, kv head)
     ze_grid_barrier* gbar = nullptr;
     int attn_blocks = 0;  // 0: shape unsupported, the four stand-alone kernels run instead
     std::vector<int> graph_variant;

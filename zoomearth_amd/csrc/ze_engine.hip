@@ -327,6 +327,7 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     chk(dev_alloc(e, &e->dpartial, (size_t)e->max_splits * c.heads * 132));
     chk(dev_alloc(e, &e->dsample, 2 * 128 + 64 + 8));
     chk(dev_alloc(e, &e->gbar, 1));
+    chk(dev_alloc(e, &e->atickets, (size_t)c.max_seqs * c.kv_heads));
     if (r == 0) e->attn_blocks = ze_layer_attn_blocks(c.hidden, c.heads, c.kv_heads, e->head_dim);
     if (r == 0 && hipHostMalloc((void**)&e->d_host_ints, (64 + c.max_seqs) * sizeof(int)) != hipSuccess)
         r = ze_fail(e, ZE_ERR_HIP, "hipHostMalloc failed");
@@ -362,7 +363,7 @@ extern "C" int ze_engine_destroy(ze_engine* e) {
                    e->st_dev, e->seen, e->out_tokens, e->fe_tmp, e->fe_img, e->fe_coef, e->vx, e->vh, e->vy, e->vqkv,
                    e->vo, e->va, e->vz, e->vz2, e->vcos, e->vsin, e->vperm, e->vinv, e->vtiles_win, e->vtiles_full,
                    e->th, e->ty, e->tqkv, e->to, e->ta, e->tsrc, e->tpos, e->ttiles, e->dh, e->dq, e->dattn, e->dact,
-                   e->dlogits, e->dpartial, e->dsample, e->gbar, e->gslab, e->gtickets, e->bseq, e->blogits, e->bpartial, e->bsample};
+                   e->dlogits, e->dpartial, e->dsample, e->gbar, e->atickets, e->gslab, e->gtickets, e->bseq, e->blogits, e->bpartial, e->bsample};
     for (void* p : dev)
         if (p) hipFree(p);
     void* host[] = {e->fe_coef_host, e->v_host_ints, e->v_host_f32, e->t_host_ints, e->d_host_ints, e->bstate_host};

@@ -516,7 +516,7 @@ int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos,
         }
         ze_launch_gemv(ZE_GV_QKV_ROPE, a, s);
         ze_launch_attn_decode(e->dq, 0, e->kc(li, seq), e->vc(li, seq), 0, e->dattn, 0, st, nullptr, 1, c.heads,
-                              c.kv_heads, hd, c.max_ctx, scale, e->dpartial, e->max_splits, s);
+                              c.kv_heads, hd, c.max_ctx, scale, e->dpartial, e->max_splits, e->atickets, s);
         ze_gemv_args o;
         memset(&o, 0, sizeof(o));
         o.W = L.o.w;
@@ -741,7 +741,7 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
         ze_launch_rope_kv_batch(e->tqkv, n, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(li, 0),
                                 e->vc(li, 0), seq_stride, c.max_ctx, s);
         ze_launch_attn_decode(e->tqkv, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, e->to, nq, e->st_dev, e->bseq, n,
-                              c.heads, c.kv_heads, hd, c.max_ctx, scale, e->bpartial, e->max_splits, s);
+                              c.heads, c.kv_heads, hd, c.max_ctx, scale, e->bpartial, e->max_splits, e->atickets, s);
         ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, n, H, nq, s);
         ze_launch_rmsnorm(e->th, H, L.post_norm, e->ty, H, n, H, c.rms_eps, s);
         ze_launch_gemm_stream(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad, n,

@@ -118,11 +118,12 @@ void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_row_stride, 
                           int group, float scale, int q_pos_offset, hipStream_t s);
 // Decode attention for one chain: q [heads, D]; caches [kv_heads, max_ctx, D]; context = st->ctx + 1 tokens.
 // Batched form: n chains; chain b = seq_ids[b] (null: chain 0 is `st` itself), q/out rows b, caches offset by
-// seq * cache_seq_stride elements, partials offset by b * max_splits * heads * 132 floats.
+// seq * cache_seq_stride elements, partials offset by b * max_splits * heads * 132 floats; tickets: n * kv_heads zeroed
+// words (they return to zero inside every launch).
 void ze_launch_attn_decode(const bf16_t* q, int q_row_stride, const bf16_t* kcache, const bf16_t* vcache,
                            size_t cache_seq_stride, bf16_t* out, int out_row_stride, const ze_seq_dev* st,
                            const int* seq_ids, int n, int heads, int kv_heads, int D, int max_ctx, float scale,
-                           float* ws_partial, int max_splits, hipStream_t s);
+                           float* ws_partial, int max_splits, unsigned* tickets, hipStream_t s);
 
 // ---- sampling
 void ze_launch_sample(const float* logits, int vocab, uint8_t* seen, float penalty, ze_seq_dev* st,
