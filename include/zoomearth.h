@@ -157,13 +157,20 @@ int ze_prefill(ze_engine* e, int seq, const int32_t* input_ids, int len, const v
 int ze_decode_step(ze_engine* e, int seq, int token, float* out_logits, void* stream);
 
 /* Generation options (replaces the kwargs of model.generate at src/eval/infer.py:109-115, src/demo.py:14-19).
- * do_sample / temperature are accepted by the Python layer and mapped to greedy (documented deviation). */
+ * do_sample = 0: greedy arg-max (src/demo.py:17).  do_sample = 1 with temperature > 0: multinomial draw from
+ * softmax(penalised logits / temperature) -- TemperatureLogitsWarper + torch.multinomial as src/eval/infer.py:109-115
+ * uses them (temperature 0.01, top_k = top_p = None); same distribution, but the random stream is this library's
+ * counter-based generator: draw = f(seed, chain slot, index of the generated token), reproducible and independent
+ * of batch composition (see ze_op_sample_temperature). */
 typedef struct ze_gen_params {
     int32_t max_new_tokens;
     float repetition_penalty;  /* 1.0 = off */
     int32_t ignore_eos;        /* scripted benchmark mode: run exactly max_new_tokens steps */
     int32_t use_graph;         /* replay the decode step as a hipGraph */
     int32_t sync_every;        /* host EOS check interval in steps (>=1) */
+    int32_t do_sample;         /* 0 greedy, 1 temperature sampling */
+    float temperature;         /* used when do_sample != 0; must be > 0 then */
+    uint64_t seed;             /* sampling stream */
 } ze_gen_params;
 
 /* replaces: GenerationMixin.generate greedy loop after prefill for one chain.  Samples the first token from the
@@ -184,6 +191,13 @@ int ze_seq_mark_seen(ze_engine* e, int seq, const int32_t* ids, int n, void* str
 /* Applies penalty + argmax to f32 logits [vocab] (device) with the seen-set of `seq`; *out_token host. */
 int ze_op_sample_greedy(ze_engine* e, int seq, const float* logits, float repetition_penalty, int32_t* out_token,
                         void* stream);
+/* One temperature-sampling draw (replaces TemperatureLogitsWarper + softmax + torch.multinomial,
+ * HF:generation/utils.py:2894-2916) on f32 logits [vocab] (device) with the seen-set of `seq`:
+ *   u = (stream64(mix64(seed ^ mix64(seq + 1)), index) >> 40) * 2^-24 ; e_i = expf(score_i / T - max score / T) ;
+ *   token = first i whose running sum of e exceeds u * sum(e)   (fp32 sums in the order given in ze_sample.hip).
+ * `index` = position of the draw in the generated sequence (what ze_generate passes). *out_token host. */
+int ze_op_sample_temperature(ze_engine* e, int seq, const float* logits, float repetition_penalty, float temperature,
+                             uint64_t seed, int index, int32_t* out_token, void* stream);
 
 /* ------------------------------------------------------------------ unit ops for parity tests (K3-K22) */
 /* C[M,N] = A[M,K] * W[N,K]^T (+bias[N]) ; bf16 in, fp32 accumulate, bf16 out (one rounding).  act: 0 none, 1 exact GELU. */

@@ -35,7 +35,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from . import indices
+from . import indices, prng
 
 
 # ----------------------------------------------------------------------------- numerics helpers
@@ -429,6 +429,85 @@ def apply_repetition_penalty(logits: np.ndarray, seen_ids, penalty: float) -> np
     sc = out[idx]
     out[idx] = np.where(sc < 0, sc * np.float32(penalty), sc / np.float32(penalty))
     return out
+
+
+SAMPLE_BLOCKS = 128
+
+
+def sample_uniform(seed: int, slot: int, index: int) -> np.float32:
+    """The draw u in [0, 1) of generated token `index` of chain slot `slot` (include/zoomearth.h,
+    ze_op_sample_temperature): 24 high bits of stream64(mix64(seed ^ mix64(slot + 1)), index)."""
+    m = (1 << 64) - 1
+    inner = int(prng.mix64(np.array([(slot + 1) & m], dtype=np.uint64))[0])
+    key = int(prng.mix64(np.array([(seed ^ inner) & m], dtype=np.uint64))[0])
+    h = int(prng.stream64(key, index, 1)[0])
+    return np.float32(h >> 40) * np.float32(2.0 ** -24)
+
+
+def sample_temperature(logits: np.ndarray, seen_ids, penalty: float, temperature: float, seed: int, slot: int,
+                       index: int):
+    """Temperature sampling as the reference runs it (src/eval/infer.py:109-115: do_sample=True, temperature=0.01,
+    top_k = top_p = None -> HF TemperatureLogitsWarper + softmax + multinomial, HF:generation/utils.py:2894-2916),
+    with this repo's counter-based uniform instead of torch's generator and the inverse-CDF rule / fp32 summation
+    order of zoomearth_amd/csrc/ze_sample.hip.  Returns (token, gap): gap = distance of the target to the nearest
+    boundary of the chosen token's CDF interval, relative to the total mass -- draws with a gap below ~1e-5 may
+    legitimately differ between implementations whose expf differs in the last bit."""
+    f32 = np.float32
+    sc = apply_repetition_penalty(np.asarray(logits, dtype=f32), seen_ids, penalty) if penalty != 1.0 else \
+        np.asarray(logits, dtype=f32)
+    vocab = sc.shape[0]
+    t = f32(temperature)
+    zmax = f32(sc.max()) / t
+    e = np.exp((sc / t - zmax).astype(f32)).astype(f32)
+    chunk = -(-vocab // SAMPLE_BLOCKS)
+    run = -(-chunk // 256)
+    pad = np.zeros(SAMPLE_BLOCKS * 256 * run, dtype=f32)
+    # element i sits in chunk i // chunk, run (i % chunk) // run, position (i % chunk) % run
+    idx = np.arange(vocab)
+    pos = (idx // chunk) * (256 * run) + (idx % chunk)
+    pad[pos] = e
+    grid = pad.reshape(SAMPLE_BLOCKS, 256, run)
+    run_cum = np.cumsum(grid, axis=2, dtype=f32)            # sequential fp32 adds inside a run
+    run_sum = run_cum[:, :, -1]
+    thr_cum = np.cumsum(run_sum, axis=1, dtype=f32)          # the 256 run sums in order
+    chunk_sum = thr_cum[:, -1]
+    blk_cum = np.cumsum(chunk_sum, dtype=f32)                # the chunk sums in order
+    total = blk_cum[-1]
+    u = sample_uniform(seed, slot, index)
+    target = f32(u * total)
+    hit = np.nonzero(blk_cum > target)[0]
+    if hit.size == 0:
+        blk = int(np.nonzero(chunk_sum > 0)[0][-1])
+        tgt_in = f32(-np.inf)
+    else:
+        blk = int(hit[0])
+        tgt_in = f32(target - (blk_cum[blk - 1] if blk else f32(0)))
+    token = -1
+    cum = f32(0)
+    for th in range(256):
+        if f32(cum + run_sum[blk, th]) > tgt_in:
+            for j in range(run):
+                i = blk * chunk + th * run + j
+                if i >= min(vocab, (blk + 1) * chunk):
+                    break
+                cum = f32(cum + grid[blk, th, j])
+                if cum > tgt_in:
+                    token = i
+                    break
+            if token >= 0:
+                break
+        else:
+            cum = f32(cum + run_sum[blk, th])
+    if token < 0:
+        nz = np.nonzero(e[blk * chunk:min(vocab, (blk + 1) * chunk)] > 0)[0]
+        token = blk * chunk + int(nz[-1])
+    # gap in float64 against the exact CDF
+    cdf = np.cumsum(e.astype(np.float64))
+    tot = cdf[-1]
+    x = float(u) * tot
+    lo = cdf[token - 1] if token else 0.0
+    gap = min(abs(x - lo), abs(cdf[token] - x)) / tot
+    return token, float(gap)
 
 
 def greedy_generate(model: Qwen25VLOracle, input_ids, pixel_values=None, grid_thw=None, max_new_tokens=16,

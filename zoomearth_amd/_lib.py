@@ -35,7 +35,8 @@ class ZeConfig(C.Structure):
 
 class ZeGenParams(C.Structure):
     _fields_ = [("max_new_tokens", C.c_int32), ("repetition_penalty", C.c_float), ("ignore_eos", C.c_int32),
-                ("use_graph", C.c_int32), ("sync_every", C.c_int32)]
+                ("use_graph", C.c_int32), ("sync_every", C.c_int32), ("do_sample", C.c_int32),
+                ("temperature", C.c_float), ("seed", C.c_uint64)]
 
 
 class ZoomEarthError(RuntimeError):
@@ -90,6 +91,8 @@ _SIGS = {
                                    C.POINTER(C.c_int32), _P]),
     "ze_seq_mark_seen": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.c_int, _P]),
     "ze_op_sample_greedy": (C.c_int, [_P, C.c_int, _P, C.c_float, C.POINTER(C.c_int32), _P]),
+    "ze_op_sample_temperature": (C.c_int, [_P, C.c_int, _P, C.c_float, C.c_float, C.c_uint64, C.c_int,
+                                           C.POINTER(C.c_int32), _P]),
     "ze_op_linear": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ze_op_rmsnorm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     "ze_op_attention": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32),

@@ -110,6 +110,8 @@ struct ze_engine {
     ze_grid_barrier* gbar = nullptr;
     int attn_blocks = 0;  // 0: shape unsupported, the four stand-alone kernels run instead
     std::vector<int> graph_variant;
+    std::vector<float> graph_temperature;
+    std::vector<unsigned long long> graph_seed;
     // split-K GEMM workspace
     float* gslab = nullptr;
     unsigned* gtickets = nullptr;
@@ -117,7 +119,7 @@ struct ze_engine {
     int* bseq = nullptr;
     float *blogits = nullptr, *bpartial = nullptr, *bsample = nullptr;
     ze_seq_dev* bstate_host = nullptr;  // pinned
-    std::map<std::tuple<int, float, int>, hipGraphExec_t> bgraphs;  // captured batched decode step per batch size
+    std::map<std::tuple<int, float, int, float, unsigned long long>, hipGraphExec_t> bgraphs;  // captured batched decode step per batch size
 
     // timers
     bool timers_on = false;

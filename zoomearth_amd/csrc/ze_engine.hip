@@ -255,6 +255,8 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     e->graph_penalty.assign(c.max_seqs, 0.f);
     e->graph_ignore_eos.assign(c.max_seqs, 0);
     e->graph_variant.assign(c.max_seqs, 0);
+    e->graph_temperature.assign(c.max_seqs, 0.f);
+    e->graph_seed.assign(c.max_seqs, 0ull);
 
     // front-end workspace: horizontal-pass image (box_h x out_w) and resized image
     const size_t side = (size_t)std::max(c.max_tile_side, 1024);
@@ -321,11 +323,11 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     chk(dev_alloc(e, &e->bseq, c.max_seqs));
     chk(dev_alloc(e, &e->blogits, (size_t)c.max_seqs * c.vocab));
     chk(dev_alloc(e, &e->bpartial, (size_t)c.max_seqs * e->max_splits * c.heads * 132));
-    chk(dev_alloc(e, &e->bsample, (size_t)c.max_seqs * 2 * 128 + 8));
+    chk(dev_alloc(e, &e->bsample, (size_t)c.max_seqs * 3 * 128 + 8));  // arg-max partials, then chunk sums
     if (r == 0 && hipHostMalloc((void**)&e->bstate_host, sizeof(ze_seq_dev) * c.max_seqs) != hipSuccess)
         r = ze_fail(e, ZE_ERR_HIP, "hipHostMalloc failed");
     chk(dev_alloc(e, &e->dpartial, (size_t)e->max_splits * c.heads * 132));
-    chk(dev_alloc(e, &e->dsample, 2 * 128 + 64 + 8));
+    chk(dev_alloc(e, &e->dsample, 2 * 128 + 64 + 128 + 8));  // arg-max partials, spare, chunk sums
     chk(dev_alloc(e, &e->gbar, 1));
     chk(dev_alloc(e, &e->atickets, (size_t)c.max_seqs * c.kv_heads));
     if (r == 0) e->attn_blocks = ze_layer_attn_blocks(c.hidden, c.heads, c.kv_heads, e->head_dim);

@@ -452,7 +452,8 @@ static int ze_check_grid_timeout(ze_engine* e, hipStream_t s) {
     return ze_fail(e, ZE_ERR_HIP, "grid barrier timed out in the fused decode kernel (workgroups not co-resident?)");
 }
 
-int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos, bool sample, hipStream_t s) {
+int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos, bool sample, const ze_sample_opts& so,
+                           hipStream_t s) {
     const ze_config& c = e->cfg;
     const int H = c.hidden, hd = e->head_dim, nq = c.heads * hd, nqkv = nq + 2 * c.kv_heads * hd;
     const ze_seq_dev* st = e->st_dev + seq;
@@ -566,7 +567,7 @@ int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos,
     if (sample)
         ze_launch_sample(e->dlogits + (size_t)seq * c.vocab, c.vocab, e->seen + (size_t)seq * c.vocab, penalty, e->st_dev + seq, e->eos_dev,
                          c.n_eos, c.pad_token_id, ignore_eos, /*advance_ctx=*/1,
-                         e->out_tokens + (size_t)seq * c.max_ctx, e->dsample, s);
+                         e->out_tokens + (size_t)seq * c.max_ctx, e->dsample, so, s);
     else
         ze_launch_advance_ctx(e->st_dev + seq, s);  // teacher forcing: the caller chooses the next token
     ZE_KCHECK();
@@ -586,7 +587,7 @@ extern "C" int ze_decode_step(ze_engine* e, int seq, int token, float* out_logit
         ZE_HIP(hipMemcpyAsync(&(e->st_dev + seq)->token, e->d_host_ints + 16, sizeof(int), hipMemcpyHostToDevice, s));
     }
     const int th = ze_timer_begin(e, 3, s);
-    ZE_TRY(ze_enqueue_decode_step(e, seq, 1.0f, 1, false, s));
+    ZE_TRY(ze_enqueue_decode_step(e, seq, 1.0f, 1, false, ze_sample_opts{}, s));
     ze_timer_end(e, th, s);
     e->ctx_host[seq] += 1;
     if (out_logits)
@@ -595,21 +596,51 @@ extern "C" int ze_decode_step(ze_engine* e, int seq, int token, float* out_logit
     return ZE_OK;
 }
 
-extern "C" int ze_op_sample_greedy(ze_engine* e, int seq, const float* logits, float repetition_penalty,
-                                   int32_t* out_token, void* stream) {
+// one sampling step on caller-supplied logits; `index` plays the role of the generated-token index of the draw
+static int op_sample(ze_engine* e, int seq, const float* logits, float repetition_penalty, const ze_sample_opts& so,
+                     int index, int32_t* out_token, hipStream_t s) {
     ZE_TRY(check_seq(e, seq));
     if (!logits || !out_token) return ze_fail(e, ZE_ERR_INVALID, "null argument");
+    if (index < 0 || index >= e->cfg.max_ctx) return ze_fail(e, ZE_ERR_INVALID, "index out of range");
     const ze_config& c = e->cfg;
-    hipStream_t s = (hipStream_t)stream;
     hipSetDevice(e->device);
-    // n_gen is rewound so the sampled token lands in out_tokens[0] of this chain's slot
+    // n_gen is set so the sampled token lands in out_tokens[index] of this chain's slot
     ZE_TRY(push_state(e, seq, s, 0, 0, 0));
+    if (index) {
+        e->d_host_ints[17] = index;
+        ZE_HIP(hipMemcpyAsync(&(e->st_dev + seq)->n_gen, e->d_host_ints + 17, sizeof(int), hipMemcpyHostToDevice, s));
+    }
     ze_launch_sample(logits, c.vocab, e->seen + (size_t)seq * c.vocab, repetition_penalty, e->st_dev + seq, e->eos_dev,
-                     c.n_eos, c.pad_token_id, 1, 0, e->out_tokens + (size_t)seq * c.max_ctx, e->dsample, s);
+                     c.n_eos, c.pad_token_id, 1, 0, e->out_tokens + (size_t)seq * c.max_ctx, e->dsample, so, s);
     ZE_KCHECK();
-    ZE_HIP(hipMemcpyAsync(out_token, e->out_tokens + (size_t)seq * c.max_ctx, sizeof(int), hipMemcpyDeviceToHost, s));
+    ZE_HIP(hipMemcpyAsync(out_token, e->out_tokens + (size_t)seq * c.max_ctx + index, sizeof(int), hipMemcpyDeviceToHost, s));
     ZE_HIP(hipStreamSynchronize(s));
     return ZE_OK;
+}
+
+extern "C" int ze_op_sample_greedy(ze_engine* e, int seq, const float* logits, float repetition_penalty,
+                                   int32_t* out_token, void* stream) {
+    return op_sample(e, seq, logits, repetition_penalty, ze_sample_opts{}, 0, out_token, (hipStream_t)stream);
+}
+
+extern "C" int ze_op_sample_temperature(ze_engine* e, int seq, const float* logits, float repetition_penalty,
+                                        float temperature, uint64_t seed, int index, int32_t* out_token, void* stream) {
+    if (!(temperature > 0.f)) return ze_fail(e, ZE_ERR_INVALID, "temperature must be positive");
+    ze_sample_opts so;
+    so.temperature = temperature;
+    so.seed = seed;
+    so.slot = seq;
+    return op_sample(e, seq, logits, repetition_penalty, so, index, out_token, (hipStream_t)stream);
+}
+
+static ze_sample_opts sample_opts_of(const ze_gen_params* p, int slot) {
+    ze_sample_opts so;
+    if (p->do_sample && p->temperature > 0.f) {
+        so.temperature = p->temperature;
+        so.seed = p->seed;
+    }
+    so.slot = slot;
+    return so;
 }
 
 extern "C" int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_t* out_tokens, int* n_out,
@@ -634,8 +665,9 @@ extern "C" int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_
 
     const int t_s = ze_timer_begin(e, 4, s);
     // first token from the prefill logits (no cache growth)
+    const ze_sample_opts so = sample_opts_of(p, seq);
     ze_launch_sample(e->dlogits + (size_t)seq * c.vocab, c.vocab, e->seen + (size_t)seq * c.vocab, pen, st, e->eos_dev,
-                     c.n_eos, c.pad_token_id, ign, 0, dev_out, e->dsample, s);
+                     c.n_eos, c.pad_token_id, ign, 0, dev_out, e->dsample, so, s);
     ze_timer_end(e, t_s, s);
     ZE_KCHECK();
 
@@ -643,7 +675,8 @@ extern "C" int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_
     hipGraphExec_t gexec = nullptr;
     if (p->use_graph && max_new > 1) {
         if (!e->graphs[seq] || e->graph_penalty[seq] != pen || e->graph_ignore_eos[seq] != ign ||
-            e->graph_variant[seq] != ze_decode_variant(e)) {
+            e->graph_variant[seq] != ze_decode_variant(e) || e->graph_temperature[seq] != so.temperature ||
+            e->graph_seed[seq] != so.seed) {
             if (e->graphs[seq]) {
                 hipGraphExecDestroy(e->graphs[seq]);
                 e->graphs[seq] = nullptr;
@@ -654,7 +687,7 @@ extern "C" int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_
             int r = ZE_OK;
             if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess)
                 r = ze_fail(e, ZE_ERR_HIP, "hipStreamBeginCapture failed");
-            if (r == ZE_OK) r = ze_enqueue_decode_step(e, seq, pen, ign, true, cs);
+            if (r == ZE_OK) r = ze_enqueue_decode_step(e, seq, pen, ign, true, so, cs);
             if (hipStreamEndCapture(cs, &graph) != hipSuccess && r == ZE_OK)
                 r = ze_fail(e, ZE_ERR_HIP, "hipStreamEndCapture failed");
             if (r == ZE_OK && hipGraphInstantiate(&e->graphs[seq], graph, nullptr, nullptr, 0) != hipSuccess)
@@ -665,6 +698,8 @@ extern "C" int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_
             e->graph_penalty[seq] = pen;
             e->graph_ignore_eos[seq] = ign;
             e->graph_variant[seq] = ze_decode_variant(e);
+            e->graph_temperature[seq] = so.temperature;
+            e->graph_seed[seq] = so.seed;
         }
         gexec = e->graphs[seq];
     }
@@ -679,7 +714,7 @@ extern "C" int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_
             if (gexec)
                 ZE_HIP(hipGraphLaunch(gexec, s));
             else
-                ZE_TRY(ze_enqueue_decode_step(e, seq, pen, ign, true, s));
+                ZE_TRY(ze_enqueue_decode_step(e, seq, pen, ign, true, so, s));
         }
         produced += burst;
         e->ctx_host[seq] += burst;
@@ -728,7 +763,8 @@ static int upload_batch(ze_engine* e, const int32_t* seqs, int n, hipStream_t s)
     return ZE_OK;
 }
 
-static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_eos, int sample, hipStream_t s) {
+static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_eos, int sample, const ze_sample_opts& so,
+                                hipStream_t s) {
     const ze_config& c = e->cfg;
     const int H = c.hidden, hd = e->head_dim, nq = c.heads * hd, nkv = c.kv_heads * hd, nqkv = nq + 2 * nkv;
     const size_t seq_stride = (size_t)c.kv_heads * c.max_ctx * hd;
@@ -753,7 +789,8 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
     ze_launch_gemm_stream(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab,
                           H, s);
     ze_launch_sample_batch(e->blogits, c.vocab, e->seen, penalty, e->st_dev, e->bseq, n, e->eos_dev, c.n_eos,
-                           c.pad_token_id, ignore_eos, 1, sample, e->out_tokens, c.max_ctx, e->bsample, s);
+                           c.pad_token_id, ignore_eos, 1, sample, e->out_tokens, c.max_ctx, e->bsample,
+                           e->bsample + (size_t)c.max_seqs * 2 * 128, so, s);
     ZE_KCHECK();
     return ZE_OK;
 }
@@ -777,7 +814,7 @@ extern "C" int ze_decode_batch(ze_engine* e, const int32_t* seqs, int n, const i
         }
     }
     const int th = ze_timer_begin(e, 3, s);
-    ZE_TRY(enqueue_decode_batch(e, n, 1.0f, 1, 0, s));
+    ZE_TRY(enqueue_decode_batch(e, n, 1.0f, 1, 0, ze_sample_opts{}, s));
     ze_timer_end(e, th, s);
     for (int i = 0; i < n; ++i) e->ctx_host[seqs[i]] += 1;
     if (out_logits)
@@ -799,11 +836,13 @@ extern "C" int ze_generate_batch(ze_engine* e, const int32_t* seqs, int n, const
     }
     const float pen = p->repetition_penalty > 0.f ? p->repetition_penalty : 1.0f;
     const int ign = p->ignore_eos ? 1 : 0;
+    const ze_sample_opts bso = sample_opts_of(p, 0);  // batched launches take the chain slot from the chain table
     // first token of every chain from the logits its prefill left behind
     for (int i = 0; i < n; ++i) {
         const int q = seqs[i];
         ze_launch_sample(e->dlogits + (size_t)q * c.vocab, c.vocab, e->seen + (size_t)q * c.vocab, pen, e->st_dev + q,
-                         e->eos_dev, c.n_eos, c.pad_token_id, ign, 0, e->out_tokens + (size_t)q * c.max_ctx, e->dsample, s);
+                         e->eos_dev, c.n_eos, c.pad_token_id, ign, 0, e->out_tokens + (size_t)q * c.max_ctx, e->dsample,
+                         sample_opts_of(p, q), s);
     }
     ZE_KCHECK();
     std::vector<int> active(seqs, seqs + n);
@@ -818,7 +857,7 @@ extern "C" int ze_generate_batch(ze_engine* e, const int32_t* seqs, int n, const
         const int na = (int)active.size();
         hipGraphExec_t gx = nullptr;
         if (p->use_graph) {  // one captured step per batch size (chain ids / positions live in device memory)
-            auto key = std::make_tuple(na, pen, ign);
+            auto key = std::make_tuple(na, pen, ign, bso.temperature, bso.seed);
             auto it = e->bgraphs.find(key);
             if (it == e->bgraphs.end()) {
                 hipStream_t cs;
@@ -827,7 +866,7 @@ extern "C" int ze_generate_batch(ze_engine* e, const int32_t* seqs, int n, const
                 int r = ZE_OK;
                 if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess)
                     r = ze_fail(e, ZE_ERR_HIP, "hipStreamBeginCapture failed");
-                if (r == ZE_OK) r = enqueue_decode_batch(e, na, pen, ign, 1, cs);
+                if (r == ZE_OK) r = enqueue_decode_batch(e, na, pen, ign, 1, bso, cs);
                 if (hipStreamEndCapture(cs, &graph) != hipSuccess && r == ZE_OK)
                     r = ze_fail(e, ZE_ERR_HIP, "hipStreamEndCapture failed");
                 hipGraphExec_t ex = nullptr;
@@ -844,7 +883,7 @@ extern "C" int ze_generate_batch(ze_engine* e, const int32_t* seqs, int n, const
             if (gx)
                 ZE_HIP(hipGraphLaunch(gx, s));
             else
-                ZE_TRY(enqueue_decode_batch(e, na, pen, ign, 1, s));
+                ZE_TRY(enqueue_decode_batch(e, na, pen, ign, 1, bso, s));
         }
         steps += burst;
         for (int q : active) {

@@ -126,9 +126,15 @@ void ze_launch_attn_decode(const bf16_t* q, int q_row_stride, const bf16_t* kcac
                            float* ws_partial, int max_splits, unsigned* tickets, hipStream_t s);
 
 // ---- sampling
+struct ze_sample_opts {
+    float temperature = 0.f;      // 0: greedy arg-max; > 0: multinomial draw from softmax(score / temperature)
+    unsigned long long seed = 0;  // draw = f(seed, chain slot, index of the generated token)
+    int slot = 0;                 // chain slot of a single-chain launch (batched launches read seq_ids)
+};
+// ws: 2 * 128 arg-max partials + 64 spare + 128 chunk sums (floats)
 void ze_launch_sample(const float* logits, int vocab, uint8_t* seen, float penalty, ze_seq_dev* st,
                       const int* eos_ids, int n_eos, int pad_id, int ignore_eos, int advance_ctx,
-                      int32_t* out_tokens, float* ws, hipStream_t s);
+                      int32_t* out_tokens, float* ws, const ze_sample_opts& so, hipStream_t s);
 void ze_launch_advance_ctx(ze_seq_dev* st, hipStream_t s);
 // batched decode helpers (one token for each of n chains)
 void ze_launch_embed_tokens_batch(const ze_seq_dev* st, const int* seq_ids, int n, const bf16_t* embed, bf16_t* out,
@@ -138,5 +144,6 @@ void ze_launch_rope_kv_batch(bf16_t* qkv, int n, int heads, int kv_heads, int D,
                              size_t cache_seq_stride, int max_ctx, hipStream_t s);
 void ze_launch_sample_batch(const float* logits, int vocab, uint8_t* seen_base, float penalty, ze_seq_dev* st,
                             const int* seq_ids, int n, const int* eos_ids, int n_eos, int pad_id, int ignore_eos,
-                            int advance_ctx, int sample, int32_t* out_tokens_base, int max_gen, float* ws, hipStream_t s);
+                            int advance_ctx, int sample, int32_t* out_tokens_base, int max_gen, float* ws,
+                            float* ws_sum, const ze_sample_opts& so, hipStream_t s);
 void ze_launch_mark_seen(uint8_t* seen, const int* ids, int n, hipStream_t s);

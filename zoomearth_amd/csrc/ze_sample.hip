@@ -3,6 +3,7 @@
 // (torch.argmax), EOS / pad bookkeeping (HF:generation/utils.py:2921-2936), and the chain-state update that
 // lets the next decode step run without a host round trip.
 #include "ze_kernels.h"
+#include "ze_prng.h"
 
 #define SAMPLE_BLOCKS 128
 
@@ -71,10 +72,17 @@ __global__ void __launch_bounds__(64) k_argmax_final(const float* __restrict__ w
     }
 }
 
+void ze_launch_multinomial(const float* logits, int vocab, const uint8_t* seen_base, const ze_seq_dev* st,
+                           const int* seq_ids, int slot0, int n, float penalty, float temperature,
+                           unsigned long long seed, float* ws_part, float* ws_sum, hipStream_t s);
+
 void ze_launch_sample(const float* logits, int vocab, uint8_t* seen, float penalty, ze_seq_dev* st,
                       const int* eos_ids, int n_eos, int pad_id, int ignore_eos, int advance_ctx,
-                      int32_t* out_tokens, float* ws, hipStream_t s) {
+                      int32_t* out_tokens, float* ws, const ze_sample_opts& so, hipStream_t s) {
     k_argmax_partial<<<SAMPLE_BLOCKS, 256, 0, s>>>(logits, vocab, seen, penalty, ws);
+    if (so.temperature > 0.f)
+        ze_launch_multinomial(logits, vocab, seen, st, nullptr, so.slot, 1, penalty, so.temperature, so.seed, ws,
+                              ws + 2 * SAMPLE_BLOCKS + 64, s);
     k_argmax_final<<<1, 64, 0, s>>>(ws, seen, st, eos_ids, n_eos, pad_id, ignore_eos, advance_ctx, out_tokens);
 }
 
@@ -164,10 +172,167 @@ __global__ void __launch_bounds__(64) k_argmax_final_batch(const float* __restri
 
 void ze_launch_sample_batch(const float* logits, int vocab, uint8_t* seen_base, float penalty, ze_seq_dev* st,
                             const int* seq_ids, int n, const int* eos_ids, int n_eos, int pad_id, int ignore_eos,
-                            int advance_ctx, int sample, int32_t* out_tokens_base, int max_gen, float* ws, hipStream_t s) {
+                            int advance_ctx, int sample, int32_t* out_tokens_base, int max_gen, float* ws,
+                            float* ws_sum, const ze_sample_opts& so, hipStream_t s) {
     if (n <= 0) return;
-    if (sample)
+    if (sample) {
         k_argmax_partial_batch<<<dim3(SAMPLE_BLOCKS, n), 256, 0, s>>>(logits, vocab, seen_base, seq_ids, penalty, ws);
+        if (so.temperature > 0.f)
+            ze_launch_multinomial(logits, vocab, seen_base, st, seq_ids, 0, n, penalty, so.temperature, so.seed, ws,
+                                  ws_sum, s);
+    }
     k_argmax_final_batch<<<n, 64, 0, s>>>(ws, seen_base, st, seq_ids, vocab, eos_ids, n_eos, pad_id, ignore_eos,
                                           advance_ctx, sample, out_tokens_base, max_gen);
+}
+
+// ------------------------------------------------------------------ temperature sampling (do_sample=True)
+// replaces: TemperatureLogitsWarper + softmax + torch.multinomial(probs, 1) in GenerationMixin._sample
+// (HF:generation/utils.py:2894-2916, HF:generation/logits_process.py:285-345) as src/eval/infer.py:109-115 calls it
+// (temperature 0.01, top_k = top_p = None).  Same distribution; the random stream is this repo's counter-based
+// generator, not torch's, so a draw is reproducible from (seed, chain slot, index of the generated token):
+//     u = (stream64(mix64(seed ^ mix64(slot + 1)), n_gen) >> 40) * 2^-24                        in [0, 1)
+//     e_i = expf(score_i / T - max_j score_j / T)        score = repetition-penalised fp32 logit
+//     token = first i (ascending) whose running sum of e exceeds u * sum(e)
+// Summation order (fp32), which the oracle (oracle/qwen25vl.py:sample_temperature) restates: the vocabulary is cut
+// into SAMPLE_BLOCKS contiguous chunks, a chunk into 256 contiguous runs; run sums, then the 256 run sums in order,
+// then the chunk sums in order.  Two extra launches per token after the arg-max partials; the pick is handed to
+// the arg-max final kernels as an unbeatable partial (+inf, token), so EOS / pad / state bookkeeping is shared.
+__device__ __forceinline__ float sample_score(const float* lg, const uint8_t* seen, float penalty, int i) {
+    float v = lg[i];
+    if (penalty != 1.0f && seen[i]) v = v < 0.f ? v * penalty : v / penalty;
+    return v;
+}
+
+__device__ __forceinline__ float sample_zmax(const float* part, float temperature) {
+    float bv = -INFINITY;
+    for (int i = threadIdx.x & 63; i < SAMPLE_BLOCKS; i += 64) bv = fmaxf(bv, part[2 * i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) bv = fmaxf(bv, __shfl_xor(bv, off, 64));
+    return bv / temperature;
+}
+
+// sum of e over this thread's contiguous run, then the 256 run sums in thread order (by thread 0) -> *total;
+// sRun[t] keeps the run sums for the caller
+__device__ __forceinline__ void sample_chunk_sums(const float* lg, const uint8_t* seen, float penalty, float temperature,
+                                                  float zmax, int start, int end, int run, float* sRun, float* total) {
+    const int t = threadIdx.x;
+    float acc = 0.f;
+    for (int j = 0; j < run; ++j) {
+        const int i = start + t * run + j;
+        if (i < end) acc += expf(sample_score(lg, seen, penalty, i) / temperature - zmax);
+    }
+    sRun[t] = acc;
+    __syncthreads();
+    if (t == 0) {
+        float tot = 0.f;
+        for (int k = 0; k < 256; ++k) tot += sRun[k];
+        *total = tot;
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) k_softmax_partial(const float* __restrict__ logits, int vocab,
+                                                         const uint8_t* __restrict__ seen_base,
+                                                         const int* __restrict__ seq_ids, float penalty,
+                                                         float temperature, const float* __restrict__ ws_part,
+                                                         float* __restrict__ ws_sum) {
+    const int b = blockIdx.y;
+    const float* lg = logits + (size_t)b * vocab;
+    const uint8_t* seen = seen_base + (seq_ids ? (size_t)seq_ids[b] * vocab : 0);
+    const float zmax = sample_zmax(ws_part + (size_t)b * 2 * SAMPLE_BLOCKS, temperature);
+    const int chunk = (vocab + SAMPLE_BLOCKS - 1) / SAMPLE_BLOCKS, run = (chunk + 255) / 256;
+    const int start = blockIdx.x * chunk, end = min(vocab, start + chunk);
+    __shared__ float sRun[256];
+    __shared__ float sTot;
+    sample_chunk_sums(lg, seen, penalty, temperature, zmax, start, end, run, sRun, &sTot);
+    if (threadIdx.x == 0) ws_sum[(size_t)b * SAMPLE_BLOCKS + blockIdx.x] = sTot;
+}
+
+__global__ void __launch_bounds__(256) k_multinomial_pick(const float* __restrict__ logits, int vocab,
+                                                          const uint8_t* __restrict__ seen_base,
+                                                          const ze_seq_dev* __restrict__ st_base,
+                                                          const int* __restrict__ seq_ids, int slot0, float penalty,
+                                                          float temperature, unsigned long long seed,
+                                                          float* __restrict__ ws_part,
+                                                          const float* __restrict__ ws_sum) {
+    const int b = blockIdx.x, slot = seq_ids ? seq_ids[b] : slot0;
+    const ze_seq_dev* st = seq_ids ? st_base + slot : st_base;
+    const float* lg = logits + (size_t)b * vocab;
+    const uint8_t* seen = seen_base + (seq_ids ? (size_t)slot * vocab : 0);
+    float* part = ws_part + (size_t)b * 2 * SAMPLE_BLOCKS;
+    const float zmax = sample_zmax(part, temperature);
+    const int chunk = (vocab + SAMPLE_BLOCKS - 1) / SAMPLE_BLOCKS, run = (chunk + 255) / 256;
+    __shared__ float sRun[256];
+    __shared__ float sTot;
+    __shared__ int sBlk;
+    __shared__ float sTarget;
+    if (threadIdx.x == 0) {
+        const float* sums = ws_sum + (size_t)b * SAMPLE_BLOCKS;
+        float total = 0.f;
+        for (int k = 0; k < SAMPLE_BLOCKS; ++k) total += sums[k];
+        const unsigned long long key = ze_mix64(seed ^ ze_mix64((unsigned long long)slot + 1ull));
+        const float u = (float)(ze_stream64(key, (unsigned long long)st->n_gen) >> 40) * 5.9604644775390625e-08f;
+        const float target = u * total;
+        float cum = 0.f;
+        int blk = -1, last_nz = 0;
+        float excl = 0.f;
+        for (int k = 0; k < SAMPLE_BLOCKS; ++k) {
+            if (sums[k] > 0.f) last_nz = k;
+            const float nxt = cum + sums[k];
+            if (blk < 0 && nxt > target) {
+                blk = k;
+                excl = cum;
+            }
+            cum = nxt;
+        }
+        if (blk < 0) {  // only by rounding: take the end of the last non-empty chunk
+            blk = last_nz;
+            excl = INFINITY;
+        }
+        sBlk = blk;
+        sTarget = target - excl;  // -inf: pick the last element with mass
+    }
+    __syncthreads();
+    const int blk = sBlk;
+    const float target = sTarget;
+    const int start = blk * chunk, end = min(vocab, start + chunk);
+    sample_chunk_sums(lg, seen, penalty, temperature, zmax, start, end, run, sRun, &sTot);
+    if (threadIdx.x == 0) {
+        int tok = -1, last_nz = start;
+        float cum = 0.f;
+        for (int t = 0; t < 256 && tok < 0; ++t) {
+            if (cum + sRun[t] > target) {  // the pick is inside run t: walk it
+                for (int j = 0; j < run; ++j) {
+                    const int i = start + t * run + j;
+                    if (i >= end) break;
+                    const float e = expf(sample_score(lg, seen, penalty, i) / temperature - zmax);
+                    cum += e;
+                    if (cum > target) {
+                        tok = i;
+                        break;
+                    }
+                }
+                if (tok < 0) cum = cum;  // rounding: fall through to the next run
+            } else {
+                cum += sRun[t];
+            }
+            if (sRun[t] > 0.f) last_nz = min(end - 1, start + t * run + run - 1);
+        }
+        if (tok < 0) {  // rounding at the very end (or target = -inf): last element of the chunk that carries mass
+            tok = last_nz;
+            while (tok > start && !(expf(sample_score(lg, seen, penalty, tok) / temperature - zmax) > 0.f)) --tok;
+        }
+        part[0] = INFINITY;  // unbeatable arg-max partial: the final kernel adopts the pick
+        reinterpret_cast<int*>(part)[1] = tok;
+    }
+}
+
+void ze_launch_multinomial(const float* logits, int vocab, const uint8_t* seen_base, const ze_seq_dev* st,
+                           const int* seq_ids, int slot0, int n, float penalty, float temperature,
+                           unsigned long long seed, float* ws_part, float* ws_sum, hipStream_t s) {
+    if (n <= 0) return;
+    k_softmax_partial<<<dim3(SAMPLE_BLOCKS, n), 256, 0, s>>>(logits, vocab, seen_base, seq_ids, penalty, temperature,
+                                                             ws_part, ws_sum);
+    k_multinomial_pick<<<n, 256, 0, s>>>(logits, vocab, seen_base, st, seq_ids, slot0, penalty, temperature, seed,
+                                         ws_part, ws_sum);
 }

@@ -229,9 +229,18 @@ class Engine:
         self._check(self.lib.ze_decode_step(self.h, seq, token, _ptr(logits), self._stream()))
         return logits
 
+    @staticmethod
+    def _gen_params(max_new_tokens, repetition_penalty, ignore_eos, use_graph, sync_every, do_sample, temperature, seed):
+        if do_sample and not (temperature and temperature > 0):
+            raise ValueError("`temperature` has to be a strictly positive float when sampling")  # as HF raises
+        return _lib.ZeGenParams(max_new_tokens, repetition_penalty, int(ignore_eos), int(use_graph), sync_every,
+                                int(bool(do_sample)), float(temperature or 0.0), int(seed) & (2 ** 64 - 1))
+
     def generate(self, seq: int, max_new_tokens: int, repetition_penalty: float = 1.0, ignore_eos: bool = False,
-                 use_graph: bool = True, sync_every: int = 16):
-        p = _lib.ZeGenParams(max_new_tokens, repetition_penalty, int(ignore_eos), int(use_graph), sync_every)
+                 use_graph: bool = True, sync_every: int = 16, do_sample: bool = False, temperature: float = 1.0,
+                 seed: int = 0):
+        p = self._gen_params(max_new_tokens, repetition_penalty, ignore_eos, use_graph, sync_every, do_sample,
+                             temperature, seed)
         out = (C.c_int32 * max(max_new_tokens, 1))()
         n = C.c_int()
         self._check(self.lib.ze_generate(self.h, seq, C.byref(p), out, C.byref(n), self._stream()))
@@ -245,10 +254,12 @@ class Engine:
         return logits
 
     def generate_batch(self, seqs, max_new_tokens: int, repetition_penalty: float = 1.0, ignore_eos: bool = False,
-                       sync_every: int = 16, use_graph: bool = True):
-        """Greedy generation for several prefilled chains at once; returns one token list per chain."""
+                       sync_every: int = 16, use_graph: bool = True, do_sample: bool = False, temperature: float = 1.0,
+                       seed: int = 0):
+        """Generation for several prefilled chains at once; returns one token list per chain."""
         sq, sp = _i32(seqs)
-        p = _lib.ZeGenParams(max_new_tokens, repetition_penalty, int(ignore_eos), int(use_graph), sync_every)
+        p = self._gen_params(max_new_tokens, repetition_penalty, ignore_eos, use_graph, sync_every, do_sample,
+                             temperature, seed)
         out = (C.c_int32 * (len(sq) * max_new_tokens))()
         n_out = (C.c_int32 * len(sq))()
         self._check(self.lib.ze_generate_batch(self.h, sp, len(sq), C.byref(p), out, n_out, self._stream()))
@@ -258,6 +269,13 @@ class Engine:
         tok = C.c_int32()
         self._check(self.lib.ze_op_sample_greedy(self.h, seq, _ptr(logits), repetition_penalty, C.byref(tok),
                                                  self._stream()))
+        return int(tok.value)
+
+    def sample_temperature(self, seq: int, logits: torch.Tensor, temperature: float, seed: int, index: int = 0,
+                           repetition_penalty: float = 1.0) -> int:
+        tok = C.c_int32()
+        self._check(self.lib.ze_op_sample_temperature(self.h, seq, _ptr(logits), repetition_penalty, temperature,
+                                                      int(seed) & (2 ** 64 - 1), index, C.byref(tok), self._stream()))
         return int(tok.value)
 
     # ------------------------------------------------------------------ unit ops (parity tests)

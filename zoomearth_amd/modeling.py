@@ -7,7 +7,9 @@ replaces: `Qwen2_5_VLForConditionalGeneration.from_pretrained(model_name, torch_
 (/root/reference/src/eval/infer.py:109-115,147-151,160-162; src/demo.py:14-19,128).
 
 Documented deviations: arithmetic is bf16 (the reference runs fp16 weights under a bf16 autocast
-wrapper); `do_sample=True, temperature=0.01` is accepted and executed as greedy; `num_beams` must be 1.
+wrapper); `do_sample=True, temperature=T` draws from softmax(logits / T) with the engine's counter-based
+random stream (`seed=` kwarg or `generation_config.seed`); `top_k` / `top_p` other than None (or top_k=1, which is
+greedy) raise NotImplementedError, as the reference sets both to None; `num_beams` must be 1.
 """
 from __future__ import annotations
 
@@ -118,6 +120,19 @@ class ZoomEarthForConditionalGeneration:
         rows_per = [g[0] * g[1] * g[2] for g in grids]
         offs = np.concatenate([[0], np.cumsum(rows_per)]).astype(int)
         pen = repetition_penalty if repetition_penalty is not None else getattr(self.generation_config, "repetition_penalty", 1.0) or 1.0
+        gc = self.generation_config
+        top_k = top_k if top_k is not None else getattr(gc, "top_k", None)
+        top_p = top_p if top_p is not None else getattr(gc, "top_p", None)
+        temperature = temperature if temperature is not None else getattr(gc, "temperature", None)
+        if do_sample and top_k == 1:
+            do_sample = False  # a one-token nucleus is the arg-max
+        if do_sample and ((top_k not in (None, 0)) or (top_p not in (None, 1.0))):
+            raise NotImplementedError("top_k / top_p filtering is not part of the ZoomEarth path "
+                                      "(src/eval/infer.py sets both to None)")
+        if do_sample and temperature is None:
+            temperature = 1.0
+        sample_kw = dict(do_sample=bool(do_sample), temperature=float(temperature or 1.0),
+                         seed=int(kw.get("seed", getattr(gc, "seed", 0) or 0)))
         gi = 0
         outs = []
         nrows = ids_cpu.shape[0]
@@ -155,10 +170,10 @@ class ZoomEarthForConditionalGeneration:
             if not batched:
                 self._chains[slot] = (tuple(ids), tuple(my_keys))
                 self._chains.move_to_end(slot)
-                outs.append(e.generate(slot, max_new_tokens, repetition_penalty=pen, ignore_eos=ignore_eos))
+                outs.append(e.generate(slot, max_new_tokens, repetition_penalty=pen, ignore_eos=ignore_eos, **sample_kw))
             slots.append(slot)
         if batched:
-            outs = e.generate_batch(slots, max_new_tokens, repetition_penalty=pen, ignore_eos=ignore_eos)
+            outs = e.generate_batch(slots, max_new_tokens, repetition_penalty=pen, ignore_eos=ignore_eos, **sample_kw)
         width = max(len(t) for t in outs)
         pad = cfg.pad_token_id
         res = torch.full((ids_cpu.shape[0], ids_cpu.shape[1] + width), pad, dtype=torch.long)
