@@ -24,8 +24,12 @@ def prefill_text(e, seq, ids):
     e.prefill(seq, ids, None, pos, delta, want_logits=True)
 
 
+KNOB = {"attn": 3, "mlp": 4}
+WHICH = "attn"
+
+
 def fused(e, on):
-    assert e.lib.ze_tune(3, 1 if on else 0) == 0
+    assert e.lib.ze_tune(KNOB[WHICH], 1 if on else 0) == 0
 
 
 def run_forced(e, ids, forced):
@@ -93,5 +97,38 @@ def test_fused_attention_block_3b_layer_shape():
         e.fill_synthetic(**CHAIN_W)
         check_engine(e, prompt_len=700, n_forced=24, n_gen=40, vocab_hi=150000)
     finally:
+        e.close()
+        torch.cuda.empty_cache()
+
+
+def test_fused_mlp_block_3b_layer_shape():
+    """O-proj + gate/up + down in one launch (ze_tune knob 4) against the three stand-alone GEMV launches."""
+    global WHICH
+    from zoomearth_amd.config import ModelConfig
+    from zoomearth_amd.engine import Engine
+    import dataclasses
+    cfg = ModelConfig.zoomearth_3b()
+    cfg = dataclasses.replace(cfg, text=dataclasses.replace(cfg.text, num_hidden_layers=4),
+                              vision=dataclasses.replace(cfg.vision, depth=1))
+    e = Engine(cfg, device=0, max_seqs=2, max_ctx=2048, max_patches=1024, max_tile_side=1024)
+    WHICH = "mlp"
+    try:
+        e.fill_synthetic(**CHAIN_W)
+        check_engine(e, prompt_len=300, n_forced=24, n_gen=40, vocab_hi=150000)
+        # chain-slot re-use with different prompts through captured steps
+        prompts = {k: text_ids(60 + i, n, 150000) for i, (k, n) in enumerate((("a", 120), ("b", 131), ("c", 99)))}
+
+        def gen(seq, name, on):
+            fused(e, on)
+            prefill_text(e, seq, prompts[name])
+            return e.generate(seq, 12, ignore_eos=True)
+
+        ref = {k: gen(0, k, False) for k in prompts}
+        for name in "abcab":
+            assert gen(1, name, True) == ref[name], name
+    finally:
+        WHICH = "attn"
+        fused(e, False)
+        e.lib.ze_tune(4, 0)
         e.close()
         torch.cuda.empty_cache()

@@ -15,4 +15,7 @@ python3 "$root/tools/summarize_prof.py" /tmp/p_stats "$out/${tag}_bench_kernel_s
 python3 "$root/tools/summarize_prof.py" /tmp/p_fetch "$out/${tag}_pmc_fetch_size.csv" --delete-raw
 ( cd "$root" && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph > /dev/null 2> "$out/${tag}_write.log" )
 python3 "$root/tools/summarize_prof.py" /tmp/p_write "$out/${tag}_pmc_write_size.csv" --delete-raw
+rm -rf /tmp/p_mfma
+( cd "$root" && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/p_mfma -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph > /dev/null 2> "$out/${tag}_mfma.log" )
+python3 "$root/tools/summarize_prof.py" /tmp/p_mfma "$out/${tag}_pmc_mfma_busy.csv" --delete-raw
 ls -la "$out" | tail -8

@@ -109,6 +109,7 @@ struct ze_engine {
     unsigned* atickets = nullptr;  // decode attention: one arrival ticket per (chain, kv head)
     ze_grid_barrier* gbar = nullptr;
     int attn_blocks = 0;  // 0: shape unsupported, the four stand-alone kernels run instead
+    int mlp_blocks = 0;   // fused O-proj + MLP launch (ze_mega.hip); 0: shape unsupported
     std::vector<int> graph_variant;
     std::vector<float> graph_temperature;
     std::vector<unsigned long long> graph_seed;

@@ -331,6 +331,7 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     chk(dev_alloc(e, &e->gbar, 1));
     chk(dev_alloc(e, &e->atickets, (size_t)c.max_seqs * c.kv_heads));
     if (r == 0) e->attn_blocks = ze_layer_attn_blocks(c.hidden, c.heads, c.kv_heads, e->head_dim);
+    if (r == 0) e->mlp_blocks = ze_layer_mlp_blocks(c.hidden, c.heads * e->head_dim, e->text_ipad);
     if (r == 0 && hipHostMalloc((void**)&e->d_host_ints, (64 + c.max_seqs) * sizeof(int)) != hipSuccess)
         r = ze_fail(e, ZE_ERR_HIP, "hipHostMalloc failed");
     e->staging_bytes = (size_t)64 << 20;

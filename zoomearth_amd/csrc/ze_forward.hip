@@ -440,12 +440,23 @@ extern "C" int ze_prefill(ze_engine* e, int seq, const int32_t* input_ids, int l
 // One token for chain `seq`: everything is read from the device-side chain state, so the same launch
 // sequence can be captured once into a hipGraph and replayed.
 // 1: the fused attention block (ze_mega.hip) replaces QKV GEMV + slices + merge + O-proj; 0: the stand-alone kernels
-static int ze_decode_variant(const ze_engine* e) { return (ze_gemv_knobs[3] > 0 && e->attn_blocks > 0) ? 1 : 0; }
+static int ze_decode_variant(const ze_engine* e) {
+    return ((ze_gemv_knobs[3] > 0 && e->attn_blocks > 0) ? 1 : 0) | ((ze_gemv_knobs[4] > 0 && e->mlp_blocks > 0) ? 2 : 0);
+}
 // the fused kernel's bounded spins gave up somewhere in the work enqueued so far (stream must be idle)
 static int ze_check_grid_timeout(ze_engine* e, hipStream_t s) {
     unsigned flag = 0;
     ZE_HIP(hipMemcpyAsync(&flag, e->gbar->timeout, sizeof(flag), hipMemcpyDeviceToHost, s));
     ZE_HIP(hipStreamSynchronize(s));
+#ifdef ZE_MLP_STAMPS
+    {  // diagnostic build (make EXTRA=-DZE_MLP_STAMPS): phase stamps of the last k_layer_mlp launch (100 MHz)
+        unsigned long long st[10];
+        hipMemcpy(st, e->gbar->timeout + 8, sizeof(st), hipMemcpyDeviceToHost);
+        fprintf(stderr, "mlp stamps (us from start):");
+        for (int i = 1; i < 10; ++i) fprintf(stderr, " %d:%.2f", i, (double)(st[i] - st[0]) / 100.0);
+        fprintf(stderr, "\n");
+    }
+#endif
     if (!flag) return ZE_OK;
     ZE_HIP(hipMemsetAsync(e->gbar, 0, sizeof(ze_grid_barrier), s));  // counters may have been left mid-barrier
     ZE_HIP(hipStreamSynchronize(s));
@@ -461,7 +472,7 @@ int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos,
     const int fused = ze_decode_variant(e);
     for (int li = 0; li < c.layers; ++li) {
         const ze_text_layer& L = e->tl[li];
-        if (fused) {
+        if (fused & 1) {
             ze_layer_attn_args f;
             memset(&f, 0, sizeof(f));
             f.wqkv = L.qkv.w;
@@ -518,6 +529,28 @@ int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos,
         ze_launch_gemv(ZE_GV_QKV_ROPE, a, s);
         ze_launch_attn_decode(e->dq, 0, e->kc(li, seq), e->vc(li, seq), 0, e->dattn, 0, st, nullptr, 1, c.heads,
                               c.kv_heads, hd, c.max_ctx, scale, e->dpartial, e->max_splits, e->atickets, s);
+        if (ze_gemv_knobs[4] > 0 && e->mlp_blocks > 0) {  // O-proj + MLP of the layer in one launch
+            ze_layer_mlp_args m;
+            memset(&m, 0, sizeof(m));
+            m.wo = L.o.w;
+            m.ldo = L.o.ld;
+            m.bo = L.o.bias;
+            m.wgu = L.gate_up.w;
+            m.ldgu = L.gate_up.ld;
+            m.wdown = L.down.w;
+            m.lddown = L.down.ld;
+            m.post_norm = L.post_norm;
+            m.eps = c.rms_eps;
+            m.attn = e->dattn;
+            m.h = e->dh;
+            m.act = e->dact;
+            m.hidden = H;
+            m.nq = nq;
+            m.ipad = e->text_ipad;
+            m.bar = e->gbar;
+            ze_launch_layer_mlp(m, e->mlp_blocks, s);
+            continue;
+        }
         ze_gemv_args o;
         memset(&o, 0, sizeof(o));
         o.W = L.o.w;
@@ -727,7 +760,7 @@ extern "C" int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_
     ze_timer_end(e, t_d, s);
     ZE_HIP(hipMemcpyAsync(out_tokens, dev_out, (size_t)produced * sizeof(int), hipMemcpyDeviceToHost, s));
     ZE_HIP(hipStreamSynchronize(s));
-    if (ze_decode_variant(e)) ZE_TRY(ze_check_grid_timeout(e, s));
+    if (ze_decode_variant(e)) ZE_TRY(ze_check_grid_timeout(e, s));  // any launch with in-launch grid barriers
     // trim at the first EOS (tokens after it are pad, as HF emits for finished rows)
     int n = produced;
     if (!ign) {

@@ -106,6 +106,21 @@ struct ze_layer_attn_args {
     float scale_log2e;
     ze_grid_barrier* bar;
 };
+// second half of a decode layer in ONE launch: O-proj + residual -> RMSNorm + gate/up + SiLU*up -> down + residual
+struct ze_layer_mlp_args {
+    const bf16_t* wo; int ldo; const bf16_t* bo;     // [hidden, heads * 128]
+    const bf16_t* wgu; int ldgu;                     // [2 * ipad, hidden], gate / up rows interleaved in blocks of 16
+    const bf16_t* wdown; int lddown;                 // [hidden, ipad]
+    const bf16_t* post_norm; float eps;
+    const bf16_t* attn;  // [heads * 128] output of the attention launch
+    bf16_t* h;           // hidden stream [hidden], updated in place
+    bf16_t* act;         // scratch [ipad]
+    int hidden, nq, ipad;
+    ze_grid_barrier* bar;
+};
+int ze_layer_mlp_blocks(int hidden, int nq, int ipad);
+void ze_launch_layer_mlp(const ze_layer_mlp_args& a, int blocks, hipStream_t s);
+
 // workgroups the fused kernel may be launched with (all co-resident, multiple of 8), 0 when the shape is unsupported
 int ze_layer_attn_blocks(int hidden, int heads, int kv_heads, int head_dim);
 void ze_launch_layer_attn(const ze_layer_attn_args& a, int blocks, hipStream_t s);

@@ -313,3 +313,328 @@ void ze_launch_layer_attn(const ze_layer_attn_args& a, int blocks, hipStream_t s
         default: hipLaunchKernelGGL(k_layer_attn<4>, dim3(blocks), dim3(256), lds, s, a); break;
     }
 }
+
+// =====================================================================================================================
+// Second half of a decode layer in ONE launch:  O-proj + residual  ->  RMSNorm + gate/up + SiLU*up  ->  down + residual
+//
+// The two all-to-all dependencies here sit between phases that STREAM (8 / 90 / 45 MB), so every compute wave
+// requests the first weight rows of the next phase BEFORE it arrives at the barrier (32 KB per wave for gate/up,
+// 12 KB for down), waits only for its own stores (counted s_waitcnt vmcnt(N): loads, stores and atomics retire in
+// issue order) and the barrier round trips run while HBM keeps streaming.  Workgroup = 4 compute waves + 1 SYNC
+// wave (320 threads, one workgroup per CU): the sync wave owns the grid barrier -- it has no loads in flight, so
+// its atomics and polls return at once, whereas a compute wave's own round trips would queue behind its 12-32
+// outstanding HBM loads (in-order return); compute waves park at the workgroup barrier meanwhile.
+//
+// STATUS (round 1, MI355X, 3B shape): bit-identical to the three stand-alone GEMV launches and SLOWER: 36.5 us per
+// layer against 4.7 + 15.8 + 10.4 = 30.9 us (651 vs 579 ms per question), so it is OFF (ze_tune knob 4).  In-kernel
+// stamps of workgroup 0 (make EXTRA=-DZE_MLP_STAMPS), us: O-proj phase 5.5 | barrier 3.3 | h reload + norm 1.3 |
+// gate/up stream 11 (13.8 stand-alone: the preload works) | store drain 1 | barrier 3.5 | act reload + staging 4 |
+// down 6.1.  The streaming phases are FASTER than their launches; the hand-offs are not: write-through drain +
+// barrier under a busy memory system + re-reading freshly written data costs 6-8 us per all-to-all hand-off,
+// a kernel boundary plus ramp about 4.  Every persistent-layer variant tried this round ends at this arithmetic
+// (see also k_layer_attn above); what remains open is point-to-point hand-off (data-tagged granules consumed as
+// they land) instead of barriers.  Kept, with its parity test, as the measured reference for that work.
+//
+// Arithmetic per output element is that of k_gemv<RESIDUAL,1,1,4> (O-proj), <SWIGLU,1,1,4> (gate/up) and
+// <RESIDUAL,1,4,6> (down: the 4 waves of a workgroup split K chunk-interleaved, partials added in wave order).
+// Shapes: hidden, heads * 128 <= 2048 and equal in 512-chunks; 4096 < ipad <= 12288 (one trip of 6 chunks per wave).
+template <int N>
+__device__ __forceinline__ void mg_wait_stores() {  // all but the N youngest vector-memory operations are done
+    static_assert(N == 0 || N == 12 || N == 33, "add the literal");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(33)" ::: "memory");
+}
+
+// grid barrier run by the sync wave (wave 4); the compute waves have drained their stores (mg_wait_stores) before
+__device__ __forceinline__ bool mg_barrier_sync_wave(ze_grid_barrier* b, unsigned target, unsigned groups,
+                                                     unsigned per_group, unsigned* s_ok) {
+    __syncthreads();  // every compute wave's stores have left the CU
+    if (threadIdx.x == 256) {
+        unsigned ok = 1;
+        const unsigned g = blockIdx.x % groups;
+        const unsigned old = __hip_atomic_fetch_add(&b->cnt[g * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == per_group - 1) {
+            __hip_atomic_store(&b->cnt[g * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned t = __hip_atomic_fetch_add(&b->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == groups - 1) {
+                __hip_atomic_store(&b->top[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (unsigned k = 0; k < groups; ++k)
+                    __hip_atomic_store(&b->gen[k * 32], target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        unsigned spins = 0;
+        while ((int)(mg_ld(&b->gen[g * 32]) - target) < 0) {
+            if (++spins > 2000000u) {
+                ok = 0;
+                break;
+            }
+        }
+        if (!ok) __hip_atomic_store(&b->timeout[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_ok = ok;
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+
+template <int NCH>
+__global__ void __launch_bounds__(320) k_layer_mlp(const ze_layer_mlp_args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                    // x of the current phase (<= 24 chunks + zero chunk)
+    bf16_t* hs = reinterpret_cast<bf16_t*>(smem + 25 * 1024);        // 4 KB: the hidden stream entering the phase
+    float* red = reinterpret_cast<float*>(smem + 29 * 1024);         // 16 floats
+    unsigned* s_ok = reinterpret_cast<unsigned*>(smem + 29 * 1024 + 64);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);        // 0..3 compute, 4 sync
+    const bool compute = wid < 4;
+    const int K = a.hidden, NQ = a.nq, IP = a.ipad;
+    constexpr int nch = NCH;
+    const int nchd = (IP + 511) >> 9;                                // chunks of the down reduction (<= 24)
+    const int lane_off = lane * 8;
+    const int gw = blockIdx.x * 4 + wid, nwaves = gridDim.x * 4;
+    const unsigned groups = 8, per_group = gridDim.x / 8;
+    if (mg_ld(&a.bar->timeout[0])) return;
+    const unsigned gen0 = mg_ld(&a.bar->gen[(blockIdx.x % 8) * 32]);
+#ifdef ZE_MLP_STAMPS
+#define MLP_STAMP(i)                                                                               \
+    do {                                                                                           \
+        if (blockIdx.x == 0 && tid == 0) {                                                         \
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime();                         \
+            reinterpret_cast<unsigned long long*>(a.bar->timeout + 8)[i] = t;                      \
+        }                                                                                          \
+    } while (0)
+#else
+#define MLP_STAMP(i)
+#endif
+    MLP_STAMP(0);
+
+    auto load_rows = [&](const bf16_t* W, int ld, int r1, int r2, int kk, uint4 (&w)[4][2]) {
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            const int off = min((u << 9) + lane_off, kk - 8);
+            w[u][0] = mg_load_w16(W + (size_t)r1 * ld + off);
+            w[u][1] = mg_load_w16(W + (size_t)r2 * ld + off);
+        }
+    };
+    const int o_pairs = K >> 1, gu_pairs = IP, d_pairs = K >> 1;
+    auto load_gu = [&](int p, uint4 (&w)[4][2]) {  // p clamped: a trip past the end re-reads the last pair
+        p = min(p, gu_pairs - 1);
+        const int r1 = (p >> 4) * 32 + (p & 15);
+        load_rows(a.wgu, a.ldgu, r1, r1 + 16, K, w);
+    };
+    auto load_down = [&](int pd, uint4 (&w)[6][2]) {  // wave w takes chunks w, w + 4, ..., w + 20
+        pd = min(pd, d_pairs - 1);
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int off = min(((wid + 4 * u) << 9) + lane_off, IP - 8);
+            w[u][0] = mg_load_w16(a.wdown + (size_t)(2 * pd) * a.lddown + off);
+            w[u][1] = mg_load_w16(a.wdown + (size_t)(2 * pd + 1) * a.lddown + off);
+        }
+    };
+
+    // ================================================================ phase O: h += Wo . attn
+    uint4 wo0[4][2], xq0 = make_uint4(0, 0, 0, 0), hq0 = make_uint4(0, 0, 0, 0);
+    if (compute) {
+        const int po = min(gw, o_pairs - 1);
+        if (tid * 8 < NQ) xq0 = *reinterpret_cast<const uint4*>(a.attn + tid * 8);
+        if (tid * 8 < K) hq0 = *reinterpret_cast<const uint4*>(a.h + tid * 8);
+        load_rows(a.wo, a.ldo, 2 * po, 2 * po + 1, NQ, wo0);
+        *reinterpret_cast<uint4*>(xs + tid * 8) = xq0;  // zero beyond NQ
+        *reinterpret_cast<uint4*>(hs + tid * 8) = hq0;
+    }
+    __syncthreads();
+    uint4 wg[4][4][2], g0 = make_uint4(0, 0, 0, 0);  // gate/up ring: four row pairs in flight per wave
+    if (compute) {
+        auto o_pair = [&](int p, const uint4 (&w)[4][2]) {
+            const int r1 = 2 * p;
+            const float b1 = a.bo ? bf16_to_f32(a.bo[r1]) : 0.f, b2 = a.bo ? bf16_to_f32(a.bo[r1 + 1]) : 0.f;
+            float a1, a2;
+            mg_fma_rows(w, xs, nch, lane, a1, a2);
+            if (lane == 0) {
+                const uint32_t hh = *reinterpret_cast<const uint32_t*>(hs + r1);
+                __builtin_amdgcn_raw_buffer_store_b32(
+                    pack_bf16x2(bf16lo(hh) + bf16_round(a1 + b1), bf16hi(hh) + bf16_round(a2 + b2)), ad_rsrc(a.h),
+                    (uint32_t)(r1 * 2), 0, 16);
+            }
+        };
+        if (gw < o_pairs) o_pair(gw, wo0);
+        for (int p = gw + nwaves; p < o_pairs; p += nwaves) {
+            uint4 w[4][2];
+            load_rows(a.wo, a.ldo, 2 * p, 2 * p + 1, NQ, w);
+            o_pair(p, w);
+        }
+        asm volatile("" ::: "memory");  // the preload below must be issued AFTER the stores above
+#pragma unroll
+        for (int k = 0; k < 4; ++k) load_gu(gw + k * nwaves, wg[k]);
+        if (tid * 8 < K) g0 = *reinterpret_cast<const uint4*>(a.post_norm + tid * 8);
+        MLP_STAMP(1);
+        mg_wait_stores<33>();
+        MLP_STAMP(2);
+    }
+    if (!mg_barrier_sync_wave(a.bar, gen0 + 1, groups, per_group, s_ok)) return;
+    MLP_STAMP(3);
+
+    // ================================================================ phase G: act = SiLU(gate) * up of RMSNorm(h)
+    if (compute) {
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (tid * 8 < K) q = ad_load16<true>(a.h, (uint32_t)(tid * 16));
+        *reinterpret_cast<uint4*>(xs + tid * 8) = q;
+        *reinterpret_cast<uint4*>(hs + tid * 8) = q;  // residual of the down projection
+        float ss = 0.f;
+        const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ss += bf16lo(u[j]) * bf16lo(u[j]) + bf16hi(u[j]) * bf16hi(u[j]);
+        ss = wave_sum(ss);
+        if (lane == 0) red[wid] = ss;
+    }
+    __syncthreads();
+    if (compute) {
+        const float inv = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + a.eps);
+        if (tid * 8 < K) {
+            const uint4 q = *reinterpret_cast<const uint4*>(xs + tid * 8);
+            const uint32_t u[4] = {q.x, q.y, q.z, q.w}, gwt[4] = {g0.x, g0.y, g0.z, g0.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                o[j] = pack_bf16x2(bf16_round(bf16lo(u[j]) * inv) * bf16lo(gwt[j]),
+                                   bf16_round(bf16hi(u[j]) * inv) * bf16hi(gwt[j]));
+            *reinterpret_cast<uint4*>(xs + tid * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    __syncthreads();
+    MLP_STAMP(4);
+    uint4 wd[3][6][2];  // down ring: three row pairs of this workgroup in flight
+    if (compute) {
+        auto gu_pair = [&](int p, const uint4 (&w)[4][2]) {
+            float a1, a2;
+            mg_fma_rows(w, xs, nch, lane, a1, a2);
+            if (lane == 0) {
+                const float v1 = bf16_round(a1 + 0.f), v2 = bf16_round(a2 + 0.f);
+                ad_store2<true>(a.act, (uint32_t)(p * 2), f32_to_bf16(bf16_round(silu_f(v1)) * v2));
+            }
+        };
+        bool more = true;
+        for (int p = gw; more && p < gu_pairs; p += 4 * nwaves) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int pk = p + k * nwaves;
+                if (pk >= gu_pairs) {  // wave-uniform
+                    more = false;
+                    break;
+                }
+                gu_pair(pk, wg[k]);
+                load_gu(pk + 4 * nwaves, wg[k]);
+            }
+        }
+        MLP_STAMP(5);
+        asm volatile("" ::: "memory");
+        load_down(blockIdx.x, wd[0]);
+        mg_wait_stores<12>();
+        MLP_STAMP(6);
+    }
+    if (!mg_barrier_sync_wave(a.bar, gen0 + 2, groups, per_group, s_ok)) return;
+    MLP_STAMP(7);
+
+    // ================================================================ phase D: h += Wdown . act
+    const int units = (d_pairs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;  // pairs of this workgroup
+    if (compute) {
+        // act first (it returns ahead of the weight rows requested behind it), zero padded to one chunk past the end
+        const int nvec = (nchd + 1) * 64;
+        uint4 xv[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int v = tid + i * 256;
+            xv[i] = ad_load16<true>(a.act, (uint32_t)(min(v, (IP >> 3) - 1) * 16));
+        }
+        load_down(blockIdx.x + gridDim.x, wd[1]);
+        load_down(blockIdx.x + 2 * gridDim.x, wd[2]);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int v = tid + i * 256;
+            if (v < nvec) *reinterpret_cast<uint4*>(xs + v * 8) = (v * 8 < IP) ? xv[i] : make_uint4(0, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    MLP_STAMP(8);
+    auto down_unit = [&](int u, const uint4 (&w)[6][2]) {  // called by every wave (workgroup barriers inside)
+        const int pd = blockIdx.x + u * gridDim.x;
+        if (compute) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int c6 = 0; c6 < 6; ++c6) {
+                const int c = min(wid + 4 * c6, nchd);  // chunk nchd is all zero
+                const uint4 xq = *reinterpret_cast<const uint4*>(xs + (c << 9) + lane_off);
+                const uint32_t xu[4] = {xq.x, xq.y, xq.z, xq.w};
+                const uint32_t w1[4] = {w[c6][0].x, w[c6][0].y, w[c6][0].z, w[c6][0].w};
+                const uint32_t w2[4] = {w[c6][1].x, w[c6][1].y, w[c6][1].z, w[c6][1].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a1 = fmaf(bf16lo(w1[j]), bf16lo(xu[j]), a1);
+                    a1 = fmaf(bf16hi(w1[j]), bf16hi(xu[j]), a1);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a2 = fmaf(bf16lo(w2[j]), bf16lo(xu[j]), a2);
+                    a2 = fmaf(bf16hi(w2[j]), bf16hi(xu[j]), a2);
+                }
+            }
+            a1 = wave_sum(a1);
+            a2 = wave_sum(a2);
+            if (lane == 0) {
+                red[wid * 2] = a1;
+                red[wid * 2 + 1] = a2;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const float s1 = red[0] + red[2] + red[4] + red[6], s2 = red[1] + red[3] + red[5] + red[7];
+            const uint32_t hh = *reinterpret_cast<const uint32_t*>(hs + 2 * pd);
+            *reinterpret_cast<uint32_t*>(a.h + 2 * pd) =
+                pack_bf16x2(bf16lo(hh) + bf16_round(s1 + 0.f), bf16hi(hh) + bf16_round(s2 + 0.f));
+        }
+        __syncthreads();
+    };
+    bool more = true;
+    for (int u0 = 0; more && u0 < units; u0 += 3) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int u = u0 + k;
+            if (u >= units) {  // workgroup-uniform
+                more = false;
+                break;
+            }
+            down_unit(u, wd[k]);
+            if (compute && u + 3 < units) load_down(blockIdx.x + (u + 3) * gridDim.x, wd[k]);
+        }
+    }
+    MLP_STAMP(9);
+}
+
+static const size_t kLayerMlpLds = 29 * 1024 + 128;
+
+template <int NCH>
+static int layer_mlp_resident(int cus) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_layer_mlp<NCH>, 320, kLayerMlpLds) != hipSuccess) return 0;
+    return occ * cus;
+}
+
+int ze_layer_mlp_blocks(int hidden, int nq, int ipad) {
+    if (hidden > 2048 || hidden % 8 || nq > 2048 || nq % 8 || ipad <= 4096 || ipad > 12288 || ipad % 16) return 0;
+    const int nch = (hidden + 511) / 512;
+    if ((nq + 511) / 512 != nch || nch != 4) return 0;  // the counted waits are written for four chunks
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    // ONE workgroup per CU: the occupancy query promises two, but five-wave workgroups put their fifth wave on the
+    // same SIMD and a second workgroup then does not fit there -- 512 workgroups were not co-resident (barrier
+    // timeouts), 256 are.
+    const int resident = layer_mlp_resident<4>(cus);
+    int blocks = std::min(cus, resident) / 8 * 8;
+    blocks = std::min(blocks, 8 * 64);
+    return blocks >= 8 ? blocks : 0;
+}
+
+void ze_launch_layer_mlp(const ze_layer_mlp_args& a, int blocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_layer_mlp<4>, dim3(blocks), dim3(320), kLayerMlpLds, s, a);
+}
