@@ -110,7 +110,8 @@ struct ze_engine {
     ze_grid_barrier* gbar = nullptr;
     int attn_blocks = 0;  // 0: shape unsupported, the four stand-alone kernels run instead
     int mlp_blocks = 0;   // fused O-proj + MLP launch (ze_mega.hip); 0: shape unsupported
-    std::vector<int> graph_variant;
+    std::vector<int> graph_variant;  // ze_tune epoch the chain's graph was captured under
+    unsigned bgraph_epoch = 0;
     std::vector<float> graph_temperature;
     std::vector<unsigned long long> graph_seed;
     // split-K GEMM workspace

@@ -14,6 +14,7 @@
     } while (0)
 #define ZE_KCHECK() ZE_HIP(hipGetLastError())
 extern int ze_gemv_knobs[8];
+static unsigned ze_tune_epoch = 0;
 
 // ================================================================== front-end
 // dst = crop(src, box).resize((dst_w, dst_h), BICUBIC), Pillow-exact (two passes, u8 intermediate).
@@ -708,7 +709,7 @@ extern "C" int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_
     hipGraphExec_t gexec = nullptr;
     if (p->use_graph && max_new > 1) {
         if (!e->graphs[seq] || e->graph_penalty[seq] != pen || e->graph_ignore_eos[seq] != ign ||
-            e->graph_variant[seq] != ze_decode_variant(e) || e->graph_temperature[seq] != so.temperature ||
+            e->graph_variant[seq] != (int)ze_tune_epoch || e->graph_temperature[seq] != so.temperature ||
             e->graph_seed[seq] != so.seed) {
             if (e->graphs[seq]) {
                 hipGraphExecDestroy(e->graphs[seq]);
@@ -730,7 +731,7 @@ extern "C" int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_
             ZE_TRY(r);
             e->graph_penalty[seq] = pen;
             e->graph_ignore_eos[seq] = ign;
-            e->graph_variant[seq] = ze_decode_variant(e);
+            e->graph_variant[seq] = (int)ze_tune_epoch;
             e->graph_temperature[seq] = so.temperature;
             e->graph_seed[seq] = so.seed;
         }
@@ -891,6 +892,11 @@ extern "C" int ze_generate_batch(ze_engine* e, const int32_t* seqs, int n, const
         hipGraphExec_t gx = nullptr;
         if (p->use_graph) {  // one captured step per batch size (chain ids / positions live in device memory)
             auto key = std::make_tuple(na, pen, ign, bso.temperature, bso.seed);
+            if (e->bgraph_epoch != ze_tune_epoch) {
+                for (auto& kv : e->bgraphs) hipGraphExecDestroy(kv.second);
+                e->bgraphs.clear();
+                e->bgraph_epoch = ze_tune_epoch;
+            }
             auto it = e->bgraphs.find(key);
             if (it == e->bgraphs.end()) {
                 hipStream_t cs;
@@ -1022,6 +1028,7 @@ extern "C" int ze_op_attention(ze_engine* e, const void* q, const void* k, const
 extern "C" int ze_tune(int knob, int value) {
     if (knob < 0 || knob >= 8) return ze_fail(nullptr, ZE_ERR_INVALID, "unknown knob");
     ze_gemv_knobs[knob] = value;
+    ++ze_tune_epoch;  // captured decode steps bake the launch policy in: engines drop their graphs on the next use
     return ZE_OK;
 }
 extern "C" int ze_profile_decode_kernel(ze_engine* e, int which, int iters, float* avg_us, double* bytes_per_launch,

@@ -424,7 +424,9 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
         hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
-    const bool ring = ze_gemv_knobs[6] == 2 || (ze_gemv_knobs[6] == 0 && grid <= cus);
+    // (weight-streaming mode, rows = chains of a batched decode step: the ring wins at every grid, 5.04 vs 5.32 ms per
+    //  step at 64 chains, 3.78 vs 4.17 at 8)
+    const bool ring = ze_gemv_knobs[6] == 2 || (ze_gemv_knobs[6] == 0 && (grid <= cus || stream_mode));
     if (K % GEMM_BK == 0 && K / GEMM_BK / ksplit >= 4 && ring) {
         // LDS-DMA ring: four stages when they fit beside nothing else (one workgroup per CU), else three
         constexpr int STAGES = ((BM + BN) * 128 * 4 <= 128 * 1024) ? 4 : 3;
