@@ -3,10 +3,11 @@
 (/root/reference/src/eval/infer.py: same CLI `--model_name --exp_name`, same ./LRS_GRO/test + ./image/ layout,
 same two-stage chain, same `results/{exp_name}{rank}.jsonl` records).
 
-Differences, all documented in DESIGN.md: the 5000-px tile is decoded ONCE per question, uploaded to HBM and
-cropped/resized by the HIP front-end (the reference decodes it twice on the CPU); greedy decoding (the reference
-samples at T=0.01); bf16 arithmetic; questions are sharded by tile across ranks; every question is wrapped in
-try/except so one malformed bbox does not kill the run (the reference crashes on a 3-number box).
+Differences, all documented in DESIGN.md: a 5000-px tile is decoded ONCE per tile by a prefetch thread, uploaded to
+HBM and cropped/resized by the HIP front-end (the reference decodes it twice per question on the CPU); sampling at
+T=0.01 draws from the same distribution with the engine's own random stream; bf16 arithmetic; questions are
+sharded by tile across ranks; every question is wrapped in try/except so one malformed bbox does not kill the run
+(the reference crashes on a 3-number box).
 """
 import argparse
 import os
@@ -19,7 +20,7 @@ from tqdm import tqdm  # noqa: E402
 
 from zoomearth_amd import hostloop as H  # noqa: E402
 from zoomearth_amd.accel import Accelerator  # noqa: E402
-from zoomearth_amd.image import DeviceImage  # noqa: E402
+from zoomearth_amd.image import TilePrefetcher  # noqa: E402
 from zoomearth_amd.modeling import ZoomEarthForConditionalGeneration  # noqa: E402
 from zoomearth_amd.processor import ZoomEarthProcessor  # noqa: E402
 
@@ -41,7 +42,6 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
     processor = ZoomEarthProcessor.from_pretrained(model_name, trust_remote_code=True, max_pixels=128 * 128 * 28 * 28)
     processor.tokenizer.padding_side = "left"
     accelerator = Accelerator(mixed_precision="bf16", project_dir="checkpoints", log_with=[])
-    # accepted for drop-in compatibility; decoding is greedy (T=0.01 sampling in the reference is near-greedy)
     model.generation_config.temperature = 0.01
     model.generation_config.top_p = None
     model.generation_config.top_k = None
@@ -55,15 +55,15 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
         return H.chat_batch(prompts, images, processor, model, device=accelerator.device, do_sample=True,
                             temperature=0.01, max_new_tokens=max_new_tokens)
 
-    tile_cache = {}
+    def tile_path(sample):
+        return os.path.join(image_dir, sample["image_name"].split("/")[-1])
+
+    # the rank's questions arrive grouped by tile: decode the next tile while the current one is being questioned
+    tiles = TilePrefetcher([tile_path(s) for ex in dl for s in ex], model.engine)
     for examples in tqdm(dl, desc="Evaluating"):
         for sample in examples:
-            image_fp = os.path.join(image_dir, sample["image_name"].split("/")[-1])
             try:
-                if image_fp not in tile_cache:
-                    tile_cache.clear()  # one resident tile at a time (questions arrive grouped by tile)
-                    tile_cache[image_fp] = DeviceImage.open(image_fp, model.engine)
-                r = H.zoom_chain(sample["question"], tile_cache[image_fp], chat)
+                r = H.zoom_chain(sample["question"], tiles.get(tile_path(sample)), chat)
                 H.record(fout, sample["question"], sample, sample, r["output1"], r["output2"], r["error"])
             except Exception as ex:  # keep going; the record marks the failure
                 H.record(fout, sample["question"], sample, sample, f"Error: {ex}", "", True)

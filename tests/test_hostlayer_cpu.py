@@ -161,3 +161,60 @@ def test_scorer(tmp_path):
     p = tmp_path / "r.jsonl"
     p.write_text("\n".join(json.dumps(x) for x in recs) + "\n")
     assert ev.evaluation_metrics(str(p))["total"] == 4
+
+
+def test_tile_prefetcher_decodes_each_tile_once_and_ahead(tmp_path):
+    """one decode per tile (the reference decodes twice per question), next tile decoded while
+    the current one is in use; errors surface at get(); out-of-order requests still work."""
+    import threading
+    import time
+    import numpy as np
+    import torch
+    from PIL import Image
+    from zoomearth_amd.image import TilePrefetcher, decode_rgb
+
+    paths = []
+    for i in range(3):
+        fp = tmp_path / f"t{i}.png"
+        Image.fromarray(np.full((40 + i, 50, 3), 10 * i, dtype=np.uint8)).save(fp)
+        paths.append(str(fp))
+    log = []
+
+    def decode(p):
+        log.append((p, threading.current_thread().name))
+        if p.endswith("bad.png"):
+            raise FileNotFoundError(p)
+        return decode_rgb(p)
+
+    class Eng:
+        device = torch.device("cpu")
+
+    import zoomearth_amd.image as I
+    orig = I.DeviceImage.__init__
+
+    def cpu_init(self, base, engine, box=None, key=None):  # DeviceImage insists on a CUDA tensor: relax for the CPU test
+        self.base, self.engine = base, engine
+        self.box = (0, 0, int(base.shape[1]), int(base.shape[0])) if box is None else box
+        self.key = key or ("img", id(base))
+
+    I.DeviceImage.__init__ = cpu_init
+    try:
+        stream = [paths[0]] * 3 + [paths[1]] * 2 + [paths[2]] + [paths[0]]  # tile 0 comes back at the end
+        pf = TilePrefetcher(stream, Eng(), decode=decode, pin=False)
+        seen = []
+        for p in stream:
+            img = pf.get(p)
+            seen.append((p, img.size))
+            time.sleep(0.02)
+        assert [s for _, s in seen] == [(50, 40)] * 3 + [(50, 41)] * 2 + [(50, 42)] + [(50, 40)]
+        assert [p for p, _ in log] == [paths[0], paths[1], paths[2], paths[0]]          # one decode per tile visit
+        assert all(name != threading.main_thread().name for _, name in log)             # all of them off-thread
+        assert pf.get(paths[0]) is pf.get(paths[0])
+        bad = str(tmp_path / "bad.png")
+        pf2 = TilePrefetcher([bad, paths[1]], Eng(), decode=decode, pin=False)
+        with pytest.raises(FileNotFoundError):
+            pf2.get(bad)
+        assert pf2.get(paths[1]).size == (50, 41)
+        assert pf2.get(paths[2]).size == (50, 42)  # never announced: decoded on demand
+    finally:
+        I.DeviceImage.__init__ = orig
