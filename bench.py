@@ -429,6 +429,24 @@ def main():
                          "avg_us": us, "bytes_per_launch": by, "other_decode_kernels": others},
             "phase_ms_per_question": {k: round(v / args.steps, 3) for k, v in phases.items()},
         }
+        if args.batch == 1:
+            # per-phase roofline fractions: algorithmic work of the as-built question (stage-1 prompt KV
+            # and view features reused) over the measured phase time, against the dense bf16 MFMA peak / the HBM peak
+            pm = line["phase_ms_per_question"]
+            f_vit, f_pre = 3.41e12, 1320 * 5.549e9 + 0.257e12          # FLOP per question
+            b_dec = (N1 + N2) * 6.171e9 + 36864.0 * (N1 * (lens[0] + N1 / 2) + N2 * (lens[1] + N2 / 2))  # bytes per question
+            line["roofline_phases"] = {
+                "vit": {"bound": "mfma", "achieved_TFLOPs": f_vit / (pm["vit"] * 1e-3) / 1e12, "peak_TFLOPs": 2500.0,
+                        "frac": f_vit / (pm["vit"] * 1e-3) / 2.5e15},
+                "prefill": {"bound": "mfma", "achieved_TFLOPs": f_pre / (pm["prefill"] * 1e-3) / 1e12, "peak_TFLOPs": 2500.0,
+                            "frac": f_pre / (pm["prefill"] * 1e-3) / 2.5e15},
+                "decode": {"bound": "hbm", "achieved_GBs": b_dec / (pm["decode"] * 1e-3) / 1e9, "peak_GBs": HBM_PEAK_GBS,
+                           "frac": b_dec / (pm["decode"] * 1e-3) / (HBM_PEAK_GBS * 1e9)},
+                "question": {"roofline_ms": (f_vit + f_pre + (N1 + N2) * 6.171e9) / 2.5e15 * 1e3 + b_dec / (HBM_PEAK_GBS * 1e9) * 1e3,
+                             "measured_ms": line["ms_per_step"]},
+            }
+            line["roofline_phases"]["question"]["frac"] = (line["roofline_phases"]["question"]["roofline_ms"] /
+                                                           line["roofline_phases"]["question"]["measured_ms"])
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             hf_note = ""
             if args.cpu_baseline in ("auto", "hf"):
