@@ -14,6 +14,26 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define FA_BQ 64
 #define FA_BK 64
 
+typedef short v4s __attribute__((ext_vector_type(4)));
+
+// LDS image of a [64 keys][128 d] bf16 tile with 256-byte rows: byte offset of 16-B chunk ch (0..15) of row `row`.
+// The XOR serves both the ds_read_b128 row reads (K as an MFMA operand) and the ds_read_b64_tr_b16 transposed reads
+// (V^T as an MFMA operand) -- cdna_hip_programming.md T10, image (b).
+__device__ __forceinline__ int fa_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+// Flash attention with the SWAPPED product: S^T = K Q^T, O^T = V^T P^T (T12 of the guide).
+//   * a lane of the S^T accumulator holds one query (column fr) and 4 keys per 16-key tile, so the softmax statistics
+//     of a query are lane-local plus two shuffles (xor 16, 32), the rescale factor is ONE scalar per lane, and the
+//     probabilities go from the accumulator straight into the B operand of the PV product -- no LDS round trip for
+//     P.  The 8 keys a lane contributes per 32-key step are (fq*4 .. +3) and (16 + fq*4 .. +3): a permutation of the
+//     contraction index, applied identically to the V^T operand.
+//   * V stays row-major in LDS (16-B staging writes); V^T fragments come from ds_read_b64_tr_b16 (per 16-lane group a
+//     4-key x 16-d block, delivered column-wise: probe tools/probes/tr_read_probe.hip), two reads per fragment at
+//     exactly the key rows of the permutation above.  The previous kernel transposed V with 2-byte LDS writes and
+//     round-tripped P through LDS: 98.7 us per prefill layer at 802 tokens, 1.5 % MFMA utilisation.
+//   * Q fragments live in registers for the whole kernel; K/V tiles are double-buffered in LDS with split staging
+//     (global loads of tile t+1 are issued before the products of tile t, written to LDS after).
+// D = 128 (LLM, causal GQA) and D = 80 (ViT; rows padded to 128 in LDS, the pad chunks are zero).
 template <int D, int CAUSAL>
 __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q, int q_rs, int q_hs,
                                                     const bf16_t* __restrict__ k, int k_rs, int k_hs,
@@ -21,160 +41,164 @@ __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q
                                                     bf16_t* __restrict__ o, int o_rs, int o_hs,
                                                     const int4* __restrict__ tiles, int group, float scale_log2e,
                                                     int q_pos_offset) {
-    constexpr int DK = (D + 31) / 32 * 32;  // padded head dim for the QK^T k-steps
-    constexpr int QCH = DK / 8;             // 16-B chunks per (padded) row
-    constexpr int DCH = D / 8;              // real chunks per row
-    constexpr int NV = D / 16;              // output n-tiles
-    // LDS images (16-B units): [chunk][row ^ (chunk&7)]
-    __shared__ uint4 sQ[QCH * FA_BQ];
-    __shared__ uint4 sK[QCH * FA_BK];
-    __shared__ uint4 sVt[(FA_BK / 8) * D];       // [key-chunk][d ^ (kc&7)] : 8 keys x bf16 per unit
-    __shared__ uint4 sP[4][(FA_BK / 8) * 16];    // per wave [key-chunk][row ^ (kc&7)]
+    constexpr int KS = (D + 31) / 32;  // 32-deep steps of the QK^T contraction (D = 80: 3, the third half zero)
+    constexpr int DCH = D / 8;         // real 16-B chunks per row
+    constexpr int NV = D / 16;         // d-tiles of the output
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 x (K tile 16 KB + V tile 16 KB)
 
     const int4 tile = tiles[blockIdx.x];
     const int q0 = tile.x, q1 = tile.y, kv0 = tile.z, kv1 = tile.w;
     const int head = blockIdx.y, kvh = head / group;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
+    const int qi = q0 + wid * 16 + fr;  // the query of this lane (column of S^T / O^T)
 
-    // ---- stage Q (zero padded rows / chunks)
-    for (int i = tid; i < QCH * FA_BQ; i += 256) {
-        const int row = i / QCH, ch = i % QCH;
+    // Q^T fragments: lane (n = fr, k-group fq) holds d = ks*32 + fq*8 .. +7 of its query
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
         uint4 val = make_uint4(0, 0, 0, 0);
-        if (q0 + row < q1 && ch < DCH)
-            val = *reinterpret_cast<const uint4*>(q + (size_t)(q0 + row) * q_rs + (size_t)head * q_hs + ch * 8);
-        sQ[ch * FA_BQ + (row ^ (ch & 7))] = val;
+        const int ch = ks * 4 + fq;
+        if (qi < q1 && ch < DCH) val = *reinterpret_cast<const uint4*>(q + (size_t)qi * q_rs + (size_t)head * q_hs + ch * 8);
+        qf[ks] = *reinterpret_cast<const bf16x8*>(&val);
     }
 
     f32x4 oacc[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) oacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run[4], l_run[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        m_run[r] = -INFINITY;
-        l_run[r] = 0.f;
-    }
+    float m_run = -INFINITY, l_run = 0.f;
     int kv_hi = kv1;
     if (CAUSAL) kv_hi = min(kv1, q1 + q_pos_offset);  // keys beyond the last query position are never visible
+    const int ntile = (kv_hi - kv0 + FA_BK - 1) / FA_BK;
 
-    for (int kt = kv0; kt < kv_hi; kt += FA_BK) {
-        __syncthreads();  // previous tile's LDS reads done (also orders the Q staging before first use)
-        // ---- stage K tile and V^T tile
-        for (int i = tid; i < QCH * FA_BK; i += 256) {
-            const int row = i / QCH, ch = i % QCH;
-            uint4 val = make_uint4(0, 0, 0, 0);
-            if (kt + row < kv_hi && ch < DCH)
-                val = *reinterpret_cast<const uint4*>(k + (size_t)(kt + row) * k_rs + (size_t)kvh * k_hs + ch * 8);
-            sK[ch * FA_BK + (row ^ (ch & 7))] = val;
-        }
-        for (int i = tid; i < DCH * FA_BK; i += 256) {
-            const int key = i / DCH, ch = i % DCH;
-            uint4 val = make_uint4(0, 0, 0, 0);
-            if (kt + key < kv_hi)
-                val = *reinterpret_cast<const uint4*>(v + (size_t)(kt + key) * v_rs + (size_t)kvh * v_hs + ch * 8);
-            const uint32_t u[4] = {val.x, val.y, val.z, val.w};
-            bf16_t* base = reinterpret_cast<bf16_t*>(sVt);
-            const int kc = key >> 3, ki = key & 7;
+    // staging: thread -> (row = tid >> 2, chunks (tid & 3) * 4 .. +3) of the 64 x 16-chunk tile
+    const int srow = tid >> 2, sch = (tid & 3) * 4;
+    uint4 rk[4], rv[4];
+    auto stage_load = [&](int kt) {
+        const int key = kt + srow;
+        const bool ok = key < kv_hi;
+        const bf16_t* kp = k + (size_t)key * k_rs + (size_t)kvh * k_hs;
+        const bf16_t* vp = v + (size_t)key * v_rs + (size_t)kvh * v_hs;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int d = ch * 8 + e;
-                const bf16_t x = (bf16_t)((e & 1) ? (u[e >> 1] >> 16) : (u[e >> 1] & 0xffff));
-                base[((size_t)(kc * D + (d ^ (kc & 7)))) * 8 + ki] = x;
+        for (int i = 0; i < 4; ++i) {
+            rk[i] = make_uint4(0, 0, 0, 0);
+            rv[i] = make_uint4(0, 0, 0, 0);
+            if (ok && sch + i < DCH) {
+                rk[i] = *reinterpret_cast<const uint4*>(kp + (sch + i) * 8);
+                rv[i] = *reinterpret_cast<const uint4*>(vp + (sch + i) * 8);
             }
         }
-        __syncthreads();
+    };
+    auto stage_write = [&](int buf) {
+        uint8_t* kb = smem + buf * 32768;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<uint4*>(kb + fa_off(srow, sch + i)) = rk[i];
+            *reinterpret_cast<uint4*>(kb + 16384 + fa_off(srow, sch + i)) = rv[i];
+        }
+    };
+    if (ntile > 0) {
+        stage_load(kv0);
+        stage_write(0);
+    }
+    __syncthreads();
 
-        // ---- S = Q K^T for this wave's 16 rows x 64 keys
+    for (int t = 0; t < ntile; ++t) {
+        const int kt = kv0 + t * FA_BK;
+        const uint8_t* kb = smem + (t & 1) * 32768;
+        const uint8_t* vb = kb + 16384;
+        if (t + 1 < ntile) stage_load(kt + FA_BK);
+        // ---- S^T = K Q^T : 4 key tiles x KS steps
         f32x4 sacc[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < DK / 32; ++ks) {
-            const int ch = ks * 4 + fq;
-            const int qrow = wid * 16 + fr;
-            const uint4 qa = sQ[ch * FA_BQ + (qrow ^ (ch & 7))];
-            const bf16x8 fa = *reinterpret_cast<const bf16x8*>(&qa);
+        for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                const int krow = n * 16 + fr;
-                const uint4 kb = sK[ch * FA_BK + (krow ^ (ch & 7))];
-                sacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, *reinterpret_cast<const bf16x8*>(&kb), sacc[n],
+                const uint4 ka = *reinterpret_cast<const uint4*>(kb + fa_off(n * 16 + fr, ks * 4 + fq));
+                sacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&ka), qf[ks], sacc[n],
                                                                  0, 0, 0);
             }
         }
-        // ---- mask + online softmax (rows = wid*16 + fq*4 + r, keys = n*16 + fr)
+        // ---- mask + online softmax for query qi: keys kt + n*16 + fq*4 + r
         float p[4][4];
+        float mx = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qi = q0 + wid * 16 + fq * 4 + r;
-            float mx = -INFINITY;
+        for (int n = 0; n < 4; ++n)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int kj = kt + n * 16 + fr;
+            for (int r = 0; r < 4; ++r) {
+                const int kj = kt + n * 16 + fq * 4 + r;
                 bool ok = kj < kv_hi;
                 if (CAUSAL) ok = ok && (kj <= qi + q_pos_offset);
                 const float sv = ok ? sacc[n][r] * scale_log2e : -INFINITY;
                 p[n][r] = sv;
                 mx = fmaxf(mx, sv);
             }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = exp2f(m_run - m_use);  // m_run = -inf -> 0
+        float rs = 0.f;
 #pragma unroll
-            for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-            const float m_new = fmaxf(m_run[r], mx);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = exp2f(m_run[r] - m_use);  // m_run = -inf -> 0
-            float rs = 0.f;
+        for (int n = 0; n < 4; ++n)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
+            for (int r = 0; r < 4; ++r) {
                 const float e = exp2f(p[n][r] - m_use);
                 p[n][r] = e;
                 rs += e;
             }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
 #pragma unroll
-            for (int off = 8; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
-            l_run[r] = l_run[r] * alpha + rs;
-            m_run[r] = m_new;
-#pragma unroll
-            for (int j = 0; j < NV; ++j) oacc[j][r] *= alpha;
+        for (int j = 0; j < NV; ++j) {
+            oacc[j][0] *= alpha;
+            oacc[j][1] *= alpha;
+            oacc[j][2] *= alpha;
+            oacc[j][3] *= alpha;
         }
-        // ---- P (bf16) -> this wave's LDS image as an A operand
-        {
-            bf16_t* pb = reinterpret_cast<bf16_t*>(sP[wid]);
+        // ---- O^T += V^T P^T : per 32-key step the lane's 8 keys are (ks*32 + fq*4 + 0..3) and (ks*32 + 16 + fq*4 + 0..3)
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+        for (int ks = 0; ks < 2; ++ks) {
+            uint32_t pw[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = fq * 4 + r, key = n * 16 + fr;
-                    const int kc = key >> 3;
-                    pb[((size_t)(kc * 16 + (row ^ (kc & 7)))) * 8 + (key & 7)] = f32_to_bf16(p[n][r]);
-                }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
-        __builtin_amdgcn_wave_barrier();
-        // ---- O += P V
-#pragma unroll
-        for (int ks = 0; ks < FA_BK / 32; ++ks) {
-            const int kc = ks * 4 + fq;
-            const uint4 pa = sP[wid][kc * 16 + (fr ^ (kc & 7))];
-            const bf16x8 fa = *reinterpret_cast<const bf16x8*>(&pa);
+            for (int h2 = 0; h2 < 2; ++h2) {
+                pw[2 * h2] = pack_bf16x2(p[2 * ks + h2][0], p[2 * ks + h2][1]);
+                pw[2 * h2 + 1] = pack_bf16x2(p[2 * ks + h2][2], p[2 * ks + h2][3]);
+            }
+            const uint4 pq = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+            const bf16x8 pb = *reinterpret_cast<const bf16x8*>(&pq);
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                const int d = j * 16 + fr;
-                const uint4 vb = sVt[kc * D + (d ^ (kc & 7))];
-                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, *reinterpret_cast<const bf16x8*>(&vb), oacc[j],
-                                                                 0, 0, 0);
+                // block of 4 keys x 16 d: lane 4q+p of the 16-lane group addresses key row (r0 + q), d = j*16 + 4p .. +3
+                const int l16 = lane & 15, tq = l16 >> 2, tp = l16 & 3;
+                const int r0a = ks * 32 + fq * 4, r0b = r0a + 16;
+                const int ch = j * 2 + (tp >> 1), half = 8 * (tp & 1);
+                const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) v4s*)(vb + fa_off(r0a + tq, ch) + half));
+                const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) v4s*)(vb + fa_off(r0b + tq, ch) + half));
+                typedef short v8s __attribute__((ext_vector_type(8)));
+                const v8s va = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&va), pb, oacc[j], 0, 0, 0);
             }
         }
+        if (t + 1 < ntile) stage_write((t + 1) & 1);
+        __syncthreads();
     }
-    // ---- normalise and store
+    // ---- normalise and store: lane holds O[qi][j*16 + fq*4 .. +3]
+    if (qi < q1) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qi = q0 + wid * 16 + fq * 4 + r;
-        if (qi >= q1) continue;
-        const float inv = l_run[r] > 0.f ? 1.0f / l_run[r] : 0.f;
-#pragma unroll
-        for (int j = 0; j < NV; ++j)
-            o[(size_t)qi * o_rs + (size_t)head * o_hs + j * 16 + fr] = f32_to_bf16(oacc[j][r] * inv);
+        for (int j = 0; j < NV; ++j) {
+            uint2 w;
+            w.x = pack_bf16x2(oacc[j][0] * inv, oacc[j][1] * inv);
+            w.y = pack_bf16x2(oacc[j][2] * inv, oacc[j][3] * inv);
+            *reinterpret_cast<uint2*>(o + (size_t)qi * o_rs + (size_t)head * o_hs + j * 16 + fq * 4) = w;
+        }
     }
 }
 
@@ -186,7 +210,7 @@ void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_rs, int q_hs
     const float sl = scale * 1.4426950408889634f;
     dim3 grid(n_tiles, heads);
 #define FA_LAUNCH(DD, CC)                                                                                      \
-    hipLaunchKernelGGL((k_flash_attn<DD, CC>), grid, dim3(256), 0, s, q, q_rs, q_hs, k, k_rs, k_hs, v, v_rs, v_hs, \
+    hipLaunchKernelGGL((k_flash_attn<DD, CC>), grid, dim3(256), 65536, s, q, q_rs, q_hs, k, k_rs, k_hs, v, v_rs, v_hs, \
                        o, o_rs, o_hs, tiles, group, sl, q_pos_offset)
     if (D == 80) {
         if (causal) FA_LAUNCH(80, 1); else FA_LAUNCH(80, 0);
