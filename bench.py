@@ -91,8 +91,9 @@ class Chain:
 
 
 class BatchChain(Chain):
-    """B question chains advanced together (BASELINE configs[2]): one multi-image ViT call per stage, per-chain
-    prefill, batched decode where the weights are streamed once per step for all chains."""
+    """B question chains advanced together (BASELINE configs[2]): one multi-image ViT call per stage, cross-chain
+    prefill passes of `group` chains, batched decode where the weights are streamed once per step for all chains."""
+    group = 16
 
     def questions(self, q0: int, B: int):
         e, cfg, H = self.e, self.e.config, self.H
@@ -103,10 +104,13 @@ class BatchChain(Chain):
         emb_v = e.vit_forward(pv_v, [g_v])  # the B questions of this step are about the same tile: one view
         n_img = g_v[1] * g_v[2] // 4
         ids1 = [question_ids(cfg, q0 + b, n_img) for b in range(B)]
+        pl = [e.rope_index(ids1[b], [g_v]) for b in range(B)]
         for b in range(B):
-            pos, delta = e.rope_index(ids1[b], [g_v])
             e.seq_reset(b)
-            e.prefill(b, ids1[b], emb_v, pos, delta, want_logits=False)
+        for g0 in range(0, B, self.group):  # chains prefilled together: their rows share every GEMM
+            gs = list(range(g0, min(B, g0 + self.group)))
+            e.prefill_batch(gs, [ids1[b] for b in gs], [emb_v] * len(gs), [pl[b][0] for b in gs], [pl[b][1] for b in gs])
+        for b in range(B):
             e.mark_seen(b, ids1[b])
         out1 = e.generate_batch(list(range(B)), N1, repetition_penalty=PENALTY, ignore_eos=True, sync_every=N1)
         # zoom crops (different sizes -> dynamic-resolution ViT batch)
@@ -121,15 +125,23 @@ class BatchChain(Chain):
             grids.append(g)
         import torch
         emb_c = e.vit_forward(torch.cat(pvs), grids)
-        off = 0
+        off, ids2s, embs, pos2s, d2s = 0, [], [], [], []
         for b in range(B):
             n_c = grids[b][1] * grids[b][2] // 4
             ids2 = ids1[b] + out1[b] + [cfg.vision_start_token_id] + [cfg.image_token_id] * n_c + [cfg.vision_end_token_id]
             pos2, delta2 = e.rope_index(ids2, [g_v, grids[b]])
             e.seq_truncate(b, len(ids1[b]))
-            e.prefill(b, ids2[len(ids1[b]):], emb_c[off:off + n_c].contiguous(), pos2[:, len(ids1[b]):], delta2, want_logits=False)
-            e.mark_seen(b, ids2)
+            ids2s.append(ids2)
+            embs.append(emb_c[off:off + n_c])
+            pos2s.append(pos2[:, len(ids1[b]):])
+            d2s.append(delta2)
             off += n_c
+        for g0 in range(0, B, self.group):
+            gs = list(range(g0, min(B, g0 + self.group)))
+            e.prefill_batch(gs, [ids2s[b][len(ids1[b]):] for b in gs], [embs[b] for b in gs], [pos2s[b] for b in gs],
+                            [d2s[b] for b in gs])
+        for b in range(B):
+            e.mark_seen(b, ids2s[b])
         out2 = e.generate_batch(list(range(B)), N2, repetition_penalty=PENALTY, ignore_eos=True, sync_every=N2)
         return out1, out2, len(ids1[0]), len(ids1[0]) + N1 + 326
 
@@ -347,6 +359,7 @@ def main():
 
     cfg = ModelConfig.zoomearth_3b()
     e = Engine(cfg, device=local, max_seqs=max(1, args.batch), max_ctx=2048, max_patches=max(4096, 1400 * args.batch),
+               max_prefill_rows=(16 * 832 if args.batch > 1 else 0),
                max_tile_side=max(args.tile, 1024))
     e.fill_synthetic(seed=0, std=0.02)
     for kv in os.environ.get("ZE_TUNE", "").split(","):  # measurement-only A/B knobs, e.g. ZE_TUNE=2:64

@@ -67,6 +67,7 @@ typedef struct ze_config {
     int32_t max_ctx;         /* tokens per chain                                  */
     int32_t max_patches;     /* ViT patches per ze_vit_forward call               */
     int32_t max_tile_side;   /* largest tile edge handed to ze_op_resize_bicubic  */
+    int32_t max_prefill_rows; /* rows of one (batched) prefill call; 0 = max_ctx    */
 } ze_config;
 
 /* ------------------------------------------------------------------ lifecycle */
@@ -177,6 +178,15 @@ typedef struct ze_gen_params {
  * logits left by ze_prefill, then runs decode steps until EOS / max_new_tokens.  out_tokens: host int32
  * [max_new_tokens]; *n_out = number of tokens produced (EOS included). */
 int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_t* out_tokens, int* n_out, void* stream);
+/* Prefill of several chains in ONE pass (BASELINE configs[2]): the rows of all chains go through every GEMM
+ * together (M = sum of lens), attention runs per chain against its own KV cache.  Arguments are the per-chain
+ * arguments of ze_prefill, concatenated in chain order: input_ids [sum lens]; position_ids [3, sum lens] (axis-major
+ * over the concatenation); image_embeds rows in chain order (n_image_rows[i] per chain); rope_deltas[i].  A chain's
+ * result is bit-identical to a ze_prefill of that chain alone.  Logits of each chain's last position stay in the
+ * engine (first token of ze_generate / ze_generate_batch).  sum lens <= max_prefill_rows. */
+int ze_prefill_batch(ze_engine* e, const int32_t* seqs, int n, const int32_t* lens, const int32_t* input_ids,
+                     const void* image_embeds, const int32_t* n_image_rows, const int32_t* position_ids,
+                     const int32_t* rope_deltas, void* stream);
 /* Batched decode (BASELINE configs[2]: many question chains per GPU).  One token for each of the n distinct chains
  * `seqs[i]`: the weights are streamed once for the whole batch (MFMA path, rows = chains); each chain keeps its own
  * KV cache, position and repetition-penalty set, and its results do not depend on the batch composition.

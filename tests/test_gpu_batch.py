@@ -114,3 +114,50 @@ def test_batch_errors(eng):
         eng.decode_batch([0, 0])
     with pytest.raises(ZoomEarthError):
         eng.decode_batch([0, 7])
+
+
+def test_prefill_batch_is_bit_identical_to_single_prefills(eng):
+    """Cross-chain prefill (rows of all chains share every GEMM): logits left for the first token and the KV caches
+    (checked through the next teacher-forced decode steps) equal those of per-chain prefills, also when a chain
+    already holds a prefix (stage-2 shape of the zoom chain)."""
+    e = eng
+    prompts = [text_ids(51, 70), text_ids(52, 5), text_ids(53, 131)]
+    forced = [[int(t) for t in text_ids(60 + s, 3)] for s in range(3)]
+
+    def single():
+        out = []
+        for s, ids in enumerate(prompts):
+            pos, delta = e.rope_index(ids, [])
+            e.seq_reset(s)
+            cut = len(ids) // 2
+            e.prefill(s, ids[:cut], None, pos[:, :cut], delta, want_logits=False)          # prefix
+            lg = e.prefill(s, ids[cut:], None, pos[:, cut:], delta, want_logits=True)       # appended tokens
+            steps = [e.decode_step(s, t).cpu().numpy() for t in forced[s]]
+            out.append((lg.cpu().numpy(), steps))
+        return out
+
+    def batched(order):
+        pl = [e.rope_index(ids, []) for ids in prompts]
+        for s, ids in enumerate(prompts):
+            cut = len(ids) // 2
+            e.seq_reset(s)
+            e.prefill(s, ids[:cut], None, pl[s][0][:, :cut], pl[s][1], want_logits=False)
+        e.prefill_batch(order, [prompts[s][len(prompts[s]) // 2:] for s in order], [None] * len(order),
+                        [pl[s][0][:, len(prompts[s]) // 2:] for s in order], [pl[s][1] for s in order])
+        out = {}
+        for s in order:
+            first = e.generate(s, 1, ignore_eos=True)  # argmax of the logits the prefill left behind
+            e.seq_truncate(s, len(prompts[s]))
+            steps = [e.decode_step(s, t).cpu().numpy() for t in forced[s]]
+            out[s] = (first, steps)
+        return out
+
+    ref = single()
+    for order in ([0, 1, 2], [2, 0], [1]):
+        got = batched(order)
+        for s in order:
+            assert got[s][0] == [int(np.argmax(ref[s][0]))]
+            for a, b in zip(ref[s][1], got[s][1]):
+                assert np.array_equal(a, b), (order, s)
+    with pytest.raises(Exception):
+        e.prefill_batch([0, 0], [[1, 2], [3]], [None, None], [np.zeros((3, 2), np.int32), np.zeros((3, 1), np.int32)], [0, 0])

@@ -30,6 +30,7 @@ class ZeConfig(C.Structure):
         ("image_token_id", C.c_int32), ("vision_start_token_id", C.c_int32), ("vision_end_token_id", C.c_int32),
         ("pad_token_id", C.c_int32), ("n_eos", C.c_int32), ("eos_token_ids", C.c_int32 * ZE_MAX_EOS),
         ("max_seqs", C.c_int32), ("max_ctx", C.c_int32), ("max_patches", C.c_int32), ("max_tile_side", C.c_int32),
+        ("max_prefill_rows", C.c_int32),
     ]
 
 
@@ -84,6 +85,8 @@ _SIGS = {
     "ze_seq_len": (C.c_int, [_P, C.c_int]),
     "ze_prefill": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.c_int, _P, C.c_int, C.POINTER(C.c_int32), C.c_int,
                              _P, _P]),
+    "ze_prefill_batch": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P,
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
     "ze_decode_step": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "ze_generate": (C.c_int, [_P, C.c_int, C.POINTER(ZeGenParams), C.POINTER(C.c_int32), C.POINTER(C.c_int), _P]),
     "ze_decode_batch": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), _P, _P]),

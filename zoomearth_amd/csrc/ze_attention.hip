@@ -40,7 +40,8 @@ __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q
                                                     const bf16_t* __restrict__ v, int v_rs, int v_hs,
                                                     bf16_t* __restrict__ o, int o_rs, int o_hs,
                                                     const int4* __restrict__ tiles, int group, float scale_log2e,
-                                                    int q_pos_offset) {
+                                                    int q_pos_offset, const int* __restrict__ tile_aux,
+                                                    size_t kv_seq_stride) {
     constexpr int KS = (D + 31) / 32;  // 32-deep steps of the QK^T contraction (D = 80: 3, the third half zero)
     constexpr int DCH = D / 8;         // real 16-B chunks per row
     constexpr int NV = D / 16;         // d-tiles of the output
@@ -48,6 +49,11 @@ __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q
 
     const int4 tile = tiles[blockIdx.x];
     const int q0 = tile.x, q1 = tile.y, kv0 = tile.z, kv1 = tile.w;
+    if (tile_aux) {  // batched prefill: this tile's chain has its own KV cache and position offset
+        k += (size_t)tile_aux[2 * blockIdx.x] * kv_seq_stride;
+        v += (size_t)tile_aux[2 * blockIdx.x] * kv_seq_stride;
+        q_pos_offset = tile_aux[2 * blockIdx.x + 1];
+    }
     const int head = blockIdx.y, kvh = head / group;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -205,13 +211,13 @@ __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q
 void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_rs, int q_hs, const bf16_t* k, int k_rs,
                           int k_hs, const bf16_t* v, int v_rs, int v_hs, bf16_t* o, int o_rs, int o_hs,
                           const int4* tiles, int n_tiles, int heads, int group, float scale, int q_pos_offset,
-                          hipStream_t s) {
+                          hipStream_t s, const int* tile_aux, size_t kv_seq_stride) {
     if (n_tiles == 0) return;
     const float sl = scale * 1.4426950408889634f;
     dim3 grid(n_tiles, heads);
 #define FA_LAUNCH(DD, CC)                                                                                      \
     hipLaunchKernelGGL((k_flash_attn<DD, CC>), grid, dim3(256), 65536, s, q, q_rs, q_hs, k, k_rs, k_hs, v, v_rs, v_hs, \
-                       o, o_rs, o_hs, tiles, group, sl, q_pos_offset)
+                       o, o_rs, o_hs, tiles, group, sl, q_pos_offset, tile_aux, kv_seq_stride)
     if (D == 80) {
         if (causal) FA_LAUNCH(80, 1); else FA_LAUNCH(80, 0);
     } else {

@@ -153,7 +153,8 @@ __global__ void __launch_bounds__(256) k_mrope_kv(bf16_t* __restrict__ qkv, int 
                                                   const bf16_t* __restrict__ cosT, const bf16_t* __restrict__ sinT,
                                                   const int* __restrict__ pos3, const int* __restrict__ axis_of,
                                                   bf16_t* __restrict__ kcache, bf16_t* __restrict__ vcache,
-                                                  int max_ctx, int past) {
+                                                  int max_ctx, int past, const int* __restrict__ row_aux,
+                                                  size_t cache_seq_stride) {
     const int half = D >> 1;
     const int nh = heads + 2 * kv_heads;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -162,10 +163,17 @@ __global__ void __launch_bounds__(256) k_mrope_kv(bf16_t* __restrict__ qkv, int 
     const int j = (int)(i % half);
     const int hh = (int)((i / half) % nh);
     const int t = (int)(i / ((size_t)half * nh));
+    // cache row of this token: past + t of the one chain, or (chain slot, cache position) per row (batched prefill)
+    int cpos = past + t;
+    if (row_aux) {
+        kcache += (size_t)row_aux[2 * t] * cache_seq_stride;
+        vcache += (size_t)row_aux[2 * t] * cache_seq_stride;
+        cpos = row_aux[2 * t + 1];
+    }
     bf16_t* p = qkv + (size_t)t * nh * D + (size_t)hh * D;
     if (hh >= heads + kv_heads) {  // v: plain copy into the cache
         const int kvh = hh - heads - kv_heads;
-        bf16_t* d = vcache + ((size_t)kvh * max_ctx + past + t) * D;
+        bf16_t* d = vcache + ((size_t)kvh * max_ctx + cpos) * D;
         d[j] = p[j];
         d[j + half] = p[j + half];
         return;
@@ -181,18 +189,19 @@ __global__ void __launch_bounds__(256) k_mrope_kv(bf16_t* __restrict__ qkv, int 
         p[j + half] = o2;
     } else {
         const int kvh = hh - heads;
-        bf16_t* d = kcache + ((size_t)kvh * max_ctx + past + t) * D;
+        bf16_t* d = kcache + ((size_t)kvh * max_ctx + cpos) * D;
         d[j] = o1;
         d[j + half] = o2;
     }
 }
 void ze_launch_mrope_kv(bf16_t* qkv, int T, int heads, int kv_heads, int D, const bf16_t* cosT, const bf16_t* sinT,
                         const int* pos3, const int* axis_of, bf16_t* kcache, bf16_t* vcache, int max_ctx, int past,
-                        hipStream_t s) {
+                        const int* row_aux, size_t cache_seq_stride, hipStream_t s) {
     const size_t total = (size_t)T * (heads + 2 * kv_heads) * (D / 2);
     if (total == 0) return;
     k_mrope_kv<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(qkv, T, heads, kv_heads, D, cosT, sinT, pos3,
-                                                               axis_of, kcache, vcache, max_ctx, past);
+                                                               axis_of, kcache, vcache, max_ctx, past, row_aux,
+                                                               cache_seq_stride);
 }
 
 // ------------------------------------------------------------------ embedding gather + image scatter (K13)

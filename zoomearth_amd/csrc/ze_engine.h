@@ -97,6 +97,9 @@ struct ze_engine {
     bf16_t *th = nullptr, *ty = nullptr, *tqkv = nullptr, *to = nullptr, *ta = nullptr;
     int *tsrc = nullptr, *tpos = nullptr;
     int4* ttiles = nullptr;
+    int* ttile_aux = nullptr;  // batched prefill: (chain slot, position offset) per attention tile
+    int* trow_aux = nullptr;   // batched prefill: (chain slot, cache position) per row
+    int prefill_rows = 0;
     int* t_host_ints = nullptr;  // pinned
     size_t t_host_ints_cap = 0;
 

@@ -294,7 +294,8 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
         r = ze_fail(e, ZE_ERR_HIP, "hipHostMalloc failed");
 
     // prefill workspace
-    const size_t tm = c.max_ctx;
+    const size_t tm = std::max(c.max_ctx, c.max_prefill_rows);  // rows of one prefill pass
+    e->prefill_rows = (int)tm;
     const int nqkv = (c.heads + 2 * c.kv_heads) * e->head_dim;
     chk(dev_alloc(e, &e->th, tm * c.hidden));
     chk(dev_alloc(e, &e->ty, tm * c.hidden));
@@ -303,8 +304,11 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     chk(dev_alloc(e, &e->ta, tm * e->text_ipad));
     chk(dev_alloc(e, &e->tsrc, tm));
     chk(dev_alloc(e, &e->tpos, tm * 3));
-    chk(dev_alloc(e, &e->ttiles, tm / 64 + 2));
-    e->t_host_ints_cap = tm * 4 + (tm / 64 + 2) * 4 + 64;
+    const size_t ntile_cap = tm / 64 + c.max_seqs + 2;
+    chk(dev_alloc(e, &e->ttiles, ntile_cap));
+    chk(dev_alloc(e, &e->ttile_aux, ntile_cap * 2));
+    chk(dev_alloc(e, &e->trow_aux, tm * 2));
+    e->t_host_ints_cap = tm * 6 + ntile_cap * 6 + 64;
     if (r == 0 && hipHostMalloc((void**)&e->t_host_ints, e->t_host_ints_cap * sizeof(int)) != hipSuccess)
         r = ze_fail(e, ZE_ERR_HIP, "hipHostMalloc failed");
 
@@ -365,7 +369,7 @@ extern "C" int ze_engine_destroy(ze_engine* e) {
     void* dev[] = {e->arena, e->staging, e->cosT, e->sinT, e->axis_of, e->lut, e->eos_dev, e->kcache, e->vcache,
                    e->st_dev, e->seen, e->out_tokens, e->fe_tmp, e->fe_img, e->fe_coef, e->vx, e->vh, e->vy, e->vqkv,
                    e->vo, e->va, e->vz, e->vz2, e->vcos, e->vsin, e->vperm, e->vinv, e->vtiles_win, e->vtiles_full,
-                   e->th, e->ty, e->tqkv, e->to, e->ta, e->tsrc, e->tpos, e->ttiles, e->dh, e->dq, e->dattn, e->dact,
+                   e->th, e->ty, e->tqkv, e->to, e->ta, e->tsrc, e->tpos, e->ttiles, e->ttile_aux, e->trow_aux, e->dh, e->dq, e->dattn, e->dact,
                    e->dlogits, e->dpartial, e->dsample, e->gbar, e->atickets, e->gslab, e->gtickets, e->bseq, e->blogits, e->bpartial, e->bsample};
     for (void* p : dev)
         if (p) hipFree(p);

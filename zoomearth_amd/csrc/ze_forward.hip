@@ -403,7 +403,7 @@ extern "C" int ze_prefill(ze_engine* e, int seq, const int32_t* input_ids, int l
         ze_launch_gemm(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, nullptr, len,
                        nqkv, H, s);
         ze_launch_mrope_kv(e->tqkv, len, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->tpos, e->axis_of,
-                           e->kc(li, seq), e->vc(li, seq), c.max_ctx, past, s);
+                           e->kc(li, seq), e->vc(li, seq), c.max_ctx, past, nullptr, 0, s);
         ze_launch_flash_attn(hd, 1, e->tqkv, nqkv, hd, e->kc(li, seq), hd, c.max_ctx * hd, e->vc(li, seq), hd,
                              c.max_ctx * hd, e->to, nq, hd, e->ttiles, nt, c.heads, c.heads / c.kv_heads, scale, past,
                              s);
@@ -435,6 +435,128 @@ extern "C" int ze_prefill(ze_engine* e, int seq, const int32_t* input_ids, int l
     e->ctx_host[seq] = past + len;
     e->delta_host[seq] = rope_delta;
     return push_state(e, seq, s, input_ids[len - 1], 0, 0);
+}
+
+// Prefill of n chains in one pass: all rows share every GEMM, attention and the KV append go per chain.
+extern "C" int ze_prefill_batch(ze_engine* e, const int32_t* seqs, int n, const int32_t* lens, const int32_t* input_ids,
+                                const void* image_embeds, const int32_t* n_image_rows, const int32_t* position_ids,
+                                const int32_t* rope_deltas, void* stream) {
+    if (!e || !seqs || !lens || !input_ids || !position_ids || !rope_deltas || n <= 0)
+        return ze_fail(e, ZE_ERR_INVALID, "bad prefill arguments");
+    const ze_config& c = e->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    const int H = c.hidden, hd = e->head_dim, nq = c.heads * hd, nkv = c.kv_heads * hd, nqkv = nq + 2 * nkv;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        ZE_TRY(check_seq(e, seqs[i]));
+        for (int k2 = 0; k2 < i; ++k2)
+            if (seqs[k2] == seqs[i]) return ze_fail(e, ZE_ERR_INVALID, "a chain appears twice in the batch");
+        if (lens[i] <= 0) return ze_fail(e, ZE_ERR_INVALID, "bad prefill arguments");
+        if (e->ctx_host[seqs[i]] + lens[i] > c.max_ctx) return ze_fail(e, ZE_ERR_NOMEM, "sequence exceeds max_ctx");
+        total += lens[i];
+    }
+    if (total > e->prefill_rows) return ze_fail(e, ZE_ERR_NOMEM, "batched prefill exceeds max_prefill_rows");
+
+    ZE_HIP(hipStreamSynchronize(s));  // pinned staging reuse
+    int* src = e->t_host_ints;
+    int* pos = src + total;
+    int* row_aux = pos + 3 * total;
+    int* tiles = row_aux + 2 * total;
+    int img = 0, nt = 0, row0 = 0, img_expected = 0;
+    std::vector<int> tile_aux;
+    for (int i = 0; i < n; ++i) {
+        const int seq = seqs[i], len = lens[i], past = e->ctx_host[seq];
+        int img_chain = 0;
+        for (int t = 0; t < len; ++t) {
+            const int id = input_ids[row0 + t];
+            if (id < 0 || id >= c.vocab) return ze_fail(e, ZE_ERR_INVALID, "token id out of range");
+            if (id == c.image_token_id) {
+                src[row0 + t] = -1 - img++;
+                ++img_chain;
+            } else {
+                src[row0 + t] = id;
+            }
+            for (int a = 0; a < 3; ++a) {
+                const int p = position_ids[(size_t)a * total + row0 + t];
+                if (p < 0 || p >= e->max_pos) return ze_fail(e, ZE_ERR_INVALID, "position id out of range");
+                pos[(size_t)a * total + row0 + t] = p;
+            }
+            row_aux[2 * (row0 + t)] = seq;
+            row_aux[2 * (row0 + t) + 1] = past + t;
+        }
+        const int want = n_image_rows ? n_image_rows[i] : 0;
+        if (img_chain != want || (img_chain > 0 && !image_embeds))
+            return ze_fail(e, ZE_ERR_MISMATCH, "Image features and image tokens do not match, tokens: " +
+                                                   std::to_string(img_chain) + ", features: " + std::to_string(want));
+        img_expected += want;
+        for (int q0 = 0; q0 < len; q0 += 64, ++nt) {
+            tiles[4 * nt + 0] = row0 + q0;
+            tiles[4 * nt + 1] = row0 + std::min(q0 + 64, len);
+            tiles[4 * nt + 2] = 0;
+            tiles[4 * nt + 3] = past + len;
+            tile_aux.push_back(seq);
+            tile_aux.push_back(past - row0);  // key index visible to row r: <= r + (past - row0)
+        }
+        row0 += len;
+    }
+    (void)img_expected;
+    int* taux = tiles + 4 * nt;
+    memcpy(taux, tile_aux.data(), tile_aux.size() * sizeof(int));
+    ZE_HIP(hipMemcpyAsync(e->tsrc, src, (size_t)total * sizeof(int), hipMemcpyHostToDevice, s));
+    ZE_HIP(hipMemcpyAsync(e->tpos, pos, (size_t)3 * total * sizeof(int), hipMemcpyHostToDevice, s));
+    ZE_HIP(hipMemcpyAsync(e->trow_aux, row_aux, (size_t)2 * total * sizeof(int), hipMemcpyHostToDevice, s));
+    ZE_HIP(hipMemcpyAsync(e->ttiles, tiles, (size_t)nt * 16, hipMemcpyHostToDevice, s));
+    ZE_HIP(hipMemcpyAsync(e->ttile_aux, taux, (size_t)nt * 2 * sizeof(int), hipMemcpyHostToDevice, s));
+
+    const int th = ze_timer_begin(e, 2, s);
+    ze_launch_embed_rows(e->tsrc, e->embed, (const bf16_t*)image_embeds, e->th, total, H, s);
+    const float scale = 1.0f / sqrtf((float)hd);
+    const size_t seq_stride = (size_t)c.kv_heads * c.max_ctx * hd;
+    for (int li = 0; li < c.layers; ++li) {
+        const ze_text_layer& L = e->tl[li];
+        ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, total, H, c.rms_eps, s);
+        ze_launch_gemm(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, nullptr, total,
+                       nqkv, H, s);
+        ze_launch_mrope_kv(e->tqkv, total, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->tpos, e->axis_of, e->kc(li, 0),
+                           e->vc(li, 0), c.max_ctx, 0, e->trow_aux, seq_stride, s);
+        ze_launch_flash_attn(hd, 1, e->tqkv, nqkv, hd, e->kc(li, 0), hd, c.max_ctx * hd, e->vc(li, 0), hd,
+                             c.max_ctx * hd, e->to, nq, hd, e->ttiles, nt, c.heads, c.heads / c.kv_heads, scale, 0, s,
+                             e->ttile_aux, seq_stride);
+        ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, total, H, nq, s);
+        ze_launch_rmsnorm(e->th, H, L.post_norm, e->ty, H, total, H, c.rms_eps, s);
+        ze_launch_gemm(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad,
+                       nullptr, total, 2 * e->text_ipad, H, s);
+        ze_launch_gemm(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, nullptr,
+                       total, H, e->text_ipad, s);
+    }
+    // last position of every chain: final norm fused into the lm_head GEMV, exactly as ze_prefill does it
+    row0 = 0;
+    for (int i = 0; i < n; ++i) {
+        ze_gemv_args a;
+        memset(&a, 0, sizeof(a));
+        a.W = e->lm_head;
+        a.ldw = H;
+        a.N = c.vocab;
+        a.K = H;
+        a.x = e->th + (size_t)(row0 + lens[i] - 1) * H;
+        a.norm_w = e->final_norm;
+        a.eps = c.rms_eps;
+        a.out_f32 = e->dlogits + (size_t)seqs[i] * c.vocab;
+        a.D = hd;
+        ze_launch_gemv(ZE_GV_LOGITS, a, s);
+        row0 += lens[i];
+    }
+    ze_timer_end(e, th, s);
+    ZE_KCHECK();
+    row0 = 0;
+    for (int i = 0; i < n; ++i) {
+        e->ctx_host[seqs[i]] += lens[i];
+        e->delta_host[seqs[i]] = rope_deltas[i];
+        ZE_TRY(push_state(e, seqs[i], s, input_ids[row0 + lens[i] - 1], 0, 0));
+        row0 += lens[i];
+    }
+    return ZE_OK;
 }
 
 // ================================================================== decode

@@ -42,7 +42,7 @@ void ze_launch_gather_cast_rows(const float* src, int k, const int* perm, bf16_t
                                 hipStream_t s);
 void ze_launch_vision_rope(bf16_t* qkv, const float* cosT, const float* sinT, int n, int heads, int D, hipStream_t s);
 void ze_launch_mrope_kv(bf16_t* qkv, int T, int heads, int kv_heads, int D, const bf16_t* cosT, const bf16_t* sinT,
-                        const int* pos3, const int* axis_of, bf16_t* kcache, bf16_t* vcache, int max_ctx, int past,
+                        const int* pos3, const int* axis_of, bf16_t* kcache, bf16_t* vcache, int max_ctx, int past, const int* row_aux, size_t cache_seq_stride,
                         hipStream_t s);
 void ze_launch_embed_rows(const int* src, const bf16_t* embed, const bf16_t* image_embeds, bf16_t* out, int T,
                           int hidden, hipStream_t s);
@@ -130,7 +130,10 @@ void ze_launch_layer_attn(const ze_layer_attn_args& a, int blocks, hipStream_t s
 void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_row_stride, int q_head_stride, const bf16_t* k,
                           int k_row_stride, int k_head_stride, const bf16_t* v, int v_row_stride, int v_head_stride,
                           bf16_t* o, int o_row_stride, int o_head_stride, const int4* tiles, int n_tiles, int heads,
-                          int group, float scale, int q_pos_offset, hipStream_t s);
+                          int group, float scale, int q_pos_offset, hipStream_t s, const int* tile_aux = nullptr,
+                          size_t kv_seq_stride = 0);
+// (tile_aux: per tile (chain slot, position offset): K/V move by slot * kv_seq_stride elements, the offset replaces
+//  q_pos_offset -- batched prefill)
 // Decode attention for one chain: q [heads, D]; caches [kv_heads, max_ctx, D]; context = st->ctx + 1 tokens.
 // Batched form: n chains; chain b = seq_ids[b] (null: chain 0 is `st` itself), q/out rows b, caches offset by
 // seq * cache_seq_stride elements, partials offset by b * max_splits * heads * 132 floats; tickets: n * kv_heads zeroed

@@ -28,7 +28,7 @@ def _i32(a):
 
 class Engine:
     def __init__(self, config: ModelConfig, device: int = 0, max_seqs: int = 4, max_ctx: int = 4096,
-                 max_patches: int = 8192, max_tile_side: int = 8192):
+                 max_patches: int = 8192, max_tile_side: int = 8192, max_prefill_rows: int = 0):
         if not torch.cuda.is_available():
             raise RuntimeError("zoomearth_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.lib = _lib.lib()
@@ -36,6 +36,8 @@ class Engine:
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
         self.zcfg = self._make_zcfg(config, max_seqs, max_ctx, max_patches, max_tile_side)
+        self.zcfg.max_prefill_rows = int(max_prefill_rows)
+        self.max_prefill_rows = max(int(max_prefill_rows), int(max_ctx))
         h = C.c_void_p()
         _lib.check(self.lib.ze_engine_create(C.byref(self.zcfg), device, C.byref(h)))
         self.h = h
@@ -223,6 +225,23 @@ class Engine:
         self._check(self.lib.ze_prefill(self.h, seq, ip, len(ids), _ptr(image_embeds), n_img, pp, rope_delta,
                                         _ptr(logits), self._stream()))
         return logits
+
+    def prefill_batch(self, seqs, ids_list, embeds_list, pos_list, deltas):
+        """One prefill pass for several chains (rows of all chains share every GEMM).  Per chain i: ids_list[i] (new
+        token ids), embeds_list[i] (bf16 [rows, hidden] or None), pos_list[i] (int32 [3, len]), deltas[i].  Each
+        chain's result is bit-identical to prefill() of that chain alone."""
+        sq, sp = _i32(seqs)
+        lens, lp = _i32([len(x) for x in ids_list])
+        ids, ip = _i32(np.concatenate([np.asarray(x, dtype=np.int32) for x in ids_list]))
+        pos = np.concatenate([np.asarray(p, dtype=np.int32).reshape(3, -1) for p in pos_list], axis=1)
+        pos, pp = _i32(np.ascontiguousarray(pos))
+        embs = [x for x in embeds_list if x is not None and x.shape[0] > 0]
+        nrows, nrp = _i32([0 if x is None else int(x.shape[0]) for x in embeds_list])
+        emb = (torch.cat(embs) if len(embs) > 1 else embs[0]).contiguous() if embs else None
+        if emb is not None:
+            assert emb.dtype == torch.bfloat16
+        dl, dp = _i32(deltas)
+        self._check(self.lib.ze_prefill_batch(self.h, sp, len(sq), lp, ip, _ptr(emb), nrp, pp, dp, self._stream()))
 
     def decode_step(self, seq: int, token: int = -1, want_logits: bool = True):
         logits = torch.empty(self.config.text.vocab_size, dtype=torch.float32, device=self.device) if want_logits else None

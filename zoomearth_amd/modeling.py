@@ -143,6 +143,7 @@ class ZoomEarthForConditionalGeneration:
             self._chains.clear()
             self._next_slot = 0
         slots = []
+        pending = []
         for b in range(nrows):
             ids = ids_cpu[b][mask[b]].astype(np.int64).tolist()
             is_img = np.asarray(ids) == cfg.image_token_id
@@ -164,15 +165,30 @@ class ZoomEarthForConditionalGeneration:
                 e.seq_truncate(slot, reuse)  # also clears the chain's seen-set
             else:
                 e.seq_reset(slot)
-            e.prefill(slot, ids[reuse:], emb, pos[:, reuse:], delta, want_logits=False)
-            if pen != 1.0:
-                e.mark_seen(slot, ids)
+            if batched:  # rows of several chains share every GEMM of the prefill (engine.prefill_batch)
+                pending.append((slot, ids[reuse:], emb, pos[:, reuse:], delta, ids))
+            else:
+                e.prefill(slot, ids[reuse:], emb, pos[:, reuse:], delta, want_logits=False)
+                if pen != 1.0:
+                    e.mark_seen(slot, ids)
             if not batched:
                 self._chains[slot] = (tuple(ids), tuple(my_keys))
                 self._chains.move_to_end(slot)
                 outs.append(e.generate(slot, max_new_tokens, repetition_penalty=pen, ignore_eos=ignore_eos, **sample_kw))
             slots.append(slot)
         if batched:
+            group, rows = [], 0
+            for item in pending + [None]:
+                if group and (item is None or rows + len(item[1]) > e.max_prefill_rows):
+                    e.prefill_batch([g[0] for g in group], [g[1] for g in group], [g[2] for g in group],
+                                    [g[3] for g in group], [g[4] for g in group])
+                    group, rows = [], 0
+                if item is not None:
+                    group.append(item)
+                    rows += len(item[1])
+            if pen != 1.0:
+                for slot, _, _, _, _, ids in pending:
+                    e.mark_seen(slot, ids)
             outs = e.generate_batch(slots, max_new_tokens, repetition_penalty=pen, ignore_eos=ignore_eos, **sample_kw)
         width = max(len(t) for t in outs)
         pad = cfg.pad_token_id
