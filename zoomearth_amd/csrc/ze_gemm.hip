@@ -34,10 +34,10 @@ __device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / 32][BN / 32], uint
     const int wm0 = (wid >> 1) * (BM / 2), wn0 = (wid & 1) * (BN / 2);
     const int fr = lane & 15, fq = lane >> 4;
     // ---------------- split-K: deterministic reduction by the last-arriving slice of the tile.
-    // Every slice parks its fp32 accumulators in a slab (one float4 per thread per MFMA tile), publishes them with an
-    // agent-scope release + ticket; the block that draws the last ticket acquires, adds the slabs IN SLICE ORDER
-    // (bit-reproducible, independent of arrival order) and runs the epilogue.  (cdna_hip_programming.md, Projection
-    // GEMM item 2: one release + one acquire per tile episode, never __threadfence per call.)
+    // Every slice parks its fp32 accumulators in a slab (one float4 per thread per MFMA tile) with write-through
+    // (sc1) stores, drains, and takes a ticket; the block that draws the last ticket adds the slabs IN SLICE ORDER
+    // (bit-reproducible, independent of arrival order) reading them with sc1 loads, and runs the epilogue.  No
+    // release / acquire fence anywhere (cdna_hip_programming.md Guideline 16, the sc1 hand-off with a counter).
     if (ksplit > 1) {
         // slabs go out WRITE-THROUGH (sc1 buffer stores): no L2 write-back fence is needed before the ticket
         // (publish-large: 3.0 us vs 8.2 us for plain stores + release fence at 64 KB per workgroup)
@@ -63,11 +63,8 @@ __device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / 32][BN / 32], uint
         if (tid == 0) {
             const unsigned old = __hip_atomic_fetch_add(&tickets[bid], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned last = (old == (unsigned)ksplit - 1u) ? 1u : 0u;
-            if (last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(&tickets[bid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-            }
+            if (last)  // ready for the next launch
+                __hip_atomic_store(&tickets[bid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *flag = last;
         }
         __syncthreads();
@@ -76,18 +73,24 @@ __device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / 32][BN / 32], uint
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int q = 0; q < ksplit; ++q) {
-            const float4* src = reinterpret_cast<const float4*>(slab) + ((size_t)(q * nwg + bid) * 256 + tid) * (TM * TN);
+        // the slabs were published write-through and are read with sc1 (L1-bypassing) loads: no acquire fence
+        // (every load of the handed-off bytes is such a load; the ticket was taken after every wave's drain)
+        {
+            const size_t slab_bytes = (size_t)ksplit * nwg * 256 * (TM * TN) * 16;
+            auto rsrc = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)min(slab_bytes, (size_t)0x7fffffff), 0x00020000);
+            for (int q = 0; q < ksplit; ++q) {
+                const unsigned base = (unsigned)((((size_t)(q * nwg + bid) * 256 + tid) * (TM * TN)) * 16);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const float4 v = src[i * TN + j];
-                    acc[i][j][0] += v.x;
-                    acc[i][j][1] += v.y;
-                    acc[i][j][2] += v.z;
-                    acc[i][j][3] += v.w;
-                }
+                    for (int j = 0; j < TN; ++j) {
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + (unsigned)(i * TN + j) * 16, 0, 16);
+                        acc[i][j][0] += __uint_as_float(v.x);
+                        acc[i][j][1] += __uint_as_float(v.y);
+                        acc[i][j][2] += __uint_as_float(v.z);
+                        acc[i][j][3] += __uint_as_float(v.w);
+                    }
+            }
         }
     }
 
