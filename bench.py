@@ -337,6 +337,9 @@ def main():
     ap.add_argument("--cpu-baseline", choices=("auto", "hf", "port"), default="auto",
                     help="auto: the installed transformers model (the reference's CPU path) when it runs, else the oracle port")
     ap.add_argument("--tile", type=int, default=5000)
+    ap.add_argument("--model", choices=("3b", "7b"), default="3b",
+                    help="3b = ZoomEarth-3B shape (the metric's workload); 7b = Qwen2.5-VL-7B backbone swap of BASELINE "
+                         "configs[4] in bf16 (its fp8 weights are not built): reported without roofline objects")
     ap.add_argument("--batch", type=int, default=1, help="question chains advanced together (1 = BASELINE configs[1]; >1 = configs[2])")
     args = ap.parse_args()
 
@@ -357,7 +360,7 @@ def main():
     from zoomearth_amd.config import ModelConfig
     from zoomearth_amd.engine import Engine
 
-    cfg = ModelConfig.zoomearth_3b()
+    cfg = ModelConfig.zoomearth_3b() if args.model == "3b" else ModelConfig.qwen25vl_7b()
     e = Engine(cfg, device=local, max_seqs=max(1, args.batch), max_ctx=2048, max_patches=max(4096, 1400 * args.batch),
                max_prefill_rows=(16 * 832 if args.batch > 1 else 0),
                max_tile_side=max(args.tile, 1024))
@@ -424,7 +427,8 @@ def main():
                 tj = json.load(f)
             traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/traffic_latest.json (rocprofv3 --pmc, round %d)" % tj["round"]
         line = {
-            "metric": "questions/sec end-to-end, ZoomEarth-3B on 5000px tiles", "value": world * args.steps * B / dt,
+            "metric": "questions/sec end-to-end, ZoomEarth-3B on 5000px tiles" if args.model == "3b" else
+                      "questions/sec end-to-end, Qwen2.5-VL-7B shape (bf16) on 5000px tiles", "value": world * args.steps * B / dt,
             "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
@@ -442,7 +446,9 @@ def main():
                          "avg_us": us, "bytes_per_launch": by, "other_decode_kernels": others},
             "phase_ms_per_question": {k: round(v / args.steps, 3) for k, v in phases.items()},
         }
-        if args.batch == 1:
+        if args.model != "3b":  # the roofline constants below are the 3B shape's
+            line.pop("roofline", None)
+        if args.batch == 1 and args.model == "3b":
             # per-phase roofline fractions: algorithmic work of the as-built question (stage-1 prompt KV
             # and view features reused) over the measured phase time, against the dense bf16 MFMA peak / the HBM peak
             pm = line["phase_ms_per_question"]
