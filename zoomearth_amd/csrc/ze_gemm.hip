@@ -23,15 +23,15 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 
 // Tail shared by the GEMM kernels: optional split-K reduction (deterministic, by the last-arriving slice of the tile)
 // and the epilogue.  acc[i][j][r] -> row = wm0 + i*16 + fq*4 + r, col = wn0 + j*16 + fr.
-template <int BM, int BN, int EPI>
-__device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / 32][BN / 32], uint8_t* smem, const bf16_t* __restrict__ bias,
+template <int BM, int BN, int EPI, int WM = 2, int WN = 2>
+__device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / (16 * WM)][BN / (16 * WN)], uint8_t* smem, const bf16_t* __restrict__ bias,
                                             const bf16_t* __restrict__ R, int ldr, bf16_t* __restrict__ C, int ldc,
                                             const int* __restrict__ c_rows, int M, int N, int ksplit, int ks, int bid,
                                             int nwg, int bm0, int bn0, float* __restrict__ slab,
                                             unsigned* __restrict__ tickets) {
-    constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN), NT = 64 * WM * WN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm0 = (wid >> 1) * (BM / 2), wn0 = (wid & 1) * (BN / 2);
+    const int wm0 = (wid / WN) * (BM / WM), wn0 = (wid % WN) * (BN / WN);
     const int fr = lane & 15, fq = lane >> 4;
     // ---------------- split-K: deterministic reduction by the last-arriving slice of the tile.
     // Every slice parks its fp32 accumulators in a slab (one float4 per thread per MFMA tile) with write-through
@@ -42,9 +42,9 @@ __device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / 32][BN / 32], uint
         // slabs go out WRITE-THROUGH (sc1 buffer stores): no L2 write-back fence is needed before the ticket
         // (publish-large: 3.0 us vs 8.2 us for plain stores + release fence at 64 KB per workgroup)
         {
-            const size_t slab_bytes = (size_t)ksplit * nwg * 256 * (TM * TN) * 16;
+            const size_t slab_bytes = (size_t)ksplit * nwg * NT * (TM * TN) * 16;
             auto rsrc = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)min(slab_bytes, (size_t)0x7fffffff), 0x00020000);
-            const unsigned base = (unsigned)((((size_t)(ks * nwg + bid) * 256 + tid) * (TM * TN)) * 16);
+            const unsigned base = (unsigned)((((size_t)(ks * nwg + bid) * NT + tid) * (TM * TN)) * 16);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -76,10 +76,10 @@ __device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / 32][BN / 32], uint
         // the slabs were published write-through and are read with sc1 (L1-bypassing) loads: no acquire fence
         // (every load of the handed-off bytes is such a load; the ticket was taken after every wave's drain)
         {
-            const size_t slab_bytes = (size_t)ksplit * nwg * 256 * (TM * TN) * 16;
+            const size_t slab_bytes = (size_t)ksplit * nwg * NT * (TM * TN) * 16;
             auto rsrc = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)min(slab_bytes, (size_t)0x7fffffff), 0x00020000);
             for (int q = 0; q < ksplit; ++q) {
-                const unsigned base = (unsigned)((((size_t)(q * nwg + bid) * 256 + tid) * (TM * TN)) * 16);
+                const unsigned base = (unsigned)((((size_t)(q * nwg + bid) * NT + tid) * (TM * TN)) * 16);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -299,16 +299,16 @@ __device__ __forceinline__ void ring_wait() {
     else static_assert(N == 0, "add the literal");
 }
 
-template <int BM, int BN, int STAGES, int EPI>
-__global__ void __launch_bounds__(256) k_gemm_ring(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
+template <int BM, int BN, int STAGES, int EPI, int WM = 2, int WN = 2>
+__global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
                                                    int ldw, const bf16_t* __restrict__ bias,
                                                    const bf16_t* __restrict__ R, int ldr, bf16_t* __restrict__ C,
                                                    int ldc, const int* __restrict__ c_rows, int M, int N, int K,
                                                    int ksplit, float* __restrict__ slab,
                                                    unsigned* __restrict__ tickets) {
-    constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN), NT = 64 * WM * WN;
     constexpr int STAGE_BYTES = (BM + BN) * 128;
-    constexpr int LPW = (BM + BN) / 32;  // DMA instructions per wave per stage
+    constexpr int LPW = (BM + BN) / 8 / (WM * WN);  // DMA instructions per wave per stage
     static_assert(STAGES == 3 || STAGES == 4, "ring depth");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(256) k_gemm_ring(const bf16_t* __restrict__ A,
     const int bm0 = (col_major ? bid % nby : bid / nbx) * BM, bn0 = (col_major ? bid / nby : bid % nbx) * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wid >> 1) * (BM / 2), wn0 = (wid & 1) * (BN / 2);
+    const int wm0 = (wid / WN) * (BM / WM), wn0 = (wid % WN) * (BN / WN);
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -347,8 +347,8 @@ __global__ void __launch_bounds__(256) k_gemm_ring(const bf16_t* __restrict__ A,
     auto issue = [&](int kt) {
         const unsigned img = smem_lds + (kt % STAGES) * STAGE_BYTES;
         const int k0 = (kt0 + kt) * GEMM_BK;
-        ring_issue<BM, 256>(A, lda, bm0, M - 1, k0, img, wid, lane);
-        ring_issue<BN, 256>(W, ldw, bn0, N - 1, k0, img + BM * 128, wid, lane);
+        ring_issue<BM, NT>(A, lda, bm0, M - 1, k0, img, wid, lane);
+        ring_issue<BN, NT>(W, ldw, bn0, N - 1, k0, img + BM * 128, wid, lane);
     };
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(256) k_gemm_ring(const bf16_t* __restrict__ A,
         }
     }
     __syncthreads();  // the tail reuses the staging LDS
-    gemm_finish<BM, BN, EPI>(acc, smem, bias, R, ldr, C, ldc, c_rows, M, N, ksplit, ks, bid, nwg, bm0, bn0, slab, tickets);
+    gemm_finish<BM, BN, EPI, WM, WN>(acc, smem, bias, R, ldr, C, ldc, c_rows, M, N, ksplit, ks, bid, nwg, bm0, bn0, slab, tickets);
 }
 
 // split-K workspace (fp32 slabs + per-tile tickets), owned by the engine and passed once
@@ -429,6 +429,69 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
     }
     // (weight-streaming mode, rows = chains of a batched decode step: the ring wins at every grid, 5.04 vs 5.32 ms per
     //  step at 64 chains, 3.78 vs 4.17 at 8)
+    // Many-tile grids (128 x 128 policy): eight waves (2 x 4, 64 x 64 per wave) on 128 x 256 tiles of the LDS-DMA ring,
+    // one workgroup per CU, when the grid is at most one round or at least 1.6 (measured: 4096^3 870 vs 756 TFLOP/s,
+    // gate/up at M = 518: 81 vs 92 us, ViT qkv 31.5 vs 34.2; a 1.2-round grid loses what the larger tile wins).
+    // knob 7: 1 = eight waves on 128 x 128 tiles (ties the register-staged kernel), 2 = 128 x 256 always, 3 = never.
+    const int grid_w = ze_cdiv(M, 128) * ze_cdiv(N, 256);
+    static int cus8 = 0;
+    if (!cus8) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus8, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus8 <= 0) cus8 = 256;
+    }
+    const bool wide = ze_gemv_knobs[7] == 2 ||
+                      (ze_gemv_knobs[7] == 0 && ze_gemv_knobs[6] == 0 && (grid_w <= cus8 || 5 * grid_w >= 8 * cus8));
+    if ((ze_gemv_knobs[7] == 1 || wide) && BM == 128 && BN == 128 && ksplit == 1 && K % GEMM_BK == 0 &&
+        K / GEMM_BK >= 4) {
+        if (wide) {
+            constexpr int ST2 = 3;
+            const size_t lds2 = (size_t)(128 + 256) * 128 * ST2;
+            const int grid2 = ze_cdiv(M, 128) * ze_cdiv(N, 256);
+#define ZE_RING8B_LAUNCH(E)                                                                                          \
+    do {                                                                                                             \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<128, 256, ST2, E, 2, 4>),                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                              \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL((k_gemm_ring<128, 256, ST2, E, 2, 4>), dim3(grid2), dim3(512), lds2, s, A, lda, W, ldw,   \
+                           bias, R, ldr, C, ldc, c_rows, M, N, K, 1, g_slab, g_tickets);                             \
+    } while (0)
+            switch (epi) {
+                case ZE_EPI_NONE: ZE_RING8B_LAUNCH(ZE_EPI_NONE); break;
+                case ZE_EPI_GELU: ZE_RING8B_LAUNCH(ZE_EPI_GELU); break;
+                case ZE_EPI_RESIDUAL: ZE_RING8B_LAUNCH(ZE_EPI_RESIDUAL); break;
+                case ZE_EPI_SWIGLU: ZE_RING8B_LAUNCH(ZE_EPI_SWIGLU); break;
+                case ZE_EPI_F32: ZE_RING8B_LAUNCH(ZE_EPI_F32); break;
+            }
+#undef ZE_RING8B_LAUNCH
+            return;
+        }
+        constexpr int ST = 4;
+        const size_t lds8 = (size_t)(BM + BN) * 128 * ST;
+#define ZE_RING8_LAUNCH(E)                                                                                           \
+    do {                                                                                                             \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<128, 128, ST, E, 2, 4>),                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);                              \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL((k_gemm_ring<128, 128, ST, E, 2, 4>), dim3(grid), dim3(512), lds8, s, A, lda, W, ldw, bias, \
+                           R, ldr, C, ldc, c_rows, M, N, K, ksplit, g_slab, g_tickets);                              \
+    } while (0)
+        switch (epi) {
+            case ZE_EPI_NONE: ZE_RING8_LAUNCH(ZE_EPI_NONE); break;
+            case ZE_EPI_GELU: ZE_RING8_LAUNCH(ZE_EPI_GELU); break;
+            case ZE_EPI_RESIDUAL: ZE_RING8_LAUNCH(ZE_EPI_RESIDUAL); break;
+            case ZE_EPI_SWIGLU: ZE_RING8_LAUNCH(ZE_EPI_SWIGLU); break;
+            case ZE_EPI_F32: ZE_RING8_LAUNCH(ZE_EPI_F32); break;
+        }
+#undef ZE_RING8_LAUNCH
+        return;
+    }
     const bool ring = ze_gemv_knobs[6] == 2 || (ze_gemv_knobs[6] == 0 && (grid <= cus || stream_mode));
     if (K % GEMM_BK == 0 && K / GEMM_BK / ksplit >= 4 && ring) {
         // LDS-DMA ring: four stages when they fit beside nothing else (one workgroup per CU), else three
