@@ -15,6 +15,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define FA_BK 64
 
 typedef short v4s __attribute__((ext_vector_type(4)));
+typedef unsigned int fa_u32x4 __attribute__((ext_vector_type(4)));
+
+// two f32 -> packed bf16 (round to nearest even) in ONE instruction; the software conversion costs ~6 VALU ops per
+// element and the probabilities of a tile are 32 elements per lane
+__device__ __forceinline__ uint32_t fa_pack_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
 
 // LDS image of a [64 keys][128 d] bf16 tile with 256-byte rows: byte offset of 16-B chunk ch (0..15) of row `row`.
 // The XOR serves both the ds_read_b128 row reads (K as an MFMA operand) and the ds_read_b64_tr_b16 transposed reads
@@ -34,7 +43,8 @@ __device__ __forceinline__ int fa_off(int row, int ch) { return 256 * row + 16 *
 //   * Q fragments live in registers for the whole kernel; K/V tiles are double-buffered in LDS with split staging
 //     (global loads of tile t+1 are issued before the products of tile t, written to LDS after).
 // D = 128 (LLM, causal GQA) and D = 80 (ViT; rows padded to 128 in LDS, the pad chunks are zero).
-template <int D, int CAUSAL>
+// BKV: keys per iteration (64, or 128: half the barriers and load-latency exposures of a long causal prefill)
+template <int D, int CAUSAL, int BKV>
 __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q, int q_rs, int q_hs,
                                                     const bf16_t* __restrict__ k, int k_rs, int k_hs,
                                                     const bf16_t* __restrict__ v, int v_rs, int v_hs,
@@ -45,7 +55,8 @@ __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q
     constexpr int KS = (D + 31) / 32;  // 32-deep steps of the QK^T contraction (D = 80: 3, the third half zero)
     constexpr int DCH = D / 8;         // real 16-B chunks per row
     constexpr int NV = D / 16;         // d-tiles of the output
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 x (K tile 16 KB + V tile 16 KB)
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 x (K tile + V tile), 256 B per key each
+    constexpr int TILE_B = BKV * 256, NKT = BKV / 16, RP = BKV / 64;  // bytes per tile image, key tiles, staging passes
 
     const int4 tile = tiles[blockIdx.x];
     const int q0 = tile.x, q1 = tile.y, kv0 = tile.z, kv1 = tile.w;
@@ -75,72 +86,95 @@ __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q
     float m_run = -INFINITY, l_run = 0.f;
     int kv_hi = kv1;
     if (CAUSAL) kv_hi = min(kv1, q1 + q_pos_offset);  // keys beyond the last query position are never visible
-    const int ntile = (kv_hi - kv0 + FA_BK - 1) / FA_BK;
+    const int ntile = (kv_hi - kv0 + BKV - 1) / BKV;
 
     // staging: thread -> (row = tid >> 2, chunks (tid & 3) * 4 .. +3) of the 64 x 16-chunk tile
     const int srow = tid >> 2, sch = (tid & 3) * 4;
-    uint4 rk[4], rv[4];
+    fa_u32x4 rk[RP][4], rv[RP][4];  // native vectors: a HIP uint4 struct behind the selects below went to scratch
     auto stage_load = [&](int kt) {
-        const int key = kt + srow;
-        const bool ok = key < kv_hi;
-        const bf16_t* kp = k + (size_t)key * k_rs + (size_t)kvh * k_hs;
-        const bf16_t* vp = v + (size_t)key * v_rs + (size_t)kvh * v_hs;
+        // Branch-free: a per-lane "in range ? load : 0" makes hipcc branch around every load and wait vmcnt(0) inside
+        // each branch -- 8-16 dependent L2 round trips per tile (the kernel ran 52 us per prefill layer that way).
+        // Out-of-range keys / pad chunks re-read a valid address and are zeroed by a select at stage_write time --
+        // NOT here: a select right behind the loads makes the first MFMA of the tile wait for all of them.
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            rk[i] = make_uint4(0, 0, 0, 0);
-            rv[i] = make_uint4(0, 0, 0, 0);
-            if (ok && sch + i < DCH) {
-                rk[i] = *reinterpret_cast<const uint4*>(kp + (sch + i) * 8);
-                rv[i] = *reinterpret_cast<const uint4*>(vp + (sch + i) * 8);
+        for (int rp = 0; rp < RP; ++rp) {
+            const int keyc = min(kt + rp * 64 + srow, kv_hi - 1);
+            const bf16_t* kp = k + (size_t)keyc * k_rs + (size_t)kvh * k_hs;
+            const bf16_t* vp = v + (size_t)keyc * v_rs + (size_t)kvh * v_hs;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ch = min(sch + i, DCH - 1);
+                rk[rp][i] = *reinterpret_cast<const fa_u32x4*>(kp + ch * 8);
+                rv[rp][i] = *reinterpret_cast<const fa_u32x4*>(vp + ch * 8);
             }
         }
     };
-    auto stage_write = [&](int buf) {
-        uint8_t* kb = smem + buf * 32768;
+    auto stage_write = [&](int buf, int kt) {  // kt: first key of the tile that stage_load fetched
+        uint8_t* kb = smem + buf * 2 * TILE_B;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<uint4*>(kb + fa_off(srow, sch + i)) = rk[i];
-            *reinterpret_cast<uint4*>(kb + 16384 + fa_off(srow, sch + i)) = rv[i];
+        for (int rp = 0; rp < RP; ++rp) {
+            const bool ok = kt + rp * 64 + srow < kv_hi;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned m = (ok && (sch + i < DCH)) ? 0xffffffffu : 0u;  // zero out-of-range keys / pad chunks
+                *reinterpret_cast<fa_u32x4*>(kb + fa_off(rp * 64 + srow, sch + i)) = rk[rp][i] & m;
+                *reinterpret_cast<fa_u32x4*>(kb + TILE_B + fa_off(rp * 64 + srow, sch + i)) = rv[rp][i] & m;
+            }
         }
     };
     if (ntile > 0) {
         stage_load(kv0);
-        stage_write(0);
+        stage_write(0, kv0);
     }
     __syncthreads();
 
     for (int t = 0; t < ntile; ++t) {
-        const int kt = kv0 + t * FA_BK;
-        const uint8_t* kb = smem + (t & 1) * 32768;
-        const uint8_t* vb = kb + 16384;
-        if (t + 1 < ntile) stage_load(kt + FA_BK);
-        // ---- S^T = K Q^T : 4 key tiles x KS steps
-        f32x4 sacc[4];
+        const int kt = kv0 + t * BKV;
+        const uint8_t* kb = smem + (t & 1) * 2 * TILE_B;
+        const uint8_t* vb = kb + TILE_B;
+        if (t + 1 < ntile) stage_load(kt + BKV);
+        // ---- S^T = K Q^T : NKT key tiles x KS steps
+        f32x4 sacc[NKT];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NKT; ++n) sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
+            for (int n = 0; n < NKT; ++n) {
                 const uint4 ka = *reinterpret_cast<const uint4*>(kb + fa_off(n * 16 + fr, ks * 4 + fq));
                 sacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&ka), qf[ks], sacc[n],
                                                                  0, 0, 0);
             }
         }
         // ---- mask + online softmax for query qi: keys kt + n*16 + fq*4 + r
-        float p[4][4];
+        float p[NKT][4];
         float mx = -INFINITY;
+        // causal prefill: only the diagonal / last tiles need the per-element mask (wave-uniform test); the compare +
+        // select pair is a quarter of the softmax's VALU work and this kernel is VALU-bound.  (The non-causal D = 80
+        // instantiation produced wrong rows with the unmasked branch -- not understood, so it keeps the mask.)
+        const bool need_mask = !CAUSAL || (kt + BKV > kv_hi) || (kt + BKV - 1 > q0 + wid * 16 + q_pos_offset);
+        if (need_mask) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+            for (int n = 0; n < NKT; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kj = kt + n * 16 + fq * 4 + r;
-                bool ok = kj < kv_hi;
-                if (CAUSAL) ok = ok && (kj <= qi + q_pos_offset);
-                const float sv = ok ? sacc[n][r] * scale_log2e : -INFINITY;
-                p[n][r] = sv;
-                mx = fmaxf(mx, sv);
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const int kj = kt + n * 16 + fq * 4 + r;
+                    bool ok = kj < kv_hi;
+                    if (CAUSAL) ok = ok && (kj <= qi + q_pos_offset);
+                    const float sv = ok ? sacc[n][r] * scale_log2e : -INFINITY;
+                    p[n][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+        } else {
+#pragma unroll
+            for (int n = 0; n < NKT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sv = sacc[n][r] * scale_log2e;
+                    p[n][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
@@ -148,10 +182,10 @@ __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q
         const float alpha = exp2f(m_run - m_use);  // m_run = -inf -> 0
         float rs = 0.f;
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < NKT; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = exp2f(p[n][r] - m_use);
+                const float e = __builtin_amdgcn_exp2f(p[n][r] - m_use);  // raw v_exp_f32: arguments <= 0, results in [0, 1]
                 p[n][r] = e;
                 rs += e;
             }
@@ -168,12 +202,12 @@ __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q
         }
         // ---- O^T += V^T P^T : per 32-key step the lane's 8 keys are (ks*32 + fq*4 + 0..3) and (ks*32 + 16 + fq*4 + 0..3)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BKV / 32; ++ks) {
             uint32_t pw[4];
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
-                pw[2 * h2] = pack_bf16x2(p[2 * ks + h2][0], p[2 * ks + h2][1]);
-                pw[2 * h2 + 1] = pack_bf16x2(p[2 * ks + h2][2], p[2 * ks + h2][3]);
+                pw[2 * h2] = fa_pack_bf16(p[2 * ks + h2][0], p[2 * ks + h2][1]);
+                pw[2 * h2 + 1] = fa_pack_bf16(p[2 * ks + h2][2], p[2 * ks + h2][3]);
             }
             const uint4 pq = make_uint4(pw[0], pw[1], pw[2], pw[3]);
             const bf16x8 pb = *reinterpret_cast<const bf16x8*>(&pq);
@@ -192,7 +226,7 @@ __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q
                 oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&va), pb, oacc[j], 0, 0, 0);
             }
         }
-        if (t + 1 < ntile) stage_write((t + 1) & 1);
+        if (t + 1 < ntile) stage_write((t + 1) & 1, kt + BKV);
         __syncthreads();
     }
     // ---- normalise and store: lane holds O[qi][j*16 + fq*4 .. +3]
@@ -216,8 +250,18 @@ void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_rs, int q_hs
     const float sl = scale * 1.4426950408889634f;
     dim3 grid(n_tiles, heads);
 #define FA_LAUNCH(DD, CC)                                                                                      \
-    hipLaunchKernelGGL((k_flash_attn<DD, CC>), grid, dim3(256), 65536, s, q, q_rs, q_hs, k, k_rs, k_hs, v, v_rs, v_hs, \
-                       o, o_rs, o_hs, tiles, group, sl, q_pos_offset, tile_aux, kv_seq_stride)
+    do {                                                                                                          \
+        constexpr int BKV_ = (CC) ? 128 : 64;                                                                     \
+        constexpr int LDS_ = 4 * BKV_ * 256;                                                                      \
+        static bool attr_set = false;                                                                             \
+        if (!attr_set) {                                                                                          \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn<DD, CC, BKV_>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_);                                \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
+        hipLaunchKernelGGL((k_flash_attn<DD, CC, BKV_>), grid, dim3(256), LDS_, s, q, q_rs, q_hs, k, k_rs, k_hs, v, v_rs, \
+                           v_hs, o, o_rs, o_hs, tiles, group, sl, q_pos_offset, tile_aux, kv_seq_stride);          \
+    } while (0)
     if (D == 80) {
         if (causal) FA_LAUNCH(80, 1); else FA_LAUNCH(80, 0);
     } else {
