@@ -161,8 +161,8 @@ int ze_decode_step(ze_engine* e, int seq, int token, float* out_logits, void* st
  * do_sample = 0: greedy arg-max (src/demo.py:17).  do_sample = 1 with temperature > 0: multinomial draw from
  * softmax(penalised logits / temperature) -- TemperatureLogitsWarper + torch.multinomial as src/eval/infer.py:109-115
  * uses them (temperature 0.01, top_k = top_p = None); same distribution, but the random stream is this library's
- * counter-based generator: draw = f(seed, chain slot, index of the generated token), reproducible and independent
- * of batch composition (see ze_op_sample_temperature). */
+ * counter-based generator: draw = f(seed, row of the chain in the call, index of the generated token): the same
+ * request reproduces whatever chain slot it lands in (see ze_op_sample_temperature). */
 typedef struct ze_gen_params {
     int32_t max_new_tokens;
     float repetition_penalty;  /* 1.0 = off */
@@ -203,7 +203,8 @@ int ze_op_sample_greedy(ze_engine* e, int seq, const float* logits, float repeti
                         void* stream);
 /* One temperature-sampling draw (replaces TemperatureLogitsWarper + softmax + torch.multinomial,
  * HF:generation/utils.py:2894-2916) on f32 logits [vocab] (device) with the seen-set of `seq`:
- *   u = (stream64(mix64(seed ^ mix64(seq + 1)), index) >> 40) * 2^-24 ; e_i = expf(score_i / T - max score / T) ;
+ *   u = (stream64(mix64(seed ^ mix64(row + 1)), index) >> 40) * 2^-24 (row = 0 here, the chain's row in a batched
+ *   generate call) ; e_i = expf(score_i / T - max score / T) ;
  *   token = first i whose running sum of e exceeds u * sum(e)   (fp32 sums in the order given in ze_sample.hip).
  * `index` = position of the draw in the generated sequence (what ze_generate passes). *out_token host. */
 int ze_op_sample_temperature(ze_engine* e, int seq, const float* logits, float repetition_penalty, float temperature,

@@ -435,8 +435,9 @@ SAMPLE_BLOCKS = 128
 
 
 def sample_uniform(seed: int, slot: int, index: int) -> np.float32:
-    """The draw u in [0, 1) of generated token `index` of chain slot `slot` (include/zoomearth.h,
-    ze_op_sample_temperature): 24 high bits of stream64(mix64(seed ^ mix64(slot + 1)), index)."""
+    """The draw u in [0, 1) of generated token `index` of the chain in row `slot` of the generate call (0 for a
+    single-chain call; include/zoomearth.h, ze_op_sample_temperature): 24 high bits of
+    stream64(mix64(seed ^ mix64(row + 1)), index)."""
     m = (1 << 64) - 1
     inner = int(prng.mix64(np.array([(slot + 1) & m], dtype=np.uint64))[0])
     key = int(prng.mix64(np.array([(seed ^ inner) & m], dtype=np.uint64))[0])

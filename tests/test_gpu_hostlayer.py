@@ -195,3 +195,45 @@ def test_from_pretrained_both_key_layouts(stack, tmp_path):
     with pytest.raises(RuntimeError, match="missing weights"):
         ZoomEarthForConditionalGeneration.from_pretrained(str(d), max_seqs=1, max_ctx=256, max_patches=1024, max_tile_side=1024)
     P.set_default_engine(model.engine)
+
+
+def test_openai_compatible_server_matches_generate(stack):
+    """POST /v1/chat/completions (the request src/eval/infer_vllm.py sends) == processor + generate + decode on the
+    chat-templated prompt; greedy and seeded sampling; error mapping."""
+    import base64
+    import io
+    from fastapi.testclient import TestClient
+    from PIL import Image
+    from zoomearth_amd import serve
+    model, proc, tile, tile_np = stack
+    small = frontend.resize_bicubic(tile_np, 256, 209)
+    buf = io.BytesIO()
+    Image.fromarray(small).save(buf, format="PNG")  # lossless, so the server sees exactly `small`
+    url = "data:image/png;base64," + base64.b64encode(buf.getvalue()).decode()
+    text = words(21, 7)
+    msgs = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": url}}, {"type": "text", "text": " " + text + " "}]}]
+    client = TestClient(serve.create_app(serve.ChatServer(model, proc, "ZoomEarth")))
+    assert client.get("/health").json() == {"status": "ok"}
+    assert client.get("/v1/models").json()["data"][0]["id"] == "ZoomEarth"
+    r = client.post("/v1/chat/completions", json={"model": "ZoomEarth", "messages": msgs, "max_tokens": 10})
+    assert r.status_code == 200, r.text
+    body = r.json()
+    # the same request by hand
+    prompt, _ = serve.build_prompt(msgs)
+    img = DeviceImage.from_numpy(small, model.engine)
+    inp = proc(text=[prompt], images=[img], return_tensors="pt", padding="longest").to(model.device)
+    g = model.generate(**inp, max_new_tokens=10, do_sample=False, num_beams=1)[0, inp["input_ids"].shape[1]:].tolist()
+    eos = set(model.config.eos_token_ids)
+    cut = next((i + 1 for i, t in enumerate(g) if t in eos), len(g))
+    want = proc.tokenizer.decode(g[:cut], skip_special_tokens=True).strip()
+    assert body["choices"][0]["message"] == {"role": "assistant", "content": want}
+    assert body["usage"]["prompt_tokens"] == inp["input_ids"].shape[1] and body["usage"]["completion_tokens"] == cut
+    assert body["choices"][0]["finish_reason"] == ("stop" if cut < len(g) or g[-1] in eos else "length")
+    # seeded sampling is reproducible and seed-dependent
+    a = client.post("/v1/chat/completions", json={"messages": msgs, "max_tokens": 12, "temperature": 1.0, "seed": 4}).json()
+    b = client.post("/v1/chat/completions", json={"messages": msgs, "max_tokens": 12, "temperature": 1.0, "seed": 4}).json()
+    c = client.post("/v1/chat/completions", json={"messages": msgs, "max_tokens": 12, "temperature": 1.0, "seed": 5}).json()
+    assert a["choices"][0]["message"] == b["choices"][0]["message"] != c["choices"][0]["message"]
+    # errors
+    assert client.post("/v1/chat/completions", json={"messages": msgs, "stream": True}).status_code == 400
+    assert client.post("/v1/chat/completions", json={"messages": [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": "http://example.com/x.png"}}]}]}).status_code == 400

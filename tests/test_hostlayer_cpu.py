@@ -218,3 +218,31 @@ def test_tile_prefetcher_decodes_each_tile_once_and_ahead(tmp_path):
         assert pf2.get(paths[2]).size == (50, 42)  # never announced: decoded on demand
     finally:
         I.DeviceImage.__init__ = orig
+
+
+def test_serve_prompt_template_and_data_urls():
+    """OpenAI messages -> Qwen2.5-VL chat template (what `vllm serve` applies for src/eval/infer_vllm.py)."""
+    import base64
+    import io
+    import numpy as np
+    from PIL import Image
+    from zoomearth_amd import serve
+
+    buf = io.BytesIO()
+    Image.fromarray(np.arange(12 * 10 * 3, dtype=np.uint8).reshape(12, 10, 3)).save(buf, format="PNG")
+    url = "data:image/png;base64," + base64.b64encode(buf.getvalue()).decode()
+    msgs = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": url}}, {"type": "text", "text": "how many?"}]},
+            {"role": "assistant", "content": [{"type": "text", "text": "<think>x</think>"}, {"type": "image_url", "image_url": {"url": url}}]}]
+    prompt, images = serve.build_prompt(msgs)
+    ph = "<|vision_start|><|image_pad|><|vision_end|>"
+    assert prompt == ("<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n"
+                      f"<|im_start|>user\n{ph}how many?<|im_end|>\n"
+                      f"<|im_start|>assistant\n<think>x</think>{ph}<|im_end|>\n"
+                      "<|im_start|>assistant\n")
+    assert [im.size for im in images] == [(10, 12), (10, 12)] and images[0].mode == "RGB"
+    p2, im2 = serve.build_prompt([{"role": "system", "content": "s"}, {"role": "user", "content": "q"}])
+    assert p2 == "<|im_start|>system\ns<|im_end|>\n<|im_start|>user\nq<|im_end|>\n<|im_start|>assistant\n" and im2 == []
+    for bad in ([], [{"role": "tool", "content": "x"}], [{"role": "user", "content": [{"type": "audio"}]}],
+                [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": "http://x/y.png"}}]}]):
+        with pytest.raises(serve.BadRequest):
+            serve.build_prompt(bad)

@@ -992,7 +992,15 @@ extern "C" int ze_generate_batch(ze_engine* e, const int32_t* seqs, int n, const
     }
     const float pen = p->repetition_penalty > 0.f ? p->repetition_penalty : 1.0f;
     const int ign = p->ignore_eos ? 1 : 0;
-    const ze_sample_opts bso = sample_opts_of(p, 0);  // batched launches take the chain slot from the chain table
+    const ze_sample_opts bso = sample_opts_of(p, 0);
+    if (bso.temperature > 0.f) {  // sampling stream of a chain = its row in this call (reproducible per request)
+        ZE_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < n; ++i) {
+            e->d_host_ints[40 + i % 16] = i;
+            ZE_HIP(hipMemcpyAsync(&(e->st_dev + seqs[i])->stream, e->d_host_ints + 40 + i % 16, sizeof(int), hipMemcpyHostToDevice, s));
+            if (i % 16 == 15) ZE_HIP(hipStreamSynchronize(s));
+        }
+    }
     // first token of every chain from the logits its prefill left behind
     for (int i = 0; i < n; ++i) {
         const int q = seqs[i];

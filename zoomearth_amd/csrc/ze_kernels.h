@@ -16,7 +16,8 @@ struct ze_seq_dev {
     int32_t finished;   // 1 after an EOS was emitted (subsequent tokens are pad)
     int32_t n_gen;      // tokens written to out_tokens so far
     int32_t max_gen;    // capacity of out_tokens
-    int32_t pad0, pad1;
+    int32_t stream;     // sampling stream of this chain: its row in the generate call (0 for single-chain calls)
+    int32_t pad1;
 };
 
 // ---- front-end
@@ -146,8 +147,8 @@ void ze_launch_attn_decode(const bf16_t* q, int q_row_stride, const bf16_t* kcac
 // ---- sampling
 struct ze_sample_opts {
     float temperature = 0.f;      // 0: greedy arg-max; > 0: multinomial draw from softmax(score / temperature)
-    unsigned long long seed = 0;  // draw = f(seed, chain slot, index of the generated token)
-    int slot = 0;                 // chain slot of a single-chain launch (batched launches read seq_ids)
+    unsigned long long seed = 0;  // draw = f(seed, ze_seq_dev::stream of the chain, index of the generated token)
+    int slot = 0;                 // unused (kept for layout)
 };
 // ws: 2 * 128 arg-max partials + 64 spare + 128 chunk sums (floats)
 void ze_launch_sample(const float* logits, int vocab, uint8_t* seen, float penalty, ze_seq_dev* st,

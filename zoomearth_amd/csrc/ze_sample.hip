@@ -189,8 +189,9 @@ void ze_launch_sample_batch(const float* logits, int vocab, uint8_t* seen_base, 
 // replaces: TemperatureLogitsWarper + softmax + torch.multinomial(probs, 1) in GenerationMixin._sample
 // (HF:generation/utils.py:2894-2916, HF:generation/logits_process.py:285-345) as src/eval/infer.py:109-115 calls it
 // (temperature 0.01, top_k = top_p = None).  Same distribution; the random stream is this repo's counter-based
-// generator, not torch's, so a draw is reproducible from (seed, chain slot, index of the generated token):
-//     u = (stream64(mix64(seed ^ mix64(slot + 1)), n_gen) >> 40) * 2^-24                        in [0, 1)
+// generator, not torch's, so a draw is reproducible from (seed, row of the chain in the generate call, index of the
+// generated token) whatever chain slot the request landed in:
+//     u = (stream64(mix64(seed ^ mix64(row + 1)), n_gen) >> 40) * 2^-24                         in [0, 1)
 //     e_i = expf(score_i / T - max_j score_j / T)        score = repetition-penalised fp32 logit
 //     token = first i (ascending) whose running sum of e exceeds u * sum(e)
 // Summation order (fp32), which the oracle (oracle/qwen25vl.py:sample_temperature) restates: the vocabulary is cut
@@ -270,7 +271,7 @@ __global__ void __launch_bounds__(256) k_multinomial_pick(const float* __restric
         const float* sums = ws_sum + (size_t)b * SAMPLE_BLOCKS;
         float total = 0.f;
         for (int k = 0; k < SAMPLE_BLOCKS; ++k) total += sums[k];
-        const unsigned long long key = ze_mix64(seed ^ ze_mix64((unsigned long long)slot + 1ull));
+        const unsigned long long key = ze_mix64(seed ^ ze_mix64((unsigned long long)st->stream + 1ull));
         const float u = (float)(ze_stream64(key, (unsigned long long)st->n_gen) >> 40) * 5.9604644775390625e-08f;
         const float target = u * total;
         float cum = 0.f;

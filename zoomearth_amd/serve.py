@@ -1,0 +1,168 @@
+"""OpenAI-compatible chat-completions shim over the engine, so the reference's `src/eval/infer_vllm.py` client
+(`OpenAI(base_url="http://localhost:8000/v1").chat.completions.create(model=..., messages=[...])`,
+/root/reference/src/eval/infer_vllm.py:19-24,153-156,218-221) can target this engine instead of `vllm serve`
+(SURVEY.md 8f rank 3).
+
+Request: the subset that client sends -- `messages` with `role` in {system, user, assistant} and `content` either a
+string or a list of `{"type": "text", "text": ...}` / `{"type": "image_url", "image_url": {"url": "data:image/...;
+base64,..."}}` items, plus `max_tokens`, `temperature`, `seed` (`n` must be 1, `stream` is not offered).
+Prompt: the Qwen2.5-VL chat template (`<|im_start|>role\\n ... <|im_end|>\\n`, an image item becomes
+`<|vision_start|><|image_pad|><|vision_end|>`, a default system turn when the conversation has none, then the
+generation prompt `<|im_start|>assistant\\n`).  temperature 0 / absent -> greedy, else temperature sampling.
+Requests are served one at a time (the engine is single-stream); images are decoded on the host and uploaded.
+
+    python -m zoomearth_amd.serve --model_name /ckpt/ZoomEarth-3B --port 8000
+"""
+
+import base64
+import io
+import threading
+import time
+import uuid
+
+DEFAULT_SYSTEM = "You are a helpful assistant."
+IMAGE_PLACEHOLDER = "<|vision_start|><|image_pad|><|vision_end|>"
+
+
+class BadRequest(ValueError):
+    pass
+
+
+def decode_data_url(url: str):
+    """data:image/...;base64,<payload> -> PIL RGB image (what infer_vllm.py's encode_pil_image_to_data_url produces)."""
+    from PIL import Image
+
+    if not isinstance(url, str) or not url.startswith("data:") or ";base64," not in url:
+        raise BadRequest("only base64 data URLs are accepted for image_url (no network access from the server)")
+    try:
+        raw = base64.b64decode(url.split(";base64,", 1)[1], validate=False)
+        Image.MAX_IMAGE_PIXELS = None
+        return Image.open(io.BytesIO(raw)).convert("RGB")
+    except Exception as ex:
+        raise BadRequest(f"cannot decode image: {ex}") from ex
+
+
+def build_prompt(messages):
+    """Qwen2.5-VL chat template over OpenAI messages -> (prompt string, [PIL images in prompt order])."""
+    if not isinstance(messages, list) or not messages:
+        raise BadRequest("messages must be a non-empty list")
+    parts, images = [], []
+    if messages[0].get("role") != "system":
+        parts.append(f"<|im_start|>system\n{DEFAULT_SYSTEM}<|im_end|>\n")
+    for m in messages:
+        role = m.get("role")
+        if role not in ("system", "user", "assistant"):
+            raise BadRequest(f"unsupported role {role!r}")
+        content = m.get("content")
+        body = []
+        if isinstance(content, str):
+            body.append(content)
+        elif isinstance(content, list):
+            for item in content:
+                kind = item.get("type") if isinstance(item, dict) else None
+                if kind == "text":
+                    body.append(str(item.get("text", "")))
+                elif kind == "image_url":
+                    iu = item.get("image_url")
+                    images.append(decode_data_url(iu.get("url") if isinstance(iu, dict) else iu))
+                    body.append(IMAGE_PLACEHOLDER)
+                else:
+                    raise BadRequest(f"unsupported content item type {kind!r}")
+        else:
+            raise BadRequest("message content must be a string or a list of items")
+        parts.append(f"<|im_start|>{role}\n{''.join(body)}<|im_end|>\n")
+    parts.append("<|im_start|>assistant\n")
+    return "".join(parts), images
+
+
+class ChatServer:
+    """Holds the model / processor pair and turns one OpenAI request dict into one response dict."""
+
+    def __init__(self, model, processor, model_id: str = "ZoomEarth"):
+        self.model, self.processor, self.model_id = model, processor, model_id
+        self._lock = threading.Lock()
+
+    def complete(self, req: dict) -> dict:
+        from .image import DeviceImage
+
+        if req.get("stream"):
+            raise BadRequest("stream=true is not offered")
+        if int(req.get("n", 1) or 1) != 1:
+            raise BadRequest("n must be 1")
+        prompt, pil_images = build_prompt(req.get("messages"))
+        max_tokens = int(req.get("max_tokens") or req.get("max_completion_tokens") or 1024)
+        temperature = req.get("temperature")
+        sample = temperature is not None and float(temperature) > 0.0
+        with self._lock:
+            images = [DeviceImage.from_pil(im, self.model.engine) for im in pil_images]
+            inputs = self.processor(text=[prompt], images=images or None, return_tensors="pt", padding="longest").to(self.model.device)
+            n_in = int(inputs["input_ids"].shape[1])
+            kw = dict(max_new_tokens=max_tokens, num_beams=1, do_sample=sample)
+            if sample:
+                kw.update(temperature=float(temperature), top_k=None, top_p=None, seed=int(req.get("seed") or 0))
+            out = self.model.generate(**inputs, **kw)[0, n_in:].tolist()
+        eos = set(self.model.config.eos_token_ids)
+        pad = self.model.config.pad_token_id
+        stop = next((i for i, t in enumerate(out) if t in eos), None)
+        ids = out if stop is None else out[: stop + 1]
+        while stop is None and ids and ids[-1] == pad:
+            ids = ids[:-1]
+        text = self.processor.tokenizer.decode(ids, skip_special_tokens=True).strip()
+        return {
+            "id": "chatcmpl-" + uuid.uuid4().hex[:24], "object": "chat.completion", "created": int(time.time()),
+            "model": req.get("model") or self.model_id,
+            "choices": [{"index": 0, "message": {"role": "assistant", "content": text},
+                         "finish_reason": "stop" if stop is not None else "length"}],
+            "usage": {"prompt_tokens": n_in, "completion_tokens": len(ids), "total_tokens": n_in + len(ids)},
+        }
+
+
+def create_app(server: ChatServer):
+    from fastapi import FastAPI, Request
+    from fastapi.responses import JSONResponse
+
+    app = FastAPI(title="zoomearth-mi355x")
+
+    @app.get("/health")
+    def health():
+        return {"status": "ok"}
+
+    @app.get("/v1/models")
+    def models():
+        return {"object": "list", "data": [{"id": server.model_id, "object": "model", "owned_by": "zoomearth-mi355x"}]}
+
+    @app.post("/v1/chat/completions")
+    async def chat(request: Request):
+        try:
+            body = await request.json()
+            return JSONResponse(server.complete(body))
+        except BadRequest as ex:
+            return JSONResponse({"error": {"message": str(ex), "type": "invalid_request_error"}}, status_code=400)
+        except Exception as ex:  # engine errors surface as a 500 with the engine's message
+            return JSONResponse({"error": {"message": str(ex), "type": "server_error"}}, status_code=500)
+
+    return app
+
+
+def main():  # pragma: no cover
+    import argparse
+
+    import uvicorn
+
+    from .modeling import ZoomEarthForConditionalGeneration
+    from .processor import ZoomEarthProcessor
+
+    ap = argparse.ArgumentParser(description="OpenAI-compatible server on the MI355X engine")
+    ap.add_argument("--model_name", required=True)
+    ap.add_argument("--served_model_name", default="ZoomEarth")
+    ap.add_argument("--host", default="127.0.0.1")
+    ap.add_argument("--port", type=int, default=8000)
+    args = ap.parse_args()
+    model = ZoomEarthForConditionalGeneration.from_pretrained(args.model_name)
+    processor = ZoomEarthProcessor.from_pretrained(args.model_name, trust_remote_code=True, max_pixels=128 * 128 * 28 * 28)
+    processor.tokenizer.padding_side = "left"
+    uvicorn.run(create_app(ChatServer(model, processor, args.served_model_name)), host=args.host, port=args.port)
+
+
+if __name__ == "__main__":  # pragma: no cover
+    main()
