@@ -431,23 +431,19 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
     //  step at 64 chains, 3.78 vs 4.17 at 8)
     // Many-tile grids (128 x 128 policy): eight waves (2 x 4, 64 x 64 per wave) on 128 x 256 tiles of the LDS-DMA ring,
     // one workgroup per CU, when the grid is at most one round or at least 1.6 (measured: 4096^3 870 vs 756 TFLOP/s,
-    // gate/up at M = 518: 81 vs 92 us, ViT qkv 31.5 vs 34.2; a 1.2-round grid loses what the larger tile wins).
-    // knob 7: 1 = eight waves on 128 x 128 tiles (ties the register-staged kernel), 2 = 128 x 256 always, 3 = never.
-    const int grid_w = ze_cdiv(M, 128) * ze_cdiv(N, 256);
-    static int cus8 = 0;
-    if (!cus8) {
-        int dev = 0;
-        hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&cus8, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus8 <= 0) cus8 = 256;
-    }
-    const bool wide = ze_gemv_knobs[7] == 2 ||
-                      (ze_gemv_knobs[7] == 0 && ze_gemv_knobs[6] == 0 && (grid_w <= cus8 || 5 * grid_w >= 8 * cus8));
-    if ((ze_gemv_knobs[7] == 1 || wide) && BM == 128 && BN == 128 && ksplit == 1 && K % GEMM_BK == 0 &&
-        K / GEMM_BK >= 4) {
-        if (wide) {
+    // gate/up at M = 518: 81 vs 92 us, ViT qkv 31.5 vs 34.2; a 1.2-round grid loses what the larger tile wins; eight
+    // waves on 128 x 128 tiles only tie the register-staged kernel).  knob 7: 2 = always, 3 = never.
+    if (BM == 128 && BN == 128 && ksplit == 1 && K % GEMM_BK == 0 && K / GEMM_BK >= 4 && ze_gemv_knobs[7] != 3) {
+        static int cus8 = 0;
+        if (!cus8) {
+            int dev = 0;
+            hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&cus8, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus8 <= 0) cus8 = 256;
+        }
+        const int grid2 = ze_cdiv(M, 128) * ze_cdiv(N, 256);
+        if (ze_gemv_knobs[7] == 2 || (ze_gemv_knobs[6] == 0 && (grid2 <= cus8 || 5 * grid2 >= 8 * cus8))) {
             constexpr int ST2 = 3;
             const size_t lds2 = (size_t)(128 + 256) * 128 * ST2;
-            const int grid2 = ze_cdiv(M, 128) * ze_cdiv(N, 256);
 #define ZE_RING8B_LAUNCH(E)                                                                                          \
     do {                                                                                                             \
         static bool attr_set = false;                                                                                \
@@ -469,28 +465,6 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
 #undef ZE_RING8B_LAUNCH
             return;
         }
-        constexpr int ST = 4;
-        const size_t lds8 = (size_t)(BM + BN) * 128 * ST;
-#define ZE_RING8_LAUNCH(E)                                                                                           \
-    do {                                                                                                             \
-        static bool attr_set = false;                                                                                \
-        if (!attr_set) {                                                                                             \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<128, 128, ST, E, 2, 4>),                  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);                              \
-            attr_set = true;                                                                                         \
-        }                                                                                                            \
-        hipLaunchKernelGGL((k_gemm_ring<128, 128, ST, E, 2, 4>), dim3(grid), dim3(512), lds8, s, A, lda, W, ldw, bias, \
-                           R, ldr, C, ldc, c_rows, M, N, K, ksplit, g_slab, g_tickets);                              \
-    } while (0)
-        switch (epi) {
-            case ZE_EPI_NONE: ZE_RING8_LAUNCH(ZE_EPI_NONE); break;
-            case ZE_EPI_GELU: ZE_RING8_LAUNCH(ZE_EPI_GELU); break;
-            case ZE_EPI_RESIDUAL: ZE_RING8_LAUNCH(ZE_EPI_RESIDUAL); break;
-            case ZE_EPI_SWIGLU: ZE_RING8_LAUNCH(ZE_EPI_SWIGLU); break;
-            case ZE_EPI_F32: ZE_RING8_LAUNCH(ZE_EPI_F32); break;
-        }
-#undef ZE_RING8_LAUNCH
-        return;
     }
     const bool ring = ze_gemv_knobs[6] == 2 || (ze_gemv_knobs[6] == 0 && (grid <= cus || stream_mode));
     if (K % GEMM_BK == 0 && K / GEMM_BK / ksplit >= 4 && ring) {
