@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256) k_layer_attn(const ze_layer_attn_args a) 
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = a.hidden;                                              // <= 2048 (host-checked)
     constexpr int nch = NCH, nchq = NCH;
-    const int lane_off = lane * 8, last_off = K - 8;
+    const int lane_off = lane * 8;
     const int ctx = a.st->ctx, pos = ctx + a.st->rope_delta;
     const int D = 128, halfD = 64;
     const int NQ = a.heads * D;  // O-proj reduction length (<= 2048)

@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(256) k_multinomial_pick(const float* __restric
                         break;
                     }
                 }
-                if (tok < 0) cum = cum;  // rounding: fall through to the next run
+                // (a run whose sum crossed the target but whose elements, re-added, did not: rounding -- go on)
             } else {
                 cum += sRun[t];
             }
