@@ -340,6 +340,9 @@ def main():
     ap.add_argument("--model", choices=("3b", "7b"), default="3b",
                     help="3b = ZoomEarth-3B shape (the metric's workload); 7b = Qwen2.5-VL-7B backbone swap of BASELINE "
                          "configs[4] in bf16 (its fp8 weights are not built): reported without roofline objects")
+    ap.add_argument("--fp8", action="store_true",
+                    help="FP8 (E4M3) decoder weights for the decode stream (BASELINE configs[4]); NOT the metric's "
+                         "precision: reported as its own configuration, without roofline objects")
     ap.add_argument("--batch", type=int, default=1, help="question chains advanced together (1 = BASELINE configs[1]; >1 = configs[2])")
     args = ap.parse_args()
 
@@ -365,6 +368,8 @@ def main():
                max_prefill_rows=(16 * 832 if args.batch > 1 else 0),
                max_tile_side=max(args.tile, 1024))
     e.fill_synthetic(seed=0, std=0.02)
+    if args.fp8:
+        e.quantize_fp8()
     for kv in os.environ.get("ZE_TUNE", "").split(","):  # measurement-only A/B knobs, e.g. ZE_TUNE=2:64
         if ":" in kv:
             e.lib.ze_tune(int(kv.split(":")[0]), int(kv.split(":")[1]))
@@ -446,9 +451,12 @@ def main():
                          "avg_us": us, "bytes_per_launch": by, "other_decode_kernels": others},
             "phase_ms_per_question": {k: round(v / args.steps, 3) for k, v in phases.items()},
         }
-        if args.model != "3b":  # the roofline constants below are the 3B shape's
+        if args.model != "3b" or args.fp8:  # the roofline constants below are the 3B bf16 shape's
             line.pop("roofline", None)
-        if args.batch == 1 and args.model == "3b":
+        if args.fp8:
+            line["dtype"] = "fp8-e4m3 decoder weights (per-row power-of-two scales) streamed by the decode GEMVs; bf16 activations, bf16 MFMA prefill on the dequantised copy"
+            line["metric"] += " [fp8 weights: reduced precision, not the headline metric]"
+        if args.batch == 1 and args.model == "3b" and not args.fp8:
             # per-phase roofline fractions: algorithmic work of the as-built question (stage-1 prompt KV
             # and view features reused) over the measured phase time, against the dense bf16 MFMA peak / the HBM peak
             pm = line["phase_ms_per_question"]

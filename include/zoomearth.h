@@ -210,6 +210,15 @@ int ze_op_sample_greedy(ze_engine* e, int seq, const float* logits, float repeti
 int ze_op_sample_temperature(ze_engine* e, int seq, const float* logits, float repetition_penalty, float temperature,
                              uint64_t seed, int index, int32_t* out_token, void* stream);
 
+/* FP8 decode weights (BASELINE.json configs[4], "fp8 weights"): quantises the decoder's linear layers (and an untied
+ * lm_head) to OCP E4M3 with one power-of-two scale per output row, REPLACES the bf16 copies by the dequantised
+ * values (exactly representable) so that prefill and decode compute with identical weights, and switches the batch-1
+ * decode GEMVs to the fp8 stream (half the HBM bytes per token).  Call once, after the weights are loaded. */
+int ze_weights_quantize_fp8(ze_engine* e, void* stream);
+/* The quantiser on one matrix: w bf16 [rows, cols] (device, overwritten with the dequantised values), q_out u8
+ * [rows, cols], scale_out f32 [rows]; cols % 16 == 0. */
+int ze_op_quantize_fp8(ze_engine* e, void* w_bf16, int rows, int cols, void* q_out, void* scale_out, void* stream);
+
 /* ------------------------------------------------------------------ unit ops for parity tests (K3-K22) */
 /* C[M,N] = A[M,K] * W[N,K]^T (+bias[N]) ; bf16 in, fp32 accumulate, bf16 out (one rounding).  act: 0 none, 1 exact GELU. */
 int ze_op_linear(ze_engine* e, const void* a_bf16, const void* w_bf16, const void* bias_bf16, void* c_bf16, int M,

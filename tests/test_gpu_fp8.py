@@ -1,0 +1,93 @@
+"""GPU: FP8 (OCP E4M3) decode weights (BASELINE configs[4], "fp8 weights") through the C ABI.
+  * the quantiser kernel vs oracle/fp8.py: bits, scales and dequantised bf16 values, exact;
+  * the whole model on the dequantised weights vs the oracle on the SAME weights (teacher-forced logits within 2x the
+    oracle's own bf16-vs-fp32 error): prefill runs bf16 MFMA GEMMs on the dequantised copy, decode streams the fp8
+    bytes -- the two paths share no kernel but must describe one model;
+  * fp8 decode vs the bf16 GEMV decode of the same (dequantised) weights: same products, another summation order."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import CHAIN_W
+from oracle import fp8, prng
+from oracle import qwen25vl as Q
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def fresh_tiny():
+    from zoomearth_amd.config import ModelConfig
+    from zoomearth_amd.engine import Engine
+    e = Engine(ModelConfig.tiny(), device=0, max_seqs=2, max_ctx=1024, max_patches=1024, max_tile_side=1024)
+    e.fill_synthetic(**CHAIN_W)
+    yield e
+    e.close()
+
+
+def test_quantiser_kernel_is_exact(fresh_tiny):
+    e = fresh_tiny
+    rng = np.random.default_rng(3)
+    w = (rng.normal(size=(97, 256)) * rng.uniform(0.001, 2.0, size=(97, 1))).astype(np.float32)
+    w[7] = 0.0
+    w[8, :] = 0.0
+    w[8, 5] = 448.0 * 2.0 ** -3
+    wb = torch.from_numpy(w).cuda().to(torch.bfloat16).contiguous()
+    w_in = wb.float().cpu().numpy()                      # the bf16 values the kernel sees
+    q, sc = e.op_quantize_fp8(wb)
+    bits, k, dq = fp8.quantize_rows(w_in)
+    assert np.array_equal(sc.cpu().numpy(), np.exp2(k.astype(np.float64)).astype(np.float32))
+    got = q.cpu().numpy()
+    same = (got == bits) | (((got & 0x7F) == 0) & ((bits & 0x7F) == 0))
+    assert same.all()
+    assert np.array_equal(wb.float().cpu().numpy(), dq)  # in place: the dequantised values, exactly
+
+
+def text_ids(seed, n):
+    return prng.uniform_ints(seed, n, 10, 1990).tolist()
+
+
+def test_fp8_model_vs_oracle_on_dequantised_weights(fresh_tiny):
+    e = fresh_tiny
+    oc = Q.tiny_config()
+    w = Q.synthetic_weights(oc, **CHAIN_W)
+    ids = text_ids(7, 120)
+    forced = [int(t) for t in text_ids(8, 10)]
+    pos, delta = e.rope_index(ids, [])
+
+    def engine_run():
+        e.seq_reset(0)
+        return [e.prefill(0, ids, None, pos, delta).cpu().numpy()] + [e.decode_step(0, t).cpu().numpy() for t in forced]
+
+    bf16_run = engine_run()
+    e.quantize_fp8()
+    got = engine_run()
+    # oracle on the dequantised weights (decoder linears only; tiny is tied, so lm_head / embedding stay bf16)
+    wq = dict(w)
+    for name, v in w.items():
+        if name.startswith("model.language_model.layers") and name.endswith("proj.weight"):
+            wq[name] = fp8.quantize_rows(v.reshape(v.shape[0], -1))[2].reshape(v.shape)
+    # q/k/v are quantised as ONE stacked matrix row-wise, which equals per-matrix row-wise quantisation
+    o32, o16 = Q.Qwen25VLOracle(oc, wq, "fp32"), Q.Qwen25VLOracle(oc, wq, "bf16")
+    ref32 = [o32.prefill(ids)] + [o32.decode_step(t) for t in forced]
+    ref16 = [o16.prefill(ids)] + [o16.decode_step(t) for t in forced]
+    yard = max(float(np.abs(a - b).max()) for a, b in zip(ref16, ref32))
+    worst = max(float(np.abs(a - b).max()) for a, b in zip(got, ref32))
+    moved = max(float(np.abs(a - b).max()) for a, b in zip(got, bf16_run))
+    print(f"fp8 model: max|engine - fp32 oracle(dq)| = {worst:.4f}, oracle bf16-vs-fp32 = {yard:.4f}, "
+          f"fp8 vs unquantised engine = {moved:.4f}")
+    assert worst <= 2.0 * yard
+    assert moved > 4.0 * yard  # the quantisation is really in effect (it moves the logits far more than bf16 noise)
+    # decode stream (fp8 GEMV) vs prefill path (bf16 GEMM on the dequantised copy): one model
+    e.seq_reset(1)
+    full = e.prefill(1, ids + forced[:1], None, *e.rope_index(ids + forced[:1], [])).cpu().numpy()
+    assert float(np.abs(full - got[1]).max()) <= 2.0 * yard
+    # generation runs (graph path) and batched decode (bf16 GEMM on the dequantised copy) agree with the fp8 GEMV path
+    e.seq_reset(0)
+    e.prefill(0, ids, None, pos, delta, want_logits=False)
+    toks = e.generate(0, 6, ignore_eos=True)
+    assert len(toks) == 6
+    e.seq_reset(1)
+    e.prefill(1, ids, None, pos, delta, want_logits=False)
+    lb = e.decode_batch([1], [forced[0]]).cpu().numpy()[0]
+    assert float(np.abs(lb - got[1]).max()) <= 2.0 * yard

@@ -25,6 +25,10 @@ struct ze_linear {
     bf16_t* w = nullptr;
     bf16_t* bias = nullptr;
     int n = 0, k = 0, ld = 0;
+    // fp8 decode copy (ze_weights_quantize_fp8): E4M3 bytes [n, ld8] + per-row scale exponent applied as 2^k
+    uint8_t* w8 = nullptr;
+    float* scale8 = nullptr;
+    int ld8 = 0;
 };
 struct ze_vit_block {
     bf16_t *norm1 = nullptr, *norm2 = nullptr;
@@ -58,6 +62,9 @@ struct ze_engine {
     bf16_t* ln_q = nullptr;
     std::vector<ze_vit_block> vb;
     bf16_t *embed = nullptr, *lm_head = nullptr, *final_norm = nullptr;
+    ze_linear lm_head8;          // fp8 copy of an untied lm_head (w / ld unused)
+    uint8_t* arena8 = nullptr;    // fp8 decode weights (0 until ze_weights_quantize_fp8)
+    bool fp8_ready = false;
     std::vector<ze_text_layer> tl;
 
     // tables

@@ -564,6 +564,7 @@ extern "C" int ze_prefill_batch(ze_engine* e, const int32_t* seqs, int n, const 
 // sequence can be captured once into a hipGraph and replayed.
 // 1: the fused attention block (ze_mega.hip) replaces QKV GEMV + slices + merge + O-proj; 0: the stand-alone kernels
 static int ze_decode_variant(const ze_engine* e) {
+    if (e->fp8_ready) return 0;  // the experimental fused launches stream bf16 rows
     return ((ze_gemv_knobs[3] > 0 && e->attn_blocks > 0) ? 1 : 0) | ((ze_gemv_knobs[4] > 0 && e->mlp_blocks > 0) ? 2 : 0);
 }
 // the fused kernel's bounded spins gave up somewhere in the work enqueued so far (stream must be idle)
@@ -629,6 +630,11 @@ int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos,
         memset(&a, 0, sizeof(a));
         a.W = L.qkv.w;
         a.ldw = L.qkv.ld;
+        if (e->fp8_ready) {
+            a.W8 = L.qkv.w8;
+            a.scale8 = L.qkv.scale8;
+            a.ldw8 = L.qkv.ld8;
+        }
         a.N = nqkv;
         a.K = H;
         a.x = e->dh;
@@ -652,7 +658,7 @@ int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos,
         ze_launch_gemv(ZE_GV_QKV_ROPE, a, s);
         ze_launch_attn_decode(e->dq, 0, e->kc(li, seq), e->vc(li, seq), 0, e->dattn, 0, st, nullptr, 1, c.heads,
                               c.kv_heads, hd, c.max_ctx, scale, e->dpartial, e->max_splits, e->atickets, s);
-        if (ze_gemv_knobs[4] > 0 && e->mlp_blocks > 0) {  // O-proj + MLP of the layer in one launch
+        if (ze_gemv_knobs[4] > 0 && e->mlp_blocks > 0 && !e->fp8_ready) {  // O-proj + MLP of the layer in one launch
             ze_layer_mlp_args m;
             memset(&m, 0, sizeof(m));
             m.wo = L.o.w;
@@ -678,6 +684,11 @@ int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos,
         memset(&o, 0, sizeof(o));
         o.W = L.o.w;
         o.ldw = L.o.ld;
+        if (e->fp8_ready) {
+            o.W8 = L.o.w8;
+            o.scale8 = L.o.scale8;
+            o.ldw8 = L.o.ld8;
+        }
         o.N = H;
         o.K = nq;
         o.x = e->dattn;
@@ -689,6 +700,11 @@ int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos,
         memset(&g, 0, sizeof(g));
         g.W = L.gate_up.w;
         g.ldw = L.gate_up.ld;
+        if (e->fp8_ready) {
+            g.W8 = L.gate_up.w8;
+            g.scale8 = L.gate_up.scale8;
+            g.ldw8 = L.gate_up.ld8;
+        }
         g.N = 2 * e->text_ipad;
         g.K = H;
         g.x = e->dh;
@@ -701,6 +717,11 @@ int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos,
         memset(&d, 0, sizeof(d));
         d.W = L.down.w;
         d.ldw = L.down.ld;
+        if (e->fp8_ready) {
+            d.W8 = L.down.w8;
+            d.scale8 = L.down.scale8;
+            d.ldw8 = L.down.ld8;
+        }
         d.N = H;
         d.K = e->text_ipad;
         d.x = e->dact;
@@ -712,6 +733,11 @@ int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos,
     memset(&a, 0, sizeof(a));
     a.W = e->lm_head;
     a.ldw = H;
+    if (e->fp8_ready && e->lm_head8.w8) {
+        a.W8 = e->lm_head8.w8;
+        a.scale8 = e->lm_head8.scale8;
+        a.ldw8 = e->lm_head8.ld8;
+    }
     a.N = c.vocab;
     a.K = H;
     a.x = e->dh;
@@ -1151,6 +1177,68 @@ extern "C" int ze_op_attention(ze_engine* e, const void* q, const void* k, const
     hipStreamSynchronize(s);
     hipFree(dt);
     if (le != hipSuccess) return ze_fail(e, ZE_ERR_HIP, hipGetErrorString(le));
+    return ZE_OK;
+}
+
+// ================================================================== fp8 decode weights
+static int quantize_linear(ze_engine* e, ze_linear& l, int rows, int cols, uint8_t*& cur8, float*& curs, hipStream_t s) {
+    l.ld8 = (cols + 15) / 16 * 16;
+    l.w8 = cur8;
+    l.scale8 = curs;
+    cur8 += (size_t)rows * l.ld8;
+    curs += rows;
+    ze_launch_quantize_rows(l.w, rows, cols, l.ld, l.w8, l.ld8, l.scale8, s);
+    return ZE_OK;
+}
+
+extern "C" int ze_weights_quantize_fp8(ze_engine* e, void* stream) {
+    if (!e) return ze_fail(e, ZE_ERR_INVALID, "null engine");
+    if (e->fp8_ready) return ZE_OK;
+    const ze_config& c = e->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    const int H = c.hidden, hd = e->head_dim, nq = c.heads * hd, nqkv = nq + 2 * c.kv_heads * hd, ip = e->text_ipad;
+    auto pad16 = [](int x) { return (size_t)((x + 15) / 16 * 16); };
+    size_t bytes = 0, rows = 0;
+    for (int li = 0; li < c.layers; ++li) {
+        bytes += (size_t)nqkv * pad16(H) + (size_t)H * pad16(nq) + (size_t)2 * ip * pad16(H) + (size_t)H * pad16(ip);
+        rows += (size_t)nqkv + H + 2 * ip + H;
+    }
+    const bool head = !c.tie_word_embeddings;  // a tied lm_head is the embedding table: it stays bf16
+    if (head) {
+        bytes += (size_t)c.vocab * pad16(H);
+        rows += c.vocab;
+    }
+    ZE_HIP(hipMalloc((void**)&e->arena8, bytes + rows * sizeof(float) + 256));
+    ZE_HIP(hipMemsetAsync(e->arena8, 0, bytes + rows * sizeof(float) + 256, s));
+    uint8_t* cur8 = e->arena8;
+    float* curs = reinterpret_cast<float*>(e->arena8 + (bytes + 255) / 256 * 256);
+    for (int li = 0; li < c.layers; ++li) {
+        ze_text_layer& L = e->tl[li];
+        quantize_linear(e, L.qkv, nqkv, H, cur8, curs, s);
+        quantize_linear(e, L.o, H, nq, cur8, curs, s);
+        quantize_linear(e, L.gate_up, 2 * ip, H, cur8, curs, s);
+        quantize_linear(e, L.down, H, ip, cur8, curs, s);
+    }
+    if (head) {
+        e->lm_head8.w = e->lm_head;
+        e->lm_head8.ld = H;
+        quantize_linear(e, e->lm_head8, c.vocab, H, cur8, curs, s);
+    }
+    ZE_KCHECK();
+    ZE_HIP(hipStreamSynchronize(s));
+    e->fp8_ready = true;
+    ++ze_tune_epoch;  // captured decode steps hold the bf16 streams
+    return ZE_OK;
+}
+
+extern "C" int ze_op_quantize_fp8(ze_engine* e, void* w_bf16, int rows, int cols, void* q_out, void* scale_out,
+                                  void* stream) {
+    if (!e || !w_bf16 || !q_out || !scale_out || rows <= 0 || cols <= 0 || cols % 16)
+        return ze_fail(e, ZE_ERR_INVALID, "bad argument (cols must be a multiple of 16)");
+    hipSetDevice(e->device);
+    ze_launch_quantize_rows((bf16_t*)w_bf16, rows, cols, cols, (uint8_t*)q_out, cols, (float*)scale_out, (hipStream_t)stream);
+    ZE_KCHECK();
     return ZE_OK;
 }
 

@@ -81,9 +81,17 @@ struct ze_gemv_args {
     // token embedding prologue (layer 0): x = embed[st->token] copied to hidden_out first
     const bf16_t* embed;  // non-null: x := embed row of st->token ; also written to embed_out by block 0
     bf16_t* embed_out;
+    // fp8 weight stream (non-null W8 selects it): E4M3 bytes [N, ldw8], row r dequantises as value * scale8[r]
+    // (scale8 a power of two, so the scaling of a row's dot product is exact)
+    const uint8_t* W8;
+    const float* scale8;
+    int ldw8;
 };
 // returns false when x[K] does not fit the LDS stage
 bool ze_launch_gemv(int epi, const ze_gemv_args& a, hipStream_t s);
+// per-row power-of-two-scale E4M3 quantisation of a bf16 matrix [rows, ld] (cols valid): writes the fp8 bytes
+// [rows, ld8], the scales, and REPLACES the bf16 values by the dequantised ones (exactly representable)
+void ze_launch_quantize_rows(bf16_t* w, int rows, int cols, int ld, uint8_t* q, int ld8, float* scale, hipStream_t s);
 
 // ---- fused decode attention block of one layer (ze_mega.hip): QKV GEMV -> slices -> merge -> O-proj in one launch
 struct ze_grid_barrier {  // zeroed once at engine creation; every word on its own 128-B line

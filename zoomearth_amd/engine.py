@@ -297,6 +297,18 @@ class Engine:
                                                       int(seed) & (2 ** 64 - 1), index, C.byref(tok), self._stream()))
         return int(tok.value)
 
+    def quantize_fp8(self):
+        """Switch the decoder's linear layers to FP8 (E4M3, per-row power-of-two scales): see ze_weights_quantize_fp8."""
+        self._check(self.lib.ze_weights_quantize_fp8(self.h, self._stream()))
+
+    def op_quantize_fp8(self, w: torch.Tensor):
+        """w bf16 [rows, cols] on the device (overwritten with the dequantised values) -> (u8 bits, f32 scales)."""
+        rows, cols = w.shape
+        q = torch.empty((rows, cols), dtype=torch.uint8, device=self.device)
+        sc = torch.empty(rows, dtype=torch.float32, device=self.device)
+        self._check(self.lib.ze_op_quantize_fp8(self.h, _ptr(w), rows, cols, _ptr(q), _ptr(sc), self._stream()))
+        return q, sc
+
     # ------------------------------------------------------------------ unit ops (parity tests)
     def op_linear(self, a, w, bias=None, act: int = 0):
         m, k = a.shape
