@@ -1,0 +1,45 @@
+"""GPU: the one-line JSON contract of bench.py (what the driver parses): keys, types, the roofline and cpu_baseline
+objects, and internal consistency (value = steps / time, frac = achieved / peak)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args, timeout=420):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                       timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    d = run_bench("--gpus", "1", "--steps", "2", "--warmup", "1")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "questions/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]          # batch 1: one question per step
+    assert 0.5 < d["value"] < 10.0
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.3 < r["frac"] < 1.0
+    assert r["traffic"] is None or 0.9 < r["traffic"] / r["bytes_per_launch"] < 1.5
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["unit"] == "questions/s" and c["cores"] >= 1
+    assert c["value"] is None or 0 < c["value"] < d["value"]
+    ph = d["roofline_phases"]
+    assert ph["decode"]["bound"] == "hbm" and ph["vit"]["bound"] == "mfma" and 0 < ph["question"]["frac"] < 1
