@@ -284,17 +284,19 @@ __device__ __forceinline__ void attn_merge_group(float* sW, float* sInv, const f
     const int og = tid >> 5, od = (tid & 31) * 4;
     const int hc = kvh * G + min(og, G - 1);  // idle threads (og >= G) shadow the last head: no branch around loads
     const uint32_t p = (uint32_t)((hc * AD_STRIDE + 4 + od) * 4), step = (uint32_t)(heads * AD_STRIDE * 4);
-    // Everything the merge needs is requested at once -- the (m, l) pairs and the first 16 slices of this thread's
-    // four output dims -- so the last arriver pays one memory round trip, not one per dependent step.
+    // Everything the merge needs is requested at once -- the (m, l) pairs and the first 24 slices of this thread's
+    // four output dims (contexts up to 1536 tokens) -- so the last arriver pays one memory round trip, not one per
+    // dependent step.
     uint4 ml[2];
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
         const int g = min(wid * 2 + hh, G - 1);
         ml[hh] = ad_load16<true>(ws, (uint32_t)((min(lane, nsplit - 1) * heads + kvh * G + g) * AD_STRIDE * 4));
     }
-    uint4 x0[16];
+    constexpr int MB = 24;
+    uint4 x0[MB];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) x0[u] = ad_load16<true>(ws, p + min(u, nsplit - 1) * step);
+    for (int u = 0; u < MB; ++u) x0[u] = ad_load16<true>(ws, p + min(u, nsplit - 1) * step);
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
         const int g = wid * 2 + hh;
@@ -313,7 +315,7 @@ __device__ __forceinline__ void attn_merge_group(float* sW, float* sInv, const f
     const int h = kvh * G + og;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < MB; ++u) {
         if (u < nsplit) {
             const float w = sW[og * 64 + u];
             a0 = fmaf(w, __uint_as_float(x0[u].x), a0);
@@ -322,7 +324,7 @@ __device__ __forceinline__ void attn_merge_group(float* sW, float* sInv, const f
             a3 = fmaf(w, __uint_as_float(x0[u].w), a3);
         }
     }
-    int s = 16;
+    int s = MB;
     for (; s + 8 <= nsplit; s += 8) {
         uint4 x[8];
 #pragma unroll
