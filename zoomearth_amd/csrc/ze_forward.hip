@@ -1137,6 +1137,9 @@ extern "C" int ze_op_linear(ze_engine* e, const void* a, const void* w, const vo
         if (!ze_launch_gemv(ZE_GV_PLAIN, g, s))
             ze_launch_gemm(ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias, nullptr, 0,
                            (bf16_t*)cmat, N, nullptr, M, N, K, s);
+    } else if (act == 2) {  // weight-streaming mode of the batched decode step (rows = chains), for measurements
+        ze_launch_gemm_stream(ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias, nullptr, 0,
+                              (bf16_t*)cmat, N, M, N, K, s);
     } else {
         ze_launch_gemm(act ? ZE_EPI_GELU : ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias,
                        nullptr, 0, (bf16_t*)cmat, N, nullptr, M, N, K, s);
