@@ -84,3 +84,15 @@ def test_attention(tiny_engine, d, heads, kvh, cu, causal):
     # P is rounded to bf16 before the PV product (as HF eager does): allow 2^-7 of the value scale
     assert np.abs(got - want).max() <= 2.0 ** -6 * max(1.0, np.abs(want).max()), np.abs(got - want).max()
     assert np.sqrt(np.mean((got - want) ** 2)) <= 4e-3
+
+
+@pytest.mark.parametrize("d,heads,kvh,t,causal", [(128, 4, 2, 500, True), (128, 4, 4, 500, False), (80, 4, 2, 500, True),
+                                                  (80, 4, 4, 500, False), (80, 2, 2, 130, True)])
+def test_attention_every_instantiation(tiny_engine, d, heads, kvh, t, causal):
+    """All four (D, causal) instantiations at a length with full, partial and (causal) diagonal key tiles.  The D = 80
+    causal one is not on the model's path but caught a compiler problem: hipcc's SLP vectoriser produced wrong rows for
+    it (the kernel is now built with -fno-slp-vectorize)."""
+    q, k, v = rnd(16, (t, heads, d)), rnd(17, (t, kvh, d)), rnd(18, (t, kvh, d))
+    got = tiny_engine.op_attention(to_dev_bf16(q), to_dev_bf16(k), to_dev_bf16(v), [0, t], causal).float().cpu().numpy()
+    want = ref_attention(q, k, v, [0, t], causal)
+    assert np.abs(got - want).max() <= 2.0 ** -6 * max(1.0, np.abs(want).max()), np.abs(got - want).max()

@@ -149,32 +149,22 @@ __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q
         // ---- mask + online softmax for query qi: keys kt + n*16 + fq*4 + r
         float p[NKT][4];
         float mx = -INFINITY;
-        // causal prefill: only the diagonal / last tiles need the per-element mask (wave-uniform test); the compare +
-        // select pair is a quarter of the softmax's VALU work and this kernel is VALU-bound.  (The non-causal D = 80
-        // instantiation produced wrong rows with the unmasked branch -- not understood, so it keeps the mask.)
-        const bool need_mask = !CAUSAL || (kt + BKV > kv_hi) || (kt + BKV - 1 > q0 + wid * 16 + q_pos_offset);
-        if (need_mask) {
+        // (This file is compiled with -fno-slp-vectorize: with hipcc's SLP vectoriser on, the D = 80 instantiations
+        //  produced wrong rows -- first seen behind a fast path that skipped this compare + select pair on fully
+        //  visible tiles, then in the plain D = 80 causal kernel; tools/check_attn.py and
+        //  test_attention_every_instantiation pin all four instantiations.  The fast path was worth 10 % of the
+        //  kernel = 0.2 ms per question and is not worth re-validating.)
 #pragma unroll
-            for (int n = 0; n < NKT; ++n)
+        for (int n = 0; n < NKT; ++n)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int kj = kt + n * 16 + fq * 4 + r;
-                    bool ok = kj < kv_hi;
-                    if (CAUSAL) ok = ok && (kj <= qi + q_pos_offset);
-                    const float sv = ok ? sacc[n][r] * scale_log2e : -INFINITY;
-                    p[n][r] = sv;
-                    mx = fmaxf(mx, sv);
-                }
-        } else {
-#pragma unroll
-            for (int n = 0; n < NKT; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float sv = sacc[n][r] * scale_log2e;
-                    p[n][r] = sv;
-                    mx = fmaxf(mx, sv);
-                }
-        }
+            for (int r = 0; r < 4; ++r) {
+                const int kj = kt + n * 16 + fq * 4 + r;
+                bool ok = kj < kv_hi;
+                if (CAUSAL) ok = ok && (kj <= qi + q_pos_offset);
+                const float sv = ok ? sacc[n][r] * scale_log2e : -INFINITY;
+                p[n][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
