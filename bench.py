@@ -81,13 +81,21 @@ class Chain:
         pv_c, g_c = e.preprocess_image(crop)
         emb_c = e.vit_forward(pv_c, [g_c])  # the view's features are reused (bit-identical, tested)
         # ---- stage 2: cached stage-1 prompt + re-fed stage-1 output + second vision block
-        ids2 = ids1 + out1 + [cfg.vision_start_token_id] + [cfg.image_token_id] * (g_c[1] * g_c[2] // 4) + [cfg.vision_end_token_id]
+        ids2 = ids1 + refeed(cfg, out1) + [cfg.vision_start_token_id] + [cfg.image_token_id] * (g_c[1] * g_c[2] // 4) + [cfg.vision_end_token_id]
         pos2, delta2 = e.rope_index(ids2, [g_v, g_c])
         e.seq_truncate(0, len(ids1))
         e.prefill(0, ids2[len(ids1):], emb_c, pos2[:, len(ids1):], delta2, want_logits=False)
         e.mark_seen(0, ids2)
         out2 = e.generate(0, N2, repetition_penalty=PENALTY, ignore_eos=True, use_graph=self.use_graph, sync_every=N2)
         return out1, out2, len(ids1), len(ids2)
+
+
+def refeed(cfg, toks):
+    """Generated ids as they re-enter the stage-2 prompt.  The reference decodes with skip_special_tokens=True and
+    re-tokenises (src/eval/infer.py:122,222), so special ids never come back; with random weights the argmax can be a
+    special id (e.g. <|image_pad|>, which would desynchronise the image-token count): map those to a plain id."""
+    lo = min([cfg.image_token_id, cfg.vision_start_token_id, cfg.vision_end_token_id, cfg.pad_token_id, *cfg.eos_token_ids])
+    return [t if t < lo else 1000 for t in toks]
 
 
 class BatchChain(Chain):
@@ -128,7 +136,7 @@ class BatchChain(Chain):
         off, ids2s, embs, pos2s, d2s = 0, [], [], [], []
         for b in range(B):
             n_c = grids[b][1] * grids[b][2] // 4
-            ids2 = ids1[b] + out1[b] + [cfg.vision_start_token_id] + [cfg.image_token_id] * n_c + [cfg.vision_end_token_id]
+            ids2 = ids1[b] + refeed(cfg, out1[b]) + [cfg.vision_start_token_id] + [cfg.image_token_id] * n_c + [cfg.vision_end_token_id]
             pos2, delta2 = e.rope_index(ids2, [g_v, grids[b]])
             e.seq_truncate(b, len(ids1[b]))
             ids2s.append(ids2)

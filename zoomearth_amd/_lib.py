@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzoomearth_hip.so")
+LIB_PATH = os.environ.get("ZE_LIB_PATH") or os.path.join(_HERE, "libzoomearth_hip.so")  # ZE_LIB_PATH: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
 
 ZE_F32, ZE_F16, ZE_BF16 = 0, 1, 2

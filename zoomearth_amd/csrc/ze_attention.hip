@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q
         // ---- mask + online softmax for query qi: keys kt + n*16 + fq*4 + r
         float p[NKT][4];
         float mx = -INFINITY;
-        // (This file is compiled with -fno-slp-vectorize: with hipcc's SLP vectoriser on, the D = 80 instantiations
+        // (The library is compiled with -fno-slp-vectorize: with hipcc's SLP vectoriser on, the D = 80 instantiations
         //  produced wrong rows -- first seen behind a fast path that skipped this compare + select pair on fully
         //  visible tiles, then in the plain D = 80 causal kernel; tools/check_attn.py and
         //  test_attention_every_instantiation pin all four instantiations.  The fast path was worth 10 % of the
