@@ -259,76 +259,3 @@ void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_rs, int q_hs
     }
 #undef FA_LAUNCH
 }
-
-// ------------------------------------------------------------------ decode attention (D = 128)
-// Flash-decoding over the KV cache of one chain: grid = (kv_heads, max_splits); a block owns one 64-token slice
-// of the context for ALL q heads of its kv head (K/V are read once per kv head).  Three phases per 64-token round,
-// each thread issuing all its global loads up front (the kernel is latency-, not bandwidth-bound: 1-2 MB per layer):
-//   A  16-lane groups take 4 tokens each: 4 K + 4 V 16-B loads in flight per lane; 32 (token, head) partial dots per
-//      lane are reduced across the 16 lanes with a halving butterfly (30 shuffles instead of 128); V goes to LDS.
-//   B  softmax statistics per head over the 64 scores (one wave handles two heads, wavefront max / sum).
-//   C  thread (head, 4-dim slice) accumulates sum_t p[t] * V[t] from LDS: no cross-thread reduction at the end.
-// Partials (m, l, o[128]) per (split, head) go to a workspace; k_attn_decode_combine merges the splits.
-// (Measured alternative, rejected: merging in the last-arriving slice block -- sc1 partial stores + ticket + agent
-//  acquire, as the split-K GEMM does -- removed the combine launch but cost 30 ms more per question: the acquire
-//  and the re-read of 90 KB of partials through memory are slower than the 4.8-us combine kernel.)
-#include "ze_attn_decode.h"
-
-__global__ void __launch_bounds__(256) k_attn_decode_split(const bf16_t* __restrict__ q, int q_row_stride,
-                                                           const bf16_t* __restrict__ kcache,
-                                                           const bf16_t* __restrict__ vcache, size_t cache_seq_stride,
-                                                           const ze_seq_dev* __restrict__ st_base,
-                                                           const int* __restrict__ seq_ids, int heads, int kv_heads,
-                                                           int max_ctx, float scale_log2e, float* __restrict__ ws,
-                                                           int max_splits, unsigned* __restrict__ tickets,
-                                                           bf16_t* __restrict__ out, int out_row_stride) {
-    // chain of this block (grid.z): batched decode indexes the chain table, single-chain decode passes its state
-    const int bz = blockIdx.z;
-    const ze_seq_dev* st = seq_ids ? st_base + seq_ids[bz] : st_base;
-    if (seq_ids) {
-        kcache += (size_t)seq_ids[bz] * cache_seq_stride;
-        vcache += (size_t)seq_ids[bz] * cache_seq_stride;
-    }
-    __shared__ ad_split_lds L;
-    const int ctx = st->ctx + 1, kvh = blockIdx.x;
-    int chunk, nsplit;
-    split_geometry(ctx, max_splits, chunk, nsplit);
-    if ((int)blockIdx.y >= nsplit) return;  // workgroup-uniform: no slice, no ticket
-    float* wsb = ws + (size_t)bz * max_splits * heads * AD_STRIDE;
-    attn_split_body<false, true>(L, q + (size_t)bz * q_row_stride, kcache, vcache, ctx, kvh, blockIdx.y, heads, kv_heads,
-                                 max_ctx, scale_log2e, wsb, max_splits);
-    // ---- merge by the last-arriving slice of this (chain, kv head).  Hand-off without fences: the partials above
-    // went out write-through (sc1), every storing wave drains, the workgroup barriers, ONE lane takes a ticket
-    // (relaxed agent-scope add on one unsharded counter); the workgroup whose add came last reads every partial
-    // with sc1 loads, in slice order, so the result does not depend on who is last.  The ticket returns to 0 for
-    // the next launch.  (With an agent-scope acquire fence + plain loads in place of the sc1 pair this merge cost
-    // 30 ms per question MORE than a separate merge launch; in this form it replaces that 4.8-us launch.)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    unsigned* flag = reinterpret_cast<unsigned*>(&L.sM[0]);  // the slice LDS is dead now
-    if (threadIdx.x == 0) {
-        unsigned* t = tickets + (size_t)bz * kv_heads + kvh;
-        const unsigned old = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned last = old == (unsigned)nsplit - 1u;
-        if (last) __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *flag = last;
-    }
-    __syncthreads();
-    if (*flag == 0u) return;
-    __syncthreads();  // everybody has read the flag before the merge reuses the LDS
-    float* sW = reinterpret_cast<float*>(&L.sV[0][0]);
-    attn_merge_group(sW, sW + AD_GMAX * 64, wsb, ctx, kvh, heads, kv_heads, max_splits,
-                     out + (size_t)bz * out_row_stride);
-}
-
-void ze_launch_attn_decode(const bf16_t* q, int q_row_stride, const bf16_t* kcache, const bf16_t* vcache,
-                           size_t cache_seq_stride, bf16_t* out, int out_row_stride, const ze_seq_dev* st,
-                           const int* seq_ids, int n, int heads, int kv_heads, int D, int max_ctx, float scale,
-                           float* ws_partial, int max_splits, unsigned* tickets, hipStream_t s) {
-    (void)D;
-    const float sl = scale * 1.4426950408889634f;
-    k_attn_decode_split<<<dim3(kv_heads, max_splits, n), 256, 0, s>>>(q, q_row_stride, kcache, vcache, cache_seq_stride,
-                                                                       st, seq_ids, heads, kv_heads, max_ctx, sl,
-                                                                       ws_partial, max_splits, tickets, out,
-                                                                       out_row_stride);
-}
