@@ -196,6 +196,15 @@ int ze_prefill_batch(ze_engine* e, const int32_t* seqs, int n, const int32_t* le
 int ze_decode_batch(ze_engine* e, const int32_t* seqs, int n, const int32_t* tokens, float* out_logits, void* stream);
 int ze_generate_batch(ze_engine* e, const int32_t* seqs, int n, const ze_gen_params* p, int32_t* out_tokens,
                       int32_t* n_out, void* stream);
+/* Rollout scoring (replaces _get_per_token_logps, src/train/RL/src/open-r1-multimodal/src/open_r1/trainer/
+ * grpo_trainer.py:494-504, as the trainer calls it under torch.no_grad for the old policy and the reference model,
+ * :660-683): ze_prefill of the sequence, plus, for EVERY position t < len - 1,
+ *   out_logps[t] = log_softmax(logits[t])[input_ids[t + 1]]
+ * with logits[t] the lm_head output in bf16 (as HF's bf16 lm_head returns it) and the log-softmax in fp32.
+ * out_logps: device f32 [len - 1].  The chain is left as after ze_prefill (KV cache filled, last-position logits
+ * ready), so a generation can continue from it.  Arguments as ze_prefill. */
+int ze_score(ze_engine* e, int seq, const int32_t* input_ids, int len, const void* image_embeds, int n_image_rows,
+             const int32_t* position_ids, int rope_delta, float* out_logps, void* stream);
 /* Marks every id in `ids` (host int32) as seen for the repetition penalty of `seq` (the prompt). */
 int ze_seq_mark_seen(ze_engine* e, int seq, const int32_t* ids, int n, void* stream);
 /* Applies penalty + argmax to f32 logits [vocab] (device) with the seen-set of `seq`; *out_token host. */
@@ -227,6 +236,10 @@ int ze_op_linear(ze_engine* e, const void* a_bf16, const void* w_bf16, const voi
 /* y = weight * bf16(x * rsqrt(mean(x^2)+eps))  (HF:...modeling_qwen2_5_vl.py:64-79), rows x cols bf16. */
 int ze_op_rmsnorm(ze_engine* e, const void* x_bf16, const void* weight_bf16, void* y_bf16, int rows, int cols,
                   float eps, void* stream);
+/* out[r] = log_softmax(logits[r, :vocab])[targets[r]] in fp32 (the pick of ze_score): logits bf16 [rows, ld] device
+ * (ld >= vocab, ld % 8 == 0), targets int32 [rows] device, out f32 [rows] device. */
+int ze_op_token_logprob(ze_engine* e, const void* logits_bf16, int rows, int vocab, int ld, const int32_t* targets,
+                        float* out, void* stream);
 /* Varlen attention over segments: q,k,v,o bf16 [T, heads, D] (D = 80 or 128); cu_seqlens host int32 [n_seg+1];
  * causal applies inside each segment; kv_heads divides heads (GQA). */
 int ze_op_attention(ze_engine* e, const void* q, const void* k, const void* v, void* o, int T, int heads,

@@ -393,8 +393,7 @@ class Qwen25VLOracle:
         # lm_head in model dtype, then the fp32 copy (HF:generation/utils.py:2894)
         return self.r(hn_last @ self.w["lm_head.weight"].T).astype(np.float32)
 
-    def prefill(self, input_ids, pixel_values=None, grid_thw=None, image_embeds=None, return_layers=False):
-        """Single sequence (no padding).  Returns fp32 logits [vocab] of the last position."""
+    def _prefill_hidden(self, input_ids, pixel_values=None, grid_thw=None, image_embeds=None, return_layers=False):
         self.reset()
         ids = np.asarray(input_ids, dtype=np.int64)
         if image_embeds is None and pixel_values is not None:
@@ -408,10 +407,25 @@ class Qwen25VLOracle:
             pos3 = np.tile(np.arange(len(ids))[None, :], (3, 1))
             self.rope_delta = 0
         h = self.embed(ids, image_embeds)
-        out = self.text_forward(h, pos3, return_layers=return_layers)
+        return self.text_forward(h, pos3, return_layers=return_layers)
+
+    def prefill(self, input_ids, pixel_values=None, grid_thw=None, image_embeds=None, return_layers=False):
+        """Single sequence (no padding).  Returns fp32 logits [vocab] of the last position."""
+        out = self._prefill_hidden(input_ids, pixel_values, grid_thw, image_embeds, return_layers)
         hn = out[0] if return_layers else out
         lg = self.logits(hn[-1])
         return (lg, out[1]) if return_layers else lg
+
+    def per_token_logps(self, input_ids, pixel_values=None, grid_thw=None, image_embeds=None):
+        """Log-probability of every next id, fp32 [len - 1]: logits[:-1].log_softmax(-1).gather(ids[1:]) as
+        `_get_per_token_logps` computes it (src/train/RL/src/open-r1-multimodal/src/open_r1/trainer/
+        grpo_trainer.py:494-504); the logits are the lm_head output in model dtype, the log-softmax is fp32."""
+        ids = np.asarray(input_ids, dtype=np.int64)
+        hn = self._prefill_hidden(ids, pixel_values, grid_thw, image_embeds)
+        lg = self.r(hn[:-1] @ self.w["lm_head.weight"].T).astype(np.float32)
+        m = lg.max(axis=-1)
+        lse = m + np.log(np.exp(lg - m[:, None]).sum(axis=-1, dtype=np.float32))
+        return (lg[np.arange(len(ids) - 1), ids[1:]] - lse).astype(np.float32)
 
     def decode_step(self, token: int):
         p = self.ctx + self.rope_delta

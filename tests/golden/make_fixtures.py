@@ -360,6 +360,49 @@ def make_tiny_chain():
     print("tiny_chain.npz", os.path.getsize(os.path.join(HERE, "tiny_chain.npz")))
 
 
+# ----------------------------------------------------------------------------- 6. rollout scoring
+def make_score():
+    """Per-token log-probs of the tiny chain's stage-2 sequence, computed with the HF model the way
+    `_get_per_token_logps` does (src/train/RL/src/open-r1-multimodal/src/open_r1/trainer/grpo_trainer.py:494-504)."""
+    import torch
+    from PIL import Image
+
+    from hf_bridge import hf_model
+
+    infer = load_ref("src/eval/infer.py", "ref_infer")
+    cfg = qwen25vl.tiny_config()
+    w = qwen25vl.synthetic_weights(cfg, seed=CHAIN["weight_seed"], std=CHAIN["std"], matrix_gain=CHAIN["matrix_gain"],
+                                   bias_std=CHAIN["bias_std"], norm_jitter=CHAIN["norm_jitter"])
+    chain = np.load(os.path.join(HERE, "tiny_chain.npz"))
+    tile = prng.synthetic_tile(CHAIN["tile_seed"], CHAIN["tile_h"], CHAIN["tile_w"])
+    pil_tile = Image.fromarray(tile)
+    view, _ = infer.resize_image(pil_tile)
+    crop, _ = infer.resize_image(infer.cut_image(pil_tile, CHAIN["bbox"]))
+    pv_v, g_v = frontend.image_to_pixel_values(np.array(view))
+    pv_c, g_c = frontend.image_to_pixel_values(np.array(crop))
+    ids = chain["ids2"].tolist() + chain["s2_tokens_fp32"].tolist()
+    t = torch.tensor([ids])
+    out = dict(ids=np.array(ids), prompt_len=np.array(len(chain["ids2"])))
+    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        m = hf_model(cfg, w, dt)
+        with torch.no_grad():
+            logits = m(input_ids=t, attention_mask=torch.ones_like(t),
+                       pixel_values=torch.from_numpy(np.concatenate([pv_v, pv_c])),
+                       image_grid_thw=torch.tensor([list(g_v), list(g_c)]),
+                       mm_token_type_ids=(t == cfg.image_token_id).int()).logits
+        lp = torch.gather(logits[0, :-1].log_softmax(dim=-1), 1, t[0, 1:].unsqueeze(1)).squeeze(1)
+        out[f"logps_{name}"] = lp.float().numpy()
+        if dt == torch.bfloat16:  # the same bf16 logits with the log-softmax in fp32 (what ze_score returns)
+            lp32 = torch.gather(logits[0, :-1].float().log_softmax(dim=-1), 1, t[0, 1:].unsqueeze(1)).squeeze(1)
+            out["logps_bf16_logits_fp32_softmax"] = lp32.numpy()
+    o32 = qwen25vl.Qwen25VLOracle(cfg, w, "fp32")
+    mine = o32.per_token_logps(ids, np.concatenate([pv_v, pv_c]), [g_v, g_c])
+    print("oracle fp32 vs HF fp32 max|d|", float(np.abs(mine - out["logps_fp32"]).max()),
+          "HF bf16 vs fp32 max|d|", float(np.abs(out["logps_bf16"] - out["logps_fp32"]).max()))
+    np.savez_compressed(os.path.join(HERE, "score.npz"), **out)
+    print("score.npz", os.path.getsize(os.path.join(HERE, "score.npz")))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["host", "bicubic", "indices", "pixels", "chain"]
     if "host" in which:
@@ -372,3 +415,5 @@ if __name__ == "__main__":
         make_pixel_values()
     if "chain" in which:
         make_tiny_chain()
+    if "score" in which:
+        make_score()

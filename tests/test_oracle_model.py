@@ -92,3 +92,23 @@ def test_bf16_round():
     y = qwen25vl.bf16_round(x)
     assert y.tolist() == [1.0, 1.0, 1.015625, -3.140625, 65536.0, np.inf]
     assert np.isnan(qwen25vl.bf16_round(np.array([np.nan], dtype=np.float32)))[0]
+
+
+def test_per_token_logps_match_reference(chain, golden_npz):
+    """Rollout scoring (`_get_per_token_logps`, grpo_trainer.py:494-504): oracle vs the HF fixture score.npz."""
+    z, c, cfg, w, tile = chain
+    s = golden_npz("score.npz")
+    view, crop = _views(c, tile)
+    pv_v, g_v = frontend.image_to_pixel_values(view)
+    pv_c, g_c = frontend.image_to_pixel_values(crop)
+    ids = s["ids"].tolist()
+    assert ids == z["ids2"].tolist() + z["s2_tokens_fp32"].tolist()
+    pv = np.concatenate([pv_v, pv_c])
+    got32 = qwen25vl.Qwen25VLOracle(cfg, w, "fp32").per_token_logps(ids, pv, [g_v, g_c])
+    assert got32.shape == (len(ids) - 1,)
+    assert np.abs(got32 - s["logps_fp32"]).max() < 5e-5
+    got16 = qwen25vl.Qwen25VLOracle(cfg, w, "bf16").per_token_logps(ids, pv, [g_v, g_c])
+    hf_err = np.abs(s["logps_bf16_logits_fp32_softmax"] - s["logps_fp32"]).max()
+    assert np.abs(got16 - s["logps_fp32"]).max() <= 1.5 * hf_err
+    # HF's own bf16 log-softmax output is the fp32-softmax value rounded to bf16
+    assert np.abs(s["logps_bf16"] - s["logps_bf16_logits_fp32_softmax"]).max() <= 2.0 ** -7 * np.abs(s["logps_bf16"]).max()

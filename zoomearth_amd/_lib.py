@@ -85,6 +85,9 @@ _SIGS = {
     "ze_seq_len": (C.c_int, [_P, C.c_int]),
     "ze_prefill": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.c_int, _P, C.c_int, C.POINTER(C.c_int32), C.c_int,
                              _P, _P]),
+    "ze_score": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.c_int, _P, C.c_int, C.POINTER(C.c_int32), C.c_int,
+                           _P, _P]),
+    "ze_op_token_logprob": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "ze_prefill_batch": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P,
                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
     "ze_decode_step": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),

@@ -353,9 +353,9 @@ extern "C" int ze_seq_mark_seen(ze_engine* e, int seq, const int32_t* ids, int n
 }
 
 // ================================================================== prefill
-extern "C" int ze_prefill(ze_engine* e, int seq, const int32_t* input_ids, int len, const void* image_embeds,
-                          int n_image_rows, const int32_t* position_ids, int rope_delta, float* out_logits,
-                          void* stream) {
+static int prefill_impl(ze_engine* e, int seq, const int32_t* input_ids, int len, const void* image_embeds,
+                        int n_image_rows, const int32_t* position_ids, int rope_delta, float* out_logits,
+                        float* out_logps, void* stream) {
     ZE_TRY(check_seq(e, seq));
     if (!input_ids || !position_ids || len <= 0) return ze_fail(e, ZE_ERR_INVALID, "bad prefill arguments");
     const ze_config& c = e->cfg;
@@ -427,6 +427,22 @@ extern "C" int ze_prefill(ze_engine* e, int seq, const int32_t* input_ids, int l
     a.out_f32 = e->dlogits + (size_t)seq * c.vocab;
     a.D = hd;
     ze_launch_gemv(ZE_GV_LOGITS, a, s);
+    if (out_logps && len > 1) {
+        // every position: final norm, lm_head GEMM in row chunks (bf16 logits as HF's lm_head gives them), then the
+        // log-softmax pick of the next id.  The logits live in the (now free) MLP activation workspace.
+        const int ldl = (c.vocab + 7) & ~7;
+        int chunk = (int)std::min<size_t>((size_t)e->prefill_rows * e->text_ipad / ldl, (size_t)len - 1);
+        if (chunk >= 128) chunk &= ~127;
+        if (chunk < 1) return ze_fail(e, ZE_ERR_NOMEM, "prefill workspace too small for one row of logits");
+        ZE_HIP(hipMemcpyAsync(e->trow_aux, input_ids + 1, (size_t)(len - 1) * sizeof(int), hipMemcpyHostToDevice, s));
+        ze_launch_rmsnorm(e->th, H, e->final_norm, e->ty, H, len - 1, H, c.rms_eps, s);
+        for (int r0 = 0; r0 < len - 1; r0 += chunk) {
+            const int m = std::min(chunk, len - 1 - r0);
+            ze_launch_gemm(ZE_EPI_NONE, e->ty + (size_t)r0 * H, H, e->lm_head, H, nullptr, nullptr, 0, e->ta, ldl,
+                           nullptr, m, c.vocab, H, s);
+            ze_launch_token_logprob(e->ta, ldl, c.vocab, e->trow_aux + r0, out_logps + r0, m, s);
+        }
+    }
     ze_timer_end(e, th, s);
     ZE_KCHECK();
     if (out_logits)
@@ -435,6 +451,21 @@ extern "C" int ze_prefill(ze_engine* e, int seq, const int32_t* input_ids, int l
     e->ctx_host[seq] = past + len;
     e->delta_host[seq] = rope_delta;
     return push_state(e, seq, s, input_ids[len - 1], 0, 0);
+}
+
+extern "C" int ze_prefill(ze_engine* e, int seq, const int32_t* input_ids, int len, const void* image_embeds,
+                          int n_image_rows, const int32_t* position_ids, int rope_delta, float* out_logits,
+                          void* stream) {
+    return prefill_impl(e, seq, input_ids, len, image_embeds, n_image_rows, position_ids, rope_delta, out_logits,
+                        nullptr, stream);
+}
+
+extern "C" int ze_score(ze_engine* e, int seq, const int32_t* input_ids, int len, const void* image_embeds,
+                        int n_image_rows, const int32_t* position_ids, int rope_delta, float* out_logps,
+                        void* stream) {
+    if (!out_logps) return ze_fail(e, ZE_ERR_INVALID, "ze_score needs an output buffer");
+    return prefill_impl(e, seq, input_ids, len, image_embeds, n_image_rows, position_ids, rope_delta, nullptr,
+                        out_logps, stream);
 }
 
 // Prefill of n chains in one pass: all rows share every GEMM, attention and the KV append go per chain.
@@ -1144,6 +1175,16 @@ extern "C" int ze_op_linear(ze_engine* e, const void* a, const void* w, const vo
         ze_launch_gemm(act ? ZE_EPI_GELU : ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias,
                        nullptr, 0, (bf16_t*)cmat, N, nullptr, M, N, K, s);
     }
+    ZE_KCHECK();
+    return ZE_OK;
+}
+
+extern "C" int ze_op_token_logprob(ze_engine* e, const void* logits, int rows, int vocab, int ld, const int32_t* targets,
+                                   float* out, void* stream) {
+    if (!logits || !targets || !out || rows < 0 || vocab <= 0 || ld < vocab || ld % 8)
+        return ze_fail(e, ZE_ERR_INVALID, "bad token_logprob arguments");
+    hipSetDevice(e->device);
+    ze_launch_token_logprob((const bf16_t*)logits, ld, vocab, targets, out, rows, (hipStream_t)stream);
     ZE_KCHECK();
     return ZE_OK;
 }

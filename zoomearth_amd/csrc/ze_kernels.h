@@ -169,6 +169,8 @@ void ze_launch_embed_tokens_batch(const ze_seq_dev* st, const int* seq_ids, int 
 void ze_launch_rope_kv_batch(bf16_t* qkv, int n, int heads, int kv_heads, int D, const bf16_t* cosT, const bf16_t* sinT,
                              const ze_seq_dev* st, const int* seq_ids, bf16_t* kcache, bf16_t* vcache,
                              size_t cache_seq_stride, int max_ctx, hipStream_t s);
+void ze_launch_token_logprob(const bf16_t* logits, int ld, int vocab, const int* targets, float* out, int rows,
+                             hipStream_t s);
 void ze_launch_sample_batch(const float* logits, int vocab, uint8_t* seen_base, float penalty, ze_seq_dev* st,
                             const int* seq_ids, int n, const int* eos_ids, int n_eos, int pad_id, int ignore_eos,
                             int advance_ctx, int sample, int32_t* out_tokens_base, int max_gen, float* ws,

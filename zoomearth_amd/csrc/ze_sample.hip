@@ -337,3 +337,59 @@ void ze_launch_multinomial(const float* logits, int vocab, const uint8_t* seen_b
     k_multinomial_pick<<<n, 256, 0, s>>>(logits, vocab, seen_base, st, seq_ids, slot0, penalty, temperature, seed,
                                          ws_part, ws_sum);
 }
+
+// ----------------------------------------------------------------------------------------------------------------
+// Per-token log-probabilities of given targets (rollout scoring: replaces logits.log_softmax(-1).gather(ids) of
+// _get_per_token_logps, src/train/RL/.../open_r1/trainer/grpo_trainer.py:494-504).  One workgroup per row of bf16
+// logits; two passes over the row (maximum, then sum of expf(l - max)), both with a fixed reduction order, so the
+// result is a function of the row alone.  out[r] = l[target] - max - logf(sum).
+__global__ void __launch_bounds__(256) k_token_logprob(const bf16_t* __restrict__ logits, int ld, int vocab,
+                                                       const int* __restrict__ targets, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bf16_t* row = logits + (size_t)r * ld;
+    const int nv = vocab / 8;  // 16-byte groups (ld % 8 == 0)
+    float m = -INFINITY;
+    for (int g = tid; g < nv; g += 256) {
+        const uint4 q = *(const uint4*)(row + (size_t)g * 8);
+        const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            m = fmaxf(m, __uint_as_float(u[j] << 16));
+            m = fmaxf(m, __uint_as_float(u[j] & 0xffff0000u));
+        }
+    }
+    for (int i = nv * 8 + tid; i < vocab; i += 256) m = fmaxf(m, bf16_to_f32(row[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) red[w] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int g = tid; g < nv; g += 256) {
+        const uint4 q = *(const uint4*)(row + (size_t)g * 8);
+        const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sum += expf(__uint_as_float(u[j] << 16) - m);
+            sum += expf(__uint_as_float(u[j] & 0xffff0000u) - m);
+        }
+    }
+    for (int i = nv * 8 + tid; i < vocab; i += 256) sum += expf(bf16_to_f32(row[i]) - m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) red[w] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+        const int t = targets[r];
+        out[r] = (t >= 0 && t < vocab) ? bf16_to_f32(row[t]) - m - logf(tot) : 0.f;
+    }
+}
+
+void ze_launch_token_logprob(const bf16_t* logits, int ld, int vocab, const int* targets, float* out, int rows,
+                             hipStream_t s) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(k_token_logprob, dim3(rows), dim3(256), 0, s, logits, ld, vocab, targets, out);
+}

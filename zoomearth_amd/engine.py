@@ -226,6 +226,31 @@ class Engine:
                                         _ptr(logits), self._stream()))
         return logits
 
+    def score(self, seq: int, new_ids, image_embeds, position_ids, rope_delta: int):
+        """prefill() plus the log-probability of every next id: returns f32 [len(new_ids) - 1] with
+        out[t] = log_softmax(logits[t])[new_ids[t + 1]] (ze_score; replaces _get_per_token_logps of the reference's
+        GRPO trainer)."""
+        ids, ip = _i32(new_ids)
+        pos, pp = _i32(position_ids)
+        assert pos.shape == (3, len(ids))
+        n_img = 0 if image_embeds is None else int(image_embeds.shape[0])
+        if image_embeds is not None:
+            assert image_embeds.dtype == torch.bfloat16 and image_embeds.is_contiguous()
+        out = torch.empty(max(len(ids) - 1, 0), dtype=torch.float32, device=self.device)
+        self._check(self.lib.ze_score(self.h, seq, ip, len(ids), _ptr(image_embeds), n_img, pp, rope_delta,
+                                      _ptr(out) if len(ids) > 1 else _ptr(torch.empty(1, dtype=torch.float32, device=self.device)),
+                                      self._stream()))
+        return out
+
+    def op_token_logprob(self, logits: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+        """log_softmax(logits, -1).gather(targets) in fp32 for bf16 logits [rows, vocab] (row stride % 8 == 0)."""
+        assert logits.dtype == torch.bfloat16 and logits.dim() == 2 and logits.stride(1) == 1
+        assert targets.dtype == torch.int32 and targets.is_contiguous()
+        out = torch.empty(logits.shape[0], dtype=torch.float32, device=self.device)
+        self._check(self.lib.ze_op_token_logprob(self.h, _ptr(logits), logits.shape[0], logits.shape[1],
+                                                 logits.stride(0), _ptr(targets), _ptr(out), self._stream()))
+        return out
+
     def prefill_batch(self, seqs, ids_list, embeds_list, pos_list, deltas):
         """One prefill pass for several chains (rows of all chains share every GEMM).  Per chain i: ids_list[i] (new
         token ids), embeds_list[i] (bf16 [rows, hidden] or None), pos_list[i] (int32 [3, len]), deltas[i].  Each

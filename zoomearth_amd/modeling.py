@@ -104,6 +104,44 @@ class ZoomEarthForConditionalGeneration:
         self._next_slot = (self._next_slot + 1) % self.engine.max_seqs
         return slot, 0
 
+    # ------------------------------------------------------------------ rollout scoring
+    @torch.no_grad()
+    def per_token_logps(self, input_ids, attention_mask=None, pixel_values=None, image_grid_thw=None,
+                        image_keys=None, **kw):
+        """Log-probability of every token given its prefix: f32 [B, L - 1], column t = log p(input_ids[:, t + 1]).
+        Same result layout as `_get_per_token_logps(model, input_ids, attention_mask, pixel_values=...,
+        image_grid_thw=...)` of the reference's GRPO trainer (src/train/RL/src/open-r1-multimodal/src/open_r1/
+        trainer/grpo_trainer.py:494-504), which it calls without gradients for the old policy and the reference
+        model (:660-683).  Padded positions (attention_mask 0) are skipped, their columns are 0."""
+        e, cfg = self.engine, self.config
+        ids_cpu = input_ids.cpu().numpy()
+        mask = attention_mask.cpu().numpy().astype(bool) if attention_mask is not None else np.ones_like(ids_cpu, bool)
+        grids = image_grid_thw.cpu().numpy().tolist() if image_grid_thw is not None else []
+        keys = list(image_keys) if image_keys is not None else [None] * len(grids)
+        rows_per = [g[0] * g[1] * g[2] for g in grids]
+        offs = np.concatenate([[0], np.cumsum(rows_per)]).astype(int)
+        out = torch.zeros((ids_cpu.shape[0], max(ids_cpu.shape[1] - 1, 0)), dtype=torch.float32, device=e.device)
+        self._chains.clear()  # scoring uses slot 0 as scratch
+        gi = 0
+        for b in range(ids_cpu.shape[0]):
+            valid = np.nonzero(mask[b])[0]
+            ids = ids_cpu[b][valid].astype(np.int64).tolist()
+            is_img = np.asarray(ids) == cfg.image_token_id
+            n_img = int((is_img & ~np.concatenate([[False], is_img[:-1]])).sum())
+            my = list(range(gi, gi + n_img))
+            gi += n_img
+            if gi > len(grids):
+                raise ValueError("Image features and image tokens do not match")
+            if len(ids) < 2:
+                continue
+            feats = [self._features(pixel_values[offs[i]:offs[i + 1]], grids[i], keys[i]) for i in my]
+            emb = (torch.cat(feats) if len(feats) > 1 else feats[0]) if feats else None
+            pos, delta = e.rope_index(ids, [grids[i] for i in my])
+            e.seq_reset(0)
+            lp = e.score(0, ids, emb, pos, delta)
+            out[b, torch.as_tensor(valid[1:] - 1, device=e.device)] = lp
+        return out.to(input_ids.device) if input_ids.device.type != "cpu" else out.cpu()
+
     # ------------------------------------------------------------------ generate
     @torch.no_grad()
     def generate(self, input_ids=None, attention_mask=None, pixel_values=None, image_grid_thw=None,
