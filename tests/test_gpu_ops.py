@@ -46,6 +46,27 @@ def test_linear(tiny_engine, m, n, k, bias, act):
         close_bf16(got, want, scale=0.05 * np.sqrt(k) * 0.05)
 
 
+@pytest.mark.parametrize("m,n,k,bias", [
+    (1, 2560, 2048, True), (8, 2048, 2048, False), (17, 200, 128, True), (33, 72, 352, True), (64, 2560, 2048, True),
+    (64, 3584, 3584, False), (64, 22016, 2048, False), (48, 2048, 11008, False), (65, 512, 256, True),
+])
+def test_linear_weight_streaming(tiny_engine, m, n, k, bias):
+    """The launcher of the batched decode step (rows = chains): the skinny MFMA kernel for short narrow matrices,
+    the split-K ring otherwise.  Same one-rounding contract as test_linear; a row's result must not depend on which
+    other rows share the launch (bit-identical alone and in the batch), and repeats are bit-identical."""
+    a, w = rnd(6, (m, k)), rnd(7, (n, k), 0.05)
+    b = rnd(8, (n,), 0.5) if bias else None
+    da, dw, db = to_dev_bf16(a), to_dev_bf16(w), to_dev_bf16(b) if bias else None
+    got_t = tiny_engine.op_linear(da, dw, db, 2)
+    got = got_t.float().cpu().numpy()
+    want = a.astype(np.float64) @ w.astype(np.float64).T + (b.astype(np.float64) if bias else 0.0)
+    close_bf16(got, want, scale=0.05 * np.sqrt(k) * 0.05)
+    assert torch.equal(got_t, tiny_engine.op_linear(da, dw, db, 2))
+    for r in {0, m // 2, m - 1}:
+        alone = tiny_engine.op_linear(da[r:r + 1].contiguous(), dw, db, 2)
+        assert torch.equal(alone[0], got_t[r]), r
+
+
 @pytest.mark.parametrize("rows,cols", [(5, 160), (1296, 1280), (3, 2048), (64, 512)])
 def test_rmsnorm(tiny_engine, rows, cols):
     x, w = rnd(4, (rows, cols), 2.0), bf16_round(1.0 + rnd(5, (cols,), 0.1))

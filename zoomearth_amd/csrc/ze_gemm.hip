@@ -17,7 +17,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define GEMM_BK 64
 
-extern int ze_gemv_knobs[8];  // [6]: 0 = shipped policy, 1 = register-staged kernel everywhere, 2 = ring wherever it applies
+extern int ze_gemv_knobs[8];  // [5]: 1 = no skinny kernel in the weight-streaming launcher; [6]: 0 = shipped policy, 1 = register-staged kernel everywhere, 2 = ring wherever it applies
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
@@ -390,6 +390,136 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
     gemm_finish<BM, BN, EPI, WM, WN>(acc, smem, bias, R, ldr, C, ldc, c_rows, M, N, ksplit, ks, bid, nwg, bm0, bn0, slab, tickets);
 }
 
+
+// ----------------------------------------------------------------------------------------------------------------
+// Skinny GEMM of the batched decode step: M <= 64 rows (one per chain), every weight byte read ONCE, straight from
+// HBM into MFMA operand registers (no LDS staging, no barrier in the loop -- the GEMV of the single-chain step with
+// the matrix cores doing the 64 dot products).  A workgroup owns BN = 16 * TN weight rows over its K range; its four
+// waves split that range (a quarter each, whole 32-deep MFMA slices), every wave multiplies its quarter against all
+// live 16-row tiles of the activations, which it reads from L2 in fragment layout (16 B per lane, like the weights).
+// The four partial tiles meet in LDS and are added in wave order; split-K slices across workgroups (long K: the
+// down projection) then go through the slab / ticket reduction of gemm_finish.  The order of every sum is a function
+// of (K, ksplit) alone, so a chain's result does not depend on how many chains share the step.
+template <int TN, int CH>
+struct skinny_frag {
+    bf16x8 a[CH][4], b[CH][TN];
+};
+
+template <int TN, int EPI>
+__global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
+                                                     int ldw, const bf16_t* __restrict__ bias,
+                                                     const bf16_t* __restrict__ R, int ldr, bf16_t* __restrict__ C,
+                                                     int ldc, int M, int N, int K, int ksplit,
+                                                     float* __restrict__ slab, unsigned* __restrict__ tickets) {
+    constexpr int BN = 16 * TN, CH = (TN == 1) ? 4 : 2;  // MFMA slices per prefetch chunk
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int nwg = (N + BN - 1) / BN;
+    const int ks = blockIdx.x / nwg, bid = blockIdx.x % nwg;
+    const int bn0 = bid * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int mt = (M + 15) >> 4;  // live 16-row tiles of the activations (1..4)
+
+    // 32-deep slices: this workgroup's share of K, then this wave's quarter of it
+    const int s_wg = (K / 32) / ksplit;
+    const int base = s_wg >> 2, rem = s_wg & 3;
+    const int s0 = ks * s_wg + wid * base + min(wid, rem), ns = base + (wid < rem ? 1 : 0);
+
+    const bf16_t* wp[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) wp[j] = W + (size_t)min(bn0 + j * 16 + fr, N - 1) * ldw + fq * 8;
+    const bf16_t* ap[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ap[i] = A + (size_t)min(i * 16 + fr, M - 1) * lda + fq * 8;
+
+    f32x4 acc[4][TN];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto load = [&](skinny_frag<TN, CH>& f, int s) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int k = (s + c) * 32;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)  // streamed once: non-temporal
+                f.b[c][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[j] + k));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < mt) f.a[c][i] = *reinterpret_cast<const bf16x8*>(ap[i] + k);
+        }
+    };
+    auto mac = [&](const skinny_frag<TN, CH>& f) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < mt) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[c][i], f.b[c][j], acc[i][j], 0, 0, 0);
+                }
+    };
+    const int nch = ns / CH;
+    {
+        skinny_frag<TN, CH> f0, f1;
+        if (nch > 0) load(f0, s0);
+        int c = 0;
+        for (; c + 2 <= nch; c += 2) {
+            load(f1, s0 + (c + 1) * CH);
+            mac(f0);
+            if (c + 2 < nch) load(f0, s0 + (c + 2) * CH);
+            mac(f1);
+        }
+        if (c < nch) mac(f0);
+    }
+    for (int s = s0 + nch * CH; s < s0 + ns; ++s) {  // fewer than CH slices left
+        const int k = s * 32;
+        bf16x8 fb[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[j] + k));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < mt) {
+                const bf16x8 fa = *reinterpret_cast<const bf16x8*>(ap[i] + k);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+            }
+    }
+
+    // the four K quarters meet in LDS: [wave][row tile][column tile][lane] float4; wave w then owns row tile w
+    f32x4* red = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < mt) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) red[((wid * 4 + i) * TN + j) * 64 + lane] = acc[i][j];
+        }
+    __syncthreads();
+    f32x4 out[1][TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (wid < mt) {
+            v = red[((0 * 4 + wid) * TN + j) * 64 + lane];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) {
+                const f32x4 t = red[((q * 4 + wid) * TN + j) * 64 + lane];
+                v[0] += t[0];
+                v[1] += t[1];
+                v[2] += t[2];
+                v[3] += t[3];
+            }
+        }
+        out[0][j] = v;
+    }
+    __syncthreads();  // gemm_finish reuses the LDS for its ticket flag
+    gemm_finish<64, BN, EPI, 4, 1>(out, smem, bias, R, ldr, C, ldc, nullptr, M, N, ksplit, ks, bid, nwg, 0, bn0, slab, tickets);
+}
+
 // split-K workspace (fp32 slabs + per-tile tickets), owned by the engine and passed once
 static float* g_slab = nullptr;
 static unsigned* g_tickets = nullptr;
@@ -506,9 +636,47 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
 #undef ZE_GEMM_LAUNCH
 }
 
+// Batched decode: the skinny kernel when the shape allows (M <= 64, whole MFMA slices), else the ring.
+template <int TN>
+static void launch_skinny(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
+                          int ldr, bf16_t* C, int ldc, int M, int N, int K, int ksplit, hipStream_t s) {
+    const int grid = ze_cdiv(N, 16 * TN) * ksplit;
+    const size_t lds = (size_t)16 * TN * 1024;
+#define ZE_SKINNY_LAUNCH(E)                                                                                        \
+    do {                                                                                                           \
+        static bool attr_set = false;                                                                              \
+        if (!attr_set) {                                                                                           \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<TN, E>),                              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
+            attr_set = true;                                                                                       \
+        }                                                                                                          \
+        hipLaunchKernelGGL((k_gemm_skinny<TN, E>), dim3(grid), dim3(256), lds, s, A, lda, W, ldw, bias, R, ldr, C, \
+                           ldc, M, N, K, ksplit, g_slab, g_tickets);                                               \
+    } while (0)
+    switch (epi) {
+        case ZE_EPI_NONE: ZE_SKINNY_LAUNCH(ZE_EPI_NONE); break;
+        case ZE_EPI_GELU: ZE_SKINNY_LAUNCH(ZE_EPI_GELU); break;
+        case ZE_EPI_RESIDUAL: ZE_SKINNY_LAUNCH(ZE_EPI_RESIDUAL); break;
+        case ZE_EPI_F32: ZE_SKINNY_LAUNCH(ZE_EPI_F32); break;
+        default: break;  // SWIGLU pairs 16-row blocks: never routed here
+    }
+#undef ZE_SKINNY_LAUNCH
+}
+
 void ze_launch_gemm_stream(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,
                            const bf16_t* R, int ldr, bf16_t* C, int ldc, int M, int N, int K, hipStream_t s) {
     if (M <= 0 || N <= 0) return;
+    // Short, narrow weight matrices (qkv, o: K <= 4096, N <= 4096): the skinny kernel, 16 weight rows per workgroup,
+    // no split-K (measured, device time per launch at 8 / 64 chains: qkv 9.8 / 13.9 us against 15.0 / 15.6 on the
+    // ring, o 8.9 / 12.9 against 14.0 / 14.9).  With 64 rows per workgroup it loses everywhere the ring streams well
+    // (gate/up 43.9 against 27.5 us at 64 chains: its 16-row x 64-B fragment loads use the vector memory path at a
+    // fraction of what the LDS-DMA's 128-B rows do), so wide or long matrices stay on the ring.  The choice is a
+    // function of (N, K, epilogue) alone: batch-composition invariance.
+    if (M <= 64 && K % 32 == 0 && K <= 4096 && N <= 4096 && epi != ZE_EPI_SWIGLU && ze_gemv_knobs[5] != 1 &&
+        (lda % 8) == 0 && (ldw % 8) == 0) {
+        launch_skinny<1>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, 1, s);
+        return;
+    }
     launch_cfg<64, 64>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s, true);
 }
 
