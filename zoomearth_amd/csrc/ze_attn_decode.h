@@ -16,10 +16,24 @@ __device__ __forceinline__ void split_geometry(int ctx, int max_splits, int& chu
 
 // LDS of one slice block (carved by the caller so fused kernels can share their LDS)
 struct ad_split_lds {
-    __attribute__((aligned(16))) bf16_t sV[AD_TOK][128];  // 16 KB
-    float sS[AD_TOK][AD_GMAX];                              // scores, then probabilities
-    float sM[AD_GMAX], sL[AD_GMAX];
+    __attribute__((aligned(16))) uint8_t sK[AD_TOK * 256];  // K tile image (ad_off layout), 16 KB
+    __attribute__((aligned(16))) uint8_t sV[AD_TOK * 256];  // V tile image, 16 KB
 };
+
+typedef __attribute__((ext_vector_type(8))) __bf16 ad_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float ad_f32x4;
+typedef short ad_v4s __attribute__((ext_vector_type(4)));
+typedef short ad_v8s __attribute__((ext_vector_type(8)));
+
+// LDS image of a [64 keys][128 d] bf16 tile with 256-byte rows: byte offset of 16-B chunk ch (0..15) of row `row`
+// (the image of the prefill flash kernel, ze_attention.hip: conflict-free for the ds_read_b128 row reads of K as an
+// MFMA operand and for the ds_read_b64_tr_b16 transposed reads of V^T).
+__device__ __forceinline__ int ad_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+__device__ __forceinline__ uint32_t ad_pack_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
 
 // FRESH: q / K / V / partials cross workgroups INSIDE the running launch (fused layer kernel): every such access
 // is a write-through (sc1) store or an L1-bypassing (sc1) load.  Arithmetic is identical in both forms.
@@ -73,43 +87,42 @@ __device__ __forceinline__ void attn_split_body(ad_split_lds& L, const bf16_t* _
                                                 const bf16_t* __restrict__ kcache, const bf16_t* __restrict__ vcache,
                                                 int ctx, int kvh, int split, int heads, int kv_heads, int max_ctx,
                                                 float scale_log2e, float* __restrict__ ws, int max_splits) {
+    // One slice of the context for the (up to) 8 q heads of a kv head, on the matrix cores with the SWAPPED products
+    // of the prefill kernel: S^T = K Q^T (16 keys x 16 head columns per MFMA tile, columns >= G are zero queries),
+    // O^T = V^T P^T.  Per 64-key round: every thread stages 4 K + 4 V 16-B pieces into the two LDS images; EVERY
+    // wave then forms the whole S^T of the round (16 MFMAs -- redundant across the four waves, which keeps the
+    // softmax statistics of a head lane-local plus two shuffles and needs no cross-wave exchange) and owns two of
+    // the eight 16-d tiles of O^T (4 MFMAs, V^T fragments by ds_read_b64_tr_b16, P from the accumulator straight
+    // into the B operand, rounded to bf16 as HF's eager attention rounds it).  Replaces 131 k fp32 FMAs per round
+    // on the vector ALUs (the slice kernel spent about 2 us of its 11.5 there).
     constexpr int D = 128;
-    auto& sV = L.sV;
-    auto& sS = L.sS;
-    auto& sM = L.sM;
-    auto& sL = L.sL;
     const int G = heads / kv_heads;
     int chunk, nsplit;
     split_geometry(ctx, max_splits, chunk, nsplit);
     if (split >= nsplit) return;
     const int t0 = split * chunk, t1 = min(ctx, t0 + chunk);
-    const int tid = threadIdx.x, gid = tid >> 4, li = tid & 15, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, gid = tid >> 4, li = tid & 15, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
 
-    // q of the (up to) 8 heads of this kv head, this lane's 8 dims, pre-scaled by scale*log2(e)
-    float qv[AD_GMAX][8];
+    // Q^T fragments: lane (head column fr, k-group fq) holds d = ks*32 + fq*8 .. +7 of its head
+    ad_bf16x8 qf[4];
 #pragma unroll
-    for (int g = 0; g < AD_GMAX; ++g) {
+    for (int ks = 0; ks < 4; ++ks) {
         uint4 u = make_uint4(0, 0, 0, 0);
-        if (g < G) u = ad_load16<FRESH>(q, (uint32_t)(((kvh * G + g) * D + li * 8) * 2));
-        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            qv[g][2 * j] = bf16lo(w[j]) * scale_log2e;
-            qv[g][2 * j + 1] = bf16hi(w[j]) * scale_log2e;
-        }
+        if (fr < G) u = ad_load16<FRESH>(q, (uint32_t)(((kvh * G + fr) * D + (ks * 4 + fq) * 8) * 2));
+        qf[ks] = *reinterpret_cast<const ad_bf16x8*>(&u);
     }
     const bf16_t* kb = kcache + (size_t)kvh * max_ctx * D;  // wave-uniform bases, per-lane byte offsets
     const bf16_t* vb = vcache + (size_t)kvh * max_ctx * D;
-    // phase-C ownership: head og, dims od..od+3
-    const int og = tid >> 5, od = (tid & 31) * 4;
-    float m_run = -INFINITY, l_run = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    ad_f32x4 oacc[2] = {ad_f32x4{0.f, 0.f, 0.f, 0.f}, ad_f32x4{0.f, 0.f, 0.f, 0.f}};
+    float m_run = -INFINITY, l_run = 0.f;
 
     for (int base = t0; base < t1; base += AD_TOK) {
-        // ---------------- phase A: loads first
-        // Only the newest row was written inside this launch (sc1 stores of the fused QKV phase) and is read with
-        // sc1 loads; every older row comes from earlier launches and is read the way the stand-alone kernel reads
-        // it.  The newest row is fetched once per lane up front (workgroup-uniform branch) and selected in, so the
-        // eight row loads below stay free of per-lane control flow.
+        // ---------------- loads first.  Only the newest row was written inside this launch (sc1 stores of the fused
+        // QKV phase) and is read with sc1 loads; every older row comes from earlier launches.  The newest row is
+        // fetched once per lane up front (workgroup-uniform branch) and selected in, so the eight row loads below
+        // stay free of per-lane control flow.
         uint4 kn = make_uint4(0, 0, 0, 0), vn = make_uint4(0, 0, 0, 0);
         const int tn = ctx - 1;
         if (FRESH && tn >= base && tn < base + AD_TOK) {
@@ -134,101 +147,98 @@ __device__ __forceinline__ void attn_split_body(ad_split_lds& L, const bf16_t* _
                 vu[i] = vn;
             }
         }
-        float v[32];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const uint32_t kw[4] = {ku[i].x, ku[i].y, ku[i].z, ku[i].w};
-            float kf[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                kf[2 * j] = bf16lo(kw[j]);
-                kf[2 * j + 1] = bf16hi(kw[j]);
-            }
-#pragma unroll
-            for (int g = 0; g < AD_GMAX; ++g) {
-                float s = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) s = fmaf(qv[g][j], kf[j], s);
-                v[i * 8 + g] = s;
-            }
-            *reinterpret_cast<uint4*>(&sV[gid + 16 * i][li * 8]) = vu[i];
-        }
-        // halving butterfly over the 16 lanes of the group: lane li ends with the totals of idx 2*li, 2*li+1
-        {
-            const bool b8 = li & 8, b4 = li & 4, b2 = li & 2, b1 = li & 1;
-            float w16[16], w8[8], w4[4], w2[2];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float keep = b8 ? v[16 + k] : v[k], send = b8 ? v[k] : v[16 + k];
-                w16[k] = keep + __shfl_xor(send, 8, 64);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float keep = b4 ? w16[8 + k] : w16[k], send = b4 ? w16[k] : w16[8 + k];
-                w8[k] = keep + __shfl_xor(send, 4, 64);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float keep = b2 ? w8[4 + k] : w8[k], send = b2 ? w8[k] : w8[4 + k];
-                w4[k] = keep + __shfl_xor(send, 2, 64);
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const float keep = b1 ? w4[2 + k] : w4[k], send = b1 ? w4[k] : w4[2 + k];
-                w2[k] = keep + __shfl_xor(send, 1, 64);
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int idx = 2 * li + k, i = idx >> 3, g = idx & 7;
-                const int tl = gid + 16 * i;
-                sS[tl][g] = (base + tl < t1) ? w2[k] : -INFINITY;
-            }
+            *reinterpret_cast<uint4*>(L.sK + ad_off(gid + 16 * i, li)) = ku[i];
+            *reinterpret_cast<uint4*>(L.sV + ad_off(gid + 16 * i, li)) = vu[i];
         }
         __syncthreads();
-        // ---------------- phase B: per-head max / sum over the 64 scores; wave w handles heads 2w, 2w+1
+        // ---------------- S^T = K Q^T: 4 key tiles x 4 steps of 32 d
+        ad_f32x4 sacc[4];
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int g = wid * 2 + hh;
-            const float s = sS[lane][g];
-            const float mx = wave_max(s);
-            const float p = (mx == -INFINITY) ? 0.f : exp2f(s - mx);
-            const float sum = wave_sum(p);
-            sS[lane][g] = p;
-            if (lane == 0) {
-                sM[g] = mx;
-                sL[g] = sum;
+        for (int n = 0; n < 4; ++n) sacc[n] = ad_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const uint4 ka = *reinterpret_cast<const uint4*>(L.sK + ad_off(n * 16 + fr, ks * 4 + fq));
+                sacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const ad_bf16x8*>(&ka), qf[ks],
+                                                                 sacc[n], 0, 0, 0);
+            }
+        // ---------------- online softmax of head fr over keys base + n*16 + fq*4 + r
+        float p[4][4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = base + n * 16 + fq * 4 + r < t1;
+                const float sv = ok ? sacc[n][r] * scale_log2e : -INFINITY;
+                p[n][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = exp2f(m_run - m_use);  // m_run = -inf -> 0
+        float rs = 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(p[n][r] - m_use);  // arguments <= 0
+                p[n][r] = e;
+                rs += e;
+            }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            oacc[jj][0] *= alpha;
+            oacc[jj][1] *= alpha;
+            oacc[jj][2] *= alpha;
+            oacc[jj][3] *= alpha;
+        }
+        // ---------------- O^T += V^T P^T for this wave's d-tiles 2*wid, 2*wid + 1: per 32-key step the lane's 8 keys
+        // are (ks*32 + fq*4 + 0..3) and (ks*32 + 16 + fq*4 + 0..3), the same permutation on both operands
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint32_t pw[4];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                pw[2 * h2] = ad_pack_bf16(p[2 * ks + h2][0], p[2 * ks + h2][1]);
+                pw[2 * h2 + 1] = ad_pack_bf16(p[2 * ks + h2][2], p[2 * ks + h2][3]);
+            }
+            const uint4 pq = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+            const ad_bf16x8 pb = *reinterpret_cast<const ad_bf16x8*>(&pq);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * wid + jj;
+                const int tq = fr >> 2, tp = fr & 3;
+                const int r0a = ks * 32 + fq * 4, r0b = r0a + 16;
+                const int ch = j * 2 + (tp >> 1), half = 8 * (tp & 1);
+                const ad_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) ad_v4s*)(L.sV + ad_off(r0a + tq, ch) + half));
+                const ad_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) ad_v4s*)(L.sV + ad_off(r0b + tq, ch) + half));
+                const ad_v8s va = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                oacc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const ad_bf16x8*>(&va), pb, oacc[jj],
+                                                                  0, 0, 0);
             }
         }
-        __syncthreads();
-        // ---------------- phase C: o[og][od..od+3] += sum_t p[t][og] * V[t][od..]
-        {
-            const float mr = sM[og], lr = sL[og];
-            const float mn = fmaxf(m_run, mr);
-            const float mu = (mn == -INFINITY) ? 0.f : mn;
-            const float a_old = exp2f(m_run - mu), a_new = exp2f(mr - mu);
-            float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-#pragma unroll 16
-            for (int t = 0; t < AD_TOK; ++t) {
-                const float p = sS[t][og];
-                const uint2 vv = *reinterpret_cast<const uint2*>(&sV[t][od]);
-                c0 = fmaf(p, bf16lo(vv.x), c0);
-                c1 = fmaf(p, bf16hi(vv.x), c1);
-                c2 = fmaf(p, bf16lo(vv.y), c2);
-                c3 = fmaf(p, bf16hi(vv.y), c3);
-            }
-            o0 = o0 * a_old + c0 * a_new;
-            o1 = o1 * a_old + c1 * a_new;
-            o2 = o2 * a_old + c2 * a_new;
-            o3 = o3 * a_old + c3 * a_new;
-            l_run = l_run * a_old + lr * a_new;
-            m_run = mn;
-        }
-        __syncthreads();  // sS / sV are rewritten by the next round
+        __syncthreads();  // the images are rewritten by the next round (and reused by the caller after the last)
     }
-    if (og < G) {
-        const uint32_t dst = (uint32_t)((split * heads + kvh * G + og) * AD_STRIDE * 4);
-        if ((tid & 31) == 0) ad_store16<PUB>(ws, dst, m_run, l_run, 0.f, 0.f);
-        ad_store16<PUB>(ws, dst + (4 + od) * 4, o0, o1, o2, o3);
+    // partial of head fr: (m, l) and O[d = (2*wid + jj)*16 + fq*4 .. +3]
+    if (fr < G) {
+        const uint32_t dst = (uint32_t)((split * heads + kvh * G + fr) * AD_STRIDE * 4);
+        if (wid == 0 && fq == 0) ad_store16<PUB>(ws, dst, m_run, l_run, 0.f, 0.f);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+            ad_store16<PUB>(ws, dst + (uint32_t)((4 + (2 * wid + jj) * 16 + fq * 4) * 4), oacc[jj][0], oacc[jj][1],
+                            oacc[jj][2], oacc[jj][3]);
     }
 }
 

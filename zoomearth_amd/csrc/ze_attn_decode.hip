@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) k_attn_decode_split(const bf16_t* __restr
     // 30 ms per question MORE than a separate merge launch; in this form it replaces that 4.8-us launch.)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    unsigned* flag = reinterpret_cast<unsigned*>(&L.sM[0]);  // the slice LDS is dead now
+    unsigned* flag = reinterpret_cast<unsigned*>(&L.sV[0]);  // the slice LDS is dead now
     if (threadIdx.x == 0) {
         unsigned* t = tickets + (size_t)bz * kv_heads + kvh;
         const unsigned old = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) k_attn_decode_split(const bf16_t* __restr
     __syncthreads();
     if (*flag == 0u) return;
     __syncthreads();  // everybody has read the flag before the merge reuses the LDS
-    float* sW = reinterpret_cast<float*>(&L.sV[0][0]);
+    float* sW = reinterpret_cast<float*>(&L.sK[0]);
     attn_merge_group(sW, sW + AD_GMAX * 64, wsb, ctx, kvh, heads, kv_heads, max_splits,
                      out + (size_t)bz * out_row_stride);
 }
