@@ -7,10 +7,13 @@
 #define AD_GMAX 8
 #define AD_STRIDE 132  // floats per (split, head) partial: m, l, pad, pad, o[128]
 #define AD_TOK 64
+#ifndef AD_MINCHUNK
+#define AD_MINCHUNK 64  // tokens per slice, at least (a multiple of AD_TOK)
+#endif
 
 __device__ __forceinline__ void split_geometry(int ctx, int max_splits, int& chunk, int& nsplit) {
     chunk = (ctx + max_splits - 1) / max_splits;
-    chunk = (chunk + AD_TOK - 1) / AD_TOK * AD_TOK;
+    chunk = (chunk + AD_MINCHUNK - 1) / AD_MINCHUNK * AD_MINCHUNK;
     nsplit = (ctx + chunk - 1) / chunk;
 }
 
@@ -284,6 +287,7 @@ __device__ __forceinline__ void attn_combine_body(float* sW, float* sInvp, const
 // wave w computes the slice weights of heads 2w, 2w+1 (lane = slice), then thread (head og, dims od..od+3)
 // accumulates in slice order -- per output element the arithmetic of attn_combine_body.  Partials are read with
 // sc1 loads (they were published sc1 inside this launch).  sW: [AD_GMAX][64] floats, sInv: [AD_GMAX].
+template <int MB = 24>
 __device__ __forceinline__ void attn_merge_group(float* sW, float* sInv, const float* __restrict__ ws, int ctx, int kvh,
                                                  int heads, int kv_heads, int max_splits, bf16_t* __restrict__ out) {
     constexpr int D = 128;
@@ -303,7 +307,6 @@ __device__ __forceinline__ void attn_merge_group(float* sW, float* sInv, const f
         const int g = min(wid * 2 + hh, G - 1);
         ml[hh] = ad_load16<true>(ws, (uint32_t)((min(lane, nsplit - 1) * heads + kvh * G + g) * AD_STRIDE * 4));
     }
-    constexpr int MB = 24;
     uint4 x0[MB];
 #pragma unroll
     for (int u = 0; u < MB; ++u) x0[u] = ad_load16<true>(ws, p + min(u, nsplit - 1) * step);

@@ -19,6 +19,10 @@
 //  and the re-read of 90 KB of partials through memory are slower than the 4.8-us combine kernel.)
 #include "ze_attn_decode.h"
 
+// MB: slices whose partials the merging workgroup requests up front (24 covers 1536 tokens in one round trip: the
+// single-chain step, where the launch is latency-bound; 8 keeps the kernel at 4 workgroups per CU for the batched
+// step, where it is throughput-bound).  The merge adds the slices in the same order either way.
+template <int MB>
 __global__ void __launch_bounds__(256) k_attn_decode_split(const bf16_t* __restrict__ q, int q_row_stride,
                                                            const bf16_t* __restrict__ kcache,
                                                            const bf16_t* __restrict__ vcache, size_t cache_seq_stride,
@@ -62,7 +66,7 @@ __global__ void __launch_bounds__(256) k_attn_decode_split(const bf16_t* __restr
     if (*flag == 0u) return;
     __syncthreads();  // everybody has read the flag before the merge reuses the LDS
     float* sW = reinterpret_cast<float*>(&L.sK[0]);
-    attn_merge_group(sW, sW + AD_GMAX * 64, wsb, ctx, kvh, heads, kv_heads, max_splits,
+    attn_merge_group<MB>(sW, sW + AD_GMAX * 64, wsb, ctx, kvh, heads, kv_heads, max_splits,
                      out + (size_t)bz * out_row_stride);
 }
 
@@ -72,8 +76,14 @@ void ze_launch_attn_decode(const bf16_t* q, int q_row_stride, const bf16_t* kcac
                            float* ws_partial, int max_splits, unsigned* tickets, hipStream_t s) {
     (void)D;
     const float sl = scale * 1.4426950408889634f;
-    k_attn_decode_split<<<dim3(kv_heads, max_splits, n), 256, 0, s>>>(q, q_row_stride, kcache, vcache, cache_seq_stride,
-                                                                       st, seq_ids, heads, kv_heads, max_ctx, sl,
-                                                                       ws_partial, max_splits, tickets, out,
-                                                                       out_row_stride);
+    if (seq_ids)
+        k_attn_decode_split<8><<<dim3(kv_heads, max_splits, n), 256, 0, s>>>(q, q_row_stride, kcache, vcache,
+                                                                              cache_seq_stride, st, seq_ids, heads, kv_heads,
+                                                                              max_ctx, sl, ws_partial, max_splits, tickets,
+                                                                              out, out_row_stride);
+    else
+        k_attn_decode_split<24><<<dim3(kv_heads, max_splits, n), 256, 0, s>>>(q, q_row_stride, kcache, vcache,
+                                                                               cache_seq_stride, st, seq_ids, heads,
+                                                                               kv_heads, max_ctx, sl, ws_partial, max_splits,
+                                                                               tickets, out, out_row_stride);
 }
