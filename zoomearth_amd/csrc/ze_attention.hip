@@ -2,8 +2,7 @@
 //  * k_flash_attn<D, CAUSAL>: varlen flash attention on MFMA 16x16x32 bf16 for the ViT (D = 80, window / full
 //    segments, non-causal) and for the LLM prefill (D = 128, causal GQA; K19).  Tiles come from a
 //    host-built list so one launch covers ragged segments.
-//  * k_attn_decode_split / k_attn_decode_combine: one-token GQA attention over the KV cache (K19 at q = 1):
-//    flash-decoding split over the context so K/V are read once per kv head (shared by its q heads).
+//  (The one-token decode attention lives in ze_attn_decode.hip / ze_attn_decode.h.)
 // Replaces: SDPA / eager_attention_forward as called at HF:models/qwen2_5_vl/modeling_qwen2_5_vl.py:225-291
 // (vision) and :670-689 (text); softmax in fp32, P rounded to bf16 for the PV MFMA (as eager does, :202).
 #include "ze_kernels.h"

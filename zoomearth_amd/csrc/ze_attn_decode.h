@@ -1,4 +1,4 @@
-// Device bodies of the one-token (decode) attention, shared by the stand-alone kernels (ze_attention.hip) and the
+// Device bodies of the one-token (decode) attention, shared by the stand-alone kernel (ze_attn_decode.hip) and the
 // fused per-layer kernel (ze_mega.hip).  Same arithmetic in both; the FRESH form moves cross-workgroup data with
 // sc1 (write-through / L1-bypassing) accesses so it can be handed over inside a running launch.
 #pragma once

@@ -6,17 +6,15 @@
 #include "ze_kernels.h"
 
 // ------------------------------------------------------------------ decode attention (D = 128)
-// Flash-decoding over the KV cache of one chain: grid = (kv_heads, max_splits); a block owns one 64-token slice
-// of the context for ALL q heads of its kv head (K/V are read once per kv head).  Three phases per 64-token round,
-// each thread issuing all its global loads up front (the kernel is latency-, not bandwidth-bound: 1-2 MB per layer):
-//   A  16-lane groups take 4 tokens each: 4 K + 4 V 16-B loads in flight per lane; 32 (token, head) partial dots per
-//      lane are reduced across the 16 lanes with a halving butterfly (30 shuffles instead of 128); V goes to LDS.
-//   B  softmax statistics per head over the 64 scores (one wave handles two heads, wavefront max / sum).
-//   C  thread (head, 4-dim slice) accumulates sum_t p[t] * V[t] from LDS: no cross-thread reduction at the end.
-// Partials (m, l, o[128]) per (split, head) go to a workspace; k_attn_decode_combine merges the splits.
-// (Measured alternative, rejected: merging in the last-arriving slice block -- sc1 partial stores + ticket + agent
-//  acquire, as the split-K GEMM does -- removed the combine launch but cost 30 ms more per question: the acquire
-//  and the re-read of 90 KB of partials through memory are slower than the 4.8-us combine kernel.)
+// Flash-decoding over the KV cache of one chain: grid = (kv_heads, max_splits, chains); a block owns one 64-token
+// slice of the context for ALL q heads of its kv head (K/V are read once per kv head).  Per 64-token round every
+// thread issues its 4 K + 4 V 16-B loads up front (the kernel is latency-, not bandwidth-bound at one chain: 1-2 MB
+// per layer), stages them into two LDS images and the slice runs on the matrix cores (attn_split_body: S^T = K Q^T,
+// online softmax per head lane-locally, O^T = V^T P^T).  Partials (m, l, o[128]) per (split, head) go to a
+// workspace and are merged by the last-arriving slice block of the (chain, kv head) in the same launch.
+// (History: the slice as fp32 FMAs on the vector ALUs with a halving-butterfly reduction cost 11.5 us per launch
+//  against 8.1 now; a separate merge launch before that 7.4 + 4.8 us; the in-launch merge with an agent-scope
+//  acquire fence + plain loads instead of the sc1 pair cost 30 ms per question MORE than the separate launch.)
 #include "ze_attn_decode.h"
 
 // MB: slices whose partials the merging workgroup requests up front (24 covers 1536 tokens in one round trip: the
