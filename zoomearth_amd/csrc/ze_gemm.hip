@@ -286,6 +286,20 @@ __device__ __forceinline__ void ring_issue(const bf16_t* __restrict__ G, int ld,
     }
 }
 
+// one 1-KiB piece (8 rows x 128 B) of a stage image: group `grp` of operand G
+__device__ __forceinline__ void ring_issue_one(const bf16_t* __restrict__ G, int ld, int row0, int row_max, int k0,
+                                               unsigned lds_img, int grp, int lane) {
+    const int row = grp * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    const bf16_t* src = G + (size_t)min(row0 + row, row_max) * ld + k0 + c * 8;
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_img + grp * 1024)
+        : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void ring_wait() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -299,7 +313,7 @@ __device__ __forceinline__ void ring_wait() {
     else static_assert(N == 0, "add the literal");
 }
 
-template <int BM, int BN, int STAGES, int EPI, int WM = 2, int WN = 2>
+template <int BM, int BN, int STAGES, int EPI, int WM = 2, int WN = 2, bool SPREAD = false>
 __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
                                                    int ldw, const bf16_t* __restrict__ bias,
                                                    const bf16_t* __restrict__ R, int ldr, bf16_t* __restrict__ C,
@@ -309,7 +323,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
     constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN), NT = 64 * WM * WN;
     constexpr int STAGE_BYTES = (BM + BN) * 128;
     constexpr int LPW = (BM + BN) / 8 / (WM * WN);  // DMA instructions per wave per stage
-    static_assert(STAGES == 3 || STAGES == 4, "ring depth");
+    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
@@ -362,7 +376,14 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
         else if (ahead == 1) ring_wait<LPW>();
         else ring_wait<0>();
         __builtin_amdgcn_s_barrier();
-        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+        // SPREAD: the refill DMAs of this K-step go out between the rows of MFMAs below instead of in one burst
+        // behind the barrier (every wave of the workgroup issuing its pieces at once leaves the matrix pipe idle
+        // for the length of the burst)
+        const bool more = kt + STAGES - 1 < nk;
+        if (!SPREAD && more) issue(kt + STAGES - 1);
+        constexpr int LPA = BM / 8 / (WM * WN);  // pieces of the A image per wave
+        const unsigned img_next = smem_lds + ((kt + STAGES - 1) % STAGES) * STAGE_BYTES;
+        const int k_next = (kt0 + kt + STAGES - 1) * GEMM_BK;
         const uint8_t* imgA = smem + (kt % STAGES) * STAGE_BYTES;
         const uint8_t* imgB = imgA + BM * 128;
 #pragma unroll
@@ -380,10 +401,23 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
                 fb[j] = *reinterpret_cast<const bf16x8*>(imgB + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                if (SPREAD && more) {
+                    const int r = kk * TM + i;  // row of MFMAs just issued, of 2 * TM per K-step
+#pragma unroll
+                    for (int pc = 0; pc < LPW; ++pc)
+                        if (pc * (2 * TM) / LPW == r) {
+                            if (pc < LPA)
+                                ring_issue_one(A, lda, bm0, M - 1, k_next, img_next, wid + pc * (NT / 64), lane);
+                            else
+                                ring_issue_one(W, ldw, bn0, N - 1, k_next, img_next + BM * 128,
+                                               wid + (pc - LPA) * (NT / 64), lane);
+                        }
+                }
+            }
         }
     }
     __syncthreads();  // the tail reuses the staging LDS
@@ -532,6 +566,34 @@ void ze_gemm_set_workspace(float* slab, size_t slab_floats, unsigned* tickets, i
     g_ticket_cap = ticket_cap;
 }
 
+// one ring instantiation without split-K, every epilogue
+template <int BM, int BN, int ST, int WM, int WN, bool SPR>
+static void launch_ring_variant(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,
+                                const bf16_t* R, int ldr, bf16_t* C, int ldc, const int* c_rows, int M, int N, int K,
+                                hipStream_t s) {
+    const int grid = ze_cdiv(M, BM) * ze_cdiv(N, BN);
+    const size_t lds = (size_t)(BM + BN) * 128 * ST;
+#define ZE_RINGV_LAUNCH(E)                                                                                          \
+    do {                                                                                                            \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) {                                                                                            \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<BM, BN, ST, E, WM, WN, SPR>),            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+            attr_set = true;                                                                                        \
+        }                                                                                                           \
+        hipLaunchKernelGGL((k_gemm_ring<BM, BN, ST, E, WM, WN, SPR>), dim3(grid), dim3(64 * WM * WN), lds, s, A,    \
+                           lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, 1, g_slab, g_tickets);               \
+    } while (0)
+    switch (epi) {
+        case ZE_EPI_NONE: ZE_RINGV_LAUNCH(ZE_EPI_NONE); break;
+        case ZE_EPI_GELU: ZE_RINGV_LAUNCH(ZE_EPI_GELU); break;
+        case ZE_EPI_RESIDUAL: ZE_RINGV_LAUNCH(ZE_EPI_RESIDUAL); break;
+        case ZE_EPI_SWIGLU: ZE_RINGV_LAUNCH(ZE_EPI_SWIGLU); break;
+        case ZE_EPI_F32: ZE_RINGV_LAUNCH(ZE_EPI_F32); break;
+    }
+#undef ZE_RINGV_LAUNCH
+}
+
 template <int BM, int BN>
 static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,
                        const bf16_t* R, int ldr, bf16_t* C, int ldc, const int* c_rows, int M, int N, int K,
@@ -559,48 +621,40 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
     }
     // (weight-streaming mode, rows = chains of a batched decode step: the ring wins at every grid, 5.04 vs 5.32 ms per
     //  step at 64 chains, 3.78 vs 4.17 at 8)
-    // Many-tile grids (128 x 128 policy): eight waves (2 x 4, 64 x 64 per wave) on 128 x 256 tiles of the LDS-DMA ring,
-    // one workgroup per CU, when the grid is at most one round or at least 1.6 (measured: 4096^3 870 vs 756 TFLOP/s,
-    // gate/up at M = 518: 81 vs 92 us, ViT qkv 31.5 vs 34.2; a 1.2-round grid loses what the larger tile wins; eight
-    // waves on 128 x 128 tiles only tie the register-staged kernel).  knob 7: 2 = always, 3 = never.
-    if (BM == 128 && BN == 128 && ksplit == 1 && K % GEMM_BK == 0 && K / GEMM_BK >= 4 && ze_gemv_knobs[7] != 3) {
+    // Many-tile grids (128 x 128 policy): eight waves (2 x 4) on the LDS-DMA ring, one workgroup per CU, the refill
+    // DMAs of a K-step spread between its rows of MFMAs (SPREAD: a burst of 6-8 DMAs per wave right behind the barrier
+    // leaves the matrix pipe idle while every wave of the workgroup is issuing).
+    //   * 128 x 256 tiles, three stages (64 x 64 per wave): 4096^3 926 TFLOP/s (870 unspread, 756 on the register-
+    //     staged 128 x 128 kernel), gate/up at M = 802 / 518: 112 / 73.5 us (124 / 81 unspread), ViT qkv 29.2 (31.5),
+    //     ViT gate/up on its 1.2-round grid 54.3 (59.1 register-staged).
+    //   * 256 x 256 tiles, two 64-KB stages (128 x 64 per wave, 253 VGPRs): half the bytes staged per FLOP; wins where
+    //     the grid is many rounds -- the batched prefill (16 chains x 802 rows): gate/up 1487 -> 1250 us (926
+    //     TFLOP/s), down 663 -> 561 (1030), qkv 165 -> 141 (955); 4096^3 1018 -- and loses to quantisation on the
+    //     single-chain grids (344 tiles = 1.3 rounds at M = 802).
+    // All of them accumulate an output element in the same K order: results are bit-identical across the choices.
+    // knob 7: 3 = register-staged only, 4 = always 256 x 256, 6 = always 128 x 256.
+    if (BM == 128 && BN == 128 && ksplit == 1 && K % GEMM_BK == 0 && K / GEMM_BK >= 4 && ze_gemv_knobs[7] != 3 &&
+        ze_gemv_knobs[6] == 0) {
         static int cus8 = 0;
         if (!cus8) {
             int dev = 0;
             hipGetDevice(&dev);
             if (hipDeviceGetAttribute(&cus8, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus8 <= 0) cus8 = 256;
         }
-        const int grid2 = ze_cdiv(M, 128) * ze_cdiv(N, 256);
-        if (ze_gemv_knobs[7] == 2 || (ze_gemv_knobs[6] == 0 && (grid2 <= cus8 || 5 * grid2 >= 8 * cus8))) {
-            constexpr int ST2 = 3;
-            const size_t lds2 = (size_t)(128 + 256) * 128 * ST2;
-#define ZE_RING8B_LAUNCH(E)                                                                                          \
-    do {                                                                                                             \
-        static bool attr_set = false;                                                                                \
-        if (!attr_set) {                                                                                             \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<128, 256, ST2, E, 2, 4>),                 \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                              \
-            attr_set = true;                                                                                         \
-        }                                                                                                            \
-        hipLaunchKernelGGL((k_gemm_ring<128, 256, ST2, E, 2, 4>), dim3(grid2), dim3(512), lds2, s, A, lda, W, ldw,   \
-                           bias, R, ldr, C, ldc, c_rows, M, N, K, 1, g_slab, g_tickets);                             \
-    } while (0)
-            switch (epi) {
-                case ZE_EPI_NONE: ZE_RING8B_LAUNCH(ZE_EPI_NONE); break;
-                case ZE_EPI_GELU: ZE_RING8B_LAUNCH(ZE_EPI_GELU); break;
-                case ZE_EPI_RESIDUAL: ZE_RING8B_LAUNCH(ZE_EPI_RESIDUAL); break;
-                case ZE_EPI_SWIGLU: ZE_RING8B_LAUNCH(ZE_EPI_SWIGLU); break;
-                case ZE_EPI_F32: ZE_RING8B_LAUNCH(ZE_EPI_F32); break;
-            }
-#undef ZE_RING8B_LAUNCH
-            return;
-        }
+        const int grid4 = ze_cdiv(M, 256) * ze_cdiv(N, 256);
+        const bool big = (2 * grid4 >= 3 * cus8) || (grid4 <= cus8 && 10 * grid4 >= 9 * cus8);
+        if (ze_gemv_knobs[7] == 4 || (ze_gemv_knobs[7] != 6 && big))
+            launch_ring_variant<256, 256, 2, 2, 4, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s);
+        else
+            launch_ring_variant<128, 256, 3, 2, 4, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s);
+        return;
     }
     const bool ring = ze_gemv_knobs[6] == 2 || (ze_gemv_knobs[6] == 0 && (grid <= cus || stream_mode));
     if (K % GEMM_BK == 0 && K / GEMM_BK / ksplit >= 4 && ring) {
         // LDS-DMA ring: four stages when they fit beside nothing else (one workgroup per CU), else three
         constexpr int STAGES = ((BM + BN) * 128 * 4 <= 128 * 1024) ? 4 : 3;
         const size_t lds_ring = (size_t)(BM + BN) * 128 * STAGES;
+        // (SPREAD on these four-wave tiles, one wave per SIMD, is 10-25 % slower: o 24.7 vs 20.9 us, down 91.6 vs 73.5)
 #define ZE_RING_LAUNCH(E)                                                                                              \
     do {                                                                                                               \
         static bool attr_set = false;                                                                                  \
