@@ -10,8 +10,9 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 L, N = 802, 48
 e = Engine(ModelConfig.zoomearth_3b(), max_seqs=B, max_ctx=1024, max_patches=2048, max_tile_side=1024)
 e.fill_synthetic(0)
-if os.environ.get('ZE_KNOB5'):
-    e.lib.ze_tune(5, int(os.environ['ZE_KNOB5']))
+for kv in os.environ.get('ZE_TUNE', '').split(','):  # e.g. ZE_TUNE=7:7
+    if ':' in kv:
+        e.lib.ze_tune(int(kv.split(':')[0]), int(kv.split(':')[1]))
 for b in (1, 8, 16, 32, 64):
     if b > B:
         break

@@ -96,6 +96,7 @@ __device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / (16 * WM)][BN / (1
 
     // ---------------- epilogue: acc[i][j][r] -> row = wm0 + i*16 + fq*4 + r, col = wn0 + j*16 + fr
     if (EPI == ZE_EPI_SWIGLU) {
+        static_assert(EPI != ZE_EPI_SWIGLU || TN % 2 == 0, "SwiGLU pairs two 16-column tiles of a wave");
         // W rows are interleaved in blocks of 16: [gate 0..15 | up 0..15 | gate 16..31 | ...]; even j = gate, odd = up
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -302,15 +303,8 @@ __device__ __forceinline__ void ring_issue_one(const bf16_t* __restrict__ G, int
 
 template <int N>
 __device__ __forceinline__ void ring_wait() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else static_assert(N == 0, "add the literal");
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 template <int BM, int BN, int STAGES, int EPI, int WM = 2, int WN = 2, bool SPREAD = false>
@@ -570,8 +564,8 @@ void ze_gemm_set_workspace(float* slab, size_t slab_floats, unsigned* tickets, i
 template <int BM, int BN, int ST, int WM, int WN, bool SPR>
 static void launch_ring_variant(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,
                                 const bf16_t* R, int ldr, bf16_t* C, int ldc, const int* c_rows, int M, int N, int K,
-                                hipStream_t s) {
-    const int grid = ze_cdiv(M, BM) * ze_cdiv(N, BN);
+                                hipStream_t s, int ksplit = 1) {
+    const int grid = ze_cdiv(M, BM) * ze_cdiv(N, BN) * ksplit;
     const size_t lds = (size_t)(BM + BN) * 128 * ST;
 #define ZE_RINGV_LAUNCH(E)                                                                                          \
     do {                                                                                                            \
@@ -582,7 +576,7 @@ static void launch_ring_variant(int epi, const bf16_t* A, int lda, const bf16_t*
             attr_set = true;                                                                                        \
         }                                                                                                           \
         hipLaunchKernelGGL((k_gemm_ring<BM, BN, ST, E, WM, WN, SPR>), dim3(grid), dim3(64 * WM * WN), lds, s, A,    \
-                           lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, 1, g_slab, g_tickets);               \
+                           lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, ksplit, g_slab, g_tickets);          \
     } while (0)
     switch (epi) {
         case ZE_EPI_NONE: ZE_RINGV_LAUNCH(ZE_EPI_NONE); break;
@@ -655,6 +649,20 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
         constexpr int STAGES = ((BM + BN) * 128 * 4 <= 128 * 1024) ? 4 : 3;
         const size_t lds_ring = (size_t)(BM + BN) * 128 * STAGES;
         // (SPREAD on these four-wave tiles, one wave per SIMD, is 10-25 % slower: o 24.7 vs 20.9 us, down 91.6 vs 73.5)
+        // 64 x 128 tiles of a one-round grid: eight waves (2 x 4, 32 x 32 per wave), two per SIMD, hide each other's DMA
+        // issue and LDS latency: o 20.4 -> 16.9 us, down 73.4 -> 62.7 (M = 802), 72.7 -> 58.4 (M = 518), ViT proj
+        // 15.6 -> 12.4, ViT down 27.3 -> 22.9, merger 37.9 -> 31.4 (1 x 8 waves and the spread refill are 2-8 % behind)
+        if (BM == 64 && BN == 128 && ksplit == 1 && ze_gemv_knobs[7] != 3) {
+            launch_ring_variant<64, 128, 4, 2, 4, false>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s);
+            return;
+        }
+        // the same on 64 x 64 tiles (4 x 2 waves, 16 x 32 per wave: the SwiGLU epilogue pairs two 16-column tiles of a
+        // wave), split-K included: merger 26.8 -> 23.3 us; the weight-streaming
+        // GEMMs of the batched decode step 4.48 -> 4.33 ms per 64-chain step, 3.27 -> 3.14 at 8 chains
+        if (BM == 64 && BN == 64 && ze_gemv_knobs[7] != 3) {
+            launch_ring_variant<64, 64, 4, 4, 2, false>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, ksplit);
+            return;
+        }
 #define ZE_RING_LAUNCH(E)                                                                                              \
     do {                                                                                                               \
         static bool attr_set = false;                                                                                  \
