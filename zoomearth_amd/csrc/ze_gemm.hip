@@ -754,6 +754,15 @@ void ze_launch_gemm(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw,
     const long b64x128 = (long)ze_cdiv(M, 64) * ze_cdiv(N, 128);
     const long b64 = (long)ze_cdiv(M, 64) * ze_cdiv(N, 64);
     const bool ringable = K % GEMM_BK == 0;
+    // In-between grids (more than one round of 64 x 128 tiles, too few 128 x 128 tiles for the many-tile policy --
+    // the LLM qkv projection at M = 802: 260 / 140 tiles): one round of 128 x 128 tiles on the eight-wave ring with the
+    // spread refill, 23.6 us against 33.7 register-staged on 64 x 128 (30.4 / 25.7 for the 64 x 128 ring in two rounds /
+    // the unspread 128 x 128 ring).
+    if (ringable && K / GEMM_BK >= 4 && b128 < 200 && b128 >= 96 && b64x128 > 256 && ze_gemv_knobs[6] == 0 &&
+        ze_gemv_knobs[7] != 3) {
+        launch_ring_variant<128, 128, 4, 2, 4, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s);
+        return;
+    }
     if (b128 >= 200)
         launch_cfg<128, 128>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, false);
     else if (b64x128 >= 160 || (ringable && (b64x128 >= 128 || b64 > 256)))
