@@ -161,3 +161,25 @@ def test_prefill_batch_is_bit_identical_to_single_prefills(eng):
                 assert np.array_equal(a, b), (order, s)
     with pytest.raises(Exception):
         e.prefill_batch([0, 0], [[1, 2], [3]], [None, None], [np.zeros((3, 2), np.int32), np.zeros((3, 1), np.int32)], [0, 0])
+
+
+def test_split_k_workspace_belongs_to_its_engine(eng):
+    """Regression: the split-K slabs / tickets of the weight-streaming GEMMs were process-wide pointers set by the most
+    recently created engine, so creating and destroying a second engine left the first one reducing through freed
+    memory (GPU memory fault in a later batched decode).  The workspace now travels with every call."""
+    from zoomearth_amd.config import ModelConfig
+    from zoomearth_amd.engine import Engine
+
+    g = torch.Generator().manual_seed(11)
+    a = (torch.randn(8, 5120, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    w = (torch.randn(512, 5120, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    before = eng.op_linear(a, w, None, 2)
+    other = Engine(ModelConfig.tiny(), max_seqs=1, max_ctx=256, max_patches=1024, max_tile_side=1024)
+    mid = other.op_linear(a, w, None, 2)
+    other.close()
+    junk = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(16)]  # reuse what `other` freed
+    after = eng.op_linear(a, w, None, 2)
+    assert torch.equal(before, mid) and torch.equal(before, after)
+    want = (a.double() @ w.double().T).float()
+    assert (after.float() - want).abs().max().item() <= 0.02 * want.abs().max().item()
+    del junk

@@ -237,3 +237,71 @@ def test_openai_compatible_server_matches_generate(stack):
     # errors
     assert client.post("/v1/chat/completions", json={"messages": msgs, "stream": True}).status_code == 400
     assert client.post("/v1/chat/completions", json={"messages": [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": "http://example.com/x.png"}}]}]}).status_code == 400
+
+
+def test_openai_server_batches_concurrent_requests(stack):
+    """Concurrent /v1/chat/completions requests (the reference client keeps many in flight, src/eval/infer_vllm.py:
+    244-271) are gathered by the dispatcher into one batched processor + generate call.  A batched row must equal the
+    same row of model.generate on the batch built by hand; a request that happened to run alone equals the single
+    path -- both are accepted per request, and at least one real batch must have formed."""
+    import base64
+    import io
+    import threading
+    from fastapi.testclient import TestClient
+    from PIL import Image
+    from zoomearth_amd import serve
+    model, proc, tile, tile_np = stack
+    reqs, prompts, imgs = [], [], []
+    for i, (w, h) in enumerate(((256, 209), (224, 224), (308, 252))):
+        small = frontend.resize_bicubic(tile_np, w, h)
+        buf = io.BytesIO()
+        Image.fromarray(small).save(buf, format="PNG")
+        url = "data:image/png;base64," + base64.b64encode(buf.getvalue()).decode()
+        msgs = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": url}},
+                                             {"type": "text", "text": " " + words(40 + i, 5 + i) + " "}]}]
+        reqs.append({"model": "ZoomEarth", "messages": msgs, "max_tokens": 8 + i})
+        prompts.append(serve.build_prompt(msgs)[0])
+        imgs.append(DeviceImage.from_numpy(small, model.engine))
+
+    def decode(row, budget):
+        row = row[:budget]
+        eos = set(model.config.eos_token_ids)
+        cut = next((j + 1 for j, t in enumerate(row) if t in eos), len(row))
+        ids = row[:cut]
+        while cut == len(row) and ids and ids[-1] == model.config.pad_token_id and ids[-1] not in eos:
+            ids = ids[:-1]
+        return proc.tokenizer.decode(ids, skip_special_tokens=True).strip()
+
+    inp = proc(text=prompts, images=imgs, return_tensors="pt", padding="longest").to(model.device)
+    g = model.generate(**inp, max_new_tokens=10, do_sample=False, num_beams=1)[:, inp["input_ids"].shape[1]:].tolist()
+    want_batched = [decode(g[i], 8 + i) for i in range(3)]
+    want_single = []
+    for i in range(3):
+        one = proc(text=[prompts[i]], images=[imgs[i]], return_tensors="pt", padding="longest").to(model.device)
+        gi = model.generate(**one, max_new_tokens=8 + i, do_sample=False, num_beams=1)[0, one["input_ids"].shape[1]:].tolist()
+        want_single.append(decode(gi, 8 + i))
+
+    srv = serve.ChatServer(model, proc, "ZoomEarth", batch_window_s=1.0)
+    # the explicit batch entry point first: exactly the hand-built batch
+    many = srv.complete_many(reqs)
+    assert [m["choices"][0]["message"]["content"] for m in many] == want_batched
+    calls = []
+    run = srv._run
+    srv._run = lambda batch: (calls.append(len(batch)), run(batch))[1]
+    client = TestClient(serve.create_app(srv))
+    out = [None] * 3
+    gate = threading.Barrier(3)
+
+    def post(i):
+        gate.wait()
+        out[i] = client.post("/v1/chat/completions", json=reqs[i])
+
+    ts = [threading.Thread(target=post, args=(i,)) for i in range(3)]
+    [t.start() for t in ts]
+    [t.join(timeout=120) for t in ts]
+    assert all(o is not None and o.status_code == 200 for o in out), [o and o.text for o in out]
+    assert sum(calls) == 3 and max(calls) >= 2, calls  # the dispatcher formed a real batch
+    for i, o in enumerate(out):
+        got = o.json()["choices"][0]["message"]["content"]
+        assert got in (want_batched[i], want_single[i]), (i, got, want_batched[i], want_single[i])
+    srv.close()

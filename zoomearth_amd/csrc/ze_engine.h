@@ -125,7 +125,10 @@ struct ze_engine {
     std::vector<float> graph_temperature;
     std::vector<unsigned long long> graph_seed;
     // split-K GEMM workspace
-    float* gslab = nullptr;
+    float* gslab = nullptr;       // split-K slabs of the weight-streaming GEMMs (ze_gemm_ws)
+    size_t gslab_floats = 0;
+    int gticket_cap = 0;
+    ze_gemm_ws gemm_ws() const { return ze_gemm_ws{gslab, gslab_floats, gtickets, gticket_cap}; }
     unsigned* gtickets = nullptr;
     // batched decode
     int* bseq = nullptr;

@@ -322,7 +322,8 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
         const size_t slab_floats = (size_t)16 << 20;  // 64 MB of fp32 split-K slabs
         chk(dev_alloc(e, &e->gslab, slab_floats, false));
         chk(dev_alloc(e, &e->gtickets, 4096, true));
-        if (r == 0) ze_gemm_set_workspace(e->gslab, slab_floats, e->gtickets, 4096);
+        e->gslab_floats = slab_floats;
+        e->gticket_cap = 4096;
     }
     chk(dev_alloc(e, &e->bseq, c.max_seqs));
     chk(dev_alloc(e, &e->blogits, (size_t)c.max_seqs * c.vocab));

@@ -986,21 +986,21 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
     for (int li = 0; li < c.layers; ++li) {
         const ze_text_layer& L = e->tl[li];
         ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, n, H, c.rms_eps, s);
-        ze_launch_gemm_stream(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, s);
+        ze_launch_gemm_stream(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, e->gemm_ws(), s);
         ze_launch_rope_kv_batch(e->tqkv, n, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(li, 0),
                                 e->vc(li, 0), seq_stride, c.max_ctx, s);
         ze_launch_attn_decode(e->tqkv, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, e->to, nq, e->st_dev, e->bseq, n,
                               c.heads, c.kv_heads, hd, c.max_ctx, scale, e->bpartial, e->max_splits, e->atickets, s);
-        ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, n, H, nq, s);
+        ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, n, H, nq, e->gemm_ws(), s);
         ze_launch_rmsnorm(e->th, H, L.post_norm, e->ty, H, n, H, c.rms_eps, s);
         ze_launch_gemm_stream(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad, n,
-                              2 * e->text_ipad, H, s);
+                              2 * e->text_ipad, H, e->gemm_ws(), s);
         ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, n, H,
-                              e->text_ipad, s);
+                              e->text_ipad, e->gemm_ws(), s);
     }
     ze_launch_rmsnorm(e->th, H, e->final_norm, e->ty, H, n, H, c.rms_eps, s);
     ze_launch_gemm_stream(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab,
-                          H, s);
+                          H, e->gemm_ws(), s);
     ze_launch_sample_batch(e->blogits, c.vocab, e->seen, penalty, e->st_dev, e->bseq, n, e->eos_dev, c.n_eos,
                            c.pad_token_id, ignore_eos, 1, sample, e->out_tokens, c.max_ctx, e->bsample,
                            e->bsample + (size_t)c.max_seqs * 2 * 128, so, s);
@@ -1170,7 +1170,7 @@ extern "C" int ze_op_linear(ze_engine* e, const void* a, const void* w, const vo
                            (bf16_t*)cmat, N, nullptr, M, N, K, s);
     } else if (act == 2) {  // weight-streaming mode of the batched decode step (rows = chains), for measurements
         ze_launch_gemm_stream(ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias, nullptr, 0,
-                              (bf16_t*)cmat, N, M, N, K, s);
+                              (bf16_t*)cmat, N, M, N, K, e->gemm_ws(), s);
     } else {
         ze_launch_gemm(act ? ZE_EPI_GELU : ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias,
                        nullptr, 0, (bf16_t*)cmat, N, nullptr, M, N, K, s);

@@ -548,23 +548,15 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
     gemm_finish<64, BN, EPI, 4, 1>(out, smem, bias, R, ldr, C, ldc, nullptr, M, N, ksplit, ks, bid, nwg, 0, bn0, slab, tickets);
 }
 
-// split-K workspace (fp32 slabs + per-tile tickets), owned by the engine and passed once
-static float* g_slab = nullptr;
-static unsigned* g_tickets = nullptr;
-static size_t g_slab_floats = 0;
-static int g_ticket_cap = 0;
-void ze_gemm_set_workspace(float* slab, size_t slab_floats, unsigned* tickets, int ticket_cap) {
-    g_slab = slab;
-    g_slab_floats = slab_floats;
-    g_tickets = tickets;
-    g_ticket_cap = ticket_cap;
-}
-
-// one ring instantiation without split-K, every epilogue
+// The split-K workspace (fp32 slabs + per-tile tickets) belongs to the calling engine and travels with every call
+// (ze_gemm_ws); the launch macros below name its two pointers g_slab / g_tickets.
+// one ring instantiation, every epilogue
 template <int BM, int BN, int ST, int WM, int WN, bool SPR>
 static void launch_ring_variant(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,
                                 const bf16_t* R, int ldr, bf16_t* C, int ldc, const int* c_rows, int M, int N, int K,
-                                hipStream_t s, int ksplit = 1) {
+                                hipStream_t s, int ksplit = 1, const ze_gemm_ws& ws = ze_gemm_ws()) {
+    float* g_slab = ws.slab;
+    unsigned* g_tickets = ws.tickets;
     const int grid = ze_cdiv(M, BM) * ze_cdiv(N, BN) * ksplit;
     const size_t lds = (size_t)(BM + BN) * 128 * ST;
 #define ZE_RINGV_LAUNCH(E)                                                                                          \
@@ -591,7 +583,11 @@ static void launch_ring_variant(int epi, const bf16_t* A, int lda, const bf16_t*
 template <int BM, int BN>
 static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,
                        const bf16_t* R, int ldr, bf16_t* C, int ldc, const int* c_rows, int M, int N, int K,
-                       hipStream_t s, bool stream_mode) {
+                       hipStream_t s, bool stream_mode, const ze_gemm_ws& ws = ze_gemm_ws()) {
+    float* g_slab = ws.slab;
+    unsigned* g_tickets = ws.tickets;
+    const size_t g_slab_floats = ws.slab_floats;
+    const int g_ticket_cap = ws.ticket_cap;
     const int nwg = ze_cdiv(M, BM) * ze_cdiv(N, BN);
     // Split K only in weight-streaming mode (batched decode, few rows): the slice count is a function of (N, K)
     // alone -- computed for ONE row tile -- so a chain's result never depends on how many chains share the step.
@@ -660,7 +656,7 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
         // wave), split-K included: merger 26.8 -> 23.3 us; the weight-streaming
         // GEMMs of the batched decode step 4.48 -> 4.33 ms per 64-chain step, 3.27 -> 3.14 at 8 chains
         if (BM == 64 && BN == 64 && ze_gemv_knobs[7] != 3) {
-            launch_ring_variant<64, 64, 4, 4, 2, false>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, ksplit);
+            launch_ring_variant<64, 64, 4, 4, 2, false>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, ksplit, ws);
             return;
         }
 #define ZE_RING_LAUNCH(E)                                                                                              \
@@ -702,6 +698,8 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
 template <int TN>
 static void launch_skinny(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
                           int ldr, bf16_t* C, int ldc, int M, int N, int K, int ksplit, hipStream_t s) {
+    float* g_slab = nullptr;  // never split: no workspace
+    unsigned* g_tickets = nullptr;
     const int grid = ze_cdiv(N, 16 * TN) * ksplit;
     const size_t lds = (size_t)16 * TN * 1024;
 #define ZE_SKINNY_LAUNCH(E)                                                                                        \
@@ -726,7 +724,8 @@ static void launch_skinny(int epi, const bf16_t* A, int lda, const bf16_t* W, in
 }
 
 void ze_launch_gemm_stream(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,
-                           const bf16_t* R, int ldr, bf16_t* C, int ldc, int M, int N, int K, hipStream_t s) {
+                           const bf16_t* R, int ldr, bf16_t* C, int ldc, int M, int N, int K, const ze_gemm_ws& ws,
+                           hipStream_t s) {
     if (M <= 0 || N <= 0) return;
     // Short, narrow weight matrices (qkv, o: K <= 4096, N <= 4096): the skinny kernel, 16 weight rows per workgroup,
     // no split-K (measured, device time per launch at 8 / 64 chains: qkv 9.8 / 13.9 us against 15.0 / 15.6 on the
@@ -741,7 +740,7 @@ void ze_launch_gemm_stream(int epi, const bf16_t* A, int lda, const bf16_t* W, i
     }
     // (64 x 128 tiles and every forced slice count 1 / 2 / 4 lose to this policy at 64 chains: gate/up 27.5 us here,
     //  27.2-59 there; down 21.3 here, 21-67 there)
-    launch_cfg<64, 64>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s, true);
+    launch_cfg<64, 64>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s, true, ws);
 }
 
 void ze_launch_gemm(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,

@@ -55,10 +55,17 @@ void ze_launch_gemm(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw,
                     int ldr, bf16_t* C, int ldc, const int* c_rows, int M, int N, int K, hipStream_t s);
 
 // Weight-streaming form for batched decode (few rows): 64x64 tiles, deterministic split-K chosen from (N, K) only.
+// split-K workspace of the calling engine (fp32 slabs + per-tile tickets); empty = never split
+struct ze_gemm_ws {
+    float* slab = nullptr;
+    size_t slab_floats = 0;
+    unsigned* tickets = nullptr;
+    int ticket_cap = 0;
+};
 void ze_launch_gemm_stream(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,
-                           const bf16_t* R, int ldr, bf16_t* C, int ldc, int M, int N, int K, hipStream_t s);
+                           const bf16_t* R, int ldr, bf16_t* C, int ldc, int M, int N, int K, const ze_gemm_ws& ws,
+                           hipStream_t s);
 // split-K workspace: fp32 slabs (>= ksplit * tiles * BM * BN floats) and zero-initialised per-tile tickets
-void ze_gemm_set_workspace(float* slab, size_t slab_floats, unsigned* tickets, int ticket_cap);
 
 // ---- decode GEMV family (batch-1 weight streaming)
 struct ze_gemv_args {

@@ -9,7 +9,11 @@ base64,..."}}` items, plus `max_tokens`, `temperature`, `seed` (`n` must be 1, `
 Prompt: the Qwen2.5-VL chat template (`<|im_start|>role\\n ... <|im_end|>\\n`, an image item becomes
 `<|vision_start|><|image_pad|><|vision_end|>`, a default system turn when the conversation has none, then the
 generation prompt `<|im_start|>assistant\\n`).  temperature 0 / absent -> greedy, else temperature sampling.
-Requests are served one at a time (the engine is single-stream); images are decoded on the host and uploaded.
+Concurrent requests (infer_vllm.py keeps up to 100 in flight, :244-271) are BATCHED: a dispatcher thread gathers the
+greedy requests that arrive within `batch_window_s` (up to the engine's `max_seqs`) and runs them as one
+processor + generate call -- rows of one batched prefill pass and one batched decode loop, each row's tokens
+independent of which other requests share the batch; sampled requests run alone (their random stream is keyed by
+the row).  Images are decoded on the host and uploaded.
 
     python -m zoomearth_amd.serve --model_name /ckpt/ZoomEarth-3B --port 8000
 """
@@ -75,34 +79,45 @@ def build_prompt(messages):
     return "".join(parts), images
 
 
+class _Parsed:
+    __slots__ = ("req", "prompt", "pil_images", "max_tokens", "sample", "temperature", "seed", "future")
+
+
 class ChatServer:
-    """Holds the model / processor pair and turns one OpenAI request dict into one response dict."""
+    """Holds the model / processor pair; turns OpenAI request dicts into response dicts, one at a time
+    (`complete`), as an explicit batch (`complete_many`) or through the batching dispatcher (`submit`)."""
 
-    def __init__(self, model, processor, model_id: str = "ZoomEarth"):
+    def __init__(self, model, processor, model_id: str = "ZoomEarth", batch_window_s: float = 0.01, max_batch=None):
         self.model, self.processor, self.model_id = model, processor, model_id
-        self._lock = threading.Lock()
+        self._lock = threading.Lock()  # the engine is single-stream
+        self.batch_window_s = batch_window_s
+        self.max_batch = int(max_batch or getattr(model.engine, "max_seqs", 1))
+        self._queue = []
+        self._cv = threading.Condition()
+        self._worker = None
+        self._stop = False
 
-    def complete(self, req: dict) -> dict:
-        from .image import DeviceImage
-
+    # ------------------------------------------------------------------ request -> response pieces
+    def _parse(self, req: dict) -> _Parsed:
         if req.get("stream"):
             raise BadRequest("stream=true is not offered")
         if int(req.get("n", 1) or 1) != 1:
             raise BadRequest("n must be 1")
-        prompt, pil_images = build_prompt(req.get("messages"))
-        max_tokens = int(req.get("max_tokens") or req.get("max_completion_tokens") or 1024)
-        temperature = req.get("temperature")
-        sample = temperature is not None and float(temperature) > 0.0
-        with self._lock:
-            images = [DeviceImage.from_pil(im, self.model.engine) for im in pil_images]
-            inputs = self.processor(text=[prompt], images=images or None, return_tensors="pt", padding="longest").to(self.model.device)
-            n_in = int(inputs["input_ids"].shape[1])
-            kw = dict(max_new_tokens=max_tokens, num_beams=1, do_sample=sample)
-            if sample:
-                kw.update(temperature=float(temperature), top_k=None, top_p=None, seed=int(req.get("seed") or 0))
-            out = self.model.generate(**inputs, **kw)[0, n_in:].tolist()
+        p = _Parsed()
+        p.req = req
+        p.prompt, p.pil_images = build_prompt(req.get("messages"))
+        p.max_tokens = int(req.get("max_tokens") or req.get("max_completion_tokens") or 1024)
+        t = req.get("temperature")
+        p.sample = t is not None and float(t) > 0.0
+        p.temperature = float(t) if p.sample else None
+        p.seed = int(req.get("seed") or 0)
+        p.future = None
+        return p
+
+    def _response(self, p: _Parsed, out, n_in: int) -> dict:
         eos = set(self.model.config.eos_token_ids)
         pad = self.model.config.pad_token_id
+        out = out[: p.max_tokens]
         stop = next((i for i, t in enumerate(out) if t in eos), None)
         ids = out if stop is None else out[: stop + 1]
         while stop is None and ids and ids[-1] == pad:
@@ -110,11 +125,90 @@ class ChatServer:
         text = self.processor.tokenizer.decode(ids, skip_special_tokens=True).strip()
         return {
             "id": "chatcmpl-" + uuid.uuid4().hex[:24], "object": "chat.completion", "created": int(time.time()),
-            "model": req.get("model") or self.model_id,
+            "model": p.req.get("model") or self.model_id,
             "choices": [{"index": 0, "message": {"role": "assistant", "content": text},
                          "finish_reason": "stop" if stop is not None else "length"}],
             "usage": {"prompt_tokens": n_in, "completion_tokens": len(ids), "total_tokens": n_in + len(ids)},
         }
+
+    def _run(self, batch):
+        """One processor + generate call for the parsed requests of `batch` (all greedy, or a single request)."""
+        from .image import DeviceImage
+
+        with self._lock:
+            images = [[DeviceImage.from_pil(im, self.model.engine) for im in p.pil_images] for p in batch]
+            flat = [im for row in images for im in row]  # consumed in prompt order, row after row
+            inputs = self.processor(text=[p.prompt for p in batch], images=flat or None, return_tensors="pt",
+                                    padding="longest").to(self.model.device)
+            width = int(inputs["input_ids"].shape[1])
+            n_in = inputs["attention_mask"].sum(dim=1).tolist()
+            p0 = batch[0]
+            kw = dict(max_new_tokens=max(p.max_tokens for p in batch), num_beams=1, do_sample=p0.sample)
+            if p0.sample:
+                kw.update(temperature=p0.temperature, top_k=None, top_p=None, seed=p0.seed)
+            out = self.model.generate(**inputs, **kw)[:, width:].tolist()
+        return [self._response(p, row, int(n)) for p, row, n in zip(batch, out, n_in)]
+
+    # ------------------------------------------------------------------ entry points
+    def complete(self, req: dict) -> dict:
+        return self._run([self._parse(req)])[0]
+
+    def complete_many(self, reqs) -> list:
+        """The requests as ONE batch (all must be greedy; at most max_seqs of them)."""
+        batch = [self._parse(r) for r in reqs]
+        if any(p.sample for p in batch) and len(batch) > 1:
+            raise BadRequest("sampled requests are not batched")
+        if len(batch) > self.max_batch:
+            raise BadRequest(f"batch of {len(batch)} exceeds max_seqs = {self.max_batch}")
+        return self._run(batch)
+
+    def submit(self, req: dict):
+        """Queues the request for the batching dispatcher; returns a concurrent.futures.Future of the response.
+        Malformed requests raise BadRequest here, before anything is queued."""
+        from concurrent.futures import Future
+
+        p = self._parse(req)
+        p.future = Future()
+        with self._cv:
+            if self._worker is None:
+                self._worker = threading.Thread(target=self._dispatch, name="ze-batcher", daemon=True)
+                self._worker.start()
+            self._queue.append(p)
+            self._cv.notify()
+        return p.future
+
+    def close(self):
+        with self._cv:
+            self._stop = True
+            self._cv.notify()
+
+    def _dispatch(self):
+        while True:
+            with self._cv:
+                while not self._queue and not self._stop:
+                    self._cv.wait()
+                if self._stop and not self._queue:
+                    return
+                deadline = time.monotonic() + self.batch_window_s
+                while len(self._queue) < self.max_batch and not self._stop:
+                    left = deadline - time.monotonic()
+                    if left <= 0:
+                        break
+                    self._cv.wait(left)
+                # a sampled request goes alone; greedy ones go together, in arrival order
+                if self._queue[0].sample:
+                    batch = [self._queue.pop(0)]
+                else:
+                    batch = [p for p in self._queue if not p.sample][: self.max_batch]
+                    taken = set(map(id, batch))
+                    self._queue = [p for p in self._queue if id(p) not in taken]
+            try:
+                for p, r in zip(batch, self._run(batch)):
+                    p.future.set_result(r)
+            except Exception as ex:  # every request of the failed batch gets the error
+                for p in batch:
+                    if not p.future.done():
+                        p.future.set_exception(ex)
 
 
 def create_app(server: ChatServer):
@@ -133,9 +227,11 @@ def create_app(server: ChatServer):
 
     @app.post("/v1/chat/completions")
     async def chat(request: Request):
+        import asyncio
+
         try:
             body = await request.json()
-            return JSONResponse(server.complete(body))
+            return JSONResponse(await asyncio.wrap_future(server.submit(body)))
         except BadRequest as ex:
             return JSONResponse({"error": {"message": str(ex), "type": "invalid_request_error"}}, status_code=400)
         except Exception as ex:  # engine errors surface as a 500 with the engine's message
