@@ -117,3 +117,15 @@ def test_batched_sampling_is_reproducible_per_row_whatever_the_slots(tiny_engine
     prefill_text(e, 1, prompts[0])
     single = e.generate(1, 16, repetition_penalty=1.1, ignore_eos=True, do_sample=True, temperature=0.9, seed=5)
     assert single[0] == full[0][0]
+
+
+def test_greedy_pick_is_memory_safe_on_nan_logits(tiny_engine):
+    """A row of NaN logits has no comparable maximum; the pick must stay inside the vocabulary (torch.argmax returns
+    index 0 there) instead of indexing the seen-set with the 'no winner' sentinel (a GPU memory fault)."""
+    e = tiny_engine
+    e.seq_reset(0)
+    vocab = e.config.text.vocab_size
+    lg = torch.full((vocab,), float("nan"), dtype=torch.float32, device="cuda")
+    assert e.sample_greedy(0, lg, 1.0) == int(torch.argmax(lg.cpu())) == 0
+    lg[7] = 1.0  # a comparable value wins over NaNs
+    assert e.sample_greedy(0, lg, 1.0) == 7

@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256) k_argmax_partial(const float* __restrict_
 __global__ void __launch_bounds__(64) k_argmax_final(const float* __restrict__ ws, uint8_t* __restrict__ seen,
                                                      ze_seq_dev* __restrict__ st, const int* __restrict__ eos_ids,
                                                      int n_eos, int pad_id, int ignore_eos, int advance_ctx,
-                                                     int32_t* __restrict__ out_tokens) {
+                                                     int32_t* __restrict__ out_tokens, int vocab) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
     for (int i = threadIdx.x; i < SAMPLE_BLOCKS; i += 64) better(bv, bi, ws[2 * i], reinterpret_cast<const int*>(ws)[2 * i + 1]);
@@ -59,6 +59,7 @@ __global__ void __launch_bounds__(64) k_argmax_final(const float* __restrict__ w
     }
     if (threadIdx.x == 0) {
         int tok = bi;
+        if ((unsigned)tok >= (unsigned)vocab) tok = 0;  // no comparable logit at all (every one NaN): torch.argmax gives 0
         if (st->finished) tok = pad_id;  // finished rows emit pad (HF:generation/utils.py:2927-2929)
         if (advance_ctx) st->ctx += 1;
         if (st->n_gen < st->max_gen) out_tokens[st->n_gen] = tok;
@@ -83,7 +84,7 @@ void ze_launch_sample(const float* logits, int vocab, uint8_t* seen, float penal
     if (so.temperature > 0.f)
         ze_launch_multinomial(logits, vocab, seen, st, nullptr, so.slot, 1, penalty, so.temperature, so.seed, ws,
                               ws + 2 * SAMPLE_BLOCKS + 64, s);
-    k_argmax_final<<<1, 64, 0, s>>>(ws, seen, st, eos_ids, n_eos, pad_id, ignore_eos, advance_ctx, out_tokens);
+    k_argmax_final<<<1, 64, 0, s>>>(ws, seen, st, eos_ids, n_eos, pad_id, ignore_eos, advance_ctx, out_tokens, vocab);
 }
 
 __global__ void k_advance_ctx(ze_seq_dev* st) { st->ctx += 1; }
@@ -157,6 +158,7 @@ __global__ void __launch_bounds__(64) k_argmax_final_batch(const float* __restri
     }
     if (threadIdx.x == 0) {
         int tok = bi;
+        if ((unsigned)tok >= (unsigned)vocab) tok = 0;  // every logit NaN: torch.argmax gives 0
         if (st->finished) tok = pad_id;
         if (advance_ctx) st->ctx += 1;
         if (st->n_gen < st->max_gen) out_base[(size_t)seq * max_gen + st->n_gen] = tok;
