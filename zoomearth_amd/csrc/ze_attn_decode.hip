@@ -17,6 +17,8 @@
 //  acquire fence + plain loads instead of the sc1 pair cost 30 ms per question MORE than the separate launch.)
 #include "ze_attn_decode.h"
 
+// (Measured, rejected: the merge as its own launch for the batched step -- slices retire without the drain + ticket tail --
+//  4.32 -> 4.28 ms per 64-chain step, 3.16 -> 3.13 at 8: not worth a second kernel.)
 // MB: slices whose partials the merging workgroup requests up front (24 covers 1536 tokens in one round trip: the
 // single-chain step, where the launch is latency-bound; 8 keeps the kernel at 4 workgroups per CU for the batched
 // step, where it is throughput-bound).  The merge adds the slices in the same order either way.
