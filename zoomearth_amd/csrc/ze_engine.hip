@@ -228,6 +228,9 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     if (ze_pad32(c.intermediate) > 29000) return bad("intermediate > 29000 unsupported by the decode GEMV");
     // MLP width padded to the GEMM K-step (64): zero rows / columns in the packed weights, so the down projection
     // takes the LDS-DMA ring kernel (K % 64 == 0) for the ViT too (3420 -> 3456)
+    // flash-decoding slices are 64 tokens: no context needs more than max_ctx / 64 of them (the launch grid covers
+    // max_splits slices per kv head, so a smaller bound also means fewer idle workgroups per launch)
+    e->max_splits = std::max(1, std::min(64, (c.max_ctx + 63) / 64));
     e->vit_ipad = (c.vit_intermediate + 63) / 64 * 64;
     e->text_ipad = (c.intermediate + 63) / 64 * 64;
     e->max_pos = c.max_ctx + 512;
