@@ -54,9 +54,12 @@ void ze_launch_fill_rows(uint64_t seed, float c_scale, float base, int rows, int
 // ------------------------------------------------------------------ RMSNorm
 // y = w * bf16(x * rsqrt(mean(x^2) + eps)); one wave per row, 16-B vector loads.
 // (HF:models/qwen2_5_vl/modeling_qwen2_5_vl.py:64-79: cast to input dtype BEFORE the weight multiply.)
+// frag != 0: y is written MFMA-fragment-major for the batched decode GEMMs (k_gemm_skinny<..., FRAG>):
+//   element (row r, col k) -> (((r / 16) * (cols / 32) + k / 32) * 64 + ((k % 32) / 8) * 16 + r % 16) * 8 + k % 8
+// i.e. a wave's A fragment of 16 rows x 32 columns is one contiguous 1-KiB block (cols % 32 == 0).
 __global__ void __launch_bounds__(256) k_rmsnorm(const bf16_t* __restrict__ x, int ldx,
                                                  const bf16_t* __restrict__ w, bf16_t* __restrict__ y, int ldy,
-                                                 int rows, int cols, float eps) {
+                                                 int rows, int cols, float eps, int frag) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -87,14 +90,34 @@ __global__ void __launch_bounds__(256) k_rmsnorm(const bf16_t* __restrict__ x, i
             const float b = bf16_round(bf16hi(u[j]) * inv) * bf16hi(gw[j]);
             o[j] = pack_bf16x2(a, b);
         }
-        *reinterpret_cast<uint4*>(yr + v * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        bf16_t* dst = yr + v * 8;
+        if (frag)
+            dst = y + ((((size_t)(row >> 4) * (cols >> 5) + (v >> 2)) * 64 + (v & 3) * 16 + (row & 15)) << 3);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
 
 void ze_launch_rmsnorm(const bf16_t* x, int ldx, const bf16_t* w, bf16_t* y, int ldy, int rows, int cols, float eps,
-                       hipStream_t s) {
+                       hipStream_t s, int frag) {
     if (rows == 0) return;
-    k_rmsnorm<<<ze_cdiv(rows, 4), 256, 0, s>>>(x, ldx, w, y, ldy, rows, cols, eps);
+    k_rmsnorm<<<ze_cdiv(rows, 4), 256, 0, s>>>(x, ldx, w, y, ldy, rows, cols, eps, frag);
+}
+
+// W [n, k] row-major (leading dimension ldw) -> MFMA-fragment-major copy: fragment (nb, ks) = rows 16 nb .. +15,
+// columns 32 ks .. +31, stored as 64 lanes x 16 B, lane = (col % 32) / 8 * 16 + row % 16.  One wave per fragment.
+__global__ void __launch_bounds__(256) k_pack_fragments(const bf16_t* __restrict__ W, int ldw, int n, int k,
+                                                        bf16_t* __restrict__ Wf) {
+    const size_t frag = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ns = k >> 5;
+    if (frag >= (size_t)(n >> 4) * ns) return;
+    const int lane = threadIdx.x & 63, nb = (int)(frag / ns), ks = (int)(frag % ns);
+    const uint4 v = *reinterpret_cast<const uint4*>(W + (size_t)(nb * 16 + (lane & 15)) * ldw + ks * 32 + (lane >> 4) * 8);
+    *reinterpret_cast<uint4*>(Wf + (frag * 64 + lane) * 8) = v;
+}
+void ze_launch_pack_fragments(const bf16_t* W, int ldw, int n, int k, bf16_t* Wf, hipStream_t s) {
+    const size_t frags = (size_t)(n >> 4) * (k >> 5);
+    if (frags == 0) return;
+    k_pack_fragments<<<(unsigned)((frags + 3) / 4), 256, 0, s>>>(W, ldw, n, k, Wf);
 }
 
 // ------------------------------------------------------------------ ViT input: f32 pixel rows -> bf16, gathered, K-padded

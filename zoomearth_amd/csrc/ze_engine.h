@@ -29,6 +29,8 @@ struct ze_linear {
     uint8_t* w8 = nullptr;
     float* scale8 = nullptr;
     int ld8 = 0;
+    // MFMA-fragment-major copy for the batched decode step (ze_launch_pack_fragments), null = none
+    bf16_t* wf = nullptr;
 };
 struct ze_vit_block {
     bf16_t *norm1 = nullptr, *norm2 = nullptr;
@@ -65,6 +67,11 @@ struct ze_engine {
     ze_linear lm_head8;          // fp8 copy of an untied lm_head (w / ld unused)
     uint8_t* arena8 = nullptr;    // fp8 decode weights (0 until ze_weights_quantize_fp8)
     bool fp8_ready = false;
+    // second, fragment-major copy of the wide decode projections (qkv, gate/up, lm_head) for batched decode: built on
+    // the first batched step, rebuilt after any weight change (the 288 GB of HBM make the extra 4.2 GB free)
+    bf16_t* arena_f = nullptr;
+    bf16_t* lm_head_f = nullptr;
+    bool frag_ready = false;
     std::vector<ze_text_layer> tl;
 
     // tables

@@ -374,7 +374,7 @@ extern "C" int ze_engine_destroy(ze_engine* e) {
                    e->st_dev, e->seen, e->out_tokens, e->fe_tmp, e->fe_img, e->fe_coef, e->vx, e->vh, e->vy, e->vqkv,
                    e->vo, e->va, e->vz, e->vz2, e->vcos, e->vsin, e->vperm, e->vinv, e->vtiles_win, e->vtiles_full,
                    e->th, e->ty, e->tqkv, e->to, e->ta, e->tsrc, e->tpos, e->ttiles, e->ttile_aux, e->trow_aux, e->dh, e->dq, e->dattn, e->dact,
-                   e->dlogits, e->dpartial, e->dsample, e->gbar, e->atickets, e->gslab, e->gtickets, e->bseq, e->blogits, e->bpartial, e->bsample, e->arena8};
+                   e->dlogits, e->dpartial, e->dsample, e->gbar, e->atickets, e->gslab, e->gtickets, e->bseq, e->blogits, e->bpartial, e->bsample, e->arena8, e->arena_f};
     for (void* p : dev)
         if (p) hipFree(p);
     void* host[] = {e->fe_coef_host, e->v_host_ints, e->v_host_f32, e->t_host_ints, e->d_host_ints, e->bstate_host};
@@ -400,6 +400,7 @@ static std::string canonical_name(const char* name) {
 
 extern "C" int ze_load_weight(ze_engine* e, const char* name, int dtype, int ndim, const int64_t* shape,
                               const void* host_ptr) {
+    if (e) e->frag_ready = false;  // the fragment-major decode copy follows the weights
     if (!e || !name || !shape || !host_ptr) return ze_fail(e, ZE_ERR_INVALID, "null argument");
     const std::string cn = canonical_name(name);
     if (cn == "lm_head.weight" && e->cfg.tie_word_embeddings) {
@@ -430,6 +431,7 @@ extern "C" int ze_load_weight(ze_engine* e, const char* name, int dtype, int ndi
 
 extern "C" int ze_weights_fill_synthetic(ze_engine* e, uint64_t seed, float std_, float matrix_gain, float bias_std,
                                          float norm_jitter) {
+    if (e) e->frag_ready = false;  // the fragment-major decode copy follows the weights
     if (!e) return ze_fail(e, ZE_ERR_INVALID, "null engine");
     hipSetDevice(e->device);
     for (auto& kv : e->dests) {
@@ -465,6 +467,7 @@ extern "C" int ze_weights_missing(ze_engine* e) {
 }
 
 extern "C" int ze_weights_arena(ze_engine* e, void** dev_ptr, size_t* bytes) {
+    if (e) e->frag_ready = false;  // the fragment-major decode copy follows the weights
     if (!e || !dev_ptr || !bytes) return ze_fail(e, ZE_ERR_INVALID, "null argument");
     *dev_ptr = e->arena;
     *bytes = e->arena_used * sizeof(bf16_t);

@@ -962,6 +962,36 @@ extern "C" int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_
 // path (rows = chains), each chain keeps its own KV cache / position / seen-set.  Rows are computed independently of
 // the batch composition (same per-element accumulation order for every tile shape), so a chain's tokens do not
 // depend on which other chains share its steps.
+// Fragment-major copies of the wide, short-K decode projections for the batched step (see ze_engine.h).  Shapes the
+// fragment kernel does not cover (rows % 16, K % 32, K > 4096) keep wf = null and stay on the row-major launchers.
+static int ensure_fragments(ze_engine* e, hipStream_t s) {
+    if (e->frag_ready) return ZE_OK;
+    const ze_config& c = e->cfg;
+    const int H = c.hidden, hd = e->head_dim, nqkv = (c.heads + 2 * c.kv_heads) * hd, n_gu = 2 * e->text_ipad;
+    const bool ok = H % 32 == 0 && H <= 4096 && nqkv % 16 == 0 && n_gu % 16 == 0 && c.vocab % 16 == 0;
+    for (int li = 0; li < c.layers; ++li) e->tl[li].qkv.wf = e->tl[li].gate_up.wf = nullptr;
+    e->lm_head_f = nullptr;
+    if (ok) {
+        const size_t per_layer = (size_t)(nqkv + n_gu) * H, total = per_layer * c.layers + (size_t)c.vocab * H;
+        if (!e->arena_f) ZE_HIP(hipMalloc((void**)&e->arena_f, total * sizeof(bf16_t)));
+        bf16_t* cur = e->arena_f;
+        for (int li = 0; li < c.layers; ++li) {
+            ze_text_layer& L = e->tl[li];
+            ze_launch_pack_fragments(L.qkv.w, L.qkv.ld, nqkv, H, cur, s);
+            L.qkv.wf = cur;
+            cur += (size_t)nqkv * H;
+            ze_launch_pack_fragments(L.gate_up.w, L.gate_up.ld, n_gu, H, cur, s);
+            L.gate_up.wf = cur;
+            cur += (size_t)n_gu * H;
+        }
+        ze_launch_pack_fragments(e->lm_head, H, c.vocab, H, cur, s);
+        e->lm_head_f = cur;
+        ZE_KCHECK();
+    }
+    e->frag_ready = true;
+    return ZE_OK;
+}
+
 static int upload_batch(ze_engine* e, const int32_t* seqs, int n, hipStream_t s) {
     if (n <= 0 || n > e->cfg.max_seqs) return ze_fail(e, ZE_ERR_INVALID, "batch size out of range");
     for (int i = 0; i < n; ++i) {
@@ -985,22 +1015,36 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
     ze_launch_embed_tokens_batch(e->st_dev, e->bseq, n, e->embed, e->th, H, s);
     for (int li = 0; li < c.layers; ++li) {
         const ze_text_layer& L = e->tl[li];
-        ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, n, H, c.rms_eps, s);
-        ze_launch_gemm_stream(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, e->gemm_ws(), s);
+        // wide short-K projections on fragment-major operands when the copy exists (ensure_fragments), n <= 64
+        const bool fq = L.qkv.wf && n <= 64 && ze_gemv_knobs[5] != 1, fg = L.gate_up.wf && n <= 64 && ze_gemv_knobs[5] != 1;
+        ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, n, H, c.rms_eps, s, fq ? 1 : 0);
+        if (fq)
+            ze_launch_gemm_frag(ZE_EPI_NONE, e->ty, L.qkv.wf, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, s);
+        else
+            ze_launch_gemm_stream(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, e->gemm_ws(), s);
         ze_launch_rope_kv_batch(e->tqkv, n, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(li, 0),
                                 e->vc(li, 0), seq_stride, c.max_ctx, s);
         ze_launch_attn_decode(e->tqkv, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, e->to, nq, e->st_dev, e->bseq, n,
                               c.heads, c.kv_heads, hd, c.max_ctx, scale, e->bpartial, e->max_splits, e->atickets, s);
         ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, n, H, nq, e->gemm_ws(), s);
-        ze_launch_rmsnorm(e->th, H, L.post_norm, e->ty, H, n, H, c.rms_eps, s);
-        ze_launch_gemm_stream(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad, n,
-                              2 * e->text_ipad, H, e->gemm_ws(), s);
+        ze_launch_rmsnorm(e->th, H, L.post_norm, e->ty, H, n, H, c.rms_eps, s, fg ? 1 : 0);
+        if (fg)
+            ze_launch_gemm_frag(ZE_EPI_SWIGLU, e->ty, L.gate_up.wf, nullptr, nullptr, 0, e->ta, e->text_ipad, n,
+                                2 * e->text_ipad, H, s);
+        else
+            ze_launch_gemm_stream(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad, n,
+                                  2 * e->text_ipad, H, e->gemm_ws(), s);
         ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, n, H,
                               e->text_ipad, e->gemm_ws(), s);
     }
-    ze_launch_rmsnorm(e->th, H, e->final_norm, e->ty, H, n, H, c.rms_eps, s);
-    ze_launch_gemm_stream(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab,
-                          H, e->gemm_ws(), s);
+    const bool fl = e->lm_head_f && n <= 64 && ze_gemv_knobs[5] != 1;
+    ze_launch_rmsnorm(e->th, H, e->final_norm, e->ty, H, n, H, c.rms_eps, s, fl ? 1 : 0);
+    if (fl)
+        ze_launch_gemm_frag(ZE_EPI_F32, e->ty, e->lm_head_f, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab, H,
+                            s);
+    else
+        ze_launch_gemm_stream(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n,
+                              c.vocab, H, e->gemm_ws(), s);
     ze_launch_sample_batch(e->blogits, c.vocab, e->seen, penalty, e->st_dev, e->bseq, n, e->eos_dev, c.n_eos,
                            c.pad_token_id, ignore_eos, 1, sample, e->out_tokens, c.max_ctx, e->bsample,
                            e->bsample + (size_t)c.max_seqs * 2 * 128, so, s);
@@ -1014,6 +1058,7 @@ extern "C" int ze_decode_batch(ze_engine* e, const int32_t* seqs, int n, const i
     const ze_config& c = e->cfg;
     hipStream_t s = (hipStream_t)stream;
     hipSetDevice(e->device);
+    ZE_TRY(ensure_fragments(e, s));
     ZE_TRY(upload_batch(e, seqs, n, s));
     if (tokens) {
         for (int i = 0; i < n; ++i) {
@@ -1043,6 +1088,7 @@ extern "C" int ze_generate_batch(ze_engine* e, const int32_t* seqs, int n, const
     hipSetDevice(e->device);
     const int max_new = p->max_new_tokens;
     if (max_new <= 0 || n <= 0) return ze_fail(e, ZE_ERR_INVALID, "max_new_tokens and n must be positive");
+    ZE_TRY(ensure_fragments(e, s));
     for (int i = 0; i < n; ++i) {
         if (seqs[i] < 0 || seqs[i] >= c.max_seqs) return ze_fail(e, ZE_ERR_NOTFOUND, "sequence id out of range");
         if (e->ctx_host[seqs[i]] + max_new - 1 > c.max_ctx) return ze_fail(e, ZE_ERR_NOMEM, "sequence exceeds max_ctx");
@@ -1272,6 +1318,7 @@ extern "C" int ze_weights_quantize_fp8(ze_engine* e, void* stream) {
     ZE_KCHECK();
     ZE_HIP(hipStreamSynchronize(s));
     e->fp8_ready = true;
+    e->frag_ready = false;  // the bf16 copies were replaced by the dequantised values
     ++ze_tune_epoch;  // captured decode steps hold the bf16 streams
     return ZE_OK;
 }

@@ -428,12 +428,18 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
 // The four partial tiles meet in LDS and are added in wave order; split-K slices across workgroups (long K: the
 // down projection) then go through the slab / ticket reduction of gemm_finish.  The order of every sum is a function
 // of (K, ksplit) alone, so a chain's result does not depend on how many chains share the step.
-template <int TN, int CH>
+template <int TN, int CH, int MT>
 struct skinny_frag {
-    bf16x8 a[CH][4], b[CH][TN];
+    bf16x8 a[CH][MT], b[CH][TN];
 };
 
-template <int TN, int EPI>
+// FRAG: both operands are stored MFMA-fragment-major (k_pack_fragments / k_rmsnorm(frag)), so every fragment load
+// of a wave is one contiguous 1-KiB read (the row-major form reads 16 rows x 64 B per load, which the vector memory
+// path serves at a fraction of that rate: it is why the row-major kernel only pays on the narrow projections).
+// MT: 16-row tiles of the activations the kernel handles (1, 2 or 4: M <= 16 * MT), a compile-time count so that no
+// load sits behind a branch -- with `if (tile < live tiles)` around them hipcc has to size every s_waitcnt vmcnt(N) for
+// the path that issues the FEWEST loads, which at 64 chains made each MFMA group wait for the prefetched chunk too.
+template <int TN, int EPI, bool FRAG = false, int MT = 4>
 __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
                                                      int ldw, const bf16_t* __restrict__ bias,
                                                      const bf16_t* __restrict__ R, int ldr, bf16_t* __restrict__ C,
@@ -447,19 +453,29 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const int mt = (M + 15) >> 4;  // live 16-row tiles of the activations (1..4)
+    constexpr int mt = MT;  // 16-row tiles of the activations (rows past M re-read the last row; never stored)
 
     // 32-deep slices: this workgroup's share of K, then this wave's quarter of it
     const int s_wg = (K / 32) / ksplit;
     const int base = s_wg >> 2, rem = s_wg & 3;
     const int s0 = ks * s_wg + wid * base + min(wid, rem), ns = base + (wid < rem ? 1 : 0);
 
+    // per-slice stride of a fragment pointer, in elements: 32 columns of a row (row-major) or one 1-KiB fragment
+    constexpr int SSTR = FRAG ? 512 : 32;
     const bf16_t* wp[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) wp[j] = W + (size_t)min(bn0 + j * 16 + fr, N - 1) * ldw + fq * 8;
     const bf16_t* ap[4];
+    if (FRAG) {
+        const int ns_all = K / 32, nb_last = (N >> 4) - 1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ap[i] = A + (size_t)min(i * 16 + fr, M - 1) * lda + fq * 8;
+        for (int j = 0; j < TN; ++j) wp[j] = W + ((size_t)min((bn0 >> 4) + j, nb_last) * ns_all * 64 + lane) * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ap[i] = A + ((size_t)min(i, mt - 1) * ns_all * 64 + lane) * 8;
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wp[j] = W + (size_t)min(bn0 + j * 16 + fr, N - 1) * ldw + fq * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ap[i] = A + (size_t)min(i * 16 + fr, M - 1) * lda + fq * 8;
+    }
 
     f32x4 acc[4][TN];
 #pragma unroll
@@ -467,10 +483,10 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto load = [&](skinny_frag<TN, CH>& f, int s) {
+    auto load = [&](skinny_frag<TN, CH, MT>& f, int s) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const int k = (s + c) * 32;
+            const int k = (s + c) * SSTR;
 #pragma unroll
             for (int j = 0; j < TN; ++j)  // streamed once: non-temporal
                 f.b[c][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[j] + k));
@@ -479,7 +495,7 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
                 if (i < mt) f.a[c][i] = *reinterpret_cast<const bf16x8*>(ap[i] + k);
         }
     };
-    auto mac = [&](const skinny_frag<TN, CH>& f) {
+    auto mac = [&](const skinny_frag<TN, CH, MT>& f) {
 #pragma unroll
         for (int c = 0; c < CH; ++c)
 #pragma unroll
@@ -492,7 +508,7 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
     };
     const int nch = ns / CH;
     {
-        skinny_frag<TN, CH> f0, f1;
+        skinny_frag<TN, CH, MT> f0, f1;
         if (nch > 0) load(f0, s0);
         int c = 0;
         for (; c + 2 <= nch; c += 2) {
@@ -504,7 +520,7 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
         if (c < nch) mac(f0);
     }
     for (int s = s0 + nch * CH; s < s0 + ns; ++s) {  // fewer than CH slices left
-        const int k = s * 32;
+        const int k = s * SSTR;
         bf16x8 fb[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[j] + k));
@@ -694,9 +710,68 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
 #undef ZE_GEMM_LAUNCH
 }
 
-// Batched decode: the skinny kernel when the shape allows (M <= 64, whole MFMA slices), else the ring.
+// Fragment-major operands, no split-K.  What bounds these launches is the memory traffic a CU can keep in flight
+// (about 25 GB/s of HBM misses per CU, the figure the decode GEMVs also show), so the weight bytes have to spread
+// evenly over all 256 CUs: with 64 rows per workgroup gate/up is 344 workgroups and the CUs that get two of them set
+// the time (22.6 us at 8 chains); 32 rows (688 workgroups) run 18.3 us, against 23.7 on the LDS-DMA ring and 15.1 for
+// the single-chain GEMV.  Every workgroup passes over ALL activation rows (from L2), which is what 64 chains pay for
+// the finer grid: 24.1 us (26.8 at 64 rows per workgroup, 25.1 at 128, 27 on the ring).  Narrow matrices (qkv) take
+// 16 rows per workgroup so that their grid still covers the chip: 5.5 / 8.1 us at 8 / 64 chains (9.8 / 13.9 row-major,
+// 15 on the ring).  lm_head: 96 us at 8 chains (120 on the ring), 140 at 64 (145).
+template <int TN, int MT>
+static void launch_frag_mt(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,
+                        bf16_t* C, int ldc, int M, int N, int K, hipStream_t s) {
+    float* g_slab = nullptr;
+    unsigned* g_tickets = nullptr;
+    const int grid = ze_cdiv(N, 16 * TN);
+    const size_t lds = (size_t)16 * TN * 1024;
+#define ZE_FRAG_LAUNCH(E)                                                                                           \
+    do {                                                                                                            \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) {                                                                                            \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<TN, E, true, MT>),                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+            attr_set = true;                                                                                        \
+        }                                                                                                           \
+        hipLaunchKernelGGL((k_gemm_skinny<TN, E, true, MT>), dim3(grid), dim3(256), lds, s, Xf, 0, Wf, 0, bias, R,  \
+                           ldr,                                                                                     \
+                           C, ldc, M, N, K, 1, g_slab, g_tickets);                                                  \
+    } while (0)
+    if constexpr (TN % 2 == 0) {
+        if (epi == ZE_EPI_SWIGLU) {
+            ZE_FRAG_LAUNCH(ZE_EPI_SWIGLU);
+            return;
+        }
+    }
+    switch (epi) {
+        case ZE_EPI_NONE: ZE_FRAG_LAUNCH(ZE_EPI_NONE); break;
+        case ZE_EPI_RESIDUAL: ZE_FRAG_LAUNCH(ZE_EPI_RESIDUAL); break;
+        case ZE_EPI_F32: ZE_FRAG_LAUNCH(ZE_EPI_F32); break;
+        default: break;
+    }
+#undef ZE_FRAG_LAUNCH
+}
+
 template <int TN>
-static void launch_skinny(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
+static void launch_frag(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,
+                        bf16_t* C, int ldc, int M, int N, int K, hipStream_t s) {
+    if (M <= 16) launch_frag_mt<TN, 1>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s);
+    else if (M <= 32) launch_frag_mt<TN, 2>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s);
+    else launch_frag_mt<TN, 4>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s);
+}
+
+void ze_launch_gemm_frag(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,
+                         bf16_t* C, int ldc, int M, int N, int K, hipStream_t s) {
+    if (M <= 0 || N <= 0) return;
+    if (N <= 4096 && epi != ZE_EPI_SWIGLU)
+        launch_frag<1>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s);
+    else
+        launch_frag<2>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s);
+}
+
+// Batched decode: the skinny kernel when the shape allows (M <= 64, whole MFMA slices), else the ring.
+template <int TN, int MT>
+static void launch_skinny_mt(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
                           int ldr, bf16_t* C, int ldc, int M, int N, int K, int ksplit, hipStream_t s) {
     float* g_slab = nullptr;  // never split: no workspace
     unsigned* g_tickets = nullptr;
@@ -706,11 +781,12 @@ static void launch_skinny(int epi, const bf16_t* A, int lda, const bf16_t* W, in
     do {                                                                                                           \
         static bool attr_set = false;                                                                              \
         if (!attr_set) {                                                                                           \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<TN, E>),                              \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<TN, E, false, MT>),                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
             attr_set = true;                                                                                       \
         }                                                                                                          \
-        hipLaunchKernelGGL((k_gemm_skinny<TN, E>), dim3(grid), dim3(256), lds, s, A, lda, W, ldw, bias, R, ldr, C, \
+        hipLaunchKernelGGL((k_gemm_skinny<TN, E, false, MT>), dim3(grid), dim3(256), lds, s, A, lda, W, ldw, bias,  \
+                           R, ldr, C,                                                                               \
                            ldc, M, N, K, ksplit, g_slab, g_tickets);                                               \
     } while (0)
     switch (epi) {
@@ -721,6 +797,14 @@ static void launch_skinny(int epi, const bf16_t* A, int lda, const bf16_t* W, in
         default: break;  // SWIGLU pairs 16-row blocks: never routed here
     }
 #undef ZE_SKINNY_LAUNCH
+}
+
+template <int TN>
+static void launch_skinny(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
+                          int ldr, bf16_t* C, int ldc, int M, int N, int K, int ksplit, hipStream_t s) {
+    if (M <= 16) launch_skinny_mt<TN, 1>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ksplit, s);
+    else if (M <= 32) launch_skinny_mt<TN, 2>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ksplit, s);
+    else launch_skinny_mt<TN, 4>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ksplit, s);
 }
 
 void ze_launch_gemm_stream(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,

@@ -38,7 +38,12 @@ void ze_launch_pack_rows(const void* src, int dtype, int row0, int nrows, int co
 void ze_launch_fill_rows(uint64_t seed, float c_scale, float base, int rows, int cols, bf16_t* dst, int ld, int mode,
                          int offset, hipStream_t s);
 void ze_launch_rmsnorm(const bf16_t* x, int ldx, const bf16_t* w, bf16_t* y, int ldy, int rows, int cols, float eps,
-                       hipStream_t s);
+                       hipStream_t s, int frag = 0);
+void ze_launch_pack_fragments(const bf16_t* W, int ldw, int n, int k, bf16_t* Wf, hipStream_t s);
+// batched decode on fragment-major operands (k_gemm_skinny<..., FRAG>): Xf from ze_launch_rmsnorm(frag = 1), Wf from
+// ze_launch_pack_fragments; M <= 64, N % 16 == 0, K % 32 == 0, K <= 4096 (no split-K)
+void ze_launch_gemm_frag(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,
+                         bf16_t* C, int ldc, int M, int N, int K, hipStream_t s);
 void ze_launch_gather_cast_rows(const float* src, int k, const int* perm, bf16_t* dst, int kp, int rows,
                                 hipStream_t s);
 void ze_launch_vision_rope(bf16_t* qkv, const float* cosT, const float* sinT, int n, int heads, int D, hipStream_t s);
