@@ -288,8 +288,11 @@ __device__ __forceinline__ void attn_combine_body(float* sW, float* sInvp, const
 // accumulates in slice order -- per output element the arithmetic of attn_combine_body.  Partials are read with
 // sc1 loads (they were published sc1 inside this launch).  sW: [AD_GMAX][64] floats, sInv: [AD_GMAX].
 template <int MB = 24>
+// out: the chain's output row (row-major), or, with frag_slices = heads * 128 / 32 != 0, the base of a fragment-major
+// buffer in which this chain is row `frag_row` (the layout of k_rmsnorm(frag), read by k_gemm_skinny<..., FRAG>).
 __device__ __forceinline__ void attn_merge_group(float* sW, float* sInv, const float* __restrict__ ws, int ctx, int kvh,
-                                                 int heads, int kv_heads, int max_splits, bf16_t* __restrict__ out) {
+                                                 int heads, int kv_heads, int max_splits, bf16_t* __restrict__ out,
+                                                 int frag_slices = 0, int frag_row = 0) {
     constexpr int D = 128;
     const int G = heads / kv_heads;
     int chunk, nsplit;
@@ -363,5 +366,10 @@ __device__ __forceinline__ void attn_merge_group(float* sW, float* sInv, const f
     uint2 o;
     o.x = pack_bf16x2(a0 * inv, a1 * inv);
     o.y = pack_bf16x2(a2 * inv, a3 * inv);
-    *reinterpret_cast<uint2*>(out + (size_t)h * D + od) = o;
+    const int col = h * D + od;
+    bf16_t* dst = out + col;
+    if (frag_slices)
+        dst = out + ((((size_t)(frag_row >> 4) * frag_slices + (col >> 5)) * 64 + ((col & 31) >> 3) * 16 + (frag_row & 15)) << 3) +
+              (col & 7);
+    *reinterpret_cast<uint2*>(dst) = o;
 }

@@ -66,8 +66,12 @@ __global__ void __launch_bounds__(256) k_attn_decode_split(const bf16_t* __restr
     if (*flag == 0u) return;
     __syncthreads();  // everybody has read the flag before the merge reuses the LDS
     float* sW = reinterpret_cast<float*>(&L.sK[0]);
-    attn_merge_group<MB>(sW, sW + AD_GMAX * 64, wsb, ctx, kvh, heads, kv_heads, max_splits,
-                     out + (size_t)bz * out_row_stride);
+    // out_row_stride < 0: fragment-major output with -out_row_stride slices per row tile, chain bz = row bz
+    if (out_row_stride < 0)
+        attn_merge_group<MB>(sW, sW + AD_GMAX * 64, wsb, ctx, kvh, heads, kv_heads, max_splits, out, -out_row_stride, bz);
+    else
+        attn_merge_group<MB>(sW, sW + AD_GMAX * 64, wsb, ctx, kvh, heads, kv_heads, max_splits,
+                             out + (size_t)bz * out_row_stride);
 }
 
 void ze_launch_attn_decode(const bf16_t* q, int q_row_stride, const bf16_t* kcache, const bf16_t* vcache,

@@ -78,18 +78,45 @@ __device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / (16 * WM)][BN / (1
         {
             const size_t slab_bytes = (size_t)ksplit * nwg * NT * (TM * TN) * 16;
             auto rsrc = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)min(slab_bytes, (size_t)0x7fffffff), 0x00020000);
-            for (int q = 0; q < ksplit; ++q) {
-                const unsigned base = (unsigned)((((size_t)(q * nwg + bid) * NT + tid) * (TM * TN)) * 16);
+            if constexpr (TM * TN <= 4) {
+                // every slice's slab requested up front (at most 8 slices: one memory round trip instead of one per
+                // slice -- the reducer is the tail of the whole launch), then added in slice order as before
+                u32x4 v[8][TM * TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int q = 0; q < 8; ++q) {
+                    const unsigned base =
+                        (unsigned)((((size_t)(min(q, ksplit - 1) * nwg + bid) * NT + tid) * (TM * TN)) * 16);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + (unsigned)(i * TN + j) * 16, 0, 16);
-                        acc[i][j][0] += __uint_as_float(v.x);
-                        acc[i][j][1] += __uint_as_float(v.y);
-                        acc[i][j][2] += __uint_as_float(v.z);
-                        acc[i][j][3] += __uint_as_float(v.w);
+                    for (int t = 0; t < TM * TN; ++t)
+                        v[q][t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + (unsigned)t * 16, 0, 16);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (q < ksplit) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) {
+                                acc[i][j][0] += __uint_as_float(v[q][i * TN + j].x);
+                                acc[i][j][1] += __uint_as_float(v[q][i * TN + j].y);
+                                acc[i][j][2] += __uint_as_float(v[q][i * TN + j].z);
+                                acc[i][j][3] += __uint_as_float(v[q][i * TN + j].w);
+                            }
                     }
+            } else {
+                for (int q = 0; q < ksplit; ++q) {
+                    const unsigned base = (unsigned)((((size_t)(q * nwg + bid) * NT + tid) * (TM * TN)) * 16);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + (unsigned)(i * TN + j) * 16, 0, 16);
+                            acc[i][j][0] += __uint_as_float(v.x);
+                            acc[i][j][1] += __uint_as_float(v.y);
+                            acc[i][j][2] += __uint_as_float(v.z);
+                            acc[i][j][3] += __uint_as_float(v.w);
+                        }
+                }
             }
         }
     }
@@ -720,22 +747,31 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
 // 15 on the ring).  lm_head: 96 us at 8 chains (120 on the ring), 140 at 64 (145).
 template <int TN, int MT>
 static void launch_frag_mt(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,
-                        bf16_t* C, int ldc, int M, int N, int K, hipStream_t s) {
-    float* g_slab = nullptr;
-    unsigned* g_tickets = nullptr;
-    const int grid = ze_cdiv(N, 16 * TN);
-    const size_t lds = (size_t)16 * TN * 1024;
+                        bf16_t* C, int ldc, int M, int N, int K, hipStream_t s, int ksplit, const ze_gemm_ws& ws) {
+    float* g_slab = ws.slab;
+    unsigned* g_tickets = ws.tickets;
+    const int grid = ze_cdiv(N, 16 * TN) * ksplit;
+    // A grid of at most one workgroup per CU asks for more LDS than half a CU has, so that the dispatcher cannot put
+    // two of them on one CU and leave another idle (the launch time is the bytes of the busiest CU).
+    static int cus_f = 0;
+    if (!cus_f) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus_f, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus_f <= 0) cus_f = 256;
+    }
+    const size_t lds = (grid <= cus_f) ? (size_t)96 * 1024 : (size_t)16 * TN * 1024;
+    const size_t lds_max = (size_t)96 * 1024;
 #define ZE_FRAG_LAUNCH(E)                                                                                           \
     do {                                                                                                            \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<TN, E, true, MT>),                     \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);                          \
             attr_set = true;                                                                                        \
         }                                                                                                           \
         hipLaunchKernelGGL((k_gemm_skinny<TN, E, true, MT>), dim3(grid), dim3(256), lds, s, Xf, 0, Wf, 0, bias, R,  \
                            ldr,                                                                                     \
-                           C, ldc, M, N, K, 1, g_slab, g_tickets);                                                  \
+                           C, ldc, M, N, K, ksplit, g_slab, g_tickets);                                             \
     } while (0)
     if constexpr (TN % 2 == 0) {
         if (epi == ZE_EPI_SWIGLU) {
@@ -754,10 +790,11 @@ static void launch_frag_mt(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf
 
 template <int TN>
 static void launch_frag(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,
-                        bf16_t* C, int ldc, int M, int N, int K, hipStream_t s) {
-    if (M <= 16) launch_frag_mt<TN, 1>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s);
-    else if (M <= 32) launch_frag_mt<TN, 2>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s);
-    else launch_frag_mt<TN, 4>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s);
+                        bf16_t* C, int ldc, int M, int N, int K, hipStream_t s, int ksplit = 1,
+                        const ze_gemm_ws& ws = ze_gemm_ws()) {
+    if (M <= 16) launch_frag_mt<TN, 1>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s, ksplit, ws);
+    else if (M <= 32) launch_frag_mt<TN, 2>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s, ksplit, ws);
+    else launch_frag_mt<TN, 4>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s, ksplit, ws);
 }
 
 void ze_launch_gemm_frag(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,

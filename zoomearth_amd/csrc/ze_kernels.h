@@ -37,6 +37,13 @@ void ze_launch_pack_rows(const void* src, int dtype, int row0, int nrows, int co
                          int offset, hipStream_t s);
 void ze_launch_fill_rows(uint64_t seed, float c_scale, float base, int rows, int cols, bf16_t* dst, int ld, int mode,
                          int offset, hipStream_t s);
+// split-K workspace of the calling engine (fp32 slabs + per-tile tickets); empty = never split
+struct ze_gemm_ws {
+    float* slab = nullptr;
+    size_t slab_floats = 0;
+    unsigned* tickets = nullptr;
+    int ticket_cap = 0;
+};
 void ze_launch_rmsnorm(const bf16_t* x, int ldx, const bf16_t* w, bf16_t* y, int ldy, int rows, int cols, float eps,
                        hipStream_t s, int frag = 0);
 void ze_launch_pack_fragments(const bf16_t* W, int ldw, int n, int k, bf16_t* Wf, hipStream_t s);
@@ -60,13 +67,6 @@ void ze_launch_gemm(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw,
                     int ldr, bf16_t* C, int ldc, const int* c_rows, int M, int N, int K, hipStream_t s);
 
 // Weight-streaming form for batched decode (few rows): 64x64 tiles, deterministic split-K chosen from (N, K) only.
-// split-K workspace of the calling engine (fp32 slabs + per-tile tickets); empty = never split
-struct ze_gemm_ws {
-    float* slab = nullptr;
-    size_t slab_floats = 0;
-    unsigned* tickets = nullptr;
-    int ticket_cap = 0;
-};
 void ze_launch_gemm_stream(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,
                            const bf16_t* R, int ldr, bf16_t* C, int ldc, int M, int N, int K, const ze_gemm_ws& ws,
                            hipStream_t s);
