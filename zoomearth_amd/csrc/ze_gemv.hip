@@ -25,6 +25,8 @@ bool ze_launch_gemv(int epi, const ze_gemv_args& a, hipStream_t s) {
     const bool many_rows = a.N >= 8192;
     if (a.W8) return ze_launch_gemv8(epi, a, s);  // fp8 weight stream (ze_gemv8.hip)
     switch (epi) {
+        // (K split over the waves -- 1280 one-pair workgroups, five per CU -- measured 8.2 us against 6.9: every workgroup
+        //  pays the x-staging prologue)
         case ZE_GV_QKV_ROPE: launch_gemv_cfg<ZE_GV_QKV_ROPE, 1, 1, 4>(a, s); break;
         case ZE_GV_SWIGLU:
             if (many_rows && ze_gemv_knobs[1] == 1) launch_gemv_cfg<ZE_GV_SWIGLU, 2, 1, 4>(a, s);

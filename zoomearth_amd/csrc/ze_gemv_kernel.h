@@ -245,8 +245,8 @@ __global__ void __launch_bounds__(256) k_gemv(const ze_gemv_args a) {
             for (int u = 0; u < CH; ++u) fma_chunk(c0 + u * c_step, w[u]);
         }
         // tail: the remaining (< CH) chunks of this wave, guarded by wave-uniform (scalar) conditions only
-        if (c0 < nch) {
-            uint4 w[CH - 1][2 * PAIRS];
+        if (CH > 1 && c0 < nch) {
+            uint4 w[CH > 1 ? CH - 1 : 1][2 * PAIRS];
 #pragma unroll
             for (int u = 0; u < CH - 1; ++u) {
                 const int c = c0 + u * c_step;
