@@ -85,7 +85,10 @@ __device__ __forceinline__ void ad_store16(void* base, uint32_t off, float a, fl
 // FRESH: q and the newest K/V row were written inside this launch (fused layer kernel).  PUB: the partials are
 // published write-through (sc1) because they are merged inside this launch (by the fused kernel's merge phase or by
 // the last-arriving slice workgroup of the stand-alone kernel).
-template <bool FRESH, bool PUB = FRESH>
+// NS: consecutive slices one workgroup handles (split = first of them).  NS = 2 requests the K/V of BOTH slices before
+// computing either (the batched step: half the workgroups, twice the bytes in flight per workgroup, the load latency
+// exposed once per two slices); results per slice -- and therefore the merge -- are the same for every NS.
+template <bool FRESH, bool PUB = FRESH, int NS = 1>
 __device__ __forceinline__ void attn_split_body(ad_split_lds& L, const bf16_t* __restrict__ q,
                                                 const bf16_t* __restrict__ kcache, const bf16_t* __restrict__ vcache,
                                                 int ctx, int kvh, int split, int heads, int kv_heads, int max_ctx,
@@ -103,7 +106,6 @@ __device__ __forceinline__ void attn_split_body(ad_split_lds& L, const bf16_t* _
     int chunk, nsplit;
     split_geometry(ctx, max_splits, chunk, nsplit);
     if (split >= nsplit) return;
-    const int t0 = split * chunk, t1 = min(ctx, t0 + chunk);
     const int tid = threadIdx.x, gid = tid >> 4, li = tid & 15, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
@@ -118,14 +120,19 @@ __device__ __forceinline__ void attn_split_body(ad_split_lds& L, const bf16_t* _
     }
     const bf16_t* kb = kcache + (size_t)kvh * max_ctx * D;  // wave-uniform bases, per-lane byte offsets
     const bf16_t* vb = vcache + (size_t)kvh * max_ctx * D;
-    ad_f32x4 oacc[2] = {ad_f32x4{0.f, 0.f, 0.f, 0.f}, ad_f32x4{0.f, 0.f, 0.f, 0.f}};
-    float m_run = -INFINITY, l_run = 0.f;
+    ad_f32x4 oacc[2];
+    float m_run, l_run;
+    auto reset = [&]() {
+        oacc[0] = oacc[1] = ad_f32x4{0.f, 0.f, 0.f, 0.f};
+        m_run = -INFINITY;
+        l_run = 0.f;
+    };
 
-    for (int base = t0; base < t1; base += AD_TOK) {
-        // ---------------- loads first.  Only the newest row was written inside this launch (sc1 stores of the fused
-        // QKV phase) and is read with sc1 loads; every older row comes from earlier launches.  The newest row is
-        // fetched once per lane up front (workgroup-uniform branch) and selected in, so the eight row loads below
-        // stay free of per-lane control flow.
+    // ---------------- loads of one 64-key round.  Only the newest row was written inside this launch (sc1 stores of the
+    // fused QKV phase) and is read with sc1 loads; every older row comes from earlier launches.  The newest row is
+    // fetched once per lane up front (workgroup-uniform branch) and selected in, so the eight row loads stay free of
+    // per-lane control flow.
+    auto load_round = [&](int base, int t1, uint4 (&ku)[4], uint4 (&vu)[4]) {
         uint4 kn = make_uint4(0, 0, 0, 0), vn = make_uint4(0, 0, 0, 0);
         const int tn = ctx - 1;
         if (FRESH && tn >= base && tn < base + AD_TOK) {
@@ -133,30 +140,30 @@ __device__ __forceinline__ void attn_split_body(ad_split_lds& L, const bf16_t* _
             kn = ad_load16<true>(kb, off);
             vn = ad_load16<true>(vb, off);
         }
-        uint4 ku[4], vu[4];
+        // Branch-free: rows past the slice re-read its last row (a valid address) and are zeroed when the images are
+        // written -- a per-lane "in range ? load : 0" puts every load behind an exec-mask branch.
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int t = base + gid + 16 * i;
-            const bool ok = t < t1;
-            ku[i] = make_uint4(0, 0, 0, 0);
-            vu[i] = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                const uint32_t off = (uint32_t)((t * D + li * 8) * 2);
-                ku[i] = ad_load16<false>(kb, off);
-                vu[i] = ad_load16<false>(vb, off);
-            }
+            const uint32_t off = (uint32_t)((min(t, t1 - 1) * D + li * 8) * 2);
+            ku[i] = ad_load16<false>(kb, off);
+            vu[i] = ad_load16<false>(vb, off);
             if (FRESH && t == tn) {
                 ku[i] = kn;
                 vu[i] = vn;
             }
         }
+    };
+    // ---------------- one 64-key round from staged registers: LDS images, S^T, online softmax, O^T
+    auto compute_round = [&](int base, int t1, const uint4 (&ku)[4], const uint4 (&vu)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<uint4*>(L.sK + ad_off(gid + 16 * i, li)) = ku[i];
-            *reinterpret_cast<uint4*>(L.sV + ad_off(gid + 16 * i, li)) = vu[i];
+            const unsigned m = (base + gid + 16 * i < t1) ? 0xffffffffu : 0u;  // rows past the slice are zero
+            *reinterpret_cast<uint4*>(L.sK + ad_off(gid + 16 * i, li)) = make_uint4(ku[i].x & m, ku[i].y & m, ku[i].z & m, ku[i].w & m);
+            *reinterpret_cast<uint4*>(L.sV + ad_off(gid + 16 * i, li)) = make_uint4(vu[i].x & m, vu[i].y & m, vu[i].z & m, vu[i].w & m);
         }
         __syncthreads();
-        // ---------------- S^T = K Q^T: 4 key tiles x 4 steps of 32 d
+        // S^T = K Q^T: 4 key tiles x 4 steps of 32 d
         ad_f32x4 sacc[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) sacc[n] = ad_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -168,7 +175,7 @@ __device__ __forceinline__ void attn_split_body(ad_split_lds& L, const bf16_t* _
                 sacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const ad_bf16x8*>(&ka), qf[ks],
                                                                  sacc[n], 0, 0, 0);
             }
-        // ---------------- online softmax of head fr over keys base + n*16 + fq*4 + r
+        // online softmax of head fr over keys base + n*16 + fq*4 + r
         float p[4][4];
         float mx = -INFINITY;
 #pragma unroll
@@ -205,8 +212,8 @@ __device__ __forceinline__ void attn_split_body(ad_split_lds& L, const bf16_t* _
             oacc[jj][2] *= alpha;
             oacc[jj][3] *= alpha;
         }
-        // ---------------- O^T += V^T P^T for this wave's d-tiles 2*wid, 2*wid + 1: per 32-key step the lane's 8 keys
-        // are (ks*32 + fq*4 + 0..3) and (ks*32 + 16 + fq*4 + 0..3), the same permutation on both operands
+        // O^T += V^T P^T for this wave's d-tiles 2*wid, 2*wid + 1: per 32-key step the lane's 8 keys are
+        // (ks*32 + fq*4 + 0..3) and (ks*32 + 16 + fq*4 + 0..3), the same permutation on both operands
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             uint32_t pw[4];
@@ -233,15 +240,47 @@ __device__ __forceinline__ void attn_split_body(ad_split_lds& L, const bf16_t* _
             }
         }
         __syncthreads();  // the images are rewritten by the next round (and reused by the caller after the last)
-    }
-    // partial of head fr: (m, l) and O[d = (2*wid + jj)*16 + fq*4 .. +3]
-    if (fr < G) {
-        const uint32_t dst = (uint32_t)((split * heads + kvh * G + fr) * AD_STRIDE * 4);
-        if (wid == 0 && fq == 0) ad_store16<PUB>(ws, dst, m_run, l_run, 0.f, 0.f);
+    };
+    // partial of head fr for slice sp: (m, l) and O[d = (2*wid + jj)*16 + fq*4 .. +3]
+    auto store_partial = [&](int sp) {
+        if (fr < G) {
+            const uint32_t dst = (uint32_t)((sp * heads + kvh * G + fr) * AD_STRIDE * 4);
+            if (wid == 0 && fq == 0) ad_store16<PUB>(ws, dst, m_run, l_run, 0.f, 0.f);
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-            ad_store16<PUB>(ws, dst + (uint32_t)((4 + (2 * wid + jj) * 16 + fq * 4) * 4), oacc[jj][0], oacc[jj][1],
-                            oacc[jj][2], oacc[jj][3]);
+            for (int jj = 0; jj < 2; ++jj)
+                ad_store16<PUB>(ws, dst + (uint32_t)((4 + (2 * wid + jj) * 16 + fq * 4) * 4), oacc[jj][0], oacc[jj][1],
+                                oacc[jj][2], oacc[jj][3]);
+        }
+    };
+
+    if (NS == 2 && chunk == AD_TOK) {
+        // two one-round slices: every load of both is in flight before the first product
+        const int sa = split * 2, sb = sa + 1;
+        if (sa >= nsplit) return;
+        const bool two = sb < nsplit;  // workgroup-uniform
+        uint4 ku[4], vu[4], ku2[4], vu2[4];
+        load_round(sa * chunk, min(ctx, sa * chunk + chunk), ku, vu);
+        if (two) load_round(sb * chunk, min(ctx, sb * chunk + chunk), ku2, vu2);
+        reset();
+        compute_round(sa * chunk, min(ctx, sa * chunk + chunk), ku, vu);
+        store_partial(sa);
+        if (two) {
+            reset();
+            compute_round(sb * chunk, min(ctx, sb * chunk + chunk), ku2, vu2);
+            store_partial(sb);
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int sp = split * NS; sp < min(nsplit, split * NS + NS); ++sp) {
+        const int t0 = sp * chunk, t1 = min(ctx, t0 + chunk);
+        reset();
+        for (int base = t0; base < t1; base += AD_TOK) {
+            uint4 ku[4], vu[4];
+            load_round(base, t1, ku, vu);
+            compute_round(base, t1, ku, vu);
+        }
+        store_partial(sp);
     }
 }
 

@@ -22,7 +22,9 @@
 // MB: slices whose partials the merging workgroup requests up front (24 covers 1536 tokens in one round trip: the
 // single-chain step, where the launch is latency-bound; 8 keeps the kernel at 4 workgroups per CU for the batched
 // step, where it is throughput-bound).  The merge adds the slices in the same order either way.
-template <int MB>
+// NS: slices per workgroup (attn_split_body): 1 for the single-chain step (most workgroups, shortest chain), 2 for
+// the batched step (grid.y = max_splits / 2).
+template <int MB, int NS>
 __global__ void __launch_bounds__(256) k_attn_decode_split(const bf16_t* __restrict__ q, int q_row_stride,
                                                            const bf16_t* __restrict__ kcache,
                                                            const bf16_t* __restrict__ vcache, size_t cache_seq_stride,
@@ -42,9 +44,9 @@ __global__ void __launch_bounds__(256) k_attn_decode_split(const bf16_t* __restr
     const int ctx = st->ctx + 1, kvh = blockIdx.x;
     int chunk, nsplit;
     split_geometry(ctx, max_splits, chunk, nsplit);
-    if ((int)blockIdx.y >= nsplit) return;  // workgroup-uniform: no slice, no ticket
+    if ((int)blockIdx.y * NS >= nsplit) return;  // workgroup-uniform: no slice, no ticket
     float* wsb = ws + (size_t)bz * max_splits * heads * AD_STRIDE;
-    attn_split_body<false, true>(L, q + (size_t)bz * q_row_stride, kcache, vcache, ctx, kvh, blockIdx.y, heads, kv_heads,
+    attn_split_body<false, true, NS>(L, q + (size_t)bz * q_row_stride, kcache, vcache, ctx, kvh, blockIdx.y, heads, kv_heads,
                                  max_ctx, scale_log2e, wsb, max_splits);
     // ---- merge by the last-arriving slice of this (chain, kv head).  Hand-off without fences: the partials above
     // went out write-through (sc1), every storing wave drains, the workgroup barriers, ONE lane takes a ticket
@@ -58,7 +60,7 @@ __global__ void __launch_bounds__(256) k_attn_decode_split(const bf16_t* __restr
     if (threadIdx.x == 0) {
         unsigned* t = tickets + (size_t)bz * kv_heads + kvh;
         const unsigned old = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned last = old == (unsigned)nsplit - 1u;
+        const unsigned last = old == (unsigned)((nsplit + NS - 1) / NS) - 1u;  // one ticket per workgroup with slices
         if (last) __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *flag = last;
     }
@@ -81,12 +83,12 @@ void ze_launch_attn_decode(const bf16_t* q, int q_row_stride, const bf16_t* kcac
     (void)D;
     const float sl = scale * 1.4426950408889634f;
     if (seq_ids)
-        k_attn_decode_split<8><<<dim3(kv_heads, max_splits, n), 256, 0, s>>>(q, q_row_stride, kcache, vcache,
+        k_attn_decode_split<8, 2><<<dim3(kv_heads, (max_splits + 1) / 2, n), 256, 0, s>>>(q, q_row_stride, kcache, vcache,
                                                                               cache_seq_stride, st, seq_ids, heads, kv_heads,
                                                                               max_ctx, sl, ws_partial, max_splits, tickets,
                                                                               out, out_row_stride);
     else
-        k_attn_decode_split<24><<<dim3(kv_heads, max_splits, n), 256, 0, s>>>(q, q_row_stride, kcache, vcache,
+        k_attn_decode_split<24, 1><<<dim3(kv_heads, max_splits, n), 256, 0, s>>>(q, q_row_stride, kcache, vcache,
                                                                                cache_seq_stride, st, seq_ids, heads,
                                                                                kv_heads, max_ctx, sl, ws_partial, max_splits,
                                                                                tickets, out, out_row_stride);
