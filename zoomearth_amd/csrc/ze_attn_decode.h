@@ -141,7 +141,8 @@ __device__ __forceinline__ void attn_split_body(ad_split_lds& L, const bf16_t* _
             vn = ad_load16<true>(vb, off);
         }
         // Branch-free: rows past the slice re-read its last row (a valid address) and are zeroed when the images are
-        // written -- a per-lane "in range ? load : 0" puts every load behind an exec-mask branch.
+        // written -- a per-lane "in range ? load : 0" puts every load behind an exec-mask branch (and with TWO such
+        // guarded groups in flight, the NS = 2 form, the build of ROCm 7.2's hipcc produced wrong rows for the second).
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int t = base + gid + 16 * i;
