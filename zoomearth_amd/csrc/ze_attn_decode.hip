@@ -82,11 +82,13 @@ void ze_launch_attn_decode(const bf16_t* q, int q_row_stride, const bf16_t* kcac
                            float* ws_partial, int max_splits, unsigned* tickets, hipStream_t s) {
     (void)D;
     const float sl = scale * 1.4426950408889634f;
+    // (two slices per workgroup with both slices' K/V requested up front -- NS = 2 -- win at contexts of about 850
+    //  tokens, 3.93 -> 3.86 ms per 64-chain step, and lose at the benchmark's 800-1400: 29.6 against 30.3 questions/s)
     if (seq_ids)
-        k_attn_decode_split<8, 2><<<dim3(kv_heads, (max_splits + 1) / 2, n), 256, 0, s>>>(q, q_row_stride, kcache, vcache,
-                                                                              cache_seq_stride, st, seq_ids, heads, kv_heads,
-                                                                              max_ctx, sl, ws_partial, max_splits, tickets,
-                                                                              out, out_row_stride);
+        k_attn_decode_split<8, 1><<<dim3(kv_heads, max_splits, n), 256, 0, s>>>(q, q_row_stride, kcache, vcache,
+                                                                                 cache_seq_stride, st, seq_ids, heads,
+                                                                                 kv_heads, max_ctx, sl, ws_partial, max_splits,
+                                                                                 tickets, out, out_row_stride);
     else
         k_attn_decode_split<24, 1><<<dim3(kv_heads, max_splits, n), 256, 0, s>>>(q, q_row_stride, kcache, vcache,
                                                                                cache_seq_stride, st, seq_ids, heads,
