@@ -230,7 +230,9 @@ int ze_op_quantize_fp8(ze_engine* e, void* w_bf16, int rows, int cols, void* q_o
 
 /* ------------------------------------------------------------------ unit ops for parity tests (K3-K22) */
 /* C[M,N] = A[M,K] * W[N,K]^T (+bias[N]) ; bf16 in, fp32 accumulate, bf16 out (one rounding).  act: 0 none, 1 exact GELU,
- * 2 none through the weight-streaming launcher of the batched decode step (split-K; for measurements). */
+ * 2 none through the weight-streaming launcher of the batched decode step (split-K; for measurements),
+ * 3 none through the fragment-major kernels of that step (operands packed inside the call; M <= 64, N % 16 == 0,
+ *   K % 32 == 0, K <= 4096). */
 int ze_op_linear(ze_engine* e, const void* a_bf16, const void* w_bf16, const void* bias_bf16, void* c_bf16, int M,
                  int N, int K, int act, void* stream);
 /* y = weight * bf16(x * rsqrt(mean(x^2)+eps))  (HF:...modeling_qwen2_5_vl.py:64-79), rows x cols bf16. */

@@ -1228,6 +1228,17 @@ extern "C" int ze_op_linear(ze_engine* e, const void* a, const void* w, const vo
         if (!ze_launch_gemv(ZE_GV_PLAIN, g, s))
             ze_launch_gemm(ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias, nullptr, 0,
                            (bf16_t*)cmat, N, nullptr, M, N, K, s);
+    } else if (act == 3) {  // the fragment-major kernels of the batched decode step, operands packed here
+        if (M > 64 || N % 16 || K % 32 || K > 4096) return ze_fail(e, ZE_ERR_INVALID, "fragment path: M <= 64, N % 16, K % 32, K <= 4096");
+        bf16_t *wf = nullptr, *xf = nullptr;
+        const size_t mp = (size_t)(M + 15) / 16 * 16;
+        ZE_HIP(hipMalloc((void**)&wf, ((size_t)N * K + mp * K) * sizeof(bf16_t)));
+        xf = wf + (size_t)N * K;
+        ze_launch_pack_fragments((const bf16_t*)w, K, N, K, wf, s);
+        ze_launch_pack_fragments((const bf16_t*)a, K, M, K, xf, s);
+        ze_launch_gemm_frag(ZE_EPI_NONE, xf, wf, (const bf16_t*)bias, nullptr, 0, (bf16_t*)cmat, N, M, N, K, s);
+        hipStreamSynchronize(s);
+        hipFree(wf);
     } else if (act == 2) {  // weight-streaming mode of the batched decode step (rows = chains), for measurements
         ze_launch_gemm_stream(ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias, nullptr, 0,
                               (bf16_t*)cmat, N, M, N, K, e->gemm_ws(), s);
