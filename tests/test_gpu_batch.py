@@ -183,3 +183,34 @@ def test_split_k_workspace_belongs_to_its_engine(eng):
     want = (a.double() @ w.double().T).float()
     assert (after.float() - want).abs().max().item() <= 0.02 * want.abs().max().item()
     del junk
+
+
+def test_wide_batch_matches_narrow_batch_bitwise():
+    """More than 32 chains switch gate/up (3B layer shape: 22016 rows) to the balanced-range kernel (one pass over the
+    activations per workgroup); a chain's logits must be bit-identical whether it decodes among 3 chains or among 40,
+    and finite.  One decoder layer, reduced vocabulary."""
+    import dataclasses
+
+    from zoomearth_amd.config import ModelConfig
+    from zoomearth_amd.engine import Engine
+
+    mc = ModelConfig.zoomearth_3b()
+    mc = dataclasses.replace(mc, text=dataclasses.replace(mc.text, num_hidden_layers=1, vocab_size=4096),
+                             vision=dataclasses.replace(mc.vision, depth=1, fullatt_block_indexes=(0,)),
+                             image_token_id=4000, vision_start_token_id=4001, vision_end_token_id=4002,
+                             eos_token_ids=(4003,), pad_token_id=4004)
+    n = 40
+    e = Engine(mc, device=0, max_seqs=n, max_ctx=128, max_patches=256, max_tile_side=512)
+    try:
+        e.fill_synthetic(seed=3, std=0.02, matrix_gain=2.0, bias_std=0.02, norm_jitter=0.1)
+        prompts = [[int(t) for t in prng.uniform_ints(50 + s, 9 + (s % 5), 10, 3990)] for s in range(n)]
+        for s, ids in enumerate(prompts):
+            prefill_text(e, s, ids)
+        wide = e.decode_batch(list(range(n)), [7 + s for s in range(n)]).cpu().numpy()
+        for s, ids in enumerate(prompts[:3]):
+            prefill_text(e, s, ids)
+        narrow = e.decode_batch([0, 1, 2], [7, 8, 9]).cpu().numpy()
+        assert np.isfinite(wide).all() and np.abs(wide).max() > 0
+        assert np.array_equal(wide[:3], narrow)
+    finally:
+        e.close()

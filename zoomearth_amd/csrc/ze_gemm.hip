@@ -466,7 +466,10 @@ struct skinny_frag {
 // MT: 16-row tiles of the activations the kernel handles (1, 2 or 4: M <= 16 * MT), a compile-time count so that no
 // load sits behind a branch -- with `if (tile < live tiles)` around them hipcc has to size every s_waitcnt vmcnt(N) for
 // the path that issues the FEWEST loads, which at 64 chains made each MFMA group wait for the prefetched chunk too.
-template <int TN, int EPI, bool FRAG = false, int MT = 4>
+// BAL: the grid is one workgroup per CU and a workgroup takes a contiguous range of 32-row pairs of blocks (gate | up),
+// floor(b P / G) .. floor((b + 1) P / G) of the P = N / 32 pairs -- at most TN / 2 of them: the weight bytes spread over
+// the CUs as evenly as the pair count allows while every workgroup passes over the activations ONCE.
+template <int TN, int EPI, bool FRAG = false, int MT = 4, bool BAL = false>
 __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
                                                      int ldw, const bf16_t* __restrict__ bias,
                                                      const bf16_t* __restrict__ R, int ldr, bf16_t* __restrict__ C,
@@ -474,9 +477,17 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
                                                      float* __restrict__ slab, unsigned* __restrict__ tickets) {
     constexpr int BN = 16 * TN, CH = (TN == 1) ? 4 : 2;  // MFMA slices per prefetch chunk
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int nwg = (N + BN - 1) / BN;
-    const int ks = blockIdx.x / nwg, bid = blockIdx.x % nwg;
-    const int bn0 = bid * BN;
+    int nwg = (N + BN - 1) / BN;
+    int ks = blockIdx.x / nwg, bid = blockIdx.x % nwg;
+    int bn0 = bid * BN;
+    if (BAL) {  // this workgroup's range of 32-row pairs; columns past it are not stored (N is cut to the range's end)
+        const int P = N >> 5, G = gridDim.x;
+        nwg = G;
+        ks = 0;
+        bid = blockIdx.x;
+        bn0 = (int)(((long)bid * P) / G) * 32;
+        N = (int)(((long)(bid + 1) * P) / G) * 32;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
@@ -797,9 +808,40 @@ static void launch_frag(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_
     else launch_frag_mt<TN, 4>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s, ksplit, ws);
 }
 
+// gate/up (SwiGLU, wide): one workgroup per CU (or a multiple), each with a balanced range of at most three 32-row
+// pairs and ONE pass over the activations
+template <int MT>
+static void launch_frag_balanced(const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, bf16_t* C, int ldc, int M, int N,
+                                 int K, int grid, hipStream_t s) {
+    const size_t lds = (size_t)16 * 6 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<6, ZE_EPI_SWIGLU, true, MT, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_gemm_skinny<6, ZE_EPI_SWIGLU, true, MT, true>), dim3(grid), dim3(256), lds, s, Xf, 0, Wf, 0, bias,
+                       nullptr, 0, C, ldc, M, N, K, 1, nullptr, nullptr);
+}
+
 void ze_launch_gemm_frag(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,
                          bf16_t* C, int ldc, int M, int N, int K, hipStream_t s) {
     if (M <= 0 || N <= 0) return;
+    // (more than 32 chains only: below that the activation pass is small and the finer 32-row grid wins, 2.84 against
+    //  2.91 ms per step at 8 chains; at 64 chains 3.86 against 3.95.  Both forms add an output's K quarters in the same
+    //  order, so the choice does not change a chain's result.)
+    if (epi == ZE_EPI_SWIGLU && N > 4096 && N % 32 == 0 && M > 32 && ze_gemv_knobs[5] != 2) {
+        static int cus_b = 0;
+        if (!cus_b) {
+            int dev = 0;
+            hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&cus_b, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus_b <= 0) cus_b = 256;
+        }
+        const int P = N / 32;
+        const int grid = cus_b * ze_cdiv(P, 3 * cus_b);  // at most three pairs per workgroup
+        launch_frag_balanced<4>(Xf, Wf, bias, C, ldc, M, N, K, grid, s);
+        return;
+    }
     if (N <= 4096 && epi != ZE_EPI_SWIGLU)
         launch_frag<1>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s);
     else
