@@ -82,6 +82,9 @@ void ze_launch_attn_decode(const bf16_t* q, int q_row_stride, const bf16_t* kcac
                            float* ws_partial, int max_splits, unsigned* tickets, hipStream_t s) {
     (void)D;
     const float sl = scale * 1.4426950408889634f;
+    // (rope + KV append fused into this launch -- q fragments rotated in registers, the last slice's workgroup rotating and
+    //  appending the new K / V row -- was bit-identical and SLOWER: 132 VGPRs instead of 120 drop the kernel from four to
+    //  three workgroups per CU, 4.42 against 3.84 ms per 64-chain step, more than the removed 4.9-us launch)
     // (two slices per workgroup with both slices' K/V requested up front -- NS = 2 -- win at contexts of about 850
     //  tokens, 3.93 -> 3.86 ms per 64-chain step, and lose at the benchmark's 800-1400: 29.6 against 30.3 questions/s)
     if (seq_ids)
