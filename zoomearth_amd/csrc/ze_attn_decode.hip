@@ -22,10 +22,13 @@
 // MB: slices whose partials the merging workgroup requests up front (24 covers 1536 tokens in one round trip: the
 // single-chain step, where the launch is latency-bound; 8 keeps the kernel at 4 workgroups per CU for the batched
 // step, where it is throughput-bound).  The merge adds the slices in the same order either way.
+// The batched instantiation (MB = 8) is compiled for five waves per SIMD (87 VGPRs, no spills; the LDS images allow five
+// workgroups per CU): occupancy is what this throughput-bound form lives on (three instead of four workgroups per CU
+// cost 15 %).
 // NS: slices per workgroup (attn_split_body): 1 for the single-chain step (most workgroups, shortest chain), 2 for
 // the batched step (grid.y = max_splits / 2).
 template <int MB, int NS>
-__global__ void __launch_bounds__(256) k_attn_decode_split(const bf16_t* __restrict__ q, int q_row_stride,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MB == 8 ? 5 : 1))) k_attn_decode_split(const bf16_t* __restrict__ q, int q_row_stride,
                                                            const bf16_t* __restrict__ kcache,
                                                            const bf16_t* __restrict__ vcache, size_t cache_seq_stride,
                                                            const ze_seq_dev* __restrict__ st_base,
