@@ -99,6 +99,11 @@ int ze_weights_missing(ze_engine* e);
 int ze_weights_arena(ze_engine* e, void** dev_ptr, size_t* bytes);
 
 /* ------------------------------------------------------------------ image front-end (K0-K2) */
+/* replaces: `Image.open(image_fp).convert("RGB")` arriving on the device (src/eval/infer.py:215,237 + the `.to(device)`
+ * of :107): copies a decoded RGB u8 [h, w, 3] tile from host memory (pinned for full PCIe rate) into the caller's
+ * device buffer on `stream`.  The copy is asynchronous when host_rgb is pinned; the tile is uploaded ONCE per tile and
+ * every view / crop of every question about it reads it in place. */
+int ze_tile_upload(ze_engine* e, const uint8_t* host_rgb, int h, int w, uint8_t* dev_rgb, void* stream);
 /* replaces: PIL `image.crop(box).resize((dst_w, dst_h), Image.BICUBIC)` on RGB u8 as used by cut_image /
  * resize_image (src/eval/infer.py:41-85, src/demo.py:30-93) and by the HF image processor
  * (HF:models/qwen2_vl/image_processing_pil_qwen2_vl.py:126-150).  Bit-exact with Pillow.
@@ -196,6 +201,22 @@ int ze_prefill_batch(ze_engine* e, const int32_t* seqs, int n, const int32_t* le
 int ze_decode_batch(ze_engine* e, const int32_t* seqs, int n, const int32_t* tokens, float* out_logits, void* stream);
 int ze_generate_batch(ze_engine* e, const int32_t* seqs, int n, const ze_gen_params* p, int32_t* out_tokens,
                       int32_t* n_out, void* stream);
+/* Continuous batching (replaces: the request stream the reference keeps in flight against its serving back-end,
+ * src/eval/infer_vllm.py:244-271, and -- run one sample at a time there -- the question loop of
+ * src/eval/infer.py:173-249).  Chains join and leave a running batch BETWEEN bursts of decode steps:
+ *   ze_prefill / ze_prefill_batch the newcomers (+ ze_seq_mark_seen), ze_chain_begin each of them (first token from
+ *   the prefill logits; `sample_stream` selects the chain's random stream when p->do_sample, e.g. the request number,
+ *   so a request reproduces whatever batch it lands in), then ze_decode_burst for ALL live chains, read which ones
+ *   finished, ze_chain_tokens them, hand their slots to waiting requests, repeat.
+ * ze_decode_burst runs `steps` sampled decode steps for the n distinct chains (fewer if a chain's max_ctx budget ends
+ * sooner) and returns the number of steps run (>= 0) or a negative ze_status; n_generated[i] / finished[i] (host,
+ * either may be NULL) report each chain's token count so far and its EOS flag after the burst.  p->max_new_tokens and
+ * p->sync_every are not used here: the caller owns the step budget.  A chain's tokens do not depend on which chains
+ * share its bursts.  ze_chain_tokens copies the chain's generated ids (trimmed after the first EOS) to the host. */
+int ze_chain_begin(ze_engine* e, int seq, const ze_gen_params* p, int sample_stream, void* stream);
+int ze_decode_burst(ze_engine* e, const int32_t* seqs, int n, int steps, const ze_gen_params* p, int32_t* n_generated,
+                    int32_t* finished, void* stream);
+int ze_chain_tokens(ze_engine* e, int seq, int32_t* out_tokens, int capacity, int* n_out, void* stream);
 /* Rollout scoring (replaces _get_per_token_logps, src/train/RL/src/open-r1-multimodal/src/open_r1/trainer/
  * grpo_trainer.py:494-504, as the trainer calls it under torch.no_grad for the old policy and the reference model,
  * :660-683): ze_prefill of the sequence, plus, for EVERY position t < len - 1,
@@ -232,7 +253,10 @@ int ze_op_quantize_fp8(ze_engine* e, void* w_bf16, int rows, int cols, void* q_o
 /* C[M,N] = A[M,K] * W[N,K]^T (+bias[N]) ; bf16 in, fp32 accumulate, bf16 out (one rounding).  act: 0 none, 1 exact GELU,
  * 2 none through the weight-streaming launcher of the batched decode step (split-K; for measurements),
  * 3 none through the fragment-major kernels of that step (operands packed inside the call; M <= 64, N % 16 == 0,
- *   K % 32 == 0, K <= 4096). */
+ *   K % 32 == 0, K <= 4096),
+ * 4 the SwiGLU epilogue of the MLP (HF:...modeling_qwen2_5_vl.py:85-96,541-554): W holds gate and up rows interleaved
+ *   in blocks of 16 ([gate 0..15 | up 0..15 | gate 16..31 | ...], N = 2 * width, width % 16 == 0), bias likewise;
+ *   C is [M, N/2] = bf16(bf16(silu(bf16(gate))) * bf16(up)). */
 int ze_op_linear(ze_engine* e, const void* a_bf16, const void* w_bf16, const void* bias_bf16, void* c_bf16, int M,
                  int N, int K, int act, void* stream);
 /* y = weight * bf16(x * rsqrt(mean(x^2)+eps))  (HF:...modeling_qwen2_5_vl.py:64-79), rows x cols bf16. */

@@ -69,6 +69,7 @@ _SIGS = {
     "ze_weights_fill_synthetic": (C.c_int, [_P, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float]),
     "ze_weights_missing": (C.c_int, [_P]),
     "ze_weights_arena": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "ze_tile_upload": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "ze_op_crop_resize": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(C.c_int32), _P, C.c_int, C.c_int, _P]),
     "ze_smart_resize": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_int),
                                   C.POINTER(C.c_int)]),
@@ -95,6 +96,10 @@ _SIGS = {
     "ze_decode_batch": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), _P, _P]),
     "ze_generate_batch": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.POINTER(ZeGenParams), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int32), _P]),
+    "ze_chain_begin": (C.c_int, [_P, C.c_int, C.POINTER(ZeGenParams), C.c_int, _P]),
+    "ze_decode_burst": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(ZeGenParams),
+                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
+    "ze_chain_tokens": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int), _P]),
     "ze_seq_mark_seen": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.c_int, _P]),
     "ze_op_sample_greedy": (C.c_int, [_P, C.c_int, _P, C.c_float, C.POINTER(C.c_int32), _P]),
     "ze_op_sample_temperature": (C.c_int, [_P, C.c_int, _P, C.c_float, C.c_float, C.c_uint64, C.c_int,

@@ -159,6 +159,8 @@ struct ze_engine {
 };
 
 // engine internals used across translation units
+extern unsigned ze_tune_epoch;
+void ze_weights_changed(ze_engine* e);
 int ze_engine_build_layout(ze_engine* e);
 int ze_timer_begin(ze_engine* e, int phase, hipStream_t s);
 void ze_timer_end(ze_engine* e, int handle, hipStream_t s);

@@ -6,6 +6,26 @@
 #include "ze_prng.h"
 
 thread_local std::string ze_global_error;
+unsigned ze_tune_epoch = 0;  // bumped whenever captured decode graphs go stale (launch policy or weight streams changed)
+static int ze_bound_device = -1;  // the launch-policy caches (hipFuncSetAttribute, CU count) are per process: one GPU per process
+
+// Every weight mutation (load, synthetic fill, arena hand-out for a broadcast / RL refresh) invalidates the derived
+// copies: the fragment-major decode copy is rebuilt on the next batched step, the fp8 stream is dropped (the caller
+// quantises again) and captured decode graphs, which bake the weight pointers in, are re-captured.
+void ze_weights_changed(ze_engine* e) {
+    e->frag_ready = false;
+    if (e->fp8_ready) {
+        e->fp8_ready = false;
+        for (auto& L : e->tl)
+            for (ze_linear* l : {&L.qkv, &L.o, &L.gate_up, &L.down}) {
+                l->w8 = nullptr;
+                l->scale8 = nullptr;
+            }
+        e->lm_head8.w8 = nullptr;
+        e->lm_head8.scale8 = nullptr;
+    }
+    ++ze_tune_epoch;
+}
 
 int ze_fail(ze_engine* e, int code, const std::string& msg) {
     if (e) e->err = msg;
@@ -213,6 +233,10 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
         return r;
     };
     if (c.heads <= 0 || c.hidden % c.heads) return bad("hidden must be divisible by heads");
+    if (c.vit_heads <= 0 || c.vit_hidden % c.vit_heads) return bad("vit_hidden must be divisible by vit_heads (> 0)");
+    if (c.kv_heads <= 0) return bad("kv_heads must be positive");
+    if (ze_bound_device >= 0 && ze_bound_device != device_id)
+        return bad("this process already drives another GPU: one process per GPU (launch attributes are cached per process)");
     e->head_dim = c.hidden / c.heads;
     e->vit_head_dim = c.vit_hidden / c.vit_heads;
     if (e->head_dim != 128) return bad("text head_dim must be 128");
@@ -236,6 +260,7 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     e->max_pos = c.max_ctx + 512;
 
     if (hipSetDevice(device_id) != hipSuccess) return bad("hipSetDevice failed");
+    ze_bound_device = device_id;
     ze_engine_build_layout(e);
     int r = 0;
     auto chk = [&](int rr) {
@@ -400,7 +425,7 @@ static std::string canonical_name(const char* name) {
 
 extern "C" int ze_load_weight(ze_engine* e, const char* name, int dtype, int ndim, const int64_t* shape,
                               const void* host_ptr) {
-    if (e) e->frag_ready = false;  // the fragment-major decode copy follows the weights
+    if (e) ze_weights_changed(e);
     if (!e || !name || !shape || !host_ptr) return ze_fail(e, ZE_ERR_INVALID, "null argument");
     const std::string cn = canonical_name(name);
     if (cn == "lm_head.weight" && e->cfg.tie_word_embeddings) {
@@ -431,7 +456,7 @@ extern "C" int ze_load_weight(ze_engine* e, const char* name, int dtype, int ndi
 
 extern "C" int ze_weights_fill_synthetic(ze_engine* e, uint64_t seed, float std_, float matrix_gain, float bias_std,
                                          float norm_jitter) {
-    if (e) e->frag_ready = false;  // the fragment-major decode copy follows the weights
+    if (e) ze_weights_changed(e);
     if (!e) return ze_fail(e, ZE_ERR_INVALID, "null engine");
     hipSetDevice(e->device);
     for (auto& kv : e->dests) {
@@ -467,7 +492,7 @@ extern "C" int ze_weights_missing(ze_engine* e) {
 }
 
 extern "C" int ze_weights_arena(ze_engine* e, void** dev_ptr, size_t* bytes) {
-    if (e) e->frag_ready = false;  // the fragment-major decode copy follows the weights
+    if (e) ze_weights_changed(e);  // the caller is about to overwrite the arena (broadcast / weight refresh)
     if (!e || !dev_ptr || !bytes) return ze_fail(e, ZE_ERR_INVALID, "null argument");
     *dev_ptr = e->arena;
     *bytes = e->arena_used * sizeof(bf16_t);

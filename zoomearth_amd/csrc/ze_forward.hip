@@ -14,7 +14,6 @@
     } while (0)
 #define ZE_KCHECK() ZE_HIP(hipGetLastError())
 extern int ze_gemv_knobs[8];
-static unsigned ze_tune_epoch = 0;
 
 // ================================================================== front-end
 // dst = crop(src, box).resize((dst_w, dst_h), BICUBIC), Pillow-exact (two passes, u8 intermediate).
@@ -84,6 +83,13 @@ static int crop_resize(ze_engine* e, const uint8_t* src, int src_h, int src_w, c
         ze_launch_resize_v(src, src_h, src_w, bx0, by0, dst_w * 3, dst, dst_h, d_ymin, d_ycnt, d_yk, cv.ksize, 1, s);
         ZE_KCHECK();
     }
+    return ZE_OK;
+}
+
+extern "C" int ze_tile_upload(ze_engine* e, const uint8_t* host_rgb, int h, int w, uint8_t* dev_rgb, void* stream) {
+    if (!e || !host_rgb || !dev_rgb || h <= 0 || w <= 0) return ze_fail(e, ZE_ERR_INVALID, "bad tile_upload arguments");
+    hipSetDevice(e->device);
+    ZE_HIP(hipMemcpyAsync(dev_rgb, host_rgb, (size_t)h * w * 3, hipMemcpyHostToDevice, (hipStream_t)stream));
     return ZE_OK;
 }
 
@@ -1094,6 +1100,70 @@ extern "C" int ze_decode_batch(ze_engine* e, const int32_t* seqs, int n, const i
     return ZE_OK;
 }
 
+// The captured batched decode step for `na` chains (chain ids / positions live in device memory, so one graph per
+// batch size and sampling setting serves every composition); nullptr in *out = run eagerly.
+static int batch_step_graph(ze_engine* e, int na, float pen, int ign, const ze_sample_opts& bso, hipGraphExec_t* out) {
+    auto key = std::make_tuple(na, pen, ign, bso.temperature, bso.seed);
+    if (e->bgraph_epoch != ze_tune_epoch) {
+        for (auto& kv : e->bgraphs) hipGraphExecDestroy(kv.second);
+        e->bgraphs.clear();
+        e->bgraph_epoch = ze_tune_epoch;
+    }
+    auto it = e->bgraphs.find(key);
+    if (it == e->bgraphs.end()) {
+        hipStream_t cs;
+        ZE_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        hipGraph_t graph = nullptr;
+        int r = ZE_OK;
+        if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess)
+            r = ze_fail(e, ZE_ERR_HIP, "hipStreamBeginCapture failed");
+        if (r == ZE_OK) r = enqueue_decode_batch(e, na, pen, ign, 1, bso, cs);
+        if (hipStreamEndCapture(cs, &graph) != hipSuccess && r == ZE_OK)
+            r = ze_fail(e, ZE_ERR_HIP, "hipStreamEndCapture failed");
+        hipGraphExec_t ex = nullptr;
+        if (r == ZE_OK && hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0) != hipSuccess)
+            r = ze_fail(e, ZE_ERR_HIP, "hipGraphInstantiate failed");
+        if (graph) hipGraphDestroy(graph);
+        hipStreamDestroy(cs);
+        ZE_TRY(r);
+        it = e->bgraphs.emplace(key, ex).first;
+    }
+    *out = it->second;
+    return ZE_OK;
+}
+
+// `steps` sampled decode steps for the chains in `active` (all with room for them)
+static int run_burst(ze_engine* e, const std::vector<int>& active, int steps, const ze_gen_params* p, float pen, int ign,
+                     const ze_sample_opts& bso, hipStream_t s) {
+    const int na = (int)active.size();
+    ZE_TRY(upload_batch(e, active.data(), na, s));
+    hipGraphExec_t gx = nullptr;
+    if (p->use_graph) ZE_TRY(batch_step_graph(e, na, pen, ign, bso, &gx));
+    for (int i = 0; i < steps; ++i) {
+        if (gx)
+            ZE_HIP(hipGraphLaunch(gx, s));
+        else
+            ZE_TRY(enqueue_decode_batch(e, na, pen, ign, 1, bso, s));
+    }
+    for (int q : active) e->ctx_host[q] += steps;
+    return ZE_OK;
+}
+
+// first token of a chain from the logits its prefill left behind; `sample_stream` = the chain's random stream
+static int begin_chain(ze_engine* e, int q, const ze_gen_params* p, float pen, int ign, int sample_stream, hipStream_t s) {
+    const ze_config& c = e->cfg;
+    ze_sample_opts so = sample_opts_of(p, q);
+    if (so.temperature > 0.f) {
+        ZE_HIP(hipStreamSynchronize(s));
+        e->d_host_ints[40] = sample_stream;
+        ZE_HIP(hipMemcpyAsync(&(e->st_dev + q)->stream, e->d_host_ints + 40, sizeof(int), hipMemcpyHostToDevice, s));
+    }
+    ze_launch_sample(e->dlogits + (size_t)q * c.vocab, c.vocab, e->seen + (size_t)q * c.vocab, pen, e->st_dev + q, e->eos_dev,
+                     c.n_eos, c.pad_token_id, ign, 0, e->out_tokens + (size_t)q * c.max_ctx, e->dsample, so, s);
+    ZE_KCHECK();
+    return ZE_OK;
+}
+
 extern "C" int ze_generate_batch(ze_engine* e, const int32_t* seqs, int n, const ze_gen_params* p, int32_t* out_tokens,
                                  int32_t* n_out, void* stream) {
     if (!e || !seqs || !p || !out_tokens || !n_out) return ze_fail(e, ZE_ERR_INVALID, "null argument");
@@ -1103,85 +1173,45 @@ extern "C" int ze_generate_batch(ze_engine* e, const int32_t* seqs, int n, const
     const int max_new = p->max_new_tokens;
     if (max_new <= 0 || n <= 0) return ze_fail(e, ZE_ERR_INVALID, "max_new_tokens and n must be positive");
     ZE_TRY(ensure_fragments(e, s));
+    // Per-chain budget, as ze_generate clamps it: the last generated token is never fed back, so a chain with `ctx`
+    // cached tokens may produce max_ctx - ctx + 1 tokens.  A chain that reaches its budget leaves the batch like one
+    // that hit EOS: what a request gets never depends on the other requests of its batch.
+    std::vector<int> limit(c.max_seqs, 0);
     for (int i = 0; i < n; ++i) {
         if (seqs[i] < 0 || seqs[i] >= c.max_seqs) return ze_fail(e, ZE_ERR_NOTFOUND, "sequence id out of range");
-        if (e->ctx_host[seqs[i]] + max_new - 1 > c.max_ctx) return ze_fail(e, ZE_ERR_NOMEM, "sequence exceeds max_ctx");
+        for (int j = 0; j < i; ++j)
+            if (seqs[j] == seqs[i]) return ze_fail(e, ZE_ERR_INVALID, "duplicate sequence id in a batch");
+        if (e->ctx_host[seqs[i]] > c.max_ctx) return ze_fail(e, ZE_ERR_NOMEM, "sequence exceeds max_ctx");
+        limit[seqs[i]] = std::min(max_new, c.max_ctx - e->ctx_host[seqs[i]] + 1);
     }
     const float pen = p->repetition_penalty > 0.f ? p->repetition_penalty : 1.0f;
     const int ign = p->ignore_eos ? 1 : 0;
     const ze_sample_opts bso = sample_opts_of(p, 0);
-    if (bso.temperature > 0.f) {  // sampling stream of a chain = its row in this call (reproducible per request)
-        ZE_HIP(hipStreamSynchronize(s));
-        for (int i = 0; i < n; ++i) {
-            e->d_host_ints[40 + i % 16] = i;
-            ZE_HIP(hipMemcpyAsync(&(e->st_dev + seqs[i])->stream, e->d_host_ints + 40 + i % 16, sizeof(int), hipMemcpyHostToDevice, s));
-            if (i % 16 == 15) ZE_HIP(hipStreamSynchronize(s));
-        }
-    }
-    // first token of every chain from the logits its prefill left behind
-    for (int i = 0; i < n; ++i) {
-        const int q = seqs[i];
-        ze_launch_sample(e->dlogits + (size_t)q * c.vocab, c.vocab, e->seen + (size_t)q * c.vocab, pen, e->st_dev + q,
-                         e->eos_dev, c.n_eos, c.pad_token_id, ign, 0, e->out_tokens + (size_t)q * c.max_ctx, e->dsample,
-                         sample_opts_of(p, q), s);
-    }
-    ZE_KCHECK();
-    std::vector<int> active(seqs, seqs + n);
+    // sampling stream of a chain = its row in this call (reproducible per request)
+    for (int i = 0; i < n; ++i) ZE_TRY(begin_chain(e, seqs[i], p, pen, ign, i, s));
+    std::vector<int> active;
     std::vector<int> produced(c.max_seqs, 0);
-    for (int q : active) produced[q] = 1;
+    for (int i = 0; i < n; ++i) {
+        produced[seqs[i]] = 1;
+        if (limit[seqs[i]] > 1) active.push_back(seqs[i]);
+    }
     const int sync_every = std::max(1, p->sync_every);
     const int td = ze_timer_begin(e, 3, s);
     int steps = 1;
     while (steps < max_new && !active.empty()) {
-        ZE_TRY(upload_batch(e, active.data(), (int)active.size(), s));
-        const int burst = std::min(sync_every, max_new - steps);
-        const int na = (int)active.size();
-        hipGraphExec_t gx = nullptr;
-        if (p->use_graph) {  // one captured step per batch size (chain ids / positions live in device memory)
-            auto key = std::make_tuple(na, pen, ign, bso.temperature, bso.seed);
-            if (e->bgraph_epoch != ze_tune_epoch) {
-                for (auto& kv : e->bgraphs) hipGraphExecDestroy(kv.second);
-                e->bgraphs.clear();
-                e->bgraph_epoch = ze_tune_epoch;
-            }
-            auto it = e->bgraphs.find(key);
-            if (it == e->bgraphs.end()) {
-                hipStream_t cs;
-                ZE_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-                hipGraph_t graph = nullptr;
-                int r = ZE_OK;
-                if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess)
-                    r = ze_fail(e, ZE_ERR_HIP, "hipStreamBeginCapture failed");
-                if (r == ZE_OK) r = enqueue_decode_batch(e, na, pen, ign, 1, bso, cs);
-                if (hipStreamEndCapture(cs, &graph) != hipSuccess && r == ZE_OK)
-                    r = ze_fail(e, ZE_ERR_HIP, "hipStreamEndCapture failed");
-                hipGraphExec_t ex = nullptr;
-                if (r == ZE_OK && hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0) != hipSuccess)
-                    r = ze_fail(e, ZE_ERR_HIP, "hipGraphInstantiate failed");
-                if (graph) hipGraphDestroy(graph);
-                hipStreamDestroy(cs);
-                ZE_TRY(r);
-                it = e->bgraphs.emplace(key, ex).first;
-            }
-            gx = it->second;
-        }
-        for (int i = 0; i < burst; ++i) {
-            if (gx)
-                ZE_HIP(hipGraphLaunch(gx, s));
-            else
-                ZE_TRY(enqueue_decode_batch(e, na, pen, ign, 1, bso, s));
-        }
+        int burst = std::min(sync_every, max_new - steps);
+        for (int q : active) burst = std::min(burst, limit[q] - produced[q]);  // >= 1: exhausted chains were dropped
+        ZE_TRY(run_burst(e, active, burst, p, pen, ign, bso, s));
         steps += burst;
-        for (int q : active) {
-            produced[q] += burst;
-            e->ctx_host[q] += burst;
-        }
-        if (!ign && steps < max_new) {  // drop the chains that emitted an EOS (continuous batching: others go on)
-            ZE_HIP(hipMemcpyAsync(e->bstate_host, e->st_dev, sizeof(ze_seq_dev) * c.max_seqs, hipMemcpyDeviceToHost, s));
-            ZE_HIP(hipStreamSynchronize(s));
+        for (int q : active) produced[q] += burst;
+        if (steps < max_new) {  // chains that emitted an EOS or used up their budget leave (continuous batching: others go on)
+            if (!ign) {
+                ZE_HIP(hipMemcpyAsync(e->bstate_host, e->st_dev, sizeof(ze_seq_dev) * c.max_seqs, hipMemcpyDeviceToHost, s));
+                ZE_HIP(hipStreamSynchronize(s));
+            }
             std::vector<int> still;
             for (int q : active)
-                if (!e->bstate_host[q].finished) still.push_back(q);
+                if ((ign || !e->bstate_host[q].finished) && produced[q] < limit[q]) still.push_back(q);
             active.swap(still);
         }
     }
@@ -1204,6 +1234,71 @@ extern "C" int ze_generate_batch(ze_engine* e, const int32_t* seqs, int n, const
         }
         n_out[i] = cnt;
     }
+    return ZE_OK;
+}
+
+// ================================================================== continuous batching (chains join and leave between bursts)
+extern "C" int ze_chain_begin(ze_engine* e, int seq, const ze_gen_params* p, int sample_stream, void* stream) {
+    ZE_TRY(check_seq(e, seq));
+    if (!p) return ze_fail(e, ZE_ERR_INVALID, "null argument");
+    hipSetDevice(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    ZE_TRY(ensure_fragments(e, s));
+    const float pen = p->repetition_penalty > 0.f ? p->repetition_penalty : 1.0f;
+    const int t_s = ze_timer_begin(e, 4, s);
+    const int r = begin_chain(e, seq, p, pen, p->ignore_eos ? 1 : 0, sample_stream, s);
+    ze_timer_end(e, t_s, s);
+    return r;
+}
+
+extern "C" int ze_decode_burst(ze_engine* e, const int32_t* seqs, int n, int steps, const ze_gen_params* p,
+                               int32_t* n_generated, int32_t* finished, void* stream) {
+    if (!e || !seqs || !p || n <= 0 || steps < 0) return ze_fail(e, ZE_ERR_INVALID, "bad burst arguments");
+    const ze_config& c = e->cfg;
+    hipSetDevice(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    ZE_TRY(ensure_fragments(e, s));
+    std::vector<int> active(seqs, seqs + n);
+    for (int q : active) {
+        if (q < 0 || q >= c.max_seqs) return ze_fail(e, ZE_ERR_NOTFOUND, "sequence id out of range");
+        steps = std::min(steps, c.max_ctx - e->ctx_host[q]);  // every chain of the burst must have room for all its steps
+    }
+    if (steps < 0) return ze_fail(e, ZE_ERR_NOMEM, "sequence exceeds max_ctx");
+    const float pen = p->repetition_penalty > 0.f ? p->repetition_penalty : 1.0f;
+    const int ign = p->ignore_eos ? 1 : 0;
+    const int td = ze_timer_begin(e, 3, s);
+    if (steps > 0) ZE_TRY(run_burst(e, active, steps, p, pen, ign, sample_opts_of(p, 0), s));
+    ze_timer_end(e, td, s);
+    ZE_HIP(hipMemcpyAsync(e->bstate_host, e->st_dev, sizeof(ze_seq_dev) * c.max_seqs, hipMemcpyDeviceToHost, s));
+    ZE_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < n; ++i) {
+        if (n_generated) n_generated[i] = e->bstate_host[seqs[i]].n_gen;
+        if (finished) finished[i] = e->bstate_host[seqs[i]].finished;
+    }
+    return steps;
+}
+
+extern "C" int ze_chain_tokens(ze_engine* e, int seq, int32_t* out, int cap, int* n_out, void* stream) {
+    ZE_TRY(check_seq(e, seq));
+    if (!out || !n_out || cap < 0) return ze_fail(e, ZE_ERR_INVALID, "null argument");
+    const ze_config& c = e->cfg;
+    hipSetDevice(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    ze_seq_dev st;
+    ZE_HIP(hipMemcpyAsync(&st, e->st_dev + seq, sizeof(st), hipMemcpyDeviceToHost, s));
+    ZE_HIP(hipStreamSynchronize(s));
+    int n = std::min(std::min(st.n_gen, cap), c.max_ctx);
+    if (n > 0) ZE_HIP(hipMemcpy(out, e->out_tokens + (size_t)seq * c.max_ctx, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    // trim at the first EOS (tokens after it are pad, as HF emits for finished rows)
+    for (int i = 0; i < n; ++i) {
+        bool is_eos = false;
+        for (int k = 0; k < c.n_eos; ++k) is_eos |= out[i] == c.eos_token_ids[k];
+        if (is_eos && st.finished) {
+            n = i + 1;
+            break;
+        }
+    }
+    *n_out = n;
     return ZE_OK;
 }
 
@@ -1239,6 +1334,10 @@ extern "C" int ze_op_linear(ze_engine* e, const void* a, const void* w, const vo
         ze_launch_gemm_frag(ZE_EPI_NONE, xf, wf, (const bf16_t*)bias, nullptr, 0, (bf16_t*)cmat, N, M, N, K, s);
         hipStreamSynchronize(s);
         hipFree(wf);
+    } else if (act == 4) {  // SwiGLU epilogue on interleaved gate/up rows: C is [M, N/2]
+        if (N % 32) return ze_fail(e, ZE_ERR_INVALID, "SwiGLU: N = 2 * width with width % 16 == 0");
+        ze_launch_gemm(ZE_EPI_SWIGLU, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias, nullptr, 0,
+                       (bf16_t*)cmat, N / 2, nullptr, M, N, K, s);
     } else if (act == 2) {  // weight-streaming mode of the batched decode step (rows = chains), for measurements
         ze_launch_gemm_stream(ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias, nullptr, 0,
                               (bf16_t*)cmat, N, M, N, K, e->gemm_ws(), s);
@@ -1308,7 +1407,7 @@ static int quantize_linear(ze_engine* e, ze_linear& l, int rows, int cols, uint8
 
 extern "C" int ze_weights_quantize_fp8(ze_engine* e, void* stream) {
     if (!e) return ze_fail(e, ZE_ERR_INVALID, "null engine");
-    if (e->fp8_ready) return ZE_OK;
+    if (e->fp8_ready) return ZE_OK;  // (a weight change clears the flag: ze_weights_changed)
     const ze_config& c = e->cfg;
     hipStream_t s = (hipStream_t)stream;
     hipSetDevice(e->device);
@@ -1324,7 +1423,7 @@ extern "C" int ze_weights_quantize_fp8(ze_engine* e, void* stream) {
         bytes += (size_t)c.vocab * pad16(H);
         rows += c.vocab;
     }
-    ZE_HIP(hipMalloc((void**)&e->arena8, bytes + rows * sizeof(float) + 256));
+    if (!e->arena8) ZE_HIP(hipMalloc((void**)&e->arena8, bytes + rows * sizeof(float) + 256));  // re-quantisation reuses it
     ZE_HIP(hipMemsetAsync(e->arena8, 0, bytes + rows * sizeof(float) + 256, s));
     uint8_t* cur8 = e->arena8;
     float* curs = reinterpret_cast<float*>(e->arena8 + (bytes + 255) / 256 * 256);

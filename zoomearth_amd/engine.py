@@ -309,6 +309,41 @@ class Engine:
         self._check(self.lib.ze_generate_batch(self.h, sp, len(sq), C.byref(p), out, n_out, self._stream()))
         return [[int(out[i * max_new_tokens + t]) for t in range(n_out[i])] for i in range(len(sq))]
 
+    # ------------------------------------------------------------------ continuous batching
+    def chain_begin(self, seq: int, params, sample_stream: int = 0):
+        """First token of a prefilled chain (from the logits its prefill left); `params` from gen_params()."""
+        self._check(self.lib.ze_chain_begin(self.h, seq, C.byref(params), int(sample_stream), self._stream()))
+
+    def gen_params(self, repetition_penalty: float = 1.0, ignore_eos: bool = False, use_graph: bool = True,
+                   do_sample: bool = False, temperature: float = 1.0, seed: int = 0):
+        return self._gen_params(0, repetition_penalty, ignore_eos, use_graph, 1, do_sample, temperature, seed)
+
+    def decode_burst(self, seqs, steps: int, params):
+        """`steps` sampled decode steps for the live chains `seqs`; returns (steps run, n_generated[], finished[])."""
+        sq, sp = _i32(seqs)
+        ng = (C.c_int32 * len(sq))()
+        fin = (C.c_int32 * len(sq))()
+        ran = self._check(self.lib.ze_decode_burst(self.h, sp, len(sq), int(steps), C.byref(params), ng, fin,
+                                                   self._stream()))
+        return ran, list(ng), [bool(f) for f in fin]
+
+    def chain_tokens(self, seq: int, capacity: int = 0):
+        cap = int(capacity) if capacity else self.max_ctx
+        out = (C.c_int32 * max(cap, 1))()
+        n = C.c_int()
+        self._check(self.lib.ze_chain_tokens(self.h, seq, out, cap, C.byref(n), self._stream()))
+        return [int(out[i]) for i in range(n.value)]
+
+    def tile_upload(self, host_rgb) -> torch.Tensor:
+        """Decoded RGB u8 [H, W, 3] host array / tensor (ideally pinned) -> device tensor (ze_tile_upload)."""
+        t = host_rgb if isinstance(host_rgb, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(host_rgb, dtype=np.uint8))
+        assert t.dtype == torch.uint8 and t.dim() == 3 and t.shape[2] == 3 and t.is_contiguous()
+        out = torch.empty(t.shape, dtype=torch.uint8, device=self.device)
+        self._check(self.lib.ze_tile_upload(self.h, C.c_void_p(t.data_ptr()), int(t.shape[0]), int(t.shape[1]), _ptr(out),
+                                            self._stream()))
+        out._ze_host_keepalive = t  # the async copy reads the host buffer until the stream reaches it
+        return out
+
     def sample_greedy(self, seq: int, logits: torch.Tensor, repetition_penalty: float = 1.0) -> int:
         tok = C.c_int32()
         self._check(self.lib.ze_op_sample_greedy(self.h, seq, _ptr(logits), repetition_penalty, C.byref(tok),
@@ -338,7 +373,7 @@ class Engine:
     def op_linear(self, a, w, bias=None, act: int = 0):
         m, k = a.shape
         n = w.shape[0]
-        out = torch.empty((m, n), dtype=torch.bfloat16, device=self.device)
+        out = torch.empty((m, n // 2 if act == 4 else n), dtype=torch.bfloat16, device=self.device)
         self._check(self.lib.ze_op_linear(self.h, _ptr(a), _ptr(w), _ptr(bias), _ptr(out), m, n, k, act, self._stream()))
         return out
 

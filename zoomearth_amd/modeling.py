@@ -199,6 +199,8 @@ class ZoomEarthForConditionalGeneration:
             feats = [self._features(pixel_values[offs[i]:offs[i + 1]], grids[i], keys[i]) for i in my[n_img_reused:]]
             emb = (torch.cat(feats) if len(feats) > 1 else feats[0]) if feats else None
             pos, delta = e.rope_index(ids, my_grids)
+            if not batched:
+                self._chains.pop(slot, None)  # re-registered only after its prefill succeeded
             if reuse:
                 e.seq_truncate(slot, reuse)  # also clears the chain's seen-set
             else:
