@@ -1,0 +1,136 @@
+"""GPU: the ZoomEarth-3B layer shape -- the dims `bench.py` runs -- through the C ABI against the oracle.
+
+Every other oracle comparison uses the tiny config or the 7B text shape; this one pins the 3B-specific fast paths
+(HF:models/qwen2_5_vl/modeling_qwen2_5_vl.py:408-471 ViT, :761-872 text model):
+  * ViT: patch-embed K = 1176 on the register-staged GEMM, MLP width 3420 zero-padded to 3456, 16 heads x 80, one
+    window-attention and one full-attention block, merger -- a 36 x 36 view (1296 patches -> 324 image tokens);
+  * prefill of the benchmark's 802-token prompt: every `k_gemm_ring` tile policy at M = 802, GQA group 8 flash attention;
+  * the batch-1 decode path: `k_gemv<2,1,1,4>` at K = 2048 / N = 22016 with the 16-row gate/up interleave, the K-split
+    down projection, `k_attn_decode_split<24,1>` with 8 q heads per kv head;
+  * the batched decode step (`ze_decode_batch`) at 1, 33 and 64 chains with ragged contexts: fragment-major qkv / o /
+    gate-up / lm_head kernels, split-K ring down projection, `k_attn_decode_split<8,1>`.
+Depth is reduced (2 ViT blocks, 2 decoder layers) and the vocabulary is 4096 so the numpy oracle finishes in seconds;
+the per-layer arithmetic is the full-size one.
+
+Tolerance (no HF fixture at this shape): the engine's output against the fp32 oracle must stay within 2x the oracle's
+own bf16-vs-fp32 error on the same teacher-forced path -- the protocol of test_gpu_model.py / SURVEY.md 8 c.2."""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import frontend, prng
+from oracle import qwen25vl as Q
+
+pytestmark = pytest.mark.gpu
+W3 = dict(seed=5, std=0.02, matrix_gain=2.0, bias_std=0.02, norm_jitter=0.1)
+IMG, VS, VE, EOS, PAD = 4000, 4001, 4002, 4003, 4004
+
+
+def configs():
+    from zoomearth_amd.config import ModelConfig
+    mc = ModelConfig.zoomearth_3b()
+    mc = dataclasses.replace(mc, text=dataclasses.replace(mc.text, num_hidden_layers=2, vocab_size=4096),
+                             vision=dataclasses.replace(mc.vision, depth=2, fullatt_block_indexes=(1,)),
+                             image_token_id=IMG, vision_start_token_id=VS, vision_end_token_id=VE,
+                             eos_token_ids=(EOS,), pad_token_id=PAD)
+    oc = Q.Config(vision=Q.VisionConfig(depth=2, fullatt_block_indexes=(1,)),
+                  text=Q.TextConfig(num_hidden_layers=2, vocab_size=4096),
+                  image_token_id=IMG, vision_start_token_id=VS, vision_end_token_id=VE, eos_token_ids=(EOS,),
+                  pad_token_id=PAD)
+    return mc, oc
+
+
+def snapshot(o):
+    return list(o.k_cache), list(o.v_cache), o.ctx, o.rope_delta
+
+
+def restore(o, snap):
+    o.k_cache, o.v_cache, o.ctx, o.rope_delta = list(snap[0]), list(snap[1]), snap[2], snap[3]
+
+
+def test_3b_layer_shape_vit_prefill_decode_vs_oracle():
+    from zoomearth_amd.engine import Engine
+    mc, oc = configs()
+    w = Q.synthetic_weights(oc, **W3)
+    o32, o16 = Q.Qwen25VLOracle(oc, w, "fp32"), Q.Qwen25VLOracle(oc, w, "bf16")
+    e = Engine(mc, device=0, max_seqs=64, max_ctx=1024, max_patches=2048, max_tile_side=1024)
+    try:
+        e.fill_synthetic(**W3)
+        # ---- front-end + ViT on a 36 x 36 grid
+        img = prng.synthetic_tile(11, 504, 504)
+        pv, grid = e.preprocess_image(torch.from_numpy(img).cuda())
+        want_pv, want_grid = frontend.image_to_pixel_values(img)
+        assert tuple(grid) == tuple(want_grid) == (1, 36, 36)
+        assert np.array_equal(pv.cpu().numpy(), want_pv)
+        emb = e.vit_forward(pv, [grid])
+        v32, v16 = o32.vit_forward(want_pv, [want_grid]), o16.vit_forward(want_pv, [want_grid])
+        got_v = emb.float().cpu().numpy()
+        yard_v = float(np.abs(v16 - v32).max())
+        err_v = float(np.abs(got_v - v32).max())
+        rms_v = float(np.sqrt(np.mean((got_v - v32) ** 2))), float(np.sqrt(np.mean((v16 - v32) ** 2)))
+        print(f"3B ViT (1296 patches): max|engine - fp32| = {err_v:.4f} (oracle bf16-vs-fp32 {yard_v:.4f}), rms {rms_v[0]:.5f} ({rms_v[1]:.5f})")
+        assert err_v <= 2.0 * yard_v and rms_v[0] <= 2.0 * rms_v[1]
+
+        # ---- prefill of the benchmark prompt (21 + 1 + 324 + 1 + 455 = 802 tokens) and 6 teacher-forced decode steps
+        n_img = grid[1] * grid[2] // 4
+        ids = prng.uniform_ints(21, 21, 10, 3990).tolist() + [VS] + [IMG] * n_img + [VE] + \
+            prng.uniform_ints(22, 455, 10, 3990).tolist()
+        assert len(ids) == 802
+        forced = [int(t) for t in prng.uniform_ints(23, 6, 10, 3990)]
+        ref32 = [o32.prefill(ids, pixel_values=want_pv, grid_thw=[want_grid])]
+        snap32 = snapshot(o32)
+        ref32 += [o32.decode_step(t) for t in forced]
+        ref16 = [o16.prefill(ids, pixel_values=want_pv, grid_thw=[want_grid])] + [o16.decode_step(t) for t in forced]
+        pos, delta = e.rope_index(ids, [grid])
+        e.seq_reset(0)
+        got = [e.prefill(0, ids, emb, pos, delta).cpu().numpy()] + [e.decode_step(0, t).cpu().numpy() for t in forced]
+        yard = max(float(np.abs(a - b).max()) for a, b in zip(ref16, ref32))
+        worst = [float(np.abs(a - b).max()) for a, b in zip(got, ref32)]
+        print(f"3B prefill(802) + 6 decode steps (batch-1 GEMV path): max|engine - fp32| per step = "
+              f"{[round(x, 4) for x in worst]}, oracle bf16-vs-fp32 = {yard:.4f}")
+        assert max(worst) <= 2.0 * yard
+        # greedy token agrees with the fp32 oracle wherever its top-1 / top-2 margin is decidable
+        undecidable = 0
+        for a, b in zip(got, ref32):
+            top2 = np.partition(b, -2)[-2:]
+            if top2[1] - top2[0] > 2.0 * 2.0 * yard:
+                assert int(np.argmax(a)) == int(np.argmax(b))
+            else:
+                undecidable += 1
+        print(f"3B greedy tokens: {len(got) - undecidable} of {len(got)} steps decidable and equal")
+
+        # ---- the same chain through the batched decode step at 1, 33 and 64 chains.  Chain c = the prompt (every
+        # eighth chain a shorter prefix of it: ragged contexts), then two teacher-forced steps with its own tokens.
+        nch = 64
+        lens = [len(ids) if c % 8 != 1 else 640 + 2 * c for c in range(nch)]
+        t1 = [int(t) for t in prng.uniform_ints(31, nch, 10, 3990)]
+        t2 = [int(t) for t in prng.uniform_ints(32, nch, 10, 3990)]
+        want = {}
+        snaps = {len(ids): snap32}
+        for c in range(nch):
+            if lens[c] not in snaps:
+                o32.prefill(ids[: lens[c]], pixel_values=want_pv, grid_thw=[want_grid])
+                snaps[lens[c]] = snapshot(o32)
+            restore(o32, snaps[lens[c]])
+            want[c] = (o32.decode_step(t1[c]), o32.decode_step(t2[c]))
+        for c in range(nch):
+            e.seq_reset(c)
+            e.prefill(c, ids[: lens[c]], emb, pos[:, : lens[c]], delta, want_logits=False)
+        for n in (1, 33, 64):
+            chains = list(range(n))
+            for c in chains:
+                e.seq_truncate(c, lens[c])
+            l1 = e.decode_batch(chains, [t1[c] for c in chains]).cpu().numpy()
+            l2 = e.decode_batch(chains, [t2[c] for c in chains]).cpu().numpy()
+            errs = [max(float(np.abs(l1[c] - want[c][0]).max()), float(np.abs(l2[c] - want[c][1]).max())) for c in chains]
+            print(f"3B batched decode, {n} chains: max|engine - fp32| = {max(errs):.4f} (2 x yardstick = {2 * yard:.4f})")
+            assert max(errs) <= 2.0 * yard, (n, int(np.argmax(errs)), max(errs))
+            if n == 64:  # batch invariance: chain 0 alone (n = 1 run) and inside the full batch are bit-identical
+                e.seq_truncate(0, lens[0])
+                alone = e.decode_batch([0], [t1[0]]).cpu().numpy()
+                assert np.array_equal(alone[0], l1[0])
+    finally:
+        e.close()
+        torch.cuda.empty_cache()

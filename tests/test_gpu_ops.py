@@ -46,6 +46,42 @@ def test_linear(tiny_engine, m, n, k, bias, act):
         close_bf16(got, want, scale=0.05 * np.sqrt(k) * 0.05)
 
 
+# The GEMM shapes of the 3B benchmark path, one per tile policy of ze_launch_gemm (ze_gemm.hip): prefill at M = 802
+# (qkv on the 128 x 128 spread ring, o / down on the eight-wave 64 x 128 ring, gate/up on 128 x 256), the ViT at
+# M = 1296 (patch embed K = 1176 on the register-staged kernel, qkv, padded MLP width 3456), the merger, the second-stage
+# prefill (M = 518) and the 16-chain batched prefill (M = 12832: 256 x 256 tiles), each against float64.
+@pytest.mark.parametrize("m,n,k,bias,swiglu", [
+    (802, 2560, 2048, True, False), (802, 2048, 2048, False, False), (802, 22016, 2048, False, True),
+    (802, 2048, 11008, False, False), (518, 22016, 2048, False, True), (518, 2048, 11008, False, False),
+    (1296, 1280, 1176, False, False), (1296, 3840, 1280, True, False), (1296, 1280, 1280, True, False),
+    (1296, 6912, 1280, True, True), (1296, 1280, 3456, True, False), (324, 5120, 5120, True, False),
+    (324, 2048, 5120, True, False), (12832, 22016, 2048, False, True), (12832, 2048, 11008, False, False),
+    (12832, 2560, 2048, True, False),
+])
+def test_linear_3b_shapes(tiny_engine, m, n, k, bias, swiglu):
+    a, w = rnd(21, (m, k)), rnd(22, (n, k), 0.05)
+    b = rnd(23, (n,), 0.5) if bias else None
+    got_t = tiny_engine.op_linear(to_dev_bf16(a), to_dev_bf16(w), to_dev_bf16(b) if bias else None, 4 if swiglu else 0)
+    # float64 reference on a row sample that touches every 64-row tile of the grid (all columns): keeps the host side
+    # of the 12832-row case at a few seconds
+    rows = np.unique(np.concatenate([np.arange(0, m, 64) + (np.arange(0, m, 64) // 64 * 37) % 64, [0, m - 1],
+                                     prng.uniform_ints(24, 192, 0, m)]).clip(0, m - 1))
+    got = got_t[torch.from_numpy(rows).cuda()].float().cpu().numpy()
+    full = a[rows].astype(np.float64) @ w.astype(np.float64).T + (b.astype(np.float64) if bias else 0.0)
+    sc = 0.05 * np.sqrt(k) * 0.05
+    if not swiglu:
+        close_bf16(got, full, scale=sc)
+        return
+    # packed rows: [gate 0..15 | up 0..15 | gate 16..31 | ...]; C = bf16(bf16(silu(bf16(g))) * bf16(u))
+    blk = full.reshape(len(rows), n // 32, 2, 16)
+    g, u = blk[:, :, 0, :].reshape(len(rows), -1), blk[:, :, 1, :].reshape(len(rows), -1)
+    want = g / (1.0 + np.exp(-g)) * u
+    # four roundings (g, u, silu, product), each up to 2^-8 relative; |d silu / dg| <= 1.1 carries g's into the product
+    tol = 2.0 ** -8 * (3.0 * np.abs(want) + 1.2 * np.maximum(np.abs(g), sc) * np.abs(u) + sc * sc)
+    bad = np.abs(got - want) > tol
+    assert not bad.any(), (int(bad.sum()), float((np.abs(got - want) / tol).max()))
+
+
 @pytest.mark.parametrize("m,n,k,bias", [
     (1, 2560, 2048, True), (8, 2048, 2048, False), (17, 200, 128, True), (33, 72, 352, True), (64, 2560, 2048, True),
     (64, 3584, 3584, False), (64, 22016, 2048, False), (48, 2048, 11008, False), (65, 512, 256, True),
