@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """LRS-GRO batch inference on the MI355X engine: drop-in for the reference's `src/eval/infer.py`
 (/root/reference/src/eval/infer.py: same CLI `--model_name --exp_name`, same ./LRS_GRO/test + ./image/ layout,
-same two-stage chain, same `results/{exp_name}{rank}.jsonl` records).
+same two-stage chain, same `results/{exp_name}{rank}.jsonl` records in the rank's dataset order).
 
-Differences, all documented in DESIGN.md: a 5000-px tile is decoded ONCE per tile by a prefetch thread, uploaded to
-HBM and cropped/resized by the HIP front-end (the reference decodes it twice per question on the CPU); sampling at
-T=0.01 draws from the same distribution with the engine's own random stream; bf16 arithmetic; questions are
-sharded by tile across ranks; every question is wrapped in try/except so one malformed bbox does not kill the run
-(the reference crashes on a 3-number box).
+Differences, all documented in DESIGN.md: up to `--batch_size` question chains advance together on the GPU (continuous
+batching, `zoomearth_amd/scheduler.py`; the reference runs `BATCH_SIZE = 1`, :27) -- a chain's output does not depend
+on the batch size; a 5000-px tile is decoded ONCE per tile by a prefetch thread, uploaded to HBM and cropped / resized
+by the HIP front-end (the reference decodes it twice per question on the CPU), and the <=512-px view of a tile is
+encoded once for all its questions; sampling at T=0.01 draws from the same distribution with the engine's own random
+stream; bf16 arithmetic; questions are sharded by tile across ranks; a question whose box does not parse into four
+numbers is recorded as an error instead of killing the run (the reference crashes on a 3-number box).
 """
 import argparse
 import os
@@ -23,8 +25,9 @@ from zoomearth_amd.accel import Accelerator  # noqa: E402
 from zoomearth_amd.image import TilePrefetcher  # noqa: E402
 from zoomearth_amd.modeling import ZoomEarthForConditionalGeneration  # noqa: E402
 from zoomearth_amd.processor import ZoomEarthProcessor  # noqa: E402
+from zoomearth_amd.scheduler import ChainScheduler  # noqa: E402
 
-BATCH_SIZE = 1
+BATCH_SIZE = 64  # question chains advanced together per GPU (the reference: 1)
 
 
 def collate_fn(examples):
@@ -33,11 +36,16 @@ def collate_fn(examples):
 
 def prepare_dataloader(ds_path, collate_fn):
     from datasets import load_from_disk
-    return DataLoader(load_from_disk(ds_path), batch_size=BATCH_SIZE, collate_fn=collate_fn, shuffle=False, num_workers=0)
+    return DataLoader(load_from_disk(ds_path), batch_size=1, collate_fn=collate_fn, shuffle=False, num_workers=0)
 
 
-def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir="./image/", max_new_tokens=1024):
-    model = ZoomEarthForConditionalGeneration.from_pretrained(model_name)
+def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir="./image/", max_new_tokens=1024,
+                    batch_size=BATCH_SIZE, max_ctx=4096, do_sample=True):
+    # capacity: the stage-2 prompt holds the stage-1 prompt, its output and a second image (<= ~3200 tokens at the
+    # default budgets); prefill passes of up to 16 prompts share their GEMMs
+    model = ZoomEarthForConditionalGeneration.from_pretrained(
+        model_name, max_seqs=batch_size, max_ctx=max_ctx, max_prefill_rows=max(max_ctx, min(batch_size, 16) * 1024),
+        max_patches=max(8192, min(batch_size, 32) * 1400))
     model.eval()
     processor = ZoomEarthProcessor.from_pretrained(model_name, trust_remote_code=True, max_pixels=128 * 128 * 28 * 28)
     processor.tokenizer.padding_side = "left"
@@ -51,26 +59,51 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
     fout = open(out_path, "w", encoding="utf-8")
     model, dl = accelerator.prepare(model, prepare_dataloader(ds_path, collate_fn))
 
-    def chat(prompts, images):
-        return H.chat_batch(prompts, images, processor, model, device=accelerator.device, do_sample=True,
-                            temperature=0.01, max_new_tokens=max_new_tokens)
-
-    def tile_path(sample):
-        return os.path.join(image_dir, sample["image_name"].split("/")[-1])
+    def tile_path(name):
+        return os.path.join(image_dir, name.split("/")[-1])
 
     # the rank's questions arrive grouped by tile: decode the next tile while the current one is being questioned
-    tiles = TilePrefetcher([tile_path(s) for ex in dl for s in ex], model.engine)
-    for examples in tqdm(dl, desc="Evaluating"):
+    tiles = TilePrefetcher([tile_path(n) for n in dl.image_names()], model.engine)
+    sched = ChainScheduler(model, processor, do_sample=do_sample, temperature=0.01 if do_sample else None, burst=8)
+    done, next_out = {}, [0]
+    bar = tqdm(total=len(dl), desc="Evaluating")
+
+    def flush():  # records leave in the rank's dataset order, whatever order the chains finish in
+        while next_out[0] in done:
+            sample, r = done.pop(next_out[0])
+            H.record(fout, sample["question"], sample, sample, r["output1"], r["output2"], r["error"])
+            next_out[0] += 1
+            bar.update(1)
+
+    view_of = (None, None, None)  # (tile path, view, scale): every question of a tile looks at the same <=512-px view
+    i = 0
+    for examples in dl:
         for sample in examples:
+            while len(sched.waiting) >= batch_size:  # keep the queue short: tiles stay resident only while needed
+                sched.step()
+                flush()
+            idx = i
+            i += 1
             try:
-                r = H.zoom_chain(sample["question"], tiles.get(tile_path(sample)), chat)
-                H.record(fout, sample["question"], sample, sample, r["output1"], r["output2"], r["error"])
+                path = tile_path(sample["image_name"])
+                tile = tiles.get(path)
+                if view_of[0] != path:
+                    view_of = (path,) + tuple(H.resize_image(tile))
+                H.submit_zoom_chain(sched, sample["question"], tile,
+                                    lambda r, idx=idx, sample=sample: done.__setitem__(idx, (sample, r)),
+                                    view=view_of[1], scale=view_of[2], stream_id=int(idx), max_new_tokens=max_new_tokens)
             except Exception as ex:  # keep going; the record marks the failure
-                H.record(fout, sample["question"], sample, sample, f"Error: {ex}", "", True)
+                done[idx] = (sample, dict(output1=f"Error: {ex}", output2="", error=True))
+    while sched.busy():
+        sched.step()
+        flush()
+    flush()
+    bar.close()
     fout.close()
     accelerator.wait_for_everyone()
     if accelerator.is_main_process:
         print("Done! Predictions has been written to: ", out_path)
+    return sched.stats
 
 
 if __name__ == "__main__":
@@ -80,5 +113,9 @@ if __name__ == "__main__":
     parser.add_argument("--dataset", type=str, default="./LRS_GRO/test")
     parser.add_argument("--image_dir", type=str, default="./image/")
     parser.add_argument("--max_new_tokens", type=int, default=1024)
+    parser.add_argument("--batch_size", type=int, default=BATCH_SIZE, help="question chains advanced together per GPU")
+    parser.add_argument("--max_ctx", type=int, default=4096, help="tokens per chain (KV capacity)")
+    parser.add_argument("--greedy", action="store_true", help="arg-max instead of the reference's T=0.01 sampling")
     args = parser.parse_args()
-    eval_model_lora(args.model_name, args.exp_name, args.dataset, args.image_dir, args.max_new_tokens)
+    eval_model_lora(args.model_name, args.exp_name, args.dataset, args.image_dir, args.max_new_tokens, args.batch_size,
+                    args.max_ctx, do_sample=not args.greedy)

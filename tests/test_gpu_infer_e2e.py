@@ -1,0 +1,144 @@
+"""GPU: the drop-in entry points end to end, as `run_scripts/infer.sh` and `run_scripts/eval.sh` run them.
+
+Builds, under tmp_path, what the reference's scripts expect in their working directory
+(/root/reference/src/eval/infer.py:145-252, run_scripts/infer.sh:1-7): an Arrow dataset at ./LRS_GRO/test
+(`load_from_disk`), PNG tiles under ./image/, and an HF-style checkpoint directory (config.json, generation_config.json,
+model.safetensors, tokenizer.json) for the tiny config.  Then
+  * `python src/infer.py --model_name ... --exp_name ... --batch_size 8` and the same with `--batch_size 1` must write
+    the SAME results JSONL, record for record (continuous batching does not change a chain's tokens);
+  * `bash run_scripts/infer.sh` (defaults: 64 chains, 1024 new tokens) writes the same records for the questions whose
+    generations stop within the short budget -- and the same schema for all;
+  * `bash run_scripts/eval.sh` scores the file.
+Random weights never write a box, so the tiny tokenizer's vocabulary is built so that every generated word IS a
+`"bbox_2d":[...]` fragment (most with four numbers, some with three: the error path) -- stage 2 really runs.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from gpu_util import CHAIN_W
+from oracle import prng
+from oracle import qwen25vl as Q
+from zoomearth_amd import checkpoint
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ["question_id", "ground_truth", "answer1", "answer2", "bbox_ref", "bbox", "prompt", "category", "stage1", "stage2",
+        "type", "image", "error", "model_id"]  # /root/reference/src/eval/infer.py:126-143
+
+
+def word(i: int) -> str:
+    if i % 3 == 0:
+        return f"w{i}"
+    x, y = (i * 37) % 400, (i * 91) % 300
+    if i % 11 == 1:
+        return f'"bbox_2d":[{x},{y},{x + 40}]'          # three numbers: cut_image cannot unpack it
+    return f'"bbox_2d":[{x},{y},{x + 30 + i % 200},{y + 20 + i % 150}]'
+
+
+def write_tokenizer(path):
+    from tokenizers import AddedToken, Tokenizer
+    from tokenizers.models import WordLevel
+    from tokenizers.pre_tokenizers import WhitespaceSplit
+    specials = {"<|endoftext|>": 2043, "<|im_end|>": 2045, "<|im_start|>": 2044, "<|vision_start|>": 2002,
+                "<|vision_end|>": 2003, "<|image_pad|>": 2005, "<unk>": 2047}
+    vocab = {word(i): i for i in range(2000)}
+    vocab.update(specials)
+    tok = Tokenizer(WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = WhitespaceSplit()
+    tok.add_special_tokens([AddedToken(t, special=True) for t in specials if t != "<unk>"])
+    tok.save(os.path.join(path, "tokenizer.json"))
+    with open(os.path.join(path, "tokenizer_config.json"), "w") as f:
+        json.dump({"pad_token": "<|endoftext|>"}, f)
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory):
+    from datasets import Dataset
+    from PIL import Image
+    d = tmp_path_factory.mktemp("lrsgro")
+    ck = d / "ckpt"
+    os.makedirs(ck)
+    hf_cfg = {"vision_config": dict(depth=4, hidden_size=160, num_heads=2, intermediate_size=220, out_hidden_size=512,
+                                    fullatt_block_indexes=[1, 3]),
+              "hidden_size": 512, "num_hidden_layers": 3, "num_attention_heads": 4, "num_key_value_heads": 2,
+              "intermediate_size": 1376, "vocab_size": 2048, "rms_norm_eps": 1e-6, "rope_theta": 1000000.0,
+              "rope_scaling": {"type": "mrope", "mrope_section": [16, 24, 24]}, "tie_word_embeddings": True,
+              "image_token_id": 2005, "vision_start_token_id": 2002, "vision_end_token_id": 2003,
+              "eos_token_id": [2045, 2043], "pad_token_id": 2043}
+    with open(ck / "config.json", "w") as f:
+        json.dump(hf_cfg, f)
+    with open(ck / "generation_config.json", "w") as f:
+        json.dump({"eos_token_id": [2045, 2043], "pad_token_id": 2043, "repetition_penalty": 1.0}, f)
+    checkpoint.write_safetensors(str(ck / "model.safetensors"), Q.synthetic_weights(Q.tiny_config(), **CHAIN_W), bf16=True)
+    write_tokenizer(str(ck))
+    os.makedirs(d / "image")
+    sizes = [(700, 640), (900, 520), (300, 280)]  # the last one is smaller than the 512-px view: no downscale
+    for t, (w, h) in enumerate(sizes):
+        Image.fromarray(prng.synthetic_tile(300 + t, h, w)).save(d / "image" / f"tile{t}.png")
+    rows = []
+    for q in range(11):
+        t = (0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 0)[q]  # grouped by tile, with one straggler at the end
+        rows.append({"question": " ".join(word(int(v)) for v in prng.uniform_ints(500 + q, 4 + q % 3, 0, 1999)),
+                     "image_name": f"some/dir/tile{t}.png", "question_id": 1000 + q, "ground_truth": word(3 * q),
+                     "category": "cat%d" % (q % 2), "type": ("count", "object", "relation")[q % 3],
+                     "bbox": [1.0 * q, 2.0, 30.0 + q, 40.0]})
+    Dataset.from_list(rows).save_to_disk(str(d / "LRS_GRO" / "test"))
+    os.symlink(os.path.join(ROOT, "src"), d / "src")
+    os.symlink(os.path.join(ROOT, "run_scripts"), d / "run_scripts")
+    return d, rows
+
+
+def run(cmd, cwd, **env):
+    r = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, PYTHONPATH=ROOT, **env))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
+
+
+def load(path):
+    with open(path, encoding="utf-8") as f:
+        return [json.loads(line) for line in f if line.strip()]
+
+
+def test_infer_entry_point_batched_equals_sequential_then_eval(workdir):
+    d, rows = workdir
+    base = [sys.executable, "src/infer.py", "--model_name", "ckpt", "--max_new_tokens", "14", "--max_ctx", "2048"]
+    run(base + ["--exp_name", "b8_", "--batch_size", "8"], d)
+    run(base + ["--exp_name", "b1_", "--batch_size", "1"], d)
+    b8, b1 = load(d / "results" / "b8_0.jsonl"), load(d / "results" / "b1_0.jsonl")
+    assert len(b8) == len(rows) == len(b1)
+    for got, one, row in zip(b8, b1, rows):  # dataset order, reference schema, identical whatever the batch size
+        assert list(got.keys()) == KEYS
+        assert got == one
+        assert got["question_id"] == row["question_id"] and got["prompt"] == row["question"]
+        assert got["image"] == row["image_name"] and got["bbox_ref"] == row["bbox"]
+        assert got["model_id"] == "ZoomEarth---LRS-GRO"
+    ok = [r for r in b8 if not r["error"]]
+    bad = [r for r in b8 if r["error"]]
+    assert len(ok) >= 3, "stage 2 never ran"
+    for r in ok:
+        assert len(r["bbox"][0]) == 4 and 1 <= len(r["stage1"].split()) <= 14
+    for r in bad:  # no box at all (stage2 == "") or a box that is not four numbers (recorded, not fatal)
+        assert r["stage2"] == "" and (r["stage1"].startswith("Error: ") or not r["bbox"])
+    # greedy decoding is its own configuration and also batch-size independent
+    run(base + ["--exp_name", "g4_", "--batch_size", "4", "--greedy"], d)
+    run(base + ["--exp_name", "g1_", "--batch_size", "1", "--greedy"], d)
+    assert load(d / "results" / "g4_0.jsonl") == load(d / "results" / "g1_0.jsonl")
+    # eval.sh semantics on the written file
+    out = run(["bash", "run_scripts/eval.sh", "results/b8_0.jsonl"], d)
+    assert "Total Samples: 11" in out and "Overall Accuracy (OA, stage 2)" in out
+
+
+def test_infer_sh_defaults(workdir):
+    """`bash run_scripts/infer.sh <ckpt> <exp>` exactly as shipped (64 chains, 1024 new tokens per stage)."""
+    d, rows = workdir
+    out = run(["bash", "run_scripts/infer.sh", "ckpt", "sh_"], d)
+    assert "Done! Predictions has been written to:" in out
+    recs = load(d / "results" / "sh_0.jsonl")
+    assert [r["question_id"] for r in recs] == [r["question_id"] for r in rows]
+    assert all(list(r.keys()) == KEYS for r in recs)

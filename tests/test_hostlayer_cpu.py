@@ -246,106 +246,3 @@ def test_serve_prompt_template_and_data_urls():
                 [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": "http://x/y.png"}}]}]):
         with pytest.raises(serve.BadRequest):
             serve.build_prompt(bad)
-
-
-def test_serve_dispatcher_batches_greedy_requests():
-    """The batching dispatcher of the OpenAI shim (the reference's client keeps up to 100 requests in flight,
-    src/eval/infer_vllm.py:244-271): greedy requests arriving together run as ONE generate call, sampled ones alone,
-    per-request max_tokens / EOS trimming, malformed requests rejected at submit, engine errors reach every future
-    of the failed batch.  Stub model: token i of a row = 100 + (first prompt id + i) % 7, id 3 is EOS."""
-    import threading
-
-    import torch
-
-    from zoomearth_amd import serve
-
-    class Tok:
-        def decode(self, ids, skip_special_tokens=True):
-            return " ".join(str(i) for i in ids if not (skip_special_tokens and i in (0, 3)))
-
-    class Proc:
-        tokenizer = Tok()
-
-        def __call__(self, text, images=None, return_tensors="pt", padding="longest"):
-            rows = [[ord(c) % 50 + 10 for c in t.split("user\n")[1][:4]] for t in text]
-            w = max(len(r) for r in rows)
-            ids = torch.tensor([[0] * (w - len(r)) + r for r in rows])
-            mask = torch.tensor([[0] * (w - len(r)) + [1] * len(r) for r in rows])
-
-            class F(dict):
-                def to(self, d):
-                    return self
-            return F(input_ids=ids, attention_mask=mask)
-
-    class Cfg:
-        eos_token_ids = (3,)
-        pad_token_id = 0
-
-    class Eng:
-        max_seqs = 4
-
-    class Model:
-        config, engine, device = Cfg(), Eng(), "cpu"
-
-        def __init__(self):
-            self.calls = []
-            self.fail = False
-
-        def generate(self, input_ids=None, attention_mask=None, max_new_tokens=8, do_sample=False, **kw):
-            self.calls.append((input_ids.shape[0], max_new_tokens, bool(do_sample), kw.get("seed")))
-            if self.fail:
-                raise RuntimeError("engine exploded")
-            new = []
-            for r in range(input_ids.shape[0]):
-                first = int(input_ids[r][attention_mask[r].bool()][0])
-                row = [100 + (first + i) % 7 for i in range(max_new_tokens)]
-                if first % 2 == 0:
-                    row[2:] = [3] + [0] * (max_new_tokens - 3)  # EOS at step 2, then pad
-                new.append(row)
-            return torch.cat([input_ids, torch.tensor(new)], dim=1)
-
-    def req(text, **kw):
-        return dict(messages=[{"role": "user", "content": text}], **kw)
-
-    model = Model()
-    srv = serve.ChatServer(model, Proc(), "stub", batch_window_s=0.5)
-    with pytest.raises(serve.BadRequest):
-        srv.submit(req("x", stream=True))
-    assert model.calls == []
-    # four greedy requests + one sampled, submitted together
-    futs = [srv.submit(req("aaaa", max_tokens=5)), srv.submit(req("bbbb", max_tokens=3)),
-            srv.submit(req("cccc", max_tokens=6, temperature=0.7, seed=9)), srv.submit(req("dd", max_tokens=4)),
-            srv.submit(req("eeee"))]
-    res = [f.result(timeout=10) for f in futs]
-    greedy_calls = [c for c in model.calls if not c[2]]
-    assert greedy_calls[0][0] == 4 and greedy_calls[0][1] == 1024  # one batch of the four greedy rows, longest budget
-    assert [c for c in model.calls if c[2]] == [(1, 6, True, 9)]    # the sampled request alone, with its seed
-    alone = [srv.complete(req("aaaa", max_tokens=5)), srv.complete(req("bbbb", max_tokens=3)), None,
-             srv.complete(req("dd", max_tokens=4)), srv.complete(req("eeee"))]
-    for got, want in zip(res, alone):
-        if want is not None:
-            assert got["choices"] == want["choices"] and got["usage"] == want["usage"]
-    assert res[0]["usage"]["completion_tokens"] <= 5 and res[1]["usage"]["completion_tokens"] <= 3
-    stops = [r["choices"][0]["finish_reason"] for r in res]
-    assert "stop" in stops and "length" in stops
-    assert srv.complete_many([req("aaaa", max_tokens=5), req("dd", max_tokens=4)])[1]["choices"] == res[3]["choices"]
-    with pytest.raises(serve.BadRequest):
-        srv.complete_many([req("a"), req("b", temperature=1.0)])
-    # engine failure reaches every waiting request
-    model.fail = True
-    f1, f2 = srv.submit(req("ffff")), srv.submit(req("gggg"))
-    for f in (f1, f2):
-        with pytest.raises(RuntimeError, match="exploded"):
-            f.result(timeout=10)
-    model.fail = False
-    # concurrent submitters from threads
-    out = {}
-
-    def worker(i):
-        out[i] = srv.submit(req("h" * (i + 1), max_tokens=4)).result(timeout=10)
-
-    ts = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
-    [t.start() for t in ts]
-    [t.join() for t in ts]
-    assert len(out) == 6 and all(o["object"] == "chat.completion" for o in out.values())
-    srv.close()

@@ -1,0 +1,313 @@
+"""CPU: host logic of continuous batching (zoomearth_amd/scheduler.py) and of the OpenAI shim's dispatcher on top of
+it, against a stub engine that speaks the Engine methods the scheduler calls.  The stub's "model": token i of a chain
+= 100 + (first prompt id + i) % 7; chains whose first prompt id is even emit EOS (id 3) as their third token.
+
+Covers (the control flow /root/reference/src/eval/infer.py:173-249 runs one sample at a time, and the in-flight request
+stream of src/eval/infer_vllm.py:244-271): more requests than KV slots, chains leaving at EOS / at their own token budget
+while others go on, slots handed to waiting requests between bursts, the two-stage follow-up on the SAME slot with the
+cached stage-1 prompt kept (seq_truncate to its length, only the appended tokens prefilled), one ViT call for all new
+images of a round with per-tile feature reuse, error isolation per request, results independent of the slot count.
+"""
+import threading
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from zoomearth_amd import hostloop as H
+from zoomearth_amd.scheduler import ChainScheduler, Request
+
+EOS, PAD, IMG = 3, 0, 7
+
+
+class StubEngine:
+    def __init__(self, max_seqs=4, max_ctx=256, max_prefill_rows=256, max_patches=64):
+        self.max_seqs, self.max_ctx, self.max_prefill_rows, self.max_patches = max_seqs, max_ctx, max_prefill_rows, max_patches
+        self.chains = {}
+        self.log = []
+        self.fail_burst = False
+
+    def gen_params(self, **kw):
+        return kw
+
+    def rope_index(self, ids, grids):
+        return np.zeros((3, len(ids)), np.int32), 0
+
+    def vit_forward(self, pv, grids):
+        self.log.append(("vit", [tuple(g) for g in grids]))
+        return torch.zeros((sum(g[0] * g[1] * g[2] for g in grids) // 4, 8))
+
+    def seq_reset(self, slot):
+        self.chains[slot] = dict(ids=[], out=[], fin=False)
+
+    def seq_truncate(self, slot, keep):
+        c = self.chains[slot]
+        assert keep <= len(c["ids"]) + max(len(c["out"]) - 1, 0)
+        self.log.append(("truncate", slot, keep))
+        c["ids"], c["out"], c["fin"] = c["ids"][:keep], [], False
+
+    def prefill_batch(self, slots, ids_l, emb_l, pos_l, dl):
+        self.log.append(("prefill", list(slots), [len(x) for x in ids_l]))
+        for s, ids, emb in zip(slots, ids_l, emb_l):
+            assert ids.count(IMG) == (0 if emb is None else emb.shape[0])
+            self.chains[s]["ids"] += list(ids)
+
+    def mark_seen(self, slot, ids):
+        pass
+
+    def _next(self, c):
+        i = len(c["out"])
+        first = c["ids"][0]
+        tok = PAD if c["fin"] else (EOS if (first % 2 == 0 and i == 2) else 100 + (first + i) % 7)
+        c["out"].append(tok)
+        c["fin"] = c["fin"] or tok == EOS
+
+    def chain_begin(self, slot, params, stream):
+        self._next(self.chains[slot])
+
+    def decode_burst(self, slots, steps, params):
+        if self.fail_burst:
+            raise RuntimeError("engine exploded")
+        assert len(set(slots)) == len(slots)
+        for s in slots:
+            steps = min(steps, self.max_ctx - (len(self.chains[s]["ids"]) + len(self.chains[s]["out"]) - 1))
+        self.log.append(("burst", len(slots), steps))
+        for _ in range(steps):
+            for s in slots:
+                self._next(self.chains[s])
+        return steps, [len(self.chains[s]["out"]) for s in slots], [self.chains[s]["fin"] for s in slots]
+
+    def chain_tokens(self, slot, cap=0):
+        out = self.chains[slot]["out"][: cap or None]
+        return out[: out.index(EOS) + 1] if EOS in out else out
+
+
+class Tok:
+    def decode(self, ids, skip_special_tokens=True):
+        return " ".join(str(i) for i in ids if not (skip_special_tokens and i in (PAD, EOS)))
+
+
+class Proc:
+    """text -> ids: one id per whitespace word (`<img>` expands to 4 image tokens per image)."""
+    tokenizer = Tok()
+
+    def __call__(self, text, images=None, return_tensors="pt", **kw):
+        out, n = [], 0
+        for w in text[0].split():
+            if w == "<img>":
+                out += [IMG] * 4
+                n += 1
+            else:
+                out.append(int(w))
+        d = dict(input_ids=torch.tensor([out]))
+        if images:
+            assert n == len(images)
+            d.update(image_grid_thw=torch.tensor([[1, 4, 4]] * n), pixel_values=torch.zeros((16 * n, 3)),
+                     image_keys=[("k", im) for im in images])
+        return d
+
+
+def make_model(**kw):
+    e = StubEngine(**kw)
+    cfg = SimpleNamespace(image_token_id=IMG, eos_token_ids=(EOS,), pad_token_id=PAD,
+                          vision=SimpleNamespace(spatial_merge_size=2))
+    return SimpleNamespace(engine=e, config=cfg, generation_config=SimpleNamespace(repetition_penalty=1.0, temperature=None),
+                           _chains={}, device="cpu")
+
+
+def expected(first, budget):
+    out = []
+    for i in range(budget):
+        t = EOS if (first % 2 == 0 and i == 2) else 100 + (first + i) % 7
+        out.append(t)
+        if t == EOS:
+            break
+    return out
+
+
+@pytest.mark.parametrize("slots", [1, 2, 4])
+def test_continuous_batching_more_requests_than_slots(slots):
+    model = make_model(max_seqs=slots)
+    sched = ChainScheduler(model, Proc(), burst=3)
+    got, order = {}, []
+    reqs = []
+    for q in range(9):
+        first = 11 + q
+        reqs.append(Request(prompt=f"{first} 50 51", images=[], max_new_tokens=2 + q,
+                            on_done=lambda r, toks, text, q=q: (got.__setitem__(q, (toks, text)), order.append(q))[0]))
+        sched.submit(reqs[-1])
+    sched.run()
+    assert sorted(got) == list(range(9))
+    for q in range(9):
+        want = expected(11 + q, 2 + q)
+        assert got[q][0] == want and got[q][1] == " ".join(str(t) for t in want if t != EOS)
+        assert reqs[q].n_prompt == 3
+    bursts = [x for x in model.engine.log if x[0] == "burst"]
+    assert max(b[1] for b in bursts) == min(slots, 9)          # the slots were really shared
+    assert sched.stats["admitted"] == 9 and not sched.live and sorted(sched.free) == list(range(slots))
+    if slots == 4:  # even-first chains stop at their EOS and their slot is re-used while longer chains go on
+        assert order.index(1) < order.index(0) or order.index(3) < order.index(2)
+
+
+def test_two_stage_follow_up_reuses_slot_and_prefix_and_view_features():
+    model = make_model(max_seqs=2)
+    e = model.engine
+    sched = ChainScheduler(model, Proc(), burst=2)
+    results = {}
+
+    def chain(q, first, view, crop):
+        p1 = f"{first} <img> 60"
+
+        def stage1(req, toks, text):
+            p2 = p1 + " " + text + " <img>"
+
+            def stage2(req2, toks2, text2):
+                results[q] = (req.slot, req2.slot, text, text2, req2.n_prompt)
+            return Request(prompt=p2, images=[view, crop], max_new_tokens=3, on_done=stage2)
+        sched.submit(Request(prompt=p1, images=[view], max_new_tokens=4, on_done=stage1))
+
+    chain(0, 21, "viewA", "crop0")
+    chain(1, 23, "viewA", "crop1")   # same tile: the view is encoded once
+    chain(2, 25, "viewB", "crop2")
+    sched.run()
+    assert sorted(results) == [0, 1, 2]
+    for q, first in ((0, 21), (1, 23), (2, 25)):
+        s1, s2, t1, t2, n2 = results[q]
+        assert s1 == s2                                      # stage 2 continued on the slot of stage 1
+        assert t1 == " ".join(str(t) for t in expected(first, 4))
+        assert n2 == 6 + 4 + 4                               # stage-1 prompt + its 4 output words + second image
+    trunc = [x for x in e.log if x[0] == "truncate"]
+    assert len(trunc) == 3 and all(t[2] == 6 for t in trunc)   # cached stage-1 prompt (1 + 4 + 1 tokens) kept
+    pre = [x for x in e.log if x[0] == "prefill"]
+    assert sorted(n for p in pre for n in p[2]) == [6, 6, 6, 8, 8, 8]   # stage 2 prefills only the appended tokens
+    vit = [g for x in e.log if x[0] == "vit" for g in x[1]]
+    assert len(vit) == 5                                     # viewA once, viewB once, three crops
+
+
+def test_errors_are_isolated_per_request():
+    model = make_model(max_seqs=2, max_ctx=12)
+    sched = ChainScheduler(model, Proc(), burst=4)
+    ok, bad = {}, {}
+    sched.submit(Request(prompt="31 <img> <img>", images=["only-one"], on_done=lambda r, t, x: ok.__setitem__(0, t),
+                         on_error=lambda r, ex: bad.__setitem__(0, str(ex))))
+    sched.submit(Request(prompt=" ".join(["33"] * 20), images=[], on_done=lambda r, t, x: ok.__setitem__(1, t),
+                         on_error=lambda r, ex: bad.__setitem__(1, str(ex))))
+    sched.submit(Request(prompt="35 36 37", images=[], max_new_tokens=50, on_done=lambda r, t, x: ok.__setitem__(2, t),
+                         on_error=lambda r, ex: bad.__setitem__(2, str(ex))))
+    sched.run()
+    assert set(bad) == {0, 1} and "max_ctx" in bad[1]
+    assert ok[2] == expected(35, 12 - 3 + 1)                 # clamped to the KV capacity, like ze_generate
+    assert sorted(sched.free) == [0, 1]
+
+
+def test_submit_zoom_chain_on_the_scheduler():
+    """hostloop.submit_zoom_chain: the reference's per-question control flow (no box -> error record after stage 1,
+    malformed box -> error record, box -> stage 2) as linked requests."""
+    model = make_model(max_seqs=3)
+
+    class P2(Proc):
+        class tokenizer:  # stage-1 "text" carries a box for chains whose first token is 104 (first id % 7 == 4)
+            @staticmethod
+            def decode(ids, skip_special_tokens=True):
+                if ids and ids[0] == 104:
+                    return '{"bbox_2d": [10, 20, 30, 40]} <answer>a</answer>'
+                if ids and ids[0] == 105:
+                    return '{"bbox_2d": [10, 20, 30]}'
+                return "nothing here"
+
+        def __call__(self, text, images=None, **kw):
+            n = text[0].count("<|image_pad|>")
+            first = int(text[0].split("Q")[1].split()[0])
+            d = dict(input_ids=torch.tensor([[first] + [IMG] * (4 * n) + [9]]))
+            if images:
+                d.update(image_grid_thw=torch.tensor([[1, 4, 4]] * n), pixel_values=torch.zeros((16 * n, 3)),
+                         image_keys=[("k", id(im)) for im in images])
+            return d
+
+    class Img:
+        width, height, size = 2000, 1500, (2000, 1500)
+
+        def crop(self, box):
+            self.box = box
+            return self
+
+        def resize(self, size, resample=None):
+            return self
+
+    sched = ChainScheduler(model, P2(), burst=4)
+    res = {}
+    for q, first in enumerate((11, 12, 13)):   # 11 % 7 == 4 -> box; 12 % 7 == 5 -> 3-number box; 13 -> no box
+        H.submit_zoom_chain(sched, f"Q{first} ?", Img(), lambda r, q=q: res.__setitem__(q, r), stream_id=q, max_new_tokens=5)
+    sched.run()
+    assert res[0]["error"] is False and res[0]["bbox"] == [10 * 2000 / 512, 20 * 2000 / 512, 30 * 2000 / 512, 40 * 2000 / 512]
+    assert res[0]["output2"] == '{"bbox_2d": [10, 20, 30, 40]} <answer>a</answer>'
+    assert res[1]["error"] is True and res[1]["output1"].startswith("Error: ") and res[1]["output2"] == ""
+    assert res[2] == dict(prompt=H.stage1_prompt("Q13 ?"), output1="nothing here", output2="", error=True, bbox=None)
+
+
+def test_serve_dispatcher_admits_into_the_running_batch():
+    """The OpenAI shim's dispatcher (src/eval/infer_vllm.py:244-271 keeps up to 100 requests in flight): greedy
+    requests join the running batch, each future resolves when its own chain ends, per-request max_tokens / EOS
+    trimming, sampled requests alone through model.generate, malformed requests rejected at submit, an engine failure
+    reaches every request of the running batch and the server recovers."""
+    from zoomearth_amd import serve
+
+    model = make_model(max_seqs=3)
+    model.calls = []
+
+    def generate(input_ids=None, attention_mask=None, max_new_tokens=8, do_sample=False, **kw):
+        model.calls.append((input_ids.shape[0], max_new_tokens, bool(do_sample), kw.get("seed")))
+        first = int(input_ids[0][0])
+        return torch.cat([input_ids, torch.tensor([expected(first, max_new_tokens)])], dim=1)
+
+    model.generate = generate
+
+    class SProc(Proc):
+        def __call__(self, text, images=None, return_tensors="pt", padding=None, **kw):
+            body = text[0].split("user\n")[1].split("<|im_end|>")[0]
+            ids = torch.tensor([[ord(c) % 50 + 10 for c in body[:4]]])
+
+            class F(dict):
+                def to(self, d):
+                    return self
+            return F(input_ids=ids, attention_mask=torch.ones_like(ids))
+
+    def req(text, **kw):
+        return dict(messages=[{"role": "user", "content": text}], **kw)
+
+    srv = serve.ChatServer(model, SProc(), "stub", batch_window_s=0.2)
+    with pytest.raises(serve.BadRequest):
+        srv.submit(req("x", stream=True))
+    futs = [srv.submit(req("aaaa", max_tokens=5)), srv.submit(req("bbbb", max_tokens=3)),
+            srv.submit(req("cccc", max_tokens=6, temperature=0.7, seed=9)), srv.submit(req("dd", max_tokens=4)),
+            srv.submit(req("eeee")), srv.submit(req("ffff", max_tokens=2))]
+    res = [f.result(timeout=10) for f in futs]
+    assert model.calls == [(1, 6, True, 9)]                  # only the sampled request went through generate, alone
+    firsts = [ord(c) % 50 + 10 for c in "abcdef"]
+    budgets = [5, 3, 6, 4, 1024, 2]
+    for i, r in enumerate(res):
+        n_in = 2 if i == 3 else 4
+        want = expected(firsts[i], min(budgets[i], 256 - n_in + 1))  # the KV capacity clamps the budget per request
+        assert r["usage"]["completion_tokens"] == len(want) and r["usage"]["prompt_tokens"] == n_in
+        assert r["choices"][0]["finish_reason"] == ("stop" if want[-1] == EOS else "length")
+        assert r["choices"][0]["message"]["content"] == " ".join(str(t) for t in want if t != EOS)
+    assert srv.complete(req("aaaa", max_tokens=5))["choices"] == res[0]["choices"]
+    # engine failure: every request of the running batch gets it, then the server serves again
+    model.engine.fail_burst = True
+    f1, f2 = srv.submit(req("gggg")), srv.submit(req("hhhh"))
+    for f in (f1, f2):
+        with pytest.raises(RuntimeError, match="exploded"):
+            f.result(timeout=10)
+    model.engine.fail_burst = False
+    out = {}
+
+    def worker(i):
+        out[i] = srv.submit(req("h" * (i + 1), max_tokens=4)).result(timeout=10)
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(7)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert len(out) == 7 and all(o["object"] == "chat.completion" for o in out.values())
+    assert srv.scheduler.stats["admitted"] >= 7
+    srv.close()

@@ -88,6 +88,11 @@ class ShardedLoader:
         self.dl, self.rank, self.world, self.by_tile = dataloader, rank, world, by_tile
 
     def _indices(self):
+        if getattr(self, "_idx", None) is None:
+            self._idx = self._compute_indices()
+        return self._idx
+
+    def _compute_indices(self):
         ds = self.dl.dataset
         n = len(ds)
         if self.world <= 1:
@@ -99,6 +104,16 @@ class ShardedLoader:
             except Exception:
                 pass
         return shard_round_robin(n, self.rank, self.world)
+
+    def image_names(self):
+        """`image_name` of this rank's rows, in iteration order, from the column alone (no row is materialised)."""
+        ds = self.dl.dataset
+        idx = self._indices()
+        try:
+            col = [r["image_name"] for r in ds] if isinstance(ds, list) else ds["image_name"]
+            return [col[j] for j in idx]
+        except Exception:
+            return [ds[j]["image_name"] for j in idx]
 
     def __len__(self):
         bs = getattr(self.dl, "batch_size", 1) or 1

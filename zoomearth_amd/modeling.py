@@ -43,13 +43,13 @@ class ZoomEarthForConditionalGeneration:
     # ------------------------------------------------------------------ construction
     @classmethod
     def from_pretrained(cls, path: str, torch_dtype=None, device=None, max_seqs: int = 4, max_ctx: int = 4096,
-                        max_patches: int = 8192, max_tile_side: int = 8192, **kw):
+                        max_patches: int = 8192, max_tile_side: int = 8192, max_prefill_rows: int = 0, **kw):
         config = ModelConfig.from_pretrained(path)
         dev = 0 if device is None else (device.index or 0 if isinstance(device, torch.device) else int(device))
         if device is None and "LOCAL_RANK" in os.environ:
             dev = int(os.environ["LOCAL_RANK"])
         engine = Engine(config, device=dev, max_seqs=max_seqs, max_ctx=max_ctx, max_patches=max_patches,
-                        max_tile_side=max_tile_side)
+                        max_tile_side=max_tile_side, max_prefill_rows=max_prefill_rows)
         try:
             engine.load_state_dict(iter_checkpoint(path))
         except Exception:

@@ -1,0 +1,264 @@
+"""Continuous batching of question chains on one GPU.
+
+replaces: the one-sample-at-a-time loop of the reference (`BATCH_SIZE = 1`, /root/reference/src/eval/infer.py:27,
+173-249) and the 100 requests its "fast" path keeps in flight against a serving back-end
+(/root/reference/src/eval/infer_vllm.py:244-271).  Up to `max_seqs` chains share every decode step -- the weights are
+streamed once per step for all of them (`ze_decode_burst`) -- and chains join and leave BETWEEN bursts: a request that
+finishes (EOS or its token budget) hands its KV slot to the next waiting request, or keeps it for a follow-up that
+extends its own prompt (stage 2 of the zoom chain: the cached stage-1 prompt is reused, only the appended tokens are
+prefilled, `ze_seq_truncate`).  Newcomers of one round are prefilled together (`ze_prefill_batch`) after ONE
+multi-resolution ViT call over all their images.
+
+A chain's tokens do not depend on which chains share its bursts (the batched kernels accumulate every output element in
+an order that is a function of the layer shape alone -- tests/test_gpu_batch.py), and its sampling stream is the
+request's own `stream_id`: results are the same for any `max_seqs`, including 1.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict, deque
+from dataclasses import dataclass, field
+from typing import Any, Callable, List, Optional
+
+import numpy as np
+import torch
+
+
+@dataclass
+class Request:
+    prompt: str
+    images: list                       # flat, in prompt order (DeviceImage / PIL / ndarray)
+    max_new_tokens: int = 1024
+    stream_id: int = 0                 # random stream of the request when sampling (e.g. the question number)
+    on_done: Optional[Callable[["Request", List[int], str], Optional["Request"]]] = None
+    on_error: Optional[Callable[["Request", Exception], None]] = None
+    tag: Any = None
+    # filled by the scheduler
+    slot: int = -1
+    n_prompt: int = 0
+    tokens: List[int] = field(default_factory=list)
+    text: str = ""
+
+
+class _Live:
+    __slots__ = ("req", "ids", "keys", "produced")
+
+    def __init__(self, req, ids, keys):
+        self.req, self.ids, self.keys, self.produced = req, ids, keys, 1
+
+
+class ChainScheduler:
+    def __init__(self, model, processor, do_sample: bool = False, temperature=None, repetition_penalty=None, seed: int = 0,
+                 burst: int = 8, max_batch: Optional[int] = None, ignore_eos: bool = False, use_graph: bool = True,
+                 feature_cache: int = 64):
+        self.model, self.processor, self.engine = model, processor, model.engine
+        gc = model.generation_config
+        pen = repetition_penalty if repetition_penalty is not None else (getattr(gc, "repetition_penalty", 1.0) or 1.0)
+        if do_sample and temperature is None:
+            temperature = getattr(gc, "temperature", None) or 1.0
+        self.penalty = float(pen)
+        self.params = self.engine.gen_params(repetition_penalty=self.penalty, ignore_eos=ignore_eos, use_graph=use_graph,
+                                             do_sample=bool(do_sample), temperature=float(temperature or 1.0), seed=seed)
+        self.burst = max(1, int(burst))
+        self.max_batch = min(int(max_batch or self.engine.max_seqs), self.engine.max_seqs)
+        self.waiting = deque()
+        self.live = OrderedDict()          # slot -> _Live
+        self.parked = {}                   # slot -> (ids tuple, image keys): finished chains whose slot waits for a follow-up
+        self.free = list(range(self.max_batch))[::-1]
+        self._features = OrderedDict()     # image key -> ViT features (LRU)
+        self._feature_cap = feature_cache
+        self.stats = dict(bursts=0, steps=0, chain_steps=0, prefill_rows=0, admitted=0, vit_calls=0)
+        model._chains.clear()              # the scheduler owns every chain slot while it runs
+
+    # ------------------------------------------------------------------ queue
+    def submit(self, req: Request) -> None:
+        self.waiting.append(req)
+
+    def busy(self) -> bool:
+        return bool(self.waiting or self.live)
+
+    def run(self) -> None:
+        while self.busy():
+            self.step()
+
+    # ------------------------------------------------------------------ one scheduling round
+    def step(self) -> None:
+        self._admit()
+        if self.live:
+            self._burst()
+
+    # -- admission: waiting requests take free slots (a follow-up keeps the slot its predecessor parked)
+    def _admit(self) -> None:
+        e = self.engine
+        batch = []
+        while self.waiting:
+            req = self.waiting[0]
+            if req.slot < 0:
+                if not self.free:
+                    break
+                req.slot = self.free.pop()
+            self.waiting.popleft()
+            batch.append(req)
+        if not batch:
+            return
+        # tokenise / preprocess each newcomer; collect the images whose features are not cached
+        prepared, todo = [], OrderedDict()
+        for req in batch:
+            try:
+                inp = self.processor(text=[req.prompt], images=list(req.images) or None, return_tensors="pt")
+                ids = inp["input_ids"][0].tolist()
+                grids = inp["image_grid_thw"].tolist() if req.images else []
+                keys = list(inp.get("image_keys", []))
+                mu = self.model.config.vision.spatial_merge_size ** 2
+                n_img_tok = sum(g[0] * g[1] * g[2] // mu for g in grids)
+                if ids.count(self.model.config.image_token_id) != n_img_tok:
+                    raise ValueError("Image features and image tokens do not match")
+                if len(ids) + 1 > e.max_ctx:
+                    raise ValueError(f"prompt of {len(ids)} tokens exceeds max_ctx = {e.max_ctx}")
+                rows = np.concatenate([[0], np.cumsum([g[0] * g[1] * g[2] for g in grids])]).astype(int)
+                reuse, n_reused = self._reusable(req.slot, ids, keys)
+                for i in range(n_reused, len(grids)):
+                    if keys[i] not in self._features and keys[i] not in todo:
+                        todo[keys[i]] = (inp["pixel_values"][rows[i]:rows[i + 1]], grids[i])
+                prepared.append((req, ids, grids, keys, reuse, n_reused))
+            except Exception as ex:  # a malformed request must not take the batch down
+                self._fail(req, ex)
+        self._encode(todo)
+        # prefill: rows of several chains share every GEMM, up to max_prefill_rows per pass
+        group, rows = [], 0
+        for item in prepared + [None]:
+            if group and (item is None or rows + len(item[1]) - item[4] > e.max_prefill_rows):
+                self._prefill(group)
+                group, rows = [], 0
+            if item is not None:
+                group.append(item)
+                rows += len(item[1]) - item[4]
+
+    def _reusable(self, slot, ids, keys):
+        """(cached prefix length, images inside it) when the slot's parked chain is a strict prefix of `ids`."""
+        rec = self.parked.pop(slot, None)
+        if rec is None:
+            return 0, 0
+        pids, pkeys = rec
+        n = len(pids)
+        if 0 < n < len(ids) and tuple(ids[:n]) == pids and tuple(keys[: len(pkeys)]) == pkeys \
+                and ids[n] != self.model.config.image_token_id and all(k is not None for k in pkeys):
+            return n, len(pkeys)
+        return 0, 0
+
+    def _encode(self, todo) -> None:
+        """ONE multi-resolution ViT call (per max_patches worth of images) for the uncached images of this round."""
+        e = self.engine
+        items = list(todo.items())
+        i = 0
+        while i < len(items):
+            j, n = i, 0
+            while j < len(items) and (j == i or n + items[j][1][0].shape[0] <= e.max_patches):
+                n += items[j][1][0].shape[0]
+                j += 1
+            pvs = [it[1][0] for it in items[i:j]]
+            grids = [it[1][1] for it in items[i:j]]
+            feats = e.vit_forward((torch.cat(pvs) if len(pvs) > 1 else pvs[0]).contiguous(), grids)
+            self.stats["vit_calls"] += 1
+            off = 0
+            mu = self.model.config.vision.spatial_merge_size ** 2
+            for (key, (_, g)) in items[i:j]:
+                k = g[0] * g[1] * g[2] // mu
+                self._features[key] = feats[off:off + k]
+                off += k
+            i = j
+        while len(self._features) > max(self._feature_cap, len(todo)):
+            self._features.popitem(last=False)
+
+    def _prefill(self, group) -> None:
+        e = self.engine
+        slots, ids_l, emb_l, pos_l, dl = [], [], [], [], []
+        ok = []
+        for req, ids, grids, keys, reuse, n_reused in group:
+            try:
+                pos, delta = e.rope_index(ids, grids)
+                feats = [self._features[k] for k in keys[n_reused:]]
+                for k in keys[n_reused:]:
+                    self._features.move_to_end(k)
+                emb = (torch.cat(feats) if len(feats) > 1 else feats[0]) if feats else None
+                if reuse:
+                    e.seq_truncate(req.slot, reuse)
+                else:
+                    e.seq_reset(req.slot)
+                slots.append(req.slot)
+                ids_l.append(ids[reuse:])
+                emb_l.append(emb)
+                pos_l.append(pos[:, reuse:])
+                dl.append(delta)
+                ok.append((req, ids, keys))
+            except Exception as ex:
+                self._fail(req, ex)
+        if not ok:
+            return
+        try:
+            e.prefill_batch(slots, ids_l, emb_l, pos_l, dl)
+        except Exception as ex:
+            for req, _, _ in ok:
+                self._fail(req, ex)
+            return
+        self.stats["prefill_rows"] += sum(len(x) for x in ids_l)
+        for req, ids, keys in ok:
+            if self.penalty != 1.0:
+                e.mark_seen(req.slot, ids)
+            e.chain_begin(req.slot, self.params, req.stream_id)
+            req.n_prompt = len(ids)
+            self.live[req.slot] = _Live(req, tuple(ids), tuple(keys))
+            self.stats["admitted"] += 1
+
+    # -- one burst of decode steps for every live chain, then retire the finished ones
+    def _burst(self) -> None:
+        e = self.engine
+        slots = list(self.live.keys())
+        budget = min(min(l.req.max_new_tokens, e.max_ctx - l.req.n_prompt + 1) - l.produced for l in self.live.values())
+        steps = max(0, min(self.burst, budget))
+        ran, n_gen, fin = e.decode_burst(slots, steps, self.params)
+        self.stats["bursts"] += 1
+        self.stats["steps"] += ran
+        self.stats["chain_steps"] += ran * len(slots)
+        for slot, ng, f in zip(slots, n_gen, fin):
+            l = self.live[slot]
+            l.produced = ng
+            if f or ng >= min(l.req.max_new_tokens, e.max_ctx - l.req.n_prompt + 1):
+                self._retire(slot)
+
+    def _retire(self, slot: int) -> None:
+        l = self.live.pop(slot)
+        req = l.req
+        req.tokens = self.engine.chain_tokens(slot, req.max_new_tokens)
+        req.text = self.processor.tokenizer.decode(req.tokens, skip_special_tokens=True).strip()
+        follow = None
+        try:
+            follow = req.on_done(req, req.tokens, req.text) if req.on_done else None
+        except Exception as ex:
+            if req.on_error:
+                req.on_error(req, ex)
+            else:
+                raise
+        if follow is not None:  # continues on this slot; its cached prompt is reusable
+            follow.slot = slot
+            self.parked[slot] = (l.ids, l.keys)
+            self.waiting.appendleft(follow)
+        else:
+            self.free.append(slot)
+
+    def _fail(self, req: Request, ex: Exception) -> None:
+        if req.slot >= 0:
+            self.parked.pop(req.slot, None)
+            self.free.append(req.slot)
+            req.slot = -1
+        if req.on_error:
+            req.on_error(req, ex)
+        else:
+            raise ex
+
+
+def run_requests(model, processor, requests, **kw) -> None:
+    """Convenience: every request through one scheduler, to completion."""
+    s = ChainScheduler(model, processor, **kw)
+    for r in requests:
+        s.submit(r)
+    s.run()

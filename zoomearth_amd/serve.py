@@ -9,11 +9,12 @@ base64,..."}}` items, plus `max_tokens`, `temperature`, `seed` (`n` must be 1, `
 Prompt: the Qwen2.5-VL chat template (`<|im_start|>role\\n ... <|im_end|>\\n`, an image item becomes
 `<|vision_start|><|image_pad|><|vision_end|>`, a default system turn when the conversation has none, then the
 generation prompt `<|im_start|>assistant\\n`).  temperature 0 / absent -> greedy, else temperature sampling.
-Concurrent requests (infer_vllm.py keeps up to 100 in flight, :244-271) are BATCHED: a dispatcher thread gathers the
-greedy requests that arrive within `batch_window_s` (up to the engine's `max_seqs`) and runs them as one
-processor + generate call -- rows of one batched prefill pass and one batched decode loop, each row's tokens
-independent of which other requests share the batch; sampled requests run alone (their random stream is keyed by
-the row).  Images are decoded on the host and uploaded.
+Concurrent requests (infer_vllm.py keeps up to 100 in flight, :244-271) share the GPU through continuous batching
+(`zoomearth_amd/scheduler.py`): a dispatcher thread admits greedy requests into the RUNNING batch between bursts of
+decode steps -- newcomers are prefilled together and join the next burst, a finished request frees its KV slot and its
+response returns at once -- with each request's tokens independent of which other requests share its steps; sampled
+requests run alone (temperature and seed are part of the captured decode step).  Images are decoded on the host and
+uploaded.
 
     python -m zoomearth_amd.serve --model_name /ckpt/ZoomEarth-3B --port 8000
 """
@@ -96,6 +97,7 @@ class ChatServer:
         self._cv = threading.Condition()
         self._worker = None
         self._stop = False
+        self.scheduler = None  # the dispatcher's ChainScheduler (stats for tests / monitoring)
 
     # ------------------------------------------------------------------ request -> response pieces
     def _parse(self, req: dict) -> _Parsed:
@@ -183,32 +185,74 @@ class ChatServer:
             self._cv.notify()
 
     def _dispatch(self):
+        """Running-batch admission (the concurrency model of /root/reference/src/eval/infer_vllm.py:244-271, where the
+        client keeps up to 100 requests in flight): greedy requests go to a `ChainScheduler` -- a request that arrives
+        while others are decoding is prefilled and joins their next burst, one that finishes frees its KV slot at once --
+        and each future resolves as soon as ITS chain ends.  A sampled request (its temperature / seed are baked into
+        the captured decode step) waits for the running chains to drain and runs alone."""
+        from .image import DeviceImage
+        from .scheduler import ChainScheduler, Request
+
+        sched = None
+        sampled, held = [], []
         while True:
             with self._cv:
-                while not self._queue and not self._stop:
+                while not self._queue and not self._stop and not sampled and not held and not (sched is not None and sched.busy()):
                     self._cv.wait()
-                if self._stop and not self._queue:
+                if self._stop and not self._queue and not sampled and not held and not (sched is not None and sched.busy()):
                     return
-                deadline = time.monotonic() + self.batch_window_s
-                while len(self._queue) < self.max_batch and not self._stop:
-                    left = deadline - time.monotonic()
-                    if left <= 0:
-                        break
-                    self._cv.wait(left)
-                # a sampled request goes alone; greedy ones go together, in arrival order
-                if self._queue[0].sample:
-                    batch = [self._queue.pop(0)]
-                else:
-                    batch = [p for p in self._queue if not p.sample][: self.max_batch]
-                    taken = set(map(id, batch))
-                    self._queue = [p for p in self._queue if id(p) not in taken]
-            try:
-                for p, r in zip(batch, self._run(batch)):
-                    p.future.set_result(r)
-            except Exception as ex:  # every request of the failed batch gets the error
-                for p in batch:
+                if sched is None or not sched.busy():  # idle: give concurrent arrivals a moment to share the first prefill
+                    deadline = time.monotonic() + self.batch_window_s
+                    while len(self._queue) < self.max_batch and not self._stop:
+                        left = deadline - time.monotonic()
+                        if left <= 0:
+                            break
+                        self._cv.wait(left)
+                new, self._queue = self._queue, []
+            with self._lock:
+                if sched is None:
+                    sched = ChainScheduler(self.model, self.processor, do_sample=False, max_batch=self.max_batch, burst=8)
+                    self.scheduler = sched
+                held.extend(new)
+                new, held = (held, []) if not sampled else ([p for p in held if p.sample], [p for p in held if not p.sample])
+                for p in new:  # (greedy arrivals wait behind a pending sampled request: it needs the engine alone)
+                    if p.sample:
+                        sampled.append(p)
+                        continue
+
+                    def done(req, tokens, text, p=p):
+                        p.future.set_result(self._response(p, tokens, req.n_prompt))
+                        return None
+
+                    def failed(req, ex, p=p):
+                        if not p.future.done():
+                            p.future.set_exception(ex)
+
+                    try:
+                        imgs = [DeviceImage.from_pil(im, self.model.engine) for im in p.pil_images]
+                        budget = max(1, min(p.max_tokens, self.model.engine.max_ctx))  # per request: never fails its batch
+                        sched.submit(Request(prompt=p.prompt, images=imgs, max_new_tokens=budget, on_done=done,
+                                             on_error=failed))
+                    except Exception as ex:
+                        failed(None, ex)
+                if sched.busy():
+                    try:
+                        sched.step()
+                    except Exception as ex:  # an engine failure: every request of the running batch gets the error
+                        for r in [l.req for l in sched.live.values()] + list(sched.waiting):
+                            if r.on_error:
+                                r.on_error(r, ex)
+                        sched = None
+                    continue
+            if sampled:  # the running batch has drained
+                p = sampled.pop(0)
+                try:
+                    p.future.set_result(self._run([p])[0])
+                except Exception as ex:
                     if not p.future.done():
                         p.future.set_exception(ex)
+                with self._lock:
+                    sched = None  # _run went through model.generate, which re-registers chain slots
 
 
 def create_app(server: ChatServer):
