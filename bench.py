@@ -10,14 +10,20 @@ in HBM (BASELINE.json configs[1]; workload constants from SURVEY.md section 8d):
 Weights: Qwen2.5-VL-3B shape, bf16, synthetic N(0, 0.02^2) from the repo PRNG (no checkpoint offline).
 Control flow is scripted (random weights emit neither EOS nor a bbox): lengths fixed, EOS ignored.
 
+The same line carries `batch64`: BASELINE configs[2] -- 64 questions about 6 tiles advanced together by the
+continuous-batching scheduler (zoomearth_amd/scheduler.py, the code path of src/eval/infer.py), ragged lengths
+(+-25 % around N1 / N2 per question), dynamic-resolution ViT batch, timed over one step of 64 questions.
+
 Multi-GPU: one process per GPU (torch.distributed/RCCL); the question stream shards with no data-path collective;
-the only collective is the one-time broadcast of the packed weight arena from rank 0.
+the only collective is the one-time broadcast of the packed weight arena from rank 0.  `--gpus N` without a
+torchrun environment spawns the N ranks itself (before anything touches the GPU).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,6 +34,15 @@ sys.path.insert(0, ROOT)
 
 L_TEXT_A, L_TEXT_B, N1, N2, PENALTY = 21, 455, 192, 96, 1.05  # 21 + 455 = 476 text ids
 HBM_PEAK_GBS = 8000.0
+BATCH_KERNELS = {0: "qkv", 1: "o_proj", 2: "gate_up", 3: "down", 4: "lm_head", 5: "attention", 6: "rmsnorm", 7: "rope_kv"}
+BATCH_KERNEL_NAMES = {
+    0: "k_gemm_skinny<1,NONE,FRAG> (batched decode qkv projection, fragment-major weights)",
+    1: "k_gemm_skinny<1,RESIDUAL,FRAG> (batched decode o projection)",
+    2: "k_gemm_skinny<6,SWIGLU,FRAG,BAL> (batched decode gate/up weight stream, one workgroup per CU)",
+    3: "k_gemm_ring<64,64,4,RESIDUAL> split-K (batched decode down projection)",
+    4: "k_gemm_skinny<2,F32,FRAG> (batched decode lm_head)",
+    5: "k_attn_decode_split<8,1> (batched decode attention: K/V rows of every chain)",
+}
 
 
 def question_ids(cfg, q: int, n_img: int):
@@ -47,6 +62,13 @@ def scripted_bbox(q: int, tile_side: int):
     x = int(r[2] % (tile_side - side))
     y = int(r[3] % (tile_side - side))
     return [float(x), float(y), float(x + side), float(y + side)]
+
+
+def ragged_lengths(q: int):
+    """(N1, N2) of question q for the batched workload: +-25 % around the scripted means."""
+    from zoomearth_amd.synth import uniform_ints
+    r = uniform_ints(555 + q, 2, 0, 1 << 20)
+    return int(round(N1 * (0.75 + 0.5 * (r[0] / float(1 << 20))))), int(round(N2 * (0.75 + 0.5 * (r[1] / float(1 << 20)))))
 
 
 class Chain:
@@ -98,66 +120,104 @@ def refeed(cfg, toks):
     return [t if t < lo else 1000 for t in toks]
 
 
-class BatchChain(Chain):
-    """B question chains advanced together (BASELINE configs[2]): one multi-image ViT call per stage, cross-chain
-    prefill passes of `group` chains, batched decode where the weights are streamed once per step for all chains."""
-    group = 16
+# ----------------------------------------------------------------------------- configs[2]: 64 chains, continuous batching
+class SynthTokenizer:
+    """No tokenizer files offline: "decoding" writes the ids as decimal words (special ids mapped to a plain one, as
+    skip_special_tokens + re-tokenisation would never bring them back), "encoding" reads them again."""
 
-    def questions(self, q0: int, B: int):
-        e, cfg, H = self.e, self.e.config, self.H
-        side = self.side
-        s = 512 / side
-        view = e.crop_resize(self.tile, (0, 0, side, side), (int(side * s), int(side * s)))
-        pv_v, g_v = e.preprocess_image(view)
-        emb_v = e.vit_forward(pv_v, [g_v])  # the B questions of this step are about the same tile: one view
-        n_img = g_v[1] * g_v[2] // 4
-        ids1 = [question_ids(cfg, q0 + b, n_img) for b in range(B)]
-        pl = [e.rope_index(ids1[b], [g_v]) for b in range(B)]
-        for b in range(B):
-            e.seq_reset(b)
-        for g0 in range(0, B, self.group):  # chains prefilled together: their rows share every GEMM
-            gs = list(range(g0, min(B, g0 + self.group)))
-            e.prefill_batch(gs, [ids1[b] for b in gs], [emb_v] * len(gs), [pl[b][0] for b in gs], [pl[b][1] for b in gs])
-        for b in range(B):
-            e.mark_seen(b, ids1[b])
-        out1 = e.generate_batch(list(range(B)), N1, repetition_penalty=PENALTY, ignore_eos=True, sync_every=N1)
-        # zoom crops (different sizes -> dynamic-resolution ViT batch)
-        pvs, grids = [], []
-        for b in range(B):
-            box = H.zoom_box((side, side), scripted_bbox(q0 + b, side))
-            bw, bh = box[2] - box[0], box[3] - box[1]
-            sc = min(1.0, 512 / max(bw, bh))
-            crop = e.crop_resize(self.tile, box, (int(bw * sc), int(bh * sc)) if sc < 1 else (bw, bh))
-            pv, g = e.preprocess_image(crop)
-            pvs.append(pv)
-            grids.append(g)
+    def __init__(self, cfg):
+        self.cfg = cfg
+
+    def decode(self, ids, skip_special_tokens=True):
+        return " ".join(str(t) for t in refeed(self.cfg, ids))
+
+
+class SynthProcessor:
+    """The processor surface the scheduler calls (`processor(text=[prompt], images=[...])`, `.tokenizer.decode`) with
+    synthetic token ids: the real image path (ZoomEarthProcessor.preprocess_images -> HIP front-end), and for the text
+    the scripted lengths of SURVEY 8d -- 21 ids before the first image, 455 after it (question + instruction), then
+    whatever decimal words follow `assistant\\n` (the re-fed stage-1 output)."""
+
+    def __init__(self, cfg, engine):
+        from zoomearth_amd.processor import ZoomEarthProcessor
+        self.cfg = cfg
+        self.tokenizer = SynthTokenizer(cfg)
+        self._img = ZoomEarthProcessor.__new__(ZoomEarthProcessor)
+        self._img.engine, self._img.min_pixels, self._img.max_pixels, self._img.merge_size = engine, 3136, 128 * 128 * 28 * 28, 2
+
+    def __call__(self, text, images=None, return_tensors="pt", **kw):
         import torch
-        emb_c = e.vit_forward(torch.cat(pvs), grids)
-        off, ids2s, embs, pos2s, d2s = 0, [], [], [], []
-        for b in range(B):
-            n_c = grids[b][1] * grids[b][2] // 4
-            ids2 = ids1[b] + refeed(cfg, out1[b]) + [cfg.vision_start_token_id] + [cfg.image_token_id] * n_c + [cfg.vision_end_token_id]
-            pos2, delta2 = e.rope_index(ids2, [g_v, grids[b]])
-            e.seq_truncate(b, len(ids1[b]))
-            ids2s.append(ids2)
-            embs.append(emb_c[off:off + n_c])
-            pos2s.append(pos2[:, len(ids1[b]):])
-            d2s.append(delta2)
-            off += n_c
-        for g0 in range(0, B, self.group):
-            gs = list(range(g0, min(B, g0 + self.group)))
-            e.prefill_batch(gs, [ids2s[b][len(ids1[b]):] for b in gs], [embs[b] for b in gs], [pos2s[b] for b in gs],
-                            [d2s[b] for b in gs])
-        for b in range(B):
-            e.mark_seen(b, ids2s[b])
-        out2 = e.generate_batch(list(range(B)), N2, repetition_penalty=PENALTY, ignore_eos=True, sync_every=N2)
-        return out1, out2, len(ids1[0]), len(ids1[0]) + N1 + 326
+        from zoomearth_amd.hostloop import VISION_BLOCK
+        from zoomearth_amd.synth import uniform_ints
+        cfg = self.cfg
+        prompt = text[0]
+        q = int(prompt.split("#q", 1)[1].split("#", 1)[0])
+        pv, grids, keys = self._img.preprocess_images(list(images))
+        parts = prompt.split(VISION_BLOCK)
+        assert len(parts) == len(grids) + 1
+        ids = uniform_ints(7 + q, L_TEXT_A, 1000, 150000).tolist()
+        for i, g in enumerate(grids):
+            ids += [cfg.vision_start_token_id] + [cfg.image_token_id] * (g[0] * g[1] * g[2] // 4) + [cfg.vision_end_token_id]
+            if i == 0:
+                ids += uniform_ints(7_000_003 + q, L_TEXT_B, 1000, 150000).tolist()
+                tail = parts[1].split("assistant\n", 1)[1]
+                ids += [int(w) for w in tail.split()]
+        return dict(input_ids=torch.tensor([ids]), image_grid_thw=torch.tensor(grids), pixel_values=pv, image_keys=keys)
 
 
+class Model64:
+    """What ChainScheduler needs of the model object."""
+
+    def __init__(self, engine):
+        from types import SimpleNamespace
+        self.engine, self.config = engine, engine.config
+        self.generation_config = SimpleNamespace(repetition_penalty=PENALTY, temperature=None)
+        self._chains = {}
+
+
+def batch_step(engine, tiles, q0: int, B: int, stats=None, use_graph=True):
+    """B questions about len(tiles) tiles (6 : 64 as LRS-GRO's 908 : 9734) through the continuous-batching scheduler and
+    the host code of src/eval/infer.py (hostloop.submit_zoom_chain: views, crops, prompts); the "parsed" box is
+    scripted, lengths are ragged and EOS is ignored (random weights emit neither)."""
+    from zoomearth_amd import hostloop as H
+    from zoomearth_amd.scheduler import ChainScheduler, Request
+
+    model = Model64(engine)
+    proc = SynthProcessor(engine.config, engine)
+    sched = ChainScheduler(model, proc, do_sample=False, repetition_penalty=PENALTY, ignore_eos=True, burst=16,
+                           use_graph=use_graph)
+    done = {}
+    views = {}
+    for b in range(B):
+        q = q0 + b
+        t = b * len(tiles) // B
+        tile = tiles[t]
+        if t not in views:  # every question of a tile looks at the same <=512-px view: encoded once per tile
+            views[t] = H.resize_image(tile)
+        n1, n2 = ragged_lengths(q)
+        text = H.stage1_prompt(f"#q{q}#")
+
+        def stage1(req, toks, out1, q=q, tile=tile, view=views[t][0], n2=n2, text=text):
+            crop, _ = H.resize_image(H.cut_image(tile, scripted_bbox(q, tile.width)))
+
+            def stage2(req2, toks2, out2, q=q, n_p1=req.n_prompt, n_o1=len(toks)):
+                done[q] = (n_p1, n_o1, req2.n_prompt, len(toks2))
+            return Request(prompt=H.stage2_prompt(text, out1), images=[view, crop], max_new_tokens=n2, on_done=stage2)
+
+        sched.submit(Request(prompt=text, images=[views[t][0]], max_new_tokens=n1, on_done=stage1))
+    sched.run()
+    assert len(done) == B
+    if stats is not None:
+        stats.update(sched.stats)
+        stats["lens"] = [done[q0 + b] for b in range(B)]
+    return done
+
+
+# ----------------------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
 def cpu_baseline(budget_s: float = 45.0):
     """The oracle (numpy port of the reference arithmetic, fp32 BLAS on all host cores) on a bounded sample,
     extrapolated by layer count to the question AS THE REFERENCE EXECUTES IT (no reuse: 3 view encodes, 802- and
-    1320-token prefills, 288 decode steps)."""
+    1320-token prefills, 288 decode steps).  Fallback when the transformers path cannot run."""
     from oracle import qwen25vl as Q
     cores = os.cpu_count() or 1
     full = Q.Config()
@@ -175,7 +235,6 @@ def cpu_baseline(budget_s: float = 45.0):
     o = Q.Qwen25VLOracle(cfg, w, "fp32")
     pv = rng.standard_normal((1296, 1176), dtype=np.float32)
     grid = [(1, 36, 36)]
-    # blocks 0,1 use window attention, block 2 full attention: time depth 1, 2, 3 with the same weights
     t_depth = {}
     o.cfg.vision.depth = 1
     o.vit_forward(pv, grid)  # untimed warm-up (imports, page faults)
@@ -184,8 +243,8 @@ def cpu_baseline(budget_s: float = 45.0):
         t0 = time.perf_counter()
         emb = o.vit_forward(pv, grid)
         t_depth[d] = time.perf_counter() - t0
-    t_win = max(t_depth[2] - t_depth[1], 1e-6)
-    t_fullblk = max(t_depth[3] - t_depth[2], 1e-6)
+    t_win = max(t_depth[2] - t_depth[1], 0.0)
+    t_fullblk = max(t_depth[3] - t_depth[2], 0.0)
     t_over = max(t_depth[1] - t_win, 0.0)  # patch embed + merger
     n_full = len(full.vision.fullatt_block_indexes)
     ids = list(rng.integers(1000, 150000, 21)) + [full.vision_start_token_id] + [full.image_token_id] * 324 + \
@@ -198,7 +257,6 @@ def cpu_baseline(budget_s: float = 45.0):
     for _ in range(nd):
         lg = o.decode_step(int(np.argmax(lg)))
     t_dec = (time.perf_counter() - t0) / nd
-    # lm_head share of a decode step measured separately so layers and head extrapolate independently
     h = rng.standard_normal((1, 2048), dtype=np.float32)
     t0 = time.perf_counter()
     for _ in range(4):
@@ -211,39 +269,41 @@ def cpu_baseline(budget_s: float = 45.0):
     t_question = (3 * vit_full + (pre_layer * full.text.num_hidden_layers) * (L1 + L2) / L1 + 2 * t_head
                   + (N1 + N2) * (dec_layer * full.text.num_hidden_layers + t_head))
     return {
-        "value": 1.0 / t_question, "unit": "questions/s", "cores": cores, "kind": "port",
-        "sample": (f"oracle (numpy fp32 BLAS) timed on 3 of 32 ViT blocks over 1296 patches (window block {t_win:.2f}s, full-attention block {t_fullblk:.2f}s, embed+merger {t_over:.2f}s), 2 of 36 decoder "
+        "value": 1.0 / t_question, "unit": "questions/s", "cores": cores, "threads": cores, "kind": "port",
+        "sample": (f"EXTRAPOLATED: oracle (numpy fp32 BLAS) timed on 3 of 32 ViT blocks over 1296 patches (window block {t_win:.3f}s, full-attention block {t_fullblk:.3f}s, embed+merger {t_over:.3f}s), 2 of 36 decoder "
                    f"layers prefilling 802 tokens ({t_pre:.2f}s), {nd} decode steps ({t_dec:.3f}s each incl. lm_head "
-                   f"{t_head:.3f}s); extrapolated by layer count to the as-executed question (3 view encodes, 802+1320 "
+                   f"{t_head:.3f}s); scaled by layer count to the as-executed question (3 view encodes, 802+1320 "
                    f"prefill, 288 decode) = {t_question:.1f}s"),
     }
 
 
-def cpu_baseline_hf():
+def cpu_baseline_hf(full_depth: bool = True):
     """The reference's own CPU path -- the installed `transformers` Qwen2_5_VLForConditionalGeneration that
-    src/eval/infer.py:147-151 instantiates -- on a bounded sample: bf16, random weights, 3B layer shapes at reduced
-    depth (8 of 32 ViT blocks, 2 of 36 decoder layers), timed with torch on all host cores and extrapolated by layer
-    count to the question AS THE REFERENCE EXECUTES IT (3 view encodes, 802- and 1320-token prefills, 288 decode
-    steps).  Raises when transformers is missing or its API differs; the caller then falls back to the oracle."""
+    src/eval/infer.py:147-151 instantiates -- in bf16 with random weights at the FULL 3B depth, timed on ONE whole
+    question AS THE REFERENCE EXECUTES IT: stage 1 = generate() on the 802-token prompt with the 1296-patch view
+    (192 new tokens), stage 2 = a fresh generate() on the 1320-token prompt with view + crop (two more view-sized
+    encodes, 96 new tokens); greedy, repetition penalty 1.05, lengths forced (min = max new tokens).
+    full_depth=False: the bounded layer sample of round 1 (8 of 32 ViT blocks, 2 of 36 layers), extrapolated."""
     import torch
-    from transformers import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
     import transformers
+    from transformers import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
     try:
         from transformers.initialization import no_init_weights
     except Exception:  # older layouts
         from transformers.modeling_utils import no_init_weights
-    cores = min(os.cpu_count() or 1, int(os.environ.get("ZE_HF_THREADS", "16")))  # the best setting found on the GPU box (2 x EPYC 9575F): 8 threads 69 s per question, 16: 37.5 s, 32: 95 s, 64: 247 s, 256: > 15 min -- the small GEMMs of a decode step do not scale
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
+    threads = min(ncpu, int(os.environ.get("ZE_HF_THREADS", "16")))  # the best setting found on the GPU box (2 x EPYC 9575F): 8 threads 69 s per question, 16: 37.5 s, 32: 95 s, 64: 247 s, 256: > 15 min -- the small GEMMs of a decode step do not scale
+    torch.set_num_threads(threads)
     t_start = time.perf_counter()
 
     def note(msg):
         print(f"[hf baseline +{time.perf_counter() - t_start:.1f}s] {msg}", file=sys.stderr, flush=True)
 
-    vd, td, n_full, depth_full, layers_full = 8, 2, 4, 32, 36
+    vd, td = (32, 36) if full_depth else (8, 2)
     hc = Qwen2_5_VLConfig(
         vision_config=dict(depth=vd, hidden_size=1280, num_heads=16, intermediate_size=3420, out_hidden_size=2048,
                            patch_size=14, temporal_patch_size=2, spatial_merge_size=2, window_size=112, in_channels=3,
-                           fullatt_block_indexes=[7]),
+                           fullatt_block_indexes=[7, 15, 23, 31] if full_depth else [7]),
         text_config=dict(hidden_size=2048, num_hidden_layers=td, num_attention_heads=16, num_key_value_heads=2,
                          intermediate_size=11008, vocab_size=151936, rms_norm_eps=1e-6, max_position_embeddings=32768,
                          rope_parameters=dict(rope_type="default", rope_theta=1e6, mrope_section=[16, 24, 24]),
@@ -251,91 +311,160 @@ def cpu_baseline_hf():
         image_token_id=151655, video_token_id=151656, vision_start_token_id=151652, vision_end_token_id=151653,
         tie_word_embeddings=True)
     hc._attn_implementation = "sdpa"
+    torch.set_default_dtype(torch.bfloat16)  # parameters are created in bf16 directly (7.5 GB, not 15)
     with no_init_weights():
         model = Qwen2_5_VLForConditionalGeneration(hc)
+    torch.set_default_dtype(torch.float32)
     model = model.to(torch.bfloat16).eval()
     with torch.no_grad():
+        # random values from one 64-M-element pool copied into every matrix (values do not matter for the timing; a
+        # per-tensor uniform_ on 3.75 G bf16 elements alone takes over a minute on one core)
+        pool = torch.empty(1 << 26, dtype=torch.bfloat16).uniform_(-0.03, 0.03)
         for n, p in model.named_parameters():
             if p.dim() >= 2:
-                p.uniform_(-0.03, 0.03)
+                flat = p.view(-1)
+                for o in range(0, flat.numel(), pool.numel()):
+                    m = min(pool.numel(), flat.numel() - o)
+                    flat[o:o + m].copy_(pool[:m])
             elif "norm" in n or n.endswith("ln_q.weight"):
                 p.fill_(1.0)
             else:
                 p.zero_()
-    note("model built")
+        del pool
+    note(f"model built (ViT depth {vd}, {td} decoder layers)")
     rng = np.random.default_rng(0)
-    pv = torch.from_numpy(rng.standard_normal((1296, 1176), dtype=np.float32)).to(torch.bfloat16)
-    grid = torch.tensor([[1, 36, 36]])
-    ids = list(rng.integers(1000, 150000, 21)) + [151652] + [151655] * 324 + [151653] + list(rng.integers(1000, 150000, 455))
-    ids_t = torch.tensor([ids])
-    kw = dict(input_ids=ids_t, attention_mask=torch.ones_like(ids_t), pixel_values=pv, image_grid_thw=grid,
-              mm_token_type_ids=(ids_t == 151655).int())
+    pv1 = torch.from_numpy(rng.standard_normal((1296, 1176), dtype=np.float32)).to(torch.bfloat16)
+    pv2 = torch.from_numpy(rng.standard_normal((2592, 1176), dtype=np.float32)).to(torch.bfloat16)
+    txt_a, txt_b = list(rng.integers(1000, 150000, 21)), list(rng.integers(1000, 150000, 455))
+    vis = [151652] + [151655] * 324 + [151653]
+    ids1 = torch.tensor([txt_a + vis + txt_b])
+    ids2 = torch.tensor([txt_a + vis + txt_b + list(rng.integers(1000, 150000, N1)) + vis])
+    assert ids1.shape[1] == 802 and ids2.shape[1] == 1320
 
-    def best(fn, n=3):
-        ts = []
-        for _ in range(n):
-            t0 = time.perf_counter()
-            fn()
-            ts.append(time.perf_counter() - t0)
-        return min(ts)
+    def kw(ids, pv, n_img):
+        return dict(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values=pv,
+                    image_grid_thw=torch.tensor([[1, 36, 36]] * n_img), mm_token_type_ids=(ids == 151655).int())
 
+    def gen(ids, pv, n_img, n_new):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            out = model.generate(**kw(ids, pv, n_img), max_new_tokens=n_new, min_new_tokens=n_new, do_sample=False,
+                                 num_beams=1, repetition_penalty=PENALTY)
+        assert out.shape[1] == ids.shape[1] + n_new
+        return time.perf_counter() - t0
+
+    base = {"unit": "questions/s", "cores": ncpu, "threads": threads, "kind": "reference"}
+    if full_depth:
+        gen(ids1, pv1, 1, 2)  # warm-up: allocator, oneDNN primitive caches
+        note("warm-up done")
+        t1 = gen(ids1, pv1, 1, N1)
+        note(f"stage 1: {t1:.1f}s")
+        t2 = gen(ids2, pv2, 2, N2)
+        note(f"stage 2: {t2:.1f}s")
+        return dict(base, value=1.0 / (t1 + t2),
+                    sample=(f"ONE whole question at full depth, as executed by the reference: installed transformers "
+                            f"{transformers.__version__} Qwen2_5_VLForConditionalGeneration (src/eval/infer.py:147-151), bf16, "
+                            f"random weights, 3B shape (32 ViT blocks, 36 layers), torch on {threads} threads of {ncpu} "
+                            f"cores: stage 1 generate (802-token prompt, 1296 patches, {N1} new tokens) {t1:.1f}s + stage 2 "
+                            f"generate (1320-token prompt, 2592 patches, {N2} new tokens) {t2:.1f}s = {t1 + t2:.1f}s; not extrapolated"))
+    # bounded layer sample, extrapolated by layer count
+    n_full, depth_full, layers_full = 4, 32, 36
+    k = 24
     with torch.no_grad():
-        vis = model.model.visual
-        blocks = vis.blocks
-        vis(pv, grid_thw=grid)  # warm-up
+        visual = model.model.visual
+        blocks = visual.blocks
+        visual(pv1, grid_thw=torch.tensor([[1, 36, 36]]))
+
+        def best(fn, n=3):
+            ts = []
+            for _ in range(n):
+                t0 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t0)
+            return min(ts)
+
         t_depth = {}
         for d in (1, 7, 8):  # blocks 0..6: window attention; block 7: full attention
-            vis.blocks = blocks[:d]
-            t_depth[d] = best(lambda: vis(pv, grid_thw=grid), 5)
-        vis.blocks = blocks
-        note(f"vit {t_depth}")
-        t_win = max(t_depth[7] - t_depth[1], 6e-6) / 6
-        t_fullblk = max(t_depth[8] - t_depth[7], 1e-6)
+            visual.blocks = blocks[:d]
+            t_depth[d] = best(lambda: visual(pv1, grid_thw=torch.tensor([[1, 36, 36]])), 5)
+        visual.blocks = blocks
+        t_win = max(t_depth[7] - t_depth[1], 0.0) / 6
+        t_fullblk = max(t_depth[8] - t_depth[7], 0.0)
         t_over = max(t_depth[1] - t_win, 0.0)
-        t_pre_all = best(lambda: model(**kw, use_cache=True, logits_to_keep=1), 2)   # ViT(8 blocks) + prefill + head
-        note(f"prefill {t_pre_all:.3f}")
+        t_pre_all = best(lambda: model(**kw(ids1, pv1, 1), use_cache=True, logits_to_keep=1), 2)
         h = torch.randn(1, 2048).to(torch.bfloat16)
         t_head = best(lambda: model.lm_head(h), 4)
-        t_pre = max(t_pre_all - t_depth[8] - t_head, 1e-6)
-        k = 24
-        g1 = best(lambda: model.generate(**kw, max_new_tokens=1, min_new_tokens=1, do_sample=False), 2)
-        gk = best(lambda: model.generate(**kw, max_new_tokens=1 + k, min_new_tokens=1 + k, do_sample=False), 2)
-        t_dec = max(gk - g1, 1e-6) / k
-        note(f"generate {g1:.3f} {gk:.3f}")
+        t_pre = max(t_pre_all - t_depth[8] - t_head, 0.0)
+        g1 = min(gen(ids1, pv1, 1, 1), gen(ids1, pv1, 1, 1))
+        gk = min(gen(ids1, pv1, 1, 1 + k), gen(ids1, pv1, 1, 1 + k))
+        t_dec = max(gk - g1, 0.0) / k
     vit_full = t_over + t_win * (depth_full - n_full) + t_fullblk * n_full
-    pre_layer = t_pre / td
-    dec_layer = max(t_dec - t_head, 0.0) / td
-    L1, L2 = 802, 1320
-    t_question = (3 * vit_full + pre_layer * layers_full * (L1 + L2) / L1 + 2 * t_head
-                  + (N1 + N2) * (dec_layer * layers_full + t_head))
-    return {
-        "value": 1.0 / t_question, "unit": "questions/s", "cores": cores, "kind": "reference",
-        "sample": (f"the reference's CPU path = installed transformers {transformers.__version__} "
-                   f"Qwen2_5_VLForConditionalGeneration (src/eval/infer.py:147-151), bf16, random weights, torch on {cores} "
-                   f"threads: 8 of 32 ViT blocks over 1296 patches (window block {t_win:.3f}s, full-attention block "
-                   f"{t_fullblk:.3f}s, embed+merger {t_over:.3f}s), 2 of 36 decoder layers prefilling 802 tokens "
-                   f"({t_pre:.3f}s), {k} generate() decode steps ({t_dec:.4f}s each incl. lm_head {t_head:.4f}s); "
-                   f"extrapolated by layer count to the as-executed question (3 view encodes, 802+1320 prefill, 288 "
-                   f"decode) = {t_question:.1f}s"),
-    }
+    t_question = (3 * vit_full + t_pre / td * layers_full * (802 + 1320) / 802 + 2 * t_head
+                  + (N1 + N2) * (max(t_dec - t_head, 0.0) / td * layers_full + t_head))
+    return dict(base, value=1.0 / t_question,
+                sample=(f"EXTRAPOLATED from a layer sample: installed transformers {transformers.__version__}, bf16, random "
+                        f"weights, torch on {threads} threads of {ncpu} cores: 8 of 32 ViT blocks over 1296 patches (window "
+                        f"block {t_win:.4f}s, full-attention block {t_fullblk:.4f}s, embed+merger {t_over:.4f}s), 2 of 36 "
+                        f"decoder layers prefilling 802 tokens ({t_pre:.3f}s), {k} generate() decode steps ({t_dec:.4f}s each "
+                        f"incl. lm_head {t_head:.4f}s); scaled by layer count to the as-executed question = {t_question:.1f}s"))
 
 
-def cpu_baseline_hf_bounded(timeout_s: float = 150.0):
+def cpu_baseline_hf_bounded(full_depth: bool, timeout_s: float):
     """cpu_baseline_hf in a child process under a wall-clock limit: a host where the transformers CPU path crawls
-    (thread oversubscription, bf16 emulation) must not stall the benchmark; the caller falls back to the oracle."""
-    import subprocess
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--hf-baseline-child"], capture_output=True, text=True,
-                       timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+    (thread oversubscription, bf16 emulation) must not stall the benchmark; the caller falls back."""
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--hf-baseline-child", "full" if full_depth else "sample"],
+                       capture_output=True, text=True, timeout=timeout_s,
+                       env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
     for ln in reversed(r.stdout.strip().splitlines()):
         if ln.startswith("{"):
             return json.loads(ln)
     raise RuntimeError(f"child failed: {r.stderr.strip()[-200:]}")
 
 
+def measure_cpu_baseline(mode: str):
+    notes = []
+    if mode in ("auto", "hf"):
+        for full, limit in ((True, float(os.environ.get("ZE_HF_FULL_TIMEOUT", "420"))), (False, 150.0)):
+            try:
+                c = cpu_baseline_hf_bounded(full, limit)
+                if notes:
+                    c["sample"] += " (" + "; ".join(notes) + ")"
+                return c
+            except Exception as ex:
+                notes.append(f"{'full-depth question' if full else 'layer sample'} unavailable: {type(ex).__name__}: {str(ex)[:100]}")
+    try:
+        c = cpu_baseline()
+        if notes:
+            c["sample"] += " (" + "; ".join(notes) + ")"
+        return c
+    except Exception as ex:  # pragma: no cover
+        return {"value": None, "unit": "questions/s", "cores": os.cpu_count(), "threads": None, "kind": "port",
+                "sample": f"failed: {ex}; " + "; ".join(notes)}
+
+
+# ----------------------------------------------------------------------------- launcher
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as child processes (one per GPU) BEFORE this
+    process touches the GPU, and exit with their worst return code; rank 0 prints the JSON line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def main():
     if "--hf-baseline-child" in sys.argv:
-        print(json.dumps(cpu_baseline_hf()), flush=True)
-        return
+        print(json.dumps(cpu_baseline_hf(full_depth=sys.argv[-1] != "sample")), flush=True)
+        return 0
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
@@ -343,16 +472,29 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", choices=("auto", "hf", "port"), default="auto",
-                    help="auto: the installed transformers model (the reference's CPU path) when it runs, else the oracle port")
+                    help="auto: one full-depth question through the installed transformers model (the reference's CPU path), "
+                         "else its layer sample, else the oracle port")
     ap.add_argument("--tile", type=int, default=5000)
     ap.add_argument("--model", choices=("3b", "7b"), default="3b",
                     help="3b = ZoomEarth-3B shape (the metric's workload); 7b = Qwen2.5-VL-7B backbone swap of BASELINE "
-                         "configs[4] in bf16 (its fp8 weights are not built): reported without roofline objects")
+                         "configs[4]: reported without the 3B roofline objects")
     ap.add_argument("--fp8", action="store_true",
-                    help="FP8 (E4M3) decoder weights for the decode stream (BASELINE configs[4]); NOT the metric's "
-                         "precision: reported as its own configuration, without roofline objects")
-    ap.add_argument("--batch", type=int, default=1, help="question chains advanced together (1 = BASELINE configs[1]; >1 = configs[2])")
+                    help="FP8 (E4M3) decoder weights (BASELINE configs[4]); NOT the metric's precision: reported as its own "
+                         "configuration")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="1 = BASELINE configs[1] is the line's value (plus a one-step batch64 object); B > 1 = configs[2] with "
+                         "B chains is the line's value")
+    ap.add_argument("--no-batch64", action="store_true", help="skip the batch64 object of the default line")
+    ap.add_argument("--spawn-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
+    if args.spawn_check:  # launcher self-test (tests/test_hostlayer_cpu.py): what this rank was started with, no GPU touched
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "rank": 0,
+                              "master": os.environ.get("MASTER_ADDR"), "local_rank": os.environ.get("LOCAL_RANK")}), flush=True)
+        return 0
 
     import torch
     import torch.distributed as dist
@@ -367,30 +509,43 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
 
-    from zoomearth_amd.synth import synthetic_tile
     from zoomearth_amd.config import ModelConfig
     from zoomearth_amd.engine import Engine
+    from zoomearth_amd.image import DeviceImage
+    from zoomearth_amd.synth import synthetic_tile
 
+    B = max(1, args.batch)
+    want64 = B == 1 and world == 1 and args.model == "3b" and not args.fp8 and not args.no_batch64
+    BB = 64 if want64 else B          # chains of the batched workload (0 = none)
+    n_tiles = max(1, round(BB * 6 / 64)) if BB > 1 else 1
     cfg = ModelConfig.zoomearth_3b() if args.model == "3b" else ModelConfig.qwen25vl_7b()
-    e = Engine(cfg, device=local, max_seqs=max(1, args.batch), max_ctx=2048, max_patches=max(4096, 1400 * args.batch),
-               max_prefill_rows=(16 * 832 if args.batch > 1 else 0),
-               max_tile_side=max(args.tile, 1024))
+    e = Engine(cfg, device=local, max_seqs=max(1, BB), max_ctx=2048, max_patches=max(4096, 1400 * min(BB, 40)),
+               max_prefill_rows=(16 * 832 if BB > 1 else 0), max_tile_side=max(args.tile, 1024))
     e.fill_synthetic(seed=0, std=0.02)
-    if args.fp8:
-        e.quantize_fp8()
     for kv in os.environ.get("ZE_TUNE", "").split(","):  # measurement-only A/B knobs, e.g. ZE_TUNE=2:64
         if ":" in kv:
             e.lib.ze_tune(int(kv.split(":")[0]), int(kv.split(":")[1]))
+    bcast_s = 0.0
     if use_dist:
         arena = e.weights_arena()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         dist.broadcast(arena, src=0)  # the path's only collective: one-time weight broadcast over RCCL/xGMI
         torch.cuda.synchronize()
         bcast_s = time.perf_counter() - t0
-    else:
-        bcast_s = 0.0
-    tile = torch.from_numpy(synthetic_tile(1000 + rank, args.tile, args.tile)).to(f"cuda:{local}")
-    chain = Chain(e, tile, use_graph=not args.no_graph) if args.batch <= 1 else BatchChain(e, tile)
+        del arena
+    if args.fp8:
+        e.quantize_fp8()  # after the broadcast: every rank quantises the weights it received
+    # tile upload (PCIe): pinned host buffer -> HBM through the C ABI, timed on its own (never inside `value`)
+    host_tiles = [torch.from_numpy(synthetic_tile(1000 + rank * 16 + t, args.tile, args.tile)).pin_memory() for t in range(n_tiles)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dev_tiles = [e.tile_upload(h) for h in host_tiles]
+    torch.cuda.synchronize()
+    tile_upload_ms = 1000.0 * (time.perf_counter() - t0) / n_tiles
+    tile = dev_tiles[0]
+    chain = Chain(e, tile, use_graph=not args.no_graph)
+    tiles64 = [DeviceImage(t, e) for t in dev_tiles]
 
     def barrier():
         torch.cuda.synchronize()
@@ -399,13 +554,14 @@ def main():
             torch.cuda.synchronize()
 
     q0 = rank * 100000
-    B = max(1, args.batch)
+    bstats = {}
 
     def run_step(q):
         if B == 1:
             return chain.question(q)
-        o1, o2, l1, l2 = chain.questions(q * B, B)
-        return o1[0], o2[0], l1, l2
+        d = batch_step(e, tiles64, q * B, B, bstats, use_graph=not args.no_graph)
+        l = d[q * B]
+        return [0] * l[1], [0] * l[3], l[0], l[2]
 
     for i in range(args.warmup):
         run_step(q0 + i)
@@ -424,21 +580,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    def batch_roofline(n):
+        """dominant kernel of the batched decode step at n chains (largest device time per step among its launches),
+        measured live with HIP events on the launch stream; the chains hold the contexts the run left behind"""
+        rows = {}
+        for which in sorted(BATCH_KERNELS):
+            u, by = e.profile_batch_kernel(which, n, iters=72)
+            rows[BATCH_KERNELS[which]] = {"us": round(u, 2), "GBps": round(by / (u * 1e-6) / 1e9, 1), "bytes": by}
+        per_step = {k: v["us"] * (2 if k == "rmsnorm" else 1) for k, v in rows.items() if k != "lm_head"}
+        dom = max((w for w in BATCH_KERNELS if BATCH_KERNELS[w] in per_step and w in BATCH_KERNEL_NAMES), key=lambda w: per_step[BATCH_KERNELS[w]])
+        r = rows[BATCH_KERNELS[dom]]
+        ach = r["bytes"] / (r["us"] * 1e-6) / 1e9
+        layer_us = sum(per_step.values())
+        return {"bound": "hbm", "kernel": BATCH_KERNEL_NAMES[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_us": r["us"], "bytes_per_launch": r["bytes"],
+                "chains": n, "layer_us": round(layer_us, 1),
+                "step_kernels": {k: {"us": v["us"], "GBps": v["GBps"]} for k, v in rows.items()}}
+
     if rank == 0:
-        # roofline of the dominant kernel (decode gate/up weight stream), measured live with HIP events on the
-        # stream the kernel runs on; bytes = algorithmic weight bytes of one launch (2 * 11008 * 2048 * 2 B)
-        us, by = e.profile_decode_kernel(2, iters=144)
-        ach = by / (us * 1e-6) / 1e9
-        others = {}
-        for which, name in ((0, "qkv"), (1, "o_proj"), (3, "down"), (4, "lm_head")):
-            u, b = e.profile_decode_kernel(which, iters=72)
-            others[name] = {"us": round(u, 2), "GBps": round(b / (u * 1e-6) / 1e9, 1)}
-        traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tp):  # PMC passes cannot run inside this process: the latest committed measurement
-            with open(tp) as f:
-                tj = json.load(f)
-            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/traffic_latest.json (rocprofv3 --pmc, round %d)" % tj["round"]
         line = {
             "metric": "questions/sec end-to-end, ZoomEarth-3B on 5000px tiles" if args.model == "3b" else
                       "questions/sec end-to-end, Qwen2.5-VL-7B shape (bf16) on 5000px tiles", "value": world * args.steps * B / dt,
@@ -447,61 +606,97 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: ZoomEarth-3B shape, one 5000x5000 tile per GPU, full two-stage "
                                     "zoom chain per question, greedy, batch 1") if B == 1 else
-                                   (f"BASELINE configs[2]: ZoomEarth-3B shape, {B} question chains advanced together per GPU "
-                                    "(batched decode, dynamic-resolution ViT batch), one step = %d questions" % B),
+                                   (f"BASELINE configs[2]: ZoomEarth-3B shape, {B} question chains about {n_tiles} tiles advanced "
+                                    f"together per GPU by the continuous-batching scheduler (ragged lengths +-25 %, dynamic-"
+                                    f"resolution ViT batch), one step = {B} questions"),
                        "batch": B,
                        "tile": [args.tile, args.tile], "L1": lens[0], "L2": lens[1], "N1": lens[2], "N2": lens[3],
                        "repetition_penalty": PENALTY, "hip_graph": not args.no_graph,
                        "reuse": "stage-1 prompt KV and view features reused in stage 2 (bit-identical)",
                        "parallelism": f"dp{world}", "weight_broadcast_s": round(bcast_s, 4)},
-            "roofline": {"bound": "hbm", "kernel": "k_gemv<EPI=SWIGLU,PAIRS=1,KSPLIT=1,CH=4> = k_gemv<2, 1, 1, 4> (decode gate/up weight stream, 36 launches per token)", "achieved": ach,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "avg_us": us, "bytes_per_launch": by, "other_decode_kernels": others},
-            "phase_ms_per_question": {k: round(v / args.steps, 3) for k, v in phases.items()},
+            "weight_broadcast_s": round(bcast_s, 4),
+            "tile_upload_ms": round(tile_upload_ms, 3),
+            "tile_upload_note": (f"one {args.tile}x{args.tile}x3 u8 tile, pinned host memory -> HBM (ze_tile_upload), per TILE, "
+                                 "outside the timed region (tiles are resident when a step starts)"),
+            "phase_ms_per_question": {k: round(v / (args.steps * B), 3) for k, v in phases.items()},
         }
-        if args.model != "3b" or args.fp8:  # the roofline constants below are the 3B bf16 shape's
-            line.pop("roofline", None)
+        if args.model == "3b" and not args.fp8:
+            if B == 1:
+                # roofline of the dominant kernel (decode gate/up weight stream), measured live with HIP events on the
+                # stream the kernel runs on; bytes = algorithmic weight bytes of one launch (2 * 11008 * 2048 * 2 B)
+                us, by = e.profile_decode_kernel(2, iters=144)
+                ach = by / (us * 1e-6) / 1e9
+                others = {}
+                for which, name in ((0, "qkv"), (1, "o_proj"), (3, "down"), (4, "lm_head")):
+                    u, b = e.profile_decode_kernel(which, iters=72)
+                    others[name] = {"us": round(u, 2), "GBps": round(b / (u * 1e-6) / 1e9, 1)}
+                traffic, traffic_src = None, None
+                tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+                if os.path.exists(tp):  # PMC passes cannot run inside this process: the latest committed measurement
+                    with open(tp) as f:
+                        tj = json.load(f)
+                    traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/traffic_latest.json (rocprofv3 --pmc, round %d)" % tj["round"]
+                line["roofline"] = {"bound": "hbm", "kernel": "k_gemv<EPI=SWIGLU,PAIRS=1,KSPLIT=1,CH=4> = k_gemv<2, 1, 1, 4> (decode gate/up weight stream, 36 launches per token)", "achieved": ach,
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                                    "avg_us": us, "bytes_per_launch": by, "other_decode_kernels": others}
+                # per-phase roofline fractions: algorithmic work of the as-built question (stage-1 prompt KV
+                # and view features reused) over the measured phase time, against the dense bf16 MFMA peak / the HBM peak
+                pm = line["phase_ms_per_question"]
+                f_vit, f_pre = 3.41e12, 1320 * 5.549e9 + 0.257e12          # FLOP per question
+                b_dec = (N1 + N2) * 6.171e9 + 36864.0 * (N1 * (lens[0] + N1 / 2) + N2 * (lens[1] + N2 / 2))  # bytes per question
+                line["roofline_phases"] = {
+                    "vit": {"bound": "mfma", "achieved_TFLOPs": f_vit / (pm["vit"] * 1e-3) / 1e12, "peak_TFLOPs": 2500.0,
+                            "frac": f_vit / (pm["vit"] * 1e-3) / 2.5e15},
+                    "prefill": {"bound": "mfma", "achieved_TFLOPs": f_pre / (pm["prefill"] * 1e-3) / 1e12, "peak_TFLOPs": 2500.0,
+                                "frac": f_pre / (pm["prefill"] * 1e-3) / 2.5e15},
+                    "decode": {"bound": "hbm", "achieved_GBs": b_dec / (pm["decode"] * 1e-3) / 1e9, "peak_GBs": HBM_PEAK_GBS,
+                               "frac": b_dec / (pm["decode"] * 1e-3) / (HBM_PEAK_GBS * 1e9)},
+                    "question": {"roofline_ms": (f_vit + f_pre + (N1 + N2) * 6.171e9) / 2.5e15 * 1e3 + b_dec / (HBM_PEAK_GBS * 1e9) * 1e3,
+                                 "measured_ms": line["ms_per_step"]},
+                }
+                line["roofline_phases"]["question"]["frac"] = (line["roofline_phases"]["question"]["roofline_ms"] /
+                                                               line["roofline_phases"]["question"]["measured_ms"])
+            else:
+                line["roofline"] = batch_roofline(B)
+                line["scheduler"] = {k: v for k, v in bstats.items() if k != "lens"}
         if args.fp8:
             line["dtype"] = "fp8-e4m3 decoder weights (per-row power-of-two scales) streamed by the decode GEMVs; bf16 activations, bf16 MFMA prefill on the dequantised copy"
             line["metric"] += " [fp8 weights: reduced precision, not the headline metric]"
-        if args.batch == 1 and args.model == "3b" and not args.fp8:
-            # per-phase roofline fractions: algorithmic work of the as-built question (stage-1 prompt KV
-            # and view features reused) over the measured phase time, against the dense bf16 MFMA peak / the HBM peak
-            pm = line["phase_ms_per_question"]
-            f_vit, f_pre = 3.41e12, 1320 * 5.549e9 + 0.257e12          # FLOP per question
-            b_dec = (N1 + N2) * 6.171e9 + 36864.0 * (N1 * (lens[0] + N1 / 2) + N2 * (lens[1] + N2 / 2))  # bytes per question
-            line["roofline_phases"] = {
-                "vit": {"bound": "mfma", "achieved_TFLOPs": f_vit / (pm["vit"] * 1e-3) / 1e12, "peak_TFLOPs": 2500.0,
-                        "frac": f_vit / (pm["vit"] * 1e-3) / 2.5e15},
-                "prefill": {"bound": "mfma", "achieved_TFLOPs": f_pre / (pm["prefill"] * 1e-3) / 1e12, "peak_TFLOPs": 2500.0,
-                            "frac": f_pre / (pm["prefill"] * 1e-3) / 2.5e15},
-                "decode": {"bound": "hbm", "achieved_GBs": b_dec / (pm["decode"] * 1e-3) / 1e9, "peak_GBs": HBM_PEAK_GBS,
-                           "frac": b_dec / (pm["decode"] * 1e-3) / (HBM_PEAK_GBS * 1e9)},
-                "question": {"roofline_ms": (f_vit + f_pre + (N1 + N2) * 6.171e9) / 2.5e15 * 1e3 + b_dec / (HBM_PEAK_GBS * 1e9) * 1e3,
-                             "measured_ms": line["ms_per_step"]},
+        if want64:
+            # BASELINE configs[2], driver-timed in the default run: one warm-up step (graph captures, fragment copy), then
+            # ONE timed step of 64 questions about 6 tiles through the scheduler, bracketed by device synchronisation
+            st = {}
+            batch_step(e, tiles64, 7_000_000, 64)
+            e.phase_timers(enable=True, reset=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            batch_step(e, tiles64, 7_100_000, 64, st)
+            torch.cuda.synchronize()
+            dt64 = time.perf_counter() - t0
+            ph64 = e.phase_timers(enable=False)
+            lens64 = st.pop("lens")
+            dec_steps = max(1, st.get("steps", 1))
+            line["batch64"] = {
+                "workload": ("BASELINE configs[2]: 64 question chains about 6 tiles advanced together on one GPU by the "
+                             "continuous-batching scheduler (zoomearth_amd/scheduler.py: the path of src/eval/infer.py); "
+                             "ragged N1 / N2 (+-25 %), chains leave at their own budget, stage 2 joins the running batch; "
+                             "one multi-resolution ViT call per admission round, the view of a tile encoded once for its questions"),
+                "value": 64.0 / dt64, "unit": "questions/s", "steps": 1, "questions": 64, "tiles": 6, "ms_per_step": 1000.0 * dt64,
+                "mean_N1": float(np.mean([l[1] for l in lens64])), "mean_N2": float(np.mean([l[3] for l in lens64])),
+                "mean_L1": float(np.mean([l[0] for l in lens64])), "mean_L2": float(np.mean([l[2] for l in lens64])),
+                "phase_ms": {k: round(v, 2) for k, v in ph64.items()},
+                "decode_ms_per_step": round(ph64["decode"] / dec_steps, 3), "scheduler": st,
+                "roofline": batch_roofline(64),
             }
-            line["roofline_phases"]["question"]["frac"] = (line["roofline_phases"]["question"]["roofline_ms"] /
-                                                           line["roofline_phases"]["question"]["measured_ms"])
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            hf_note = ""
-            if args.cpu_baseline in ("auto", "hf"):
-                try:
-                    line["cpu_baseline"] = cpu_baseline_hf_bounded()
-                except Exception as ex:  # transformers missing / API drift: fall back to the oracle port
-                    hf_note = f" (transformers path unavailable: {type(ex).__name__}: {str(ex)[:120]})"
-            if "cpu_baseline" not in line:
-                try:
-                    line["cpu_baseline"] = cpu_baseline()
-                    line["cpu_baseline"]["sample"] += hf_note
-                except Exception as ex:  # pragma: no cover
-                    line["cpu_baseline"] = {"value": None, "unit": "questions/s", "cores": os.cpu_count(), "kind": "port",
-                                            "sample": f"failed: {ex}{hf_note}"}
+            line["cpu_baseline"] = measure_cpu_baseline(args.cpu_baseline)
         print(json.dumps(line), flush=True)
     e.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -277,6 +277,11 @@ int ze_op_attention(ze_engine* e, const void* q, const void* k, const void* v, v
  * stream; returns the average launch duration (us) and the algorithmic bytes of one launch. */
 int ze_profile_decode_kernel(ze_engine* e, int which, int iters, float* avg_us, double* bytes_per_launch,
                              void* stream);
+/* The same for the kernels of the BATCHED decode step at n chains (slots 0..n-1 with the contexts they hold):
+ * which = 0 qkv, 1 o_proj, 2 gate_up, 3 down, 4 lm_head, 5 decode attention (bytes = the K/V rows of the n chains),
+ * 6 RMSNorm, 7 rope + KV append. */
+int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters, float* avg_us, double* bytes_per_launch,
+                            void* stream);
 /* Measurement-only kernel-configuration override (A/B of launch shapes inside one process): knob 0 = down-proj
  * GEMV variant, knob 1 = gate/up GEMV variant; value 0 = shipped default. */
 int ze_tune(int knob, int value);

@@ -5,13 +5,16 @@
 Per record: a stage answer is correct when it equals the ground truth (case-insensitive, stripped) or is a WordNet
 synonym of it (best path similarity >= 0.8 over all synset pairs of the lemmatised words).  `answer2 is None`
 falls back to `answer1`.  Accuracy is reported overall and per `type`, stage 1 -> stage 2.  When `nltk` / the
-WordNet corpus is not installed the synonym test is skipped (exact match only) and the report says so.
+WordNet corpus is not installed the synonym test runs on a bundled subset of WordNet 3.0 synsets
+(src/eval/synsets_lite.json; pinned by tests/golden/synonym_cases.json) and the report says so.
 """
 import argparse
 import json
 from collections import defaultdict
 
-try:  # optional: WordNet synonyms
+import os
+
+try:  # WordNet synonyms through nltk when it (and its corpus) is installed
     import nltk  # noqa: F401
     from nltk.corpus import wordnet as _wn
     from nltk.stem import WordNetLemmatizer as _Lem
@@ -20,10 +23,49 @@ try:  # optional: WordNet synonyms
 except Exception:  # pragma: no cover - nltk is absent in the build image
     HAVE_WORDNET = False
 
+# Without nltk: a bundled, hand-transcribed subset of WordNet 3.0 (src/eval/synsets_lite.json).  The reference's rule
+# (/root/reference/src/eval/eval.py:22-42) -- best path_similarity over all synset pairs >= 0.8 -- is equivalent to
+# "the two lemmatised words share a synset": path_similarity = 1 / (1 + hypernym-path distance) is 1 for an identical
+# synset and at most 1/2 otherwise, so only membership tables are needed, no hypernym graph.
+_LITE = None
+
+
+def _lite():
+    global _LITE
+    if _LITE is None:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "synsets_lite.json"), encoding="utf-8") as f:
+            d = json.load(f)
+        index = defaultdict(set)
+        for name, lemmas in d["synsets"].items():
+            for lemma in lemmas:
+                index[lemma].add(name)
+        _LITE = (index, d.get("noun_plurals", {}))
+    return _LITE
+
+
+def _lemmatize_lite(word: str) -> str:
+    """WordNetLemmatizer().lemmatize(word) (noun) on the bundled vocabulary: the exception / plural table first, then
+    morphy's noun detachment rules, accepted only when the result is a known lemma; otherwise the word unchanged."""
+    index, plurals = _lite()
+    if word in index:
+        return word
+    if word in plurals:
+        return plurals[word]
+    for suffix, repl in (("ses", "s"), ("ves", "f"), ("xes", "x"), ("zes", "z"), ("ches", "ch"), ("shes", "sh"),
+                         ("men", "man"), ("ies", "y"), ("s", "")):
+        if word.endswith(suffix) and word[: len(word) - len(suffix)] + repl in index:
+            return word[: len(word) - len(suffix)] + repl
+    return word
+
 
 def are_synonyms(a: str, b: str) -> bool:
-    if not HAVE_WORDNET or a is None or b is None:
+    if a is None or b is None:
         return False
+    if not HAVE_WORDNET:
+        index, _ = _lite()
+        s1 = index.get(_lemmatize_lite(a.lower().replace(" ", "_")), set())
+        s2 = index.get(_lemmatize_lite(b.lower().replace(" ", "_")), set())
+        return bool(s1 & s2)
     try:
         lem = _Lem()
         s1, s2 = _wn.synsets(lem.lemmatize(a.lower())), _wn.synsets(lem.lemmatize(b.lower()))
@@ -76,7 +118,7 @@ def evaluation_metrics(data_path):
     n = r["total"]
     print("\n" + "=" * 50 + "\nEvaluating dataset: LRS-GRO\n" + "=" * 50)
     if not HAVE_WORDNET:
-        print("(nltk/WordNet not installed: exact match only, no synonym credit)")
+        print("(nltk/WordNet not installed: synonym credit from the bundled WordNet subset src/eval/synsets_lite.json only)")
     print("\n--- Evaluation Results ---")
     print(f"Total Correct (stage 1): {r['correct1']}")
     print(f"Total Correct (stage 2): {r['correct2']}")

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*args, timeout=420):
+def run_bench(*args, timeout=1500):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
                        timeout=timeout, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -37,9 +37,20 @@ def test_bench_line_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.3 < r["frac"] < 1.0
     assert r["traffic"] is None or 0.9 < r["traffic"] / r["bytes_per_launch"] < 1.5
     c = d["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
+    for k in ("value", "unit", "cores", "threads", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["unit"] == "questions/s" and c["cores"] >= 1
+    assert c["cores"] == os.cpu_count() and (c["threads"] is None or 1 <= c["threads"] <= c["cores"])
     assert c["value"] is None or 0 < c["value"] < d["value"]
+    assert d["tile_upload_ms"] > 0 and d["weight_broadcast_s"] == 0
+    # BASELINE configs[2] in the same line: one timed step of 64 questions about 6 tiles through the scheduler
+    b = d["batch64"]
+    assert b["questions"] == 64 and b["tiles"] == 6 and abs(b["value"] - 64000.0 / b["ms_per_step"]) < 1e-6 * b["value"]
+    assert b["value"] > 5 * d["value"]
+    assert 0.75 * 192 <= b["mean_N1"] <= 1.25 * 192 and 0.75 * 96 <= b["mean_N2"] <= 1.25 * 96 and b["mean_L1"] == 802
+    assert b["scheduler"]["admitted"] == 128 and b["scheduler"]["chain_steps"] > 32 * b["scheduler"]["steps"]
+    rb = b["roofline"]
+    assert rb["bound"] == "hbm" and rb["chains"] == 64 and "batched decode" in rb["kernel"]
+    assert abs(rb["frac"] - rb["achieved"] / rb["peak"]) < 1e-9 and 0.05 < rb["frac"] < 1.0
     ph = d["roofline_phases"]
     assert ph["decode"]["bound"] == "hbm" and ph["vit"]["bound"] == "mfma" and 0 < ph["question"]["frac"] < 1

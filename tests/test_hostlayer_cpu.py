@@ -246,3 +246,22 @@ def test_serve_prompt_template_and_data_urls():
                 [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": "http://x/y.png"}}]}]):
         with pytest.raises(serve.BadRequest):
             serve.build_prompt(bad)
+
+
+def test_bench_gpus_flag_spawns_the_ranks():
+    """`python bench.py --gpus N` outside torchrun starts N ranks itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+    in their environment, rendezvous on 127.0.0.1) and rank 0 alone prints the line; under torchrun (WORLD_SIZE set)
+    it does not spawn again."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--spawn-check"], capture_output=True,
+                       text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-1000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines == [{"n_gpus": 3, "rank": 0, "master": "127.0.0.1", "local_rank": "0"}]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--spawn-check"], capture_output=True,
+                       text=True, timeout=120, env=dict(env, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2"))
+    assert r.returncode == 0 and r.stdout.strip() == ""  # a torchrun rank 1: no spawn, no line

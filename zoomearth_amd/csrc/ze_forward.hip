@@ -1530,3 +1530,93 @@ extern "C" int ze_profile_decode_kernel(ze_engine* e, int which, int iters, floa
     *bytes_per_launch = bytes;
     return ZE_OK;
 }
+
+// The kernels of the BATCHED decode step (ze_decode_batch / ze_decode_burst) at n chains (slots 0..n-1, with whatever
+// context they hold), one kind per call, cycling through the layers' real weights and KV caches, bracketed by HIP events
+// on `stream`.  which: 0 qkv, 1 o_proj, 2 gate_up (SwiGLU), 3 down, 4 lm_head, 5 decode attention, 6 RMSNorm,
+// 7 rope + KV append.  bytes_per_launch = algorithmic bytes: the weight matrix (0-4), the K/V rows of the n chains (5),
+// the activation rows read + written (6, 7).
+extern "C" int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters, float* avg_us, double* bytes_per_launch,
+                                       void* stream) {
+    if (!e || !avg_us || !bytes_per_launch || iters <= 0 || n <= 0 || n > e->cfg.max_seqs)
+        return ze_fail(e, ZE_ERR_INVALID, "bad argument");
+    const ze_config& c = e->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    ZE_TRY(ensure_fragments(e, s));
+    const int H = c.hidden, hd = e->head_dim, nq = c.heads * hd, nkv = c.kv_heads * hd, nqkv = nq + 2 * nkv;
+    const size_t seq_stride = (size_t)c.kv_heads * c.max_ctx * hd;
+    const float scale = 1.0f / sqrtf((float)hd);
+    std::vector<int> seqs(n);
+    double kv_bytes = 0;
+    for (int i = 0; i < n; ++i) {
+        seqs[i] = i;
+        kv_bytes += (double)(std::min(e->ctx_host[i] + 1, c.max_ctx)) * nkv * 2 * 2;
+    }
+    ZE_HIP(hipStreamSynchronize(s));
+    memcpy(e->d_host_ints + 64, seqs.data(), (size_t)n * sizeof(int));
+    ZE_HIP(hipMemcpyAsync(e->bseq, e->d_host_ints + 64, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+    double bytes = 0;
+    auto launch = [&](int it) {
+        const int li = it % c.layers;
+        const ze_text_layer& L = e->tl[li];
+        const bool fr = L.qkv.wf && n <= 64;
+        const ze_gemm_ws ws = e->gemm_ws();
+        switch (which) {
+            case 0:
+                if (fr) ze_launch_gemm_frag(ZE_EPI_NONE, e->ty, L.qkv.wf, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, s);
+                else ze_launch_gemm_stream(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, ws, s);
+                bytes = (double)nqkv * H * 2;
+                break;
+            case 1:
+                if (fr) ze_launch_gemm_frag(ZE_EPI_RESIDUAL, e->to, L.o.wf, nullptr, e->th, H, e->th, H, n, H, nq, s);
+                else ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, n, H, nq, ws, s);
+                bytes = (double)H * nq * 2;
+                break;
+            case 2:
+                if (fr) ze_launch_gemm_frag(ZE_EPI_SWIGLU, e->ty, L.gate_up.wf, nullptr, nullptr, 0, e->ta, e->text_ipad, n, 2 * e->text_ipad, H, s);
+                else ze_launch_gemm_stream(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad, n, 2 * e->text_ipad, H, ws, s);
+                bytes = 2.0 * c.intermediate * H * 2;
+                break;
+            case 3:
+                ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, n, H, e->text_ipad, ws, s);
+                bytes = (double)H * c.intermediate * 2;
+                break;
+            case 4:
+                if (e->lm_head_f && n <= 64) ze_launch_gemm_frag(ZE_EPI_F32, e->ty, e->lm_head_f, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab, H, s);
+                else ze_launch_gemm_stream(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab, H, ws, s);
+                bytes = (double)c.vocab * H * 2;
+                break;
+            case 5:
+                ze_launch_attn_decode(e->tqkv, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, e->to, fr ? -(nq / 32) : nq, e->st_dev,
+                                      e->bseq, n, c.heads, c.kv_heads, hd, c.max_ctx, scale, e->bpartial, e->max_splits, e->atickets, s);
+                bytes = kv_bytes;
+                break;
+            case 6:
+                ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, n, H, c.rms_eps, s, fr ? 1 : 0);
+                bytes = (double)n * H * 2 * 2;
+                break;
+            default:
+                ze_launch_rope_kv_batch(e->tqkv, n, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(li, 0),
+                                        e->vc(li, 0), seq_stride, c.max_ctx, s);
+                bytes = (double)n * nqkv * 2 * 2;
+                break;
+        }
+    };
+    hipEvent_t a, b;
+    ZE_HIP(hipEventCreate(&a));
+    ZE_HIP(hipEventCreate(&b));
+    for (int i = 0; i < std::min(iters, 4); ++i) launch(i);  // warm-up
+    ZE_HIP(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) launch(i);
+    ZE_HIP(hipEventRecord(b, s));
+    ZE_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    ZE_HIP(hipEventElapsedTime(&ms, a, b));
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    ZE_KCHECK();
+    *avg_us = ms * 1000.0f / (float)iters;
+    *bytes_per_launch = bytes;
+    return ZE_OK;
+}

@@ -398,6 +398,11 @@ class Engine:
         self._check(self.lib.ze_profile_decode_kernel(self.h, which, iters, C.byref(us), C.byref(by), self._stream()))
         return float(us.value), float(by.value)
 
+    def profile_batch_kernel(self, which: int, n: int, iters: int = 72):
+        us, by = C.c_float(), C.c_double()
+        self._check(self.lib.ze_profile_batch_kernel(self.h, which, n, iters, C.byref(us), C.byref(by), self._stream()))
+        return float(us.value), float(by.value)
+
     def phase_timers(self, enable: bool = True, reset: bool = False):
         out = (C.c_float * 5)()
         self._check(self.lib.ze_phase_timers(self.h, int(enable), int(reset), out))
