@@ -185,7 +185,8 @@ def batch_step(engine, tiles, q0: int, B: int, stats=None, use_graph=True):
     model = Model64(engine)
     proc = SynthProcessor(engine.config, engine)
     sched = ChainScheduler(model, proc, do_sample=False, repetition_penalty=PENALTY, ignore_eos=True, burst=16,
-                           use_graph=use_graph)
+                           use_graph=use_graph, min_admit=int(os.environ.get("ZE_MIN_ADMIT", "8")),
+                           max_wait_bursts=int(os.environ.get("ZE_MAX_WAIT", "2")))
     done = {}
     views = {}
     for b in range(B):

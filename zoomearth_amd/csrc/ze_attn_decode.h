@@ -332,11 +332,12 @@ template <int MB = 24>
 // buffer in which this chain is row `frag_row` (the layout of k_rmsnorm(frag), read by k_gemm_skinny<..., FRAG>).
 __device__ __forceinline__ void attn_merge_group(float* sW, float* sInv, const float* __restrict__ ws, int ctx, int kvh,
                                                  int heads, int kv_heads, int max_splits, bf16_t* __restrict__ out,
-                                                 int frag_slices = 0, int frag_row = 0) {
+                                                 int frag_slices = 0, int frag_row = 0, int nsplit_given = 0) {
     constexpr int D = 128;
     const int G = heads / kv_heads;
     int chunk, nsplit;
     split_geometry(ctx, max_splits, chunk, nsplit);
+    if (nsplit_given > 0) nsplit = nsplit_given;  // the caller's own partition (ze_attn_batch.hip)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int og = tid >> 5, od = (tid & 31) * 4;
     const int hc = kvh * G + min(og, G - 1);  // idle threads (og >= G) shadow the last head: no branch around loads

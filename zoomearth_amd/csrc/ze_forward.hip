@@ -13,7 +13,7 @@
         if (_r != 0) return _r; \
     } while (0)
 #define ZE_KCHECK() ZE_HIP(hipGetLastError())
-extern int ze_gemv_knobs[8];
+extern int ze_gemv_knobs[16];
 
 // ================================================================== front-end
 // dst = crop(src, box).resize((dst_w, dst_h), BICUBIC), Pillow-exact (two passes, u8 intermediate).
@@ -1018,6 +1018,22 @@ static int upload_batch(ze_engine* e, const int32_t* seqs, int n, hipStream_t s)
     return ZE_OK;
 }
 
+// decode attention of the batched step: the LDS-DMA streaming kernel (ze_attn_batch.hip); knob 8 = 1: the 64-token-slice
+// kernel of the single-chain step with a chain dimension (the round-1 form, kept for A/B measurements)
+static void launch_batch_attention(ze_engine* e, int li, int n, bool frag_out, hipStream_t s) {
+    const ze_config& c = e->cfg;
+    const int hd = e->head_dim, nq = c.heads * hd, nqkv = nq + 2 * c.kv_heads * hd;
+    const size_t seq_stride = (size_t)c.kv_heads * c.max_ctx * hd;
+    const float scale = 1.0f / sqrtf((float)hd);
+    if (ze_gemv_knobs[8] == 1)
+        ze_launch_attn_decode(e->tqkv, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, e->to, frag_out ? -(nq / 32) : nq, e->st_dev,
+                              e->bseq, n, c.heads, c.kv_heads, hd, c.max_ctx, scale, e->bpartial, e->max_splits, e->atickets, s);
+    else
+        ze_launch_attn_decode_stream(e->tqkv, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, e->to, frag_out ? -(nq / 32) : nq,
+                                     e->st_dev, e->bseq, n, c.heads, c.kv_heads, c.max_ctx, scale, e->bpartial,
+                                     (c.max_ctx + 255) / 256, e->atickets, s);
+}
+
 static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_eos, int sample, const ze_sample_opts& so,
                                 hipStream_t s) {
     const ze_config& c = e->cfg;
@@ -1038,9 +1054,7 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
             ze_launch_gemm_stream(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, ws, s);
         ze_launch_rope_kv_batch(e->tqkv, n, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(li, 0),
                                 e->vc(li, 0), seq_stride, c.max_ctx, s);
-        ze_launch_attn_decode(e->tqkv, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, e->to, fr ? -(nq / 32) : nq, e->st_dev,
-                              e->bseq, n, c.heads, c.kv_heads, hd, c.max_ctx, scale, e->bpartial, e->max_splits, e->atickets,
-                              s);
+        launch_batch_attention(e, li, n, fr, s);
         if (fr)
             ze_launch_gemm_frag(ZE_EPI_RESIDUAL, e->to, L.o.wf, nullptr, e->th, H, e->th, H, n, H, nq, s);
         else
@@ -1459,7 +1473,7 @@ extern "C" int ze_op_quantize_fp8(ze_engine* e, void* w_bf16, int rows, int cols
 
 // ================================================================== measurement
 extern "C" int ze_tune(int knob, int value) {
-    if (knob < 0 || knob >= 8) return ze_fail(nullptr, ZE_ERR_INVALID, "unknown knob");
+    if (knob < 0 || knob >= 16) return ze_fail(nullptr, ZE_ERR_INVALID, "unknown knob");
     ze_gemv_knobs[knob] = value;
     ++ze_tune_epoch;  // captured decode steps bake the launch policy in: engines drop their graphs on the next use
     return ZE_OK;
@@ -1588,8 +1602,7 @@ extern "C" int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters
                 bytes = (double)c.vocab * H * 2;
                 break;
             case 5:
-                ze_launch_attn_decode(e->tqkv, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, e->to, fr ? -(nq / 32) : nq, e->st_dev,
-                                      e->bseq, n, c.heads, c.kv_heads, hd, c.max_ctx, scale, e->bpartial, e->max_splits, e->atickets, s);
+                launch_batch_attention(e, li, n, fr, s);
                 bytes = kv_bytes;
                 break;
             case 6:

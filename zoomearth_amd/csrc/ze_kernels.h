@@ -164,6 +164,14 @@ void ze_launch_attn_decode(const bf16_t* q, int q_row_stride, const bf16_t* kcac
                            const int* seq_ids, int n, int heads, int kv_heads, int D, int max_ctx, float scale,
                            float* ws_partial, int max_splits, unsigned* tickets, hipStream_t s);
 
+// Batched decode attention (ze_attn_batch.hip): parts of 256 tokens per (chain, kv head) streamed through an LDS-DMA
+// double buffer; same argument meaning as the batched form above, max_parts = ceil(max_ctx / 256) (the partial
+// workspace holds max_parts * heads * 132 floats per chain); seq_ids must not be null.
+void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_t* kcache, const bf16_t* vcache,
+                                  size_t cache_seq_stride, bf16_t* out, int out_row_stride, const ze_seq_dev* st,
+                                  const int* seq_ids, int n, int heads, int kv_heads, int max_ctx, float scale,
+                                  float* ws_partial, int max_parts, unsigned* tickets, hipStream_t s);
+
 // ---- sampling
 struct ze_sample_opts {
     float temperature = 0.f;      // 0: greedy arg-max; > 0: multinomial draw from softmax(score / temperature)

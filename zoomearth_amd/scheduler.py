@@ -49,7 +49,7 @@ class _Live:
 class ChainScheduler:
     def __init__(self, model, processor, do_sample: bool = False, temperature=None, repetition_penalty=None, seed: int = 0,
                  burst: int = 8, max_batch: Optional[int] = None, ignore_eos: bool = False, use_graph: bool = True,
-                 feature_cache: int = 64):
+                 feature_cache: int = 64, min_admit: int = 1, max_wait_bursts: int = 2):
         self.model, self.processor, self.engine = model, processor, model.engine
         gc = model.generation_config
         pen = repetition_penalty if repetition_penalty is not None else (getattr(gc, "repetition_penalty", 1.0) or 1.0)
@@ -58,6 +58,12 @@ class ChainScheduler:
         self.penalty = float(pen)
         self.params = self.engine.gen_params(repetition_penalty=self.penalty, ignore_eos=ignore_eos, use_graph=use_graph,
                                              do_sample=bool(do_sample), temperature=float(temperature or 1.0), seed=seed)
+        # Admission hysteresis: while chains are decoding, newcomers wait until `min_admit` of them can share one ViT call
+        # and one prefill pass (a 520-row prefill alone runs its GEMMs at a third of the rate of a 4000-row pass), but
+        # never longer than `max_wait_bursts` bursts; with nothing decoding they are admitted at once.
+        self.min_admit = max(1, int(min_admit))
+        self.max_wait_bursts = max(0, int(max_wait_bursts))
+        self._waited = 0
         self.burst = max(1, int(burst))
         self.max_batch = min(int(max_batch or self.engine.max_seqs), self.engine.max_seqs)
         self.waiting = deque()
@@ -89,6 +95,12 @@ class ChainScheduler:
     # -- admission: waiting requests take free slots (a follow-up keeps the slot its predecessor parked)
     def _admit(self) -> None:
         e = self.engine
+        if self.live and self.min_admit > 1:
+            ready = sum(1 for r in self.waiting if r.slot >= 0) + min(len(self.free), sum(1 for r in self.waiting if r.slot < 0))
+            if 0 < ready < self.min_admit and self._waited < self.max_wait_bursts:
+                self._waited += 1
+                return
+        self._waited = 0
         batch = []
         while self.waiting:
             req = self.waiting[0]
