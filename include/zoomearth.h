@@ -253,7 +253,7 @@ int ze_op_quantize_fp8(ze_engine* e, void* w_bf16, int rows, int cols, void* q_o
 /* C[M,N] = A[M,K] * W[N,K]^T (+bias[N]) ; bf16 in, fp32 accumulate, bf16 out (one rounding).  act: 0 none, 1 exact GELU,
  * 2 none through the weight-streaming launcher of the batched decode step (split-K; for measurements),
  * 3 none through the fragment-major kernels of that step (operands packed inside the call; M <= 64, N % 16 == 0,
- *   K % 32 == 0, K <= 4096),
+ *   K % 32 == 0, K <= 4096); 5 the same operands through the sixteen-wave one-shot kernel of the qkv / o projections,
  * 4 the SwiGLU epilogue of the MLP (HF:...modeling_qwen2_5_vl.py:85-96,541-554): W holds gate and up rows interleaved
  *   in blocks of 16 ([gate 0..15 | up 0..15 | gate 16..31 | ...], N = 2 * width, width % 16 == 0), bias likewise;
  *   C is [M, N/2] = bf16(bf16(silu(bf16(gate))) * bf16(up)). */

@@ -123,6 +123,26 @@ def test_linear_fragment_major(tiny_engine, m, n, k, bias):
         assert torch.equal(alone[0], got_t[r]), r
 
 
+@pytest.mark.parametrize("m,n,k,bias", [
+    (1, 2560, 2048, True), (8, 2048, 2048, False), (17, 208, 128, True), (33, 80, 352, True), (64, 2560, 2048, True),
+    (64, 3584, 3584, False), (64, 4608, 3584, True), (3, 16, 32, False), (40, 2048, 4096, False),
+])
+def test_linear_one_shot(tiny_engine, m, n, k, bias):
+    """The sixteen-wave one-shot kernel of the batched step's qkv / o projections (ze_gemm_oneshot.hip): one-rounding
+    contract vs float64, a row's result independent of the other rows, repeats bit-identical."""
+    a, w = rnd(12, (m, k)), rnd(13, (n, k), 0.05)
+    b = rnd(14, (n,), 0.5) if bias else None
+    da, dw, db = to_dev_bf16(a), to_dev_bf16(w), to_dev_bf16(b) if bias else None
+    got_t = tiny_engine.op_linear(da, dw, db, 5)
+    got = got_t.float().cpu().numpy()
+    want = a.astype(np.float64) @ w.astype(np.float64).T + (b.astype(np.float64) if bias else 0.0)
+    close_bf16(got, want, scale=0.05 * np.sqrt(k) * 0.05)
+    assert torch.equal(got_t, tiny_engine.op_linear(da, dw, db, 5))
+    for r in {0, m // 2, m - 1}:
+        alone = tiny_engine.op_linear(da[r:r + 1].contiguous(), dw, db, 5)
+        assert torch.equal(alone[0], got_t[r]), r
+
+
 @pytest.mark.parametrize("rows,cols", [(5, 160), (1296, 1280), (3, 2048), (64, 512)])
 def test_rmsnorm(tiny_engine, rows, cols):
     x, w = rnd(4, (rows, cols), 2.0), bf16_round(1.0 + rnd(5, (cols,), 0.1))

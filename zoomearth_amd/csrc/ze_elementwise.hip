@@ -169,20 +169,26 @@ void ze_launch_rmsnorm(const bf16_t* x, int ldx, const bf16_t* w, bf16_t* y, int
 // W [n, k] row-major (leading dimension ldw) -> MFMA-fragment-major copy: fragment (nb, ks) = rows 16 nb .. +15,
 // columns 32 ks .. +31, stored as 64 lanes x 16 B, lane = (col % 32) / 8 * 16 + row % 16.  One wave per fragment.
 // Rows past n (a last, partial block of 16) repeat row n - 1.
+// rope_dim = D > 0 (the qkv projection, n % D == 0): block nb = head h = nb / (D/16), group j = nb % (D/16) holds rows
+// h*D + 8j .. +7 and h*D + D/2 + 8j .. +7 -- the rotate_half partners of M-RoPE side by side (ze_gemm_oneshot.hip).
 __global__ void __launch_bounds__(256) k_pack_fragments(const bf16_t* __restrict__ W, int ldw, int n, int k,
-                                                        bf16_t* __restrict__ Wf) {
+                                                        bf16_t* __restrict__ Wf, int rope_dim) {
     const size_t frag = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int ns = k >> 5;
     if (frag >= (size_t)((n + 15) >> 4) * ns) return;
     const int lane = threadIdx.x & 63, nb = (int)(frag / ns), ks = (int)(frag % ns);
-    const int row = min(nb * 16 + (lane & 15), n - 1);
+    int row = min(nb * 16 + (lane & 15), n - 1);
+    if (rope_dim > 0) {
+        const int bph = rope_dim >> 4, h = nb / bph, j = nb % bph, r = lane & 15;
+        row = h * rope_dim + (r < 8 ? 8 * j + r : (rope_dim >> 1) + 8 * j + (r - 8));
+    }
     const uint4 v = *reinterpret_cast<const uint4*>(W + (size_t)row * ldw + ks * 32 + (lane >> 4) * 8);
     *reinterpret_cast<uint4*>(Wf + (frag * 64 + lane) * 8) = v;
 }
-void ze_launch_pack_fragments(const bf16_t* W, int ldw, int n, int k, bf16_t* Wf, hipStream_t s) {
+void ze_launch_pack_fragments(const bf16_t* W, int ldw, int n, int k, bf16_t* Wf, hipStream_t s, int rope_dim) {
     const size_t frags = (size_t)((n + 15) >> 4) * (k >> 5);
     if (frags == 0) return;
-    k_pack_fragments<<<(unsigned)((frags + 3) / 4), 256, 0, s>>>(W, ldw, n, k, Wf);
+    k_pack_fragments<<<(unsigned)((frags + 3) / 4), 256, 0, s>>>(W, ldw, n, k, Wf, rope_dim);
 }
 
 // ------------------------------------------------------------------ ViT input: f32 pixel rows -> bf16, gathered, K-padded

@@ -985,16 +985,16 @@ static int ensure_fragments(ze_engine* e, hipStream_t s) {
         const size_t total = per_layer * c.layers + (size_t)c.vocab * H;
         if (!e->arena_f) ZE_HIP(hipMalloc((void**)&e->arena_f, total * sizeof(bf16_t)));
         bf16_t* cur = e->arena_f;
-        auto pack = [&](ze_linear& l, int rows, int cols) {
-            ze_launch_pack_fragments(l.w, l.ld, rows, cols, cur, s);
+        auto pack = [&](ze_linear& l, int rows, int cols, int rope_dim) {
+            ze_launch_pack_fragments(l.w, l.ld, rows, cols, cur, s, rope_dim);
             l.wf = cur;
             cur += (size_t)rows * cols;
         };
         for (int li = 0; li < c.layers; ++li) {
             ze_text_layer& L = e->tl[li];
-            pack(L.qkv, nqkv, H);
-            pack(L.o, H, nq);
-            pack(L.gate_up, 2 * ip, H);
+            pack(L.qkv, nqkv, H, hd);  // rows permuted per head for the fused M-RoPE epilogue (ze_gemm_oneshot.hip)
+            pack(L.o, H, nq, 0);
+            pack(L.gate_up, 2 * ip, H, 0);
         }
         ze_launch_pack_fragments(e->lm_head, H, c.vocab, H, cur, s);
         e->lm_head_f = cur;
@@ -1048,14 +1048,18 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
         const bool fr = L.qkv.wf && n <= 64 && ze_gemv_knobs[5] != 1;
         const ze_gemm_ws ws = e->gemm_ws();
         ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, n, H, c.rms_eps, s, fr ? 1 : 0);
-        if (fr)
-            ze_launch_gemm_frag(ZE_EPI_NONE, e->ty, L.qkv.wf, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, s);
-        else
+        if (fr) {  // projection + M-RoPE + KV append in one launch (the fragment copy of qkv is packed for it)
+            ze_launch_qkv_rope_oneshot(e->ty, L.qkv.wf, L.qkv.bias, e->tqkv, nqkv, n, H, c.heads, c.kv_heads, e->cosT, e->sinT,
+                                       e->st_dev, e->bseq, e->kc(li, 0), e->vc(li, 0), seq_stride, c.max_ctx, s);
+        } else {
             ze_launch_gemm_stream(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, ws, s);
-        ze_launch_rope_kv_batch(e->tqkv, n, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(li, 0),
-                                e->vc(li, 0), seq_stride, c.max_ctx, s);
+            ze_launch_rope_kv_batch(e->tqkv, n, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(li, 0),
+                                    e->vc(li, 0), seq_stride, c.max_ctx, s);
+        }
         launch_batch_attention(e, li, n, fr, s);
-        if (fr)
+        if (fr && ze_gemv_knobs[9] != 1)
+            ze_launch_gemm_oneshot(ZE_EPI_RESIDUAL, e->to, L.o.wf, nullptr, e->th, H, e->th, H, n, H, nq, s);
+        else if (fr)
             ze_launch_gemm_frag(ZE_EPI_RESIDUAL, e->to, L.o.wf, nullptr, e->th, H, e->th, H, n, H, nq, s);
         else
             ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, n, H, nq, ws, s);
@@ -1337,7 +1341,7 @@ extern "C" int ze_op_linear(ze_engine* e, const void* a, const void* w, const vo
         if (!ze_launch_gemv(ZE_GV_PLAIN, g, s))
             ze_launch_gemm(ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias, nullptr, 0,
                            (bf16_t*)cmat, N, nullptr, M, N, K, s);
-    } else if (act == 3) {  // the fragment-major kernels of the batched decode step, operands packed here
+    } else if (act == 3 || act == 5) {  // the fragment-major kernels of the batched decode step, operands packed here
         if (M > 64 || N % 16 || K % 32 || K > 4096) return ze_fail(e, ZE_ERR_INVALID, "fragment path: M <= 64, N % 16, K % 32, K <= 4096");
         bf16_t *wf = nullptr, *xf = nullptr;
         const size_t mp = (size_t)(M + 15) / 16 * 16;
@@ -1345,7 +1349,10 @@ extern "C" int ze_op_linear(ze_engine* e, const void* a, const void* w, const vo
         xf = wf + (size_t)N * K;
         ze_launch_pack_fragments((const bf16_t*)w, K, N, K, wf, s);
         ze_launch_pack_fragments((const bf16_t*)a, K, M, K, xf, s);
-        ze_launch_gemm_frag(ZE_EPI_NONE, xf, wf, (const bf16_t*)bias, nullptr, 0, (bf16_t*)cmat, N, M, N, K, s);
+        if (act == 5)  // the sixteen-wave one-shot kernel (qkv / o projections)
+            ze_launch_gemm_oneshot(ZE_EPI_NONE, xf, wf, (const bf16_t*)bias, nullptr, 0, (bf16_t*)cmat, N, M, N, K, s);
+        else
+            ze_launch_gemm_frag(ZE_EPI_NONE, xf, wf, (const bf16_t*)bias, nullptr, 0, (bf16_t*)cmat, N, M, N, K, s);
         hipStreamSynchronize(s);
         hipFree(wf);
     } else if (act == 4) {  // SwiGLU epilogue on interleaved gate/up rows: C is [M, N/2]
@@ -1578,12 +1585,14 @@ extern "C" int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters
         const ze_gemm_ws ws = e->gemm_ws();
         switch (which) {
             case 0:
-                if (fr) ze_launch_gemm_frag(ZE_EPI_NONE, e->ty, L.qkv.wf, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, s);
+                if (fr) ze_launch_qkv_rope_oneshot(e->ty, L.qkv.wf, L.qkv.bias, e->tqkv, nqkv, n, H, c.heads, c.kv_heads, e->cosT, e->sinT,
+                                                   e->st_dev, e->bseq, e->kc(li, 0), e->vc(li, 0), seq_stride, c.max_ctx, s);
                 else ze_launch_gemm_stream(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, ws, s);
                 bytes = (double)nqkv * H * 2;
                 break;
             case 1:
-                if (fr) ze_launch_gemm_frag(ZE_EPI_RESIDUAL, e->to, L.o.wf, nullptr, e->th, H, e->th, H, n, H, nq, s);
+                if (fr && ze_gemv_knobs[9] != 1) ze_launch_gemm_oneshot(ZE_EPI_RESIDUAL, e->to, L.o.wf, nullptr, e->th, H, e->th, H, n, H, nq, s);
+                else if (fr) ze_launch_gemm_frag(ZE_EPI_RESIDUAL, e->to, L.o.wf, nullptr, e->th, H, e->th, H, n, H, nq, s);
                 else ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, n, H, nq, ws, s);
                 bytes = (double)H * nq * 2;
                 break;

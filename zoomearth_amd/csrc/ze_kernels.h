@@ -46,7 +46,17 @@ struct ze_gemm_ws {
 };
 void ze_launch_rmsnorm(const bf16_t* x, int ldx, const bf16_t* w, bf16_t* y, int ldy, int rows, int cols, float eps,
                        hipStream_t s, int frag = 0);
-void ze_launch_pack_fragments(const bf16_t* W, int ldw, int n, int k, bf16_t* Wf, hipStream_t s);
+void ze_launch_pack_fragments(const bf16_t* W, int ldw, int n, int k, bf16_t* Wf, hipStream_t s, int rope_dim = 0);
+// One-shot skinny GEMMs of the batched decode step (ze_gemm_oneshot.hip): sixteen waves per workgroup, one memory round
+// trip per launch.  epi: ZE_EPI_NONE (+bias) or ZE_EPI_RESIDUAL; M <= 64, N % 16 == 0, K % 32 == 0.
+void ze_launch_gemm_oneshot(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,
+                            bf16_t* C, int ldc, int M, int N, int K, hipStream_t s);
+// qkv projection + M-RoPE + KV append in one launch; Wf_perm = ze_launch_pack_fragments(..., rope_dim = 128); q heads go
+// to q_out rows (stride ldq, original column order), k / v rows into the caches at each chain's position.
+void ze_launch_qkv_rope_oneshot(const bf16_t* Xf, const bf16_t* Wf_perm, const bf16_t* bias, bf16_t* q_out, int ldq, int M,
+                                int K, int heads, int kv_heads, const bf16_t* cosT, const bf16_t* sinT,
+                                const ze_seq_dev* st, const int* seq_ids, bf16_t* kcache, bf16_t* vcache,
+                                size_t cache_seq_stride, int max_ctx, hipStream_t s);
 // batched decode on fragment-major operands (k_gemm_skinny<..., FRAG>): Xf from ze_launch_rmsnorm(frag = 1), Wf from
 // ze_launch_pack_fragments; M <= 64, N % 16 == 0, K % 32 == 0, K <= 4096 (no split-K)
 void ze_launch_gemm_frag(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,
