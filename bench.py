@@ -36,12 +36,12 @@ L_TEXT_A, L_TEXT_B, N1, N2, PENALTY = 21, 455, 192, 96, 1.05  # 21 + 455 = 476 t
 HBM_PEAK_GBS = 8000.0
 BATCH_KERNELS = {0: "qkv", 1: "o_proj", 2: "gate_up", 3: "down", 4: "lm_head", 5: "attention", 6: "rmsnorm", 7: "rope_kv"}
 BATCH_KERNEL_NAMES = {
-    0: "k_gemm_skinny<1,NONE,FRAG> (batched decode qkv projection, fragment-major weights)",
-    1: "k_gemm_skinny<1,RESIDUAL,FRAG> (batched decode o projection)",
+    0: "k_gemm_oneshot<QKV,4> (batched decode qkv projection + M-RoPE + KV append, sixteen waves per workgroup)",
+    1: "k_gemm_oneshot<RESIDUAL,4> (batched decode o projection)",
     2: "k_gemm_skinny<6,SWIGLU,FRAG,BAL> (batched decode gate/up weight stream, one workgroup per CU)",
     3: "k_gemm_ring<64,64,4,RESIDUAL> split-K (batched decode down projection)",
     4: "k_gemm_skinny<2,F32,FRAG> (batched decode lm_head)",
-    5: "k_attn_decode_split<8,1> (batched decode attention: K/V rows of every chain)",
+    5: "k_attn_decode_stream<8> (batched decode attention: K/V rows of every chain through an LDS-DMA ring)",
 }
 
 
