@@ -91,3 +91,58 @@ def test_fp8_model_vs_oracle_on_dequantised_weights(fresh_tiny):
     e.prefill(1, ids, None, pos, delta, want_logits=False)
     lb = e.decode_batch([1], [forced[0]]).cpu().numpy()[0]
     assert float(np.abs(lb - got[1]).max()) <= 2.0 * yard
+
+
+def test_fp8_fragment_stream_of_the_batched_step_is_the_dequantised_model_bit_for_bit(fresh_tiny):
+    """Batched decode of the quantised engine streams FP8 weight fragments (k_pack_fragments8) and dequantises them in
+    registers (v_cvt_scalef32_pk_bf16_fp8 with the row's power-of-two scale); q * 2^k is exact in bf16, so the logits
+    must equal, bit for bit, those of the same kernels fed the dequantised bf16 fragments (ze_tune knob 10 = 1)."""
+    e = fresh_tiny
+    e.quantize_fp8()
+    ids = [text_ids(20 + s, 60 + 17 * s) for s in range(2)]
+    forced = [[int(t) for t in text_ids(30 + s, 3)] for s in range(2)]
+
+    def run(knob):
+        e.lib.ze_tune(10, knob)
+        out = []
+        for s in range(2):
+            e.seq_reset(s)
+            e.prefill(s, ids[s], None, *e.rope_index(ids[s], []), want_logits=False)
+        for step in range(3):
+            out.append(e.decode_batch([0, 1], [forced[0][step], forced[1][step]]).cpu().numpy())
+        return out
+
+    try:
+        fp8_stream, bf16_frags = run(0), run(1)
+    finally:
+        e.lib.ze_tune(10, 0)
+    for a, b in zip(fp8_stream, bf16_frags):
+        assert np.array_equal(a, b)
+
+
+def test_weight_reload_after_quantisation_drops_the_fp8_stream(fresh_tiny):
+    """load / fill / arena hand-out after quantize_fp8() must not leave the decode GEMVs on stale fp8 copies:
+    after new weights arrive, decode (GEMV path) and prefill (GEMM path) describe the NEW model again."""
+    e = fresh_tiny
+    ids = text_ids(41, 90)
+    tok = int(text_ids(42, 1)[0])
+    pos, delta = e.rope_index(ids, [])
+    e.quantize_fp8()
+    e.seq_reset(0)
+    e.prefill(0, ids, None, pos, delta, want_logits=False)
+    e.generate(0, 4, ignore_eos=True)                     # captures a decode graph on the fp8 streams
+    e.fill_synthetic(seed=9, std=0.02, matrix_gain=4.0, bias_std=0.02, norm_jitter=0.1)   # new weights, unquantised
+    e.seq_reset(0)
+    e.prefill(0, ids, None, pos, delta, want_logits=False)
+    dec = e.decode_step(0, tok).cpu().numpy()             # GEMV path: must read the new bf16 weights
+    e.seq_reset(1)
+    full = e.prefill(1, ids + [tok], None, *e.rope_index(ids + [tok], [])).cpu().numpy()
+    assert float(np.abs(dec - full).max()) < 0.2, float(np.abs(dec - full).max())
+    e.seq_reset(0)
+    e.prefill(0, ids, None, pos, delta, want_logits=False)
+    toks = e.generate(0, 4, ignore_eos=True)              # the graph was re-captured
+    assert len(toks) == 4
+    e.quantize_fp8()                                      # quantising again works (the fp8 arena is reused)
+    e.seq_reset(0)
+    e.prefill(0, ids, None, pos, delta, want_logits=False)
+    assert len(e.generate(0, 4, ignore_eos=True)) == 4

@@ -185,6 +185,26 @@ __global__ void __launch_bounds__(256) k_pack_fragments(const bf16_t* __restrict
     const uint4 v = *reinterpret_cast<const uint4*>(W + (size_t)row * ldw + ks * 32 + (lane >> 4) * 8);
     *reinterpret_cast<uint4*>(Wf + (frag * 64 + lane) * 8) = v;
 }
+__global__ void __launch_bounds__(256) k_pack_fragments8(const uint8_t* __restrict__ W, int ld8, int n, int k,
+                                                         uint8_t* __restrict__ Wf, int rope_dim) {
+    const size_t frag = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ns = k >> 5;
+    if (frag >= (size_t)((n + 15) >> 4) * ns) return;
+    const int lane = threadIdx.x & 63, nb = (int)(frag / ns), ks = (int)(frag % ns);
+    int row = min(nb * 16 + (lane & 15), n - 1);
+    if (rope_dim > 0) {
+        const int bph = rope_dim >> 4, h = nb / bph, j = nb % bph, r = lane & 15;
+        row = h * rope_dim + (r < 8 ? 8 * j + r : (rope_dim >> 1) + 8 * j + (r - 8));
+    }
+    const uint2 v = *reinterpret_cast<const uint2*>(W + (size_t)row * ld8 + ks * 32 + (lane >> 4) * 8);
+    *reinterpret_cast<uint2*>(Wf + (frag * 64 + lane) * 8) = v;
+}
+void ze_launch_pack_fragments8(const uint8_t* W8, int ld8, int n, int k, uint8_t* Wf8, hipStream_t s, int rope_dim) {
+    const size_t frags = (size_t)((n + 15) >> 4) * (k >> 5);
+    if (frags == 0) return;
+    k_pack_fragments8<<<(unsigned)((frags + 3) / 4), 256, 0, s>>>(W8, ld8, n, k, Wf8, rope_dim);
+}
+
 void ze_launch_pack_fragments(const bf16_t* W, int ldw, int n, int k, bf16_t* Wf, hipStream_t s, int rope_dim) {
     const size_t frags = (size_t)((n + 15) >> 4) * (k >> 5);
     if (frags == 0) return;

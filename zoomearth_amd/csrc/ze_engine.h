@@ -31,6 +31,8 @@ struct ze_linear {
     int ld8 = 0;
     // MFMA-fragment-major copy for the batched decode step (ze_launch_pack_fragments), null = none
     bf16_t* wf = nullptr;
+    // the same in FP8 (ze_launch_pack_fragments8 of w8), streamed with scale8 when the engine is quantised, null = none
+    uint8_t* wf8 = nullptr;
 };
 struct ze_vit_block {
     bf16_t *norm1 = nullptr, *norm2 = nullptr;
@@ -70,6 +72,7 @@ struct ze_engine {
     // second, fragment-major copy of the wide decode projections (qkv, gate/up, lm_head) for batched decode: built on
     // the first batched step, rebuilt after any weight change (the 288 GB of HBM make the extra 4.2 GB free)
     bf16_t* arena_f = nullptr;
+    uint8_t* arena_f8 = nullptr;  // FP8 fragment copies (fp8_ready only)
     bf16_t* lm_head_f = nullptr;
     bool frag_ready = false;
     std::vector<ze_text_layer> tl;

@@ -20,9 +20,11 @@ void ze_weights_changed(ze_engine* e) {
             for (ze_linear* l : {&L.qkv, &L.o, &L.gate_up, &L.down}) {
                 l->w8 = nullptr;
                 l->scale8 = nullptr;
+                l->wf8 = nullptr;
             }
         e->lm_head8.w8 = nullptr;
         e->lm_head8.scale8 = nullptr;
+        e->lm_head8.wf8 = nullptr;
     }
     ++ze_tune_epoch;
 }
@@ -399,7 +401,7 @@ extern "C" int ze_engine_destroy(ze_engine* e) {
                    e->st_dev, e->seen, e->out_tokens, e->fe_tmp, e->fe_img, e->fe_coef, e->vx, e->vh, e->vy, e->vqkv,
                    e->vo, e->va, e->vz, e->vz2, e->vcos, e->vsin, e->vperm, e->vinv, e->vtiles_win, e->vtiles_full,
                    e->th, e->ty, e->tqkv, e->to, e->ta, e->tsrc, e->tpos, e->ttiles, e->ttile_aux, e->trow_aux, e->dh, e->dq, e->dattn, e->dact,
-                   e->dlogits, e->dpartial, e->dsample, e->gbar, e->atickets, e->gslab, e->gtickets, e->bseq, e->blogits, e->bpartial, e->bsample, e->arena8, e->arena_f};
+                   e->dlogits, e->dpartial, e->dsample, e->gbar, e->atickets, e->gslab, e->gtickets, e->bseq, e->blogits, e->bpartial, e->bsample, e->arena8, e->arena_f, e->arena_f8};
     for (void* p : dev)
         if (p) hipFree(p);
     void* host[] = {e->fe_coef_host, e->v_host_ints, e->v_host_f32, e->t_host_ints, e->d_host_ints, e->bstate_host};

@@ -998,6 +998,31 @@ static int ensure_fragments(ze_engine* e, hipStream_t s) {
         }
         ze_launch_pack_fragments(e->lm_head, H, c.vocab, H, cur, s);
         e->lm_head_f = cur;
+        // FP8 engine: the same fragments at one byte per weight (qkv, o, gate/up, an untied lm_head); the batched step
+        // streams these and dequantises in registers -- identical values, half the weight bytes
+        for (int li = 0; li < c.layers; ++li) {
+            ze_text_layer& L = e->tl[li];
+            L.qkv.wf8 = L.o.wf8 = L.gate_up.wf8 = nullptr;
+        }
+        e->lm_head8.wf8 = nullptr;
+        if (e->fp8_ready) {
+            const bool head8 = e->lm_head8.w8 != nullptr;
+            const size_t bytes = ((size_t)(nqkv + 2 * ip) * H + (size_t)H * nq) * c.layers + (head8 ? (size_t)c.vocab * H : 0);
+            if (!e->arena_f8) ZE_HIP(hipMalloc((void**)&e->arena_f8, bytes));
+            uint8_t* c8 = e->arena_f8;
+            auto pack8 = [&](ze_linear& l, int rows, int cols, int rope_dim) {
+                ze_launch_pack_fragments8(l.w8, l.ld8, rows, cols, c8, s, rope_dim);
+                l.wf8 = c8;
+                c8 += (size_t)rows * cols;
+            };
+            for (int li = 0; li < c.layers; ++li) {
+                ze_text_layer& L = e->tl[li];
+                pack8(L.qkv, nqkv, H, hd);
+                pack8(L.o, H, nq, 0);
+                pack8(L.gate_up, 2 * ip, H, 0);
+            }
+            if (head8) pack8(e->lm_head8, c.vocab, H, 0);
+        }
         ZE_KCHECK();
     }
     e->frag_ready = true;
@@ -1049,25 +1074,30 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
         const ze_gemm_ws ws = e->gemm_ws();
         ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, n, H, c.rms_eps, s, fr ? 1 : 0);
         if (fr) {  // projection + M-RoPE + KV append in one launch (the fragment copy of qkv is packed for it)
-            ze_launch_qkv_rope_oneshot(e->ty, L.qkv.wf, L.qkv.bias, e->tqkv, nqkv, n, H, c.heads, c.kv_heads, e->cosT, e->sinT,
-                                       e->st_dev, e->bseq, e->kc(li, 0), e->vc(li, 0), seq_stride, c.max_ctx, s);
+            const bool w8 = L.qkv.wf8 && ze_gemv_knobs[10] != 1;  // FP8 fragment stream (quantised engine)
+            ze_launch_qkv_rope_oneshot(e->ty, w8 ? (const bf16_t*)L.qkv.wf8 : L.qkv.wf, L.qkv.bias, e->tqkv, nqkv, n, H, c.heads,
+                                       c.kv_heads, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(li, 0), e->vc(li, 0), seq_stride,
+                                       c.max_ctx, s, w8 ? L.qkv.scale8 : nullptr);
         } else {
             ze_launch_gemm_stream(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, ws, s);
             ze_launch_rope_kv_batch(e->tqkv, n, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(li, 0),
                                     e->vc(li, 0), seq_stride, c.max_ctx, s);
         }
         launch_batch_attention(e, li, n, fr, s);
-        if (fr && ze_gemv_knobs[9] != 1)
-            ze_launch_gemm_oneshot(ZE_EPI_RESIDUAL, e->to, L.o.wf, nullptr, e->th, H, e->th, H, n, H, nq, s);
-        else if (fr)
+        if (fr && ze_gemv_knobs[9] != 1) {
+            const bool w8 = L.o.wf8 && ze_gemv_knobs[10] != 1;
+            ze_launch_gemm_oneshot(ZE_EPI_RESIDUAL, e->to, w8 ? (const bf16_t*)L.o.wf8 : L.o.wf, nullptr, e->th, H, e->th, H, n, H,
+                                   nq, s, w8 ? L.o.scale8 : nullptr);
+        } else if (fr)
             ze_launch_gemm_frag(ZE_EPI_RESIDUAL, e->to, L.o.wf, nullptr, e->th, H, e->th, H, n, H, nq, s);
         else
             ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, n, H, nq, ws, s);
         ze_launch_rmsnorm(e->th, H, L.post_norm, e->ty, H, n, H, c.rms_eps, s, fr ? 1 : 0);
-        if (fr)
-            ze_launch_gemm_frag(ZE_EPI_SWIGLU, e->ty, L.gate_up.wf, nullptr, nullptr, 0, e->ta, e->text_ipad, n,
-                                2 * e->text_ipad, H, s);
-        else
+        if (fr) {
+            const bool w8 = L.gate_up.wf8 && ze_gemv_knobs[10] != 1;
+            ze_launch_gemm_frag(ZE_EPI_SWIGLU, e->ty, w8 ? (const bf16_t*)L.gate_up.wf8 : L.gate_up.wf, nullptr, nullptr, 0, e->ta,
+                                e->text_ipad, n, 2 * e->text_ipad, H, s, w8 ? L.gate_up.scale8 : nullptr);
+        } else
             ze_launch_gemm_stream(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad, n,
                                   2 * e->text_ipad, H, ws, s);
         // the down projection (K = 11008) stays on the split-K ring: the fragment kernel with K split over 8 x 32
@@ -1077,10 +1107,11 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
     }
     const bool fl = e->lm_head_f && n <= 64 && ze_gemv_knobs[5] != 1;
     ze_launch_rmsnorm(e->th, H, e->final_norm, e->ty, H, n, H, c.rms_eps, s, fl ? 1 : 0);
-    if (fl)
-        ze_launch_gemm_frag(ZE_EPI_F32, e->ty, e->lm_head_f, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab, H,
-                            s);
-    else
+    if (fl) {
+        const bool w8 = e->lm_head8.wf8 && ze_gemv_knobs[10] != 1;
+        ze_launch_gemm_frag(ZE_EPI_F32, e->ty, w8 ? (const bf16_t*)e->lm_head8.wf8 : e->lm_head_f, nullptr, nullptr, 0,
+                            (bf16_t*)e->blogits, c.vocab, n, c.vocab, H, s, w8 ? e->lm_head8.scale8 : nullptr);
+    } else
         ze_launch_gemm_stream(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n,
                               c.vocab, H, e->gemm_ws(), s);
     ze_launch_sample_batch(e->blogits, c.vocab, e->seen, penalty, e->st_dev, e->bseq, n, e->eos_dev, c.n_eos,

@@ -9,6 +9,8 @@
 //    the staging write (8 lanes = 8 chunks of one row, ds_write_b128) covers all 32 banks (conflict-free).
 // Staging is register based and split (issue global loads for tile t+1 before the MFMAs of tile t, write LDS after),
 // two LDS buffers, one barrier per K-tile.
+#include <type_traits>
+
 #include "ze_kernels.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -458,10 +460,28 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
 // The four partial tiles meet in LDS and are added in wave order; split-K slices across workgroups (long K: the
 // down projection) then go through the slab / ticket reduction of gemm_finish.  The order of every sum is a function
 // of (K, ksplit) alone, so a chain's result does not depend on how many chains share the step.
-template <int TN, int CH, int MT>
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;  // an FP8 weight fragment of one lane: 8 bytes
+template <int TN, int CH, int MT, bool W8 = false>
 struct skinny_frag {
-    bf16x8 a[CH][MT], b[CH][TN];
+    bf16x8 a[CH][MT];
+    typename std::conditional<W8, u32x2_t, bf16x8>::type b[CH][TN];
 };
+
+// FP8 (E4M3) weight fragment -> bf16 MFMA operand: 8 bytes per lane, all of ONE weight row, times that row's
+// power-of-two scale (v_cvt_scalef32_pk_bf16_fp8: two values per instruction).  q * 2^k is exact in bf16, so the
+// product is the one the dequantised bf16 copy gives, bit for bit, at half the weight bytes.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ bf16x8 deq_fp8x8(u32x2_t w, float scale) {
+    union {
+        bf16x2_t h[4];
+        bf16x8 v;
+    } u;
+    u.h[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.x, scale, false);
+    u.h[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.x, scale, true);
+    u.h[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.y, scale, false);
+    u.h[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.y, scale, true);
+    return u.v;
+}
 
 // FRAG: both operands are stored MFMA-fragment-major (k_pack_fragments / k_rmsnorm(frag)), so every fragment load
 // of a wave is one contiguous 1-KiB read (the row-major form reads 16 rows x 64 B per load, which the vector memory
@@ -472,12 +492,16 @@ struct skinny_frag {
 // BAL: the grid is one workgroup per CU and a workgroup takes a contiguous range of 32-row pairs of blocks (gate | up),
 // floor(b P / G) .. floor((b + 1) P / G) of the P = N / 32 pairs -- at most TN / 2 of them: the weight bytes spread over
 // the CUs as evenly as the pair count allows while every workgroup passes over the activations ONCE.
-template <int TN, int EPI, bool FRAG = false, int MT = 4, bool BAL = false>
+// W8: the fragment-major weights are FP8 (8 B per lane per fragment, k_pack_fragments8) with one power-of-two scale per
+// weight row in `wscale`; they are dequantised in registers (deq_fp8x8) right before the MFMA.
+template <int TN, int EPI, bool FRAG = false, int MT = 4, bool BAL = false, bool W8 = false>
 __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
                                                      int ldw, const bf16_t* __restrict__ bias,
                                                      const bf16_t* __restrict__ R, int ldr, bf16_t* __restrict__ C,
                                                      int ldc, int M, int N, int K, int ksplit,
-                                                     float* __restrict__ slab, unsigned* __restrict__ tickets) {
+                                                     float* __restrict__ slab, unsigned* __restrict__ tickets,
+                                                     const float* __restrict__ wscale = nullptr) {
+    static_assert(!W8 || FRAG, "fp8 weights come fragment-major");
     constexpr int BN = 16 * TN, CH = (TN == 1) ? 4 : 2;  // MFMA slices per prefetch chunk
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     int nwg = (N + BN - 1) / BN;
@@ -503,12 +527,20 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
 
     // per-slice stride of a fragment pointer, in elements: 32 columns of a row (row-major) or one 1-KiB fragment
     constexpr int SSTR = FRAG ? 512 : 32;
+    constexpr int WSTR = W8 ? 256 : SSTR;  // an fp8 fragment is 512 B = 256 bf16-sized elements
     const bf16_t* wp[TN];
     const bf16_t* ap[4];
+    float wsc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) wsc[j] = 1.0f;
     if (FRAG) {
         const int ns_all = K / 32, nb_last = (N >> 4) - 1;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) wp[j] = W + ((size_t)min((bn0 >> 4) + j, nb_last) * ns_all * 64 + lane) * 8;
+        for (int j = 0; j < TN; ++j) {
+            const int blk = min((bn0 >> 4) + j, nb_last);
+            wp[j] = W + ((size_t)blk * ns_all * 64 + lane) * (W8 ? 4 : 8);
+            if (W8) wsc[j] = wscale[blk * 16 + fr];
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) ap[i] = A + ((size_t)min(i, mt - 1) * ns_all * 64 + lane) * 8;
     } else {
@@ -524,32 +556,40 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto load = [&](skinny_frag<TN, CH, MT>& f, int s) {
+    typedef typename std::conditional<W8, u32x2_t, bf16x8>::type wfrag_t;
+    auto load = [&](skinny_frag<TN, CH, MT, W8>& f, int s) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const int k = (s + c) * SSTR;
+            const int k = (s + c) * SSTR, kw = (s + c) * WSTR;
 #pragma unroll
             for (int j = 0; j < TN; ++j)  // streamed once: non-temporal
-                f.b[c][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[j] + k));
+                f.b[c][j] = __builtin_nontemporal_load(reinterpret_cast<const wfrag_t*>(wp[j] + kw));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (i < mt) f.a[c][i] = *reinterpret_cast<const bf16x8*>(ap[i] + k);
         }
     };
-    auto mac = [&](const skinny_frag<TN, CH, MT>& f) {
+    auto mac = [&](const skinny_frag<TN, CH, MT, W8>& f) {
 #pragma unroll
-        for (int c = 0; c < CH; ++c)
+        for (int c = 0; c < CH; ++c) {
+            bf16x8 fb[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (W8) fb[j] = deq_fp8x8(f.b[c][j], wsc[j]);
+                else fb[j] = f.b[c][j];
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (i < mt) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[c][i], f.b[c][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[c][i], fb[j], acc[i][j], 0, 0, 0);
                 }
+        }
     };
     const int nch = ns / CH;
     {
-        skinny_frag<TN, CH, MT> f0, f1;
+        skinny_frag<TN, CH, MT, W8> f0, f1;
         if (nch > 0) load(f0, s0);
         int c = 0;
         for (; c + 2 <= nch; c += 2) {
@@ -561,10 +601,14 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
         if (c < nch) mac(f0);
     }
     for (int s = s0 + nch * CH; s < s0 + ns; ++s) {  // fewer than CH slices left
-        const int k = s * SSTR;
+        const int k = s * SSTR, kw = s * WSTR;
         bf16x8 fb[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[j] + k));
+        for (int j = 0; j < TN; ++j) {
+            const wfrag_t raw = __builtin_nontemporal_load(reinterpret_cast<const wfrag_t*>(wp[j] + kw));
+            if constexpr (W8) fb[j] = deq_fp8x8(raw, wsc[j]);
+            else fb[j] = raw;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i < mt) {
@@ -759,9 +803,10 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
 // the finer grid: 24.1 us (26.8 at 64 rows per workgroup, 25.1 at 128, 27 on the ring).  Narrow matrices (qkv) take
 // 16 rows per workgroup so that their grid still covers the chip: 5.5 / 8.1 us at 8 / 64 chains (9.8 / 13.9 row-major,
 // 15 on the ring).  lm_head: 96 us at 8 chains (120 on the ring), 140 at 64 (145).
-template <int TN, int MT>
+template <int TN, int MT, bool W8 = false>
 static void launch_frag_mt(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,
-                        bf16_t* C, int ldc, int M, int N, int K, hipStream_t s, int ksplit, const ze_gemm_ws& ws) {
+                        bf16_t* C, int ldc, int M, int N, int K, hipStream_t s, int ksplit, const ze_gemm_ws& ws,
+                        const float* wscale = nullptr) {
     float* g_slab = ws.slab;
     unsigned* g_tickets = ws.tickets;
     const int grid = ze_cdiv(N, 16 * TN) * ksplit;
@@ -779,13 +824,13 @@ static void launch_frag_mt(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf
     do {                                                                                                            \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<TN, E, true, MT>),                     \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<TN, E, true, MT, false, W8>),          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);                          \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL((k_gemm_skinny<TN, E, true, MT>), dim3(grid), dim3(256), lds, s, Xf, 0, Wf, 0, bias, R,  \
-                           ldr,                                                                                     \
-                           C, ldc, M, N, K, ksplit, g_slab, g_tickets);                                             \
+        hipLaunchKernelGGL((k_gemm_skinny<TN, E, true, MT, false, W8>), dim3(grid), dim3(256), lds, s, Xf, 0, Wf,   \
+                           0, bias, R, ldr,                                                                         \
+                           C, ldc, M, N, K, ksplit, g_slab, g_tickets, wscale);                                     \
     } while (0)
     if constexpr (TN % 2 == 0) {
         if (epi == ZE_EPI_SWIGLU) {
@@ -805,7 +850,13 @@ static void launch_frag_mt(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf
 template <int TN>
 static void launch_frag(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,
                         bf16_t* C, int ldc, int M, int N, int K, hipStream_t s, int ksplit = 1,
-                        const ze_gemm_ws& ws = ze_gemm_ws()) {
+                        const ze_gemm_ws& ws = ze_gemm_ws(), const float* wscale = nullptr) {
+    if (wscale) {  // fp8 fragment stream
+        if (M <= 16) launch_frag_mt<TN, 1, true>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s, ksplit, ws, wscale);
+        else if (M <= 32) launch_frag_mt<TN, 2, true>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s, ksplit, ws, wscale);
+        else launch_frag_mt<TN, 4, true>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s, ksplit, ws, wscale);
+        return;
+    }
     if (M <= 16) launch_frag_mt<TN, 1>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s, ksplit, ws);
     else if (M <= 32) launch_frag_mt<TN, 2>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s, ksplit, ws);
     else launch_frag_mt<TN, 4>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s, ksplit, ws);
@@ -813,22 +864,22 @@ static void launch_frag(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_
 
 // gate/up (SwiGLU, wide): one workgroup per CU (or a multiple), each with a balanced range of at most three 32-row
 // pairs and ONE pass over the activations
-template <int MT>
+template <int MT, bool W8 = false>
 static void launch_frag_balanced(const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, bf16_t* C, int ldc, int M, int N,
-                                 int K, int grid, hipStream_t s) {
+                                 int K, int grid, hipStream_t s, const float* wscale = nullptr) {
     const size_t lds = (size_t)16 * 6 * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<6, ZE_EPI_SWIGLU, true, MT, true>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<6, ZE_EPI_SWIGLU, true, MT, true, W8>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gemm_skinny<6, ZE_EPI_SWIGLU, true, MT, true>), dim3(grid), dim3(256), lds, s, Xf, 0, Wf, 0, bias,
-                       nullptr, 0, C, ldc, M, N, K, 1, nullptr, nullptr);
+    hipLaunchKernelGGL((k_gemm_skinny<6, ZE_EPI_SWIGLU, true, MT, true, W8>), dim3(grid), dim3(256), lds, s, Xf, 0, Wf, 0, bias,
+                       nullptr, 0, C, ldc, M, N, K, 1, nullptr, nullptr, wscale);
 }
 
 void ze_launch_gemm_frag(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,
-                         bf16_t* C, int ldc, int M, int N, int K, hipStream_t s) {
+                         bf16_t* C, int ldc, int M, int N, int K, hipStream_t s, const float* wscale) {
     if (M <= 0 || N <= 0) return;
     // (more than 32 chains only: below that the activation pass is small and the finer 32-row grid wins, 2.84 against
     //  2.91 ms per step at 8 chains; at 64 chains 3.86 against 3.95.  Both forms add an output's K quarters in the same
@@ -842,13 +893,14 @@ void ze_launch_gemm_frag(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16
         }
         const int P = N / 32;
         const int grid = cus_b * ze_cdiv(P, 3 * cus_b);  // at most three pairs per workgroup
-        launch_frag_balanced<4>(Xf, Wf, bias, C, ldc, M, N, K, grid, s);
+        if (wscale) launch_frag_balanced<4, true>(Xf, Wf, bias, C, ldc, M, N, K, grid, s, wscale);
+        else launch_frag_balanced<4>(Xf, Wf, bias, C, ldc, M, N, K, grid, s);
         return;
     }
     if (N <= 4096 && epi != ZE_EPI_SWIGLU)
-        launch_frag<1>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s);
+        launch_frag<1>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s, 1, ze_gemm_ws(), wscale);
     else
-        launch_frag<2>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s);
+        launch_frag<2>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s, 1, ze_gemm_ws(), wscale);
 }
 
 // Batched decode: the skinny kernel when the shape allows (M <= 64, whole MFMA slices), else the ring.

@@ -28,6 +28,7 @@ struct ze_oneshot_args {
     const bf16_t* Xf;      // activations, fragment-major (k_rmsnorm(frag) / attention merge)
     const bf16_t* Wf;      // weights, fragment-major (row-permuted for OS_EPI_QKV)
     const bf16_t* bias;    // [N] in ORIGINAL row order, or null
+    const float* wscale;   // W8: per-row power-of-two scales of the FP8 fragment copy, ORIGINAL row order
     const bf16_t* R;       // residual rows (OS_EPI_RESIDUAL)
     bf16_t* C;             // output rows (BIAS / RESIDUAL: [M, ldc]; QKV: the q buffer, row stride ldc)
     int ldr, ldc, M, N, K;
@@ -40,7 +41,22 @@ struct ze_oneshot_args {
     int heads, kv_heads, max_ctx;
 };
 
-template <int EPI, int MT>
+typedef __attribute__((ext_vector_type(2))) __bf16 os_bf16x2;
+typedef __attribute__((ext_vector_type(2))) unsigned int os_u32x2;
+__device__ __forceinline__ os_bf16x8 os_deq_fp8x8(os_u32x2 w, float scale) {  // see deq_fp8x8 (ze_gemm.hip)
+    union {
+        os_bf16x2 h[4];
+        os_bf16x8 v;
+    } u;
+    u.h[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.x, scale, false);
+    u.h[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.x, scale, true);
+    u.h[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.y, scale, false);
+    u.h[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.y, scale, true);
+    return u.v;
+}
+
+// W8: Wf is the FP8 fragment copy (8 B per lane per fragment), dequantised in registers with the row's scale
+template <int EPI, int MT, bool W8 = false>
 __global__ void __launch_bounds__(1024) k_gemm_oneshot(const ze_oneshot_args a) {
     constexpr int D = 128;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -78,18 +94,25 @@ __global__ void __launch_bounds__(1024) k_gemm_oneshot(const ze_oneshot_args a) 
     os_f32x4 acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = os_f32x4{0.f, 0.f, 0.f, 0.f};
-    const bf16_t* wp = a.Wf + ((size_t)nb * ns_all * 64 + lane) * 8;
+    const bf16_t* wp = a.Wf + ((size_t)nb * ns_all * 64 + lane) * (W8 ? 4 : 8);
+    const float wsc = W8 ? a.wscale[col] : 1.0f;  // fragment row fr of this block IS output column `col`
     const bf16_t* ap[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) ap[i] = a.Xf + ((size_t)i * ns_all * 64 + lane) * 8;
     for (int c0 = 0; c0 < ns; c0 += 4) {
         os_bf16x8 fb[4], fa[4][MT];
+        os_u32x2 fb8[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const size_t k = (size_t)(s0 + min(c0 + c, ns - 1)) * 512;  // slices past the share re-read its last one
-            fb[c] = __builtin_nontemporal_load(reinterpret_cast<const os_bf16x8*>(wp + k));
+            if constexpr (W8) fb8[c] = __builtin_nontemporal_load(reinterpret_cast<const os_u32x2*>(wp + (k >> 1)));
+            else fb[c] = __builtin_nontemporal_load(reinterpret_cast<const os_bf16x8*>(wp + k));
 #pragma unroll
             for (int i = 0; i < MT; ++i) fa[c][i] = *reinterpret_cast<const os_bf16x8*>(ap[i] + k);
+        }
+        if constexpr (W8) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) fb[c] = os_deq_fp8x8(fb8[c], wsc);
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -181,32 +204,38 @@ __global__ void __launch_bounds__(1024) k_gemm_oneshot(const ze_oneshot_args a) 
     }
 }
 
-template <int EPI>
-static void launch_oneshot(const ze_oneshot_args& a, hipStream_t s) {
+template <int EPI, bool W8>
+static void launch_oneshot_w(const ze_oneshot_args& a, hipStream_t s) {
     const int grid = a.N / 16;
 #define ZE_OS_LAUNCH(MT)                                                                                              \
     do {                                                                                                              \
         const size_t lds = (size_t)(16 + 4) * MT * 64 * 16;                                                           \
         static bool attr_set = false;                                                                                 \
         if (!attr_set) {                                                                                              \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_oneshot<EPI, MT>),                              \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_oneshot<EPI, MT, W8>),                          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
             attr_set = true;                                                                                          \
         }                                                                                                             \
-        hipLaunchKernelGGL((k_gemm_oneshot<EPI, MT>), dim3(grid), dim3(1024), lds, s, a);                             \
+        hipLaunchKernelGGL((k_gemm_oneshot<EPI, MT, W8>), dim3(grid), dim3(1024), lds, s, a);                         \
     } while (0)
     if (a.M <= 16) ZE_OS_LAUNCH(1);
     else if (a.M <= 32) ZE_OS_LAUNCH(2);
     else ZE_OS_LAUNCH(4);
 #undef ZE_OS_LAUNCH
 }
+template <int EPI>
+static void launch_oneshot(const ze_oneshot_args& a, hipStream_t s) {
+    if (a.wscale) launch_oneshot_w<EPI, true>(a, s);
+    else launch_oneshot_w<EPI, false>(a, s);
+}
 
 // C = X W^T (+ bias) (+ residual): M <= 64, N % 16 == 0, K % 32 == 0
 void ze_launch_gemm_oneshot(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,
-                            bf16_t* C, int ldc, int M, int N, int K, hipStream_t s) {
+                            bf16_t* C, int ldc, int M, int N, int K, hipStream_t s, const float* wscale) {
     if (M <= 0 || N <= 0) return;
     ze_oneshot_args a;
     memset(&a, 0, sizeof(a));
+    a.wscale = wscale;
     a.Xf = Xf; a.Wf = Wf; a.bias = bias; a.R = R; a.ldr = ldr; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
     if (epi == ZE_EPI_RESIDUAL) launch_oneshot<OS_EPI_RESIDUAL>(a, s);
     else launch_oneshot<OS_EPI_BIAS>(a, s);
@@ -216,10 +245,11 @@ void ze_launch_gemm_oneshot(int epi, const bf16_t* Xf, const bf16_t* Wf, const b
 void ze_launch_qkv_rope_oneshot(const bf16_t* Xf, const bf16_t* Wf_perm, const bf16_t* bias, bf16_t* q_out, int ldq, int M,
                                 int K, int heads, int kv_heads, const bf16_t* cosT, const bf16_t* sinT,
                                 const ze_seq_dev* st, const int* seq_ids, bf16_t* kcache, bf16_t* vcache,
-                                size_t cache_seq_stride, int max_ctx, hipStream_t s) {
+                                size_t cache_seq_stride, int max_ctx, hipStream_t s, const float* wscale) {
     if (M <= 0) return;
     ze_oneshot_args a;
     memset(&a, 0, sizeof(a));
+    a.wscale = wscale;
     a.Xf = Xf; a.Wf = Wf_perm; a.bias = bias; a.C = q_out; a.ldc = ldq; a.M = M; a.N = (heads + 2 * kv_heads) * 128; a.K = K;
     a.st = st; a.seq_ids = seq_ids; a.cosT = cosT; a.sinT = sinT; a.kcache = kcache; a.vcache = vcache;
     a.cache_seq_stride = cache_seq_stride; a.heads = heads; a.kv_heads = kv_heads; a.max_ctx = max_ctx;

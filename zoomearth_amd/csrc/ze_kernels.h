@@ -50,17 +50,21 @@ void ze_launch_pack_fragments(const bf16_t* W, int ldw, int n, int k, bf16_t* Wf
 // One-shot skinny GEMMs of the batched decode step (ze_gemm_oneshot.hip): sixteen waves per workgroup, one memory round
 // trip per launch.  epi: ZE_EPI_NONE (+bias) or ZE_EPI_RESIDUAL; M <= 64, N % 16 == 0, K % 32 == 0.
 void ze_launch_gemm_oneshot(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,
-                            bf16_t* C, int ldc, int M, int N, int K, hipStream_t s);
+                            bf16_t* C, int ldc, int M, int N, int K, hipStream_t s, const float* wscale = nullptr);
 // qkv projection + M-RoPE + KV append in one launch; Wf_perm = ze_launch_pack_fragments(..., rope_dim = 128); q heads go
 // to q_out rows (stride ldq, original column order), k / v rows into the caches at each chain's position.
 void ze_launch_qkv_rope_oneshot(const bf16_t* Xf, const bf16_t* Wf_perm, const bf16_t* bias, bf16_t* q_out, int ldq, int M,
                                 int K, int heads, int kv_heads, const bf16_t* cosT, const bf16_t* sinT,
                                 const ze_seq_dev* st, const int* seq_ids, bf16_t* kcache, bf16_t* vcache,
-                                size_t cache_seq_stride, int max_ctx, hipStream_t s);
+                                size_t cache_seq_stride, int max_ctx, hipStream_t s, const float* wscale = nullptr);
 // batched decode on fragment-major operands (k_gemm_skinny<..., FRAG>): Xf from ze_launch_rmsnorm(frag = 1), Wf from
 // ze_launch_pack_fragments; M <= 64, N % 16 == 0, K % 32 == 0, K <= 4096 (no split-K)
+// wscale != null: Wf is the FP8 fragment copy (ze_launch_pack_fragments8) and wscale the per-row power-of-two scales
 void ze_launch_gemm_frag(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,
-                         bf16_t* C, int ldc, int M, int N, int K, hipStream_t s);
+                         bf16_t* C, int ldc, int M, int N, int K, hipStream_t s, const float* wscale = nullptr);
+// FP8 weights [n, ld8] row-major (ze_launch_quantize_rows) -> fragment-major: fragment (nb, ks) = 64 lanes x 8 B,
+// lane = (col % 32) / 8 * 16 + row % 16 holds columns 8 (lane / 16) .. +7 of its row; rope_dim as ze_launch_pack_fragments
+void ze_launch_pack_fragments8(const uint8_t* W8, int ld8, int n, int k, uint8_t* Wf8, hipStream_t s, int rope_dim = 0);
 void ze_launch_gather_cast_rows(const float* src, int k, const int* perm, bf16_t* dst, int kp, int rows,
                                 hipStream_t s);
 void ze_launch_vision_rope(bf16_t* qkv, const float* cosT, const float* sinT, int n, int heads, int D, hipStream_t s);
