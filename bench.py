@@ -531,7 +531,14 @@ def main():
         arena = e.weights_arena()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        dist.broadcast(arena, src=0)  # the path's only collective: one-time weight broadcast over RCCL/xGMI
+        # the path's only collective: one-time weight broadcast over RCCL/xGMI.  Default: the plain collective (the form
+        # verified on hardware); ZE_BCAST=scatter_allgather: scatter + all-gather, every link of the point-to-point mesh
+        # carrying 1/N of the arena (tested with 2 gloo processes; no multi-GPU box was available to this build)
+        from zoomearth_amd.accel import scatter_allgather_broadcast
+        if os.environ.get("ZE_BCAST", "broadcast") == "scatter_allgather":
+            scatter_allgather_broadcast(arena, 0, dist)
+        else:
+            dist.broadcast(arena, src=0)
         torch.cuda.synchronize()
         bcast_s = time.perf_counter() - t0
         del arena

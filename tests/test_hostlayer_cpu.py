@@ -107,12 +107,16 @@ acc = accel.Accelerator()
 assert acc.process_index == rank and acc.num_processes == world
 dist.init_process_group("gloo", rank=rank, world_size=world)
 # the path's only collective: one-time broadcast of the packed weight arena (here a CPU stand-in buffer)
-arena = torch.arange(4096, dtype=torch.uint8) if rank == 0 else torch.zeros(4096, dtype=torch.uint8)
-acc.broadcast_weights(arena, src=0)
-chk = torch.tensor([int(arena.to(torch.int64).sum())])
-gathered = [torch.zeros_like(chk) for _ in range(world)]
-dist.all_gather(gathered, chk)
-assert all(int(g) == int(gathered[0]) for g in gathered) and int(chk) == int(torch.arange(4096, dtype=torch.uint8).to(torch.int64).sum())
+# both forms: scatter + all-gather (pieces of 256-byte multiples + a tail broadcast) and the plain broadcast
+for mode, size in (("scatter_allgather", 4096 + 777), ("broadcast", 4096), ("scatter_allgather", 300)):
+    ref = (torch.arange(size, dtype=torch.int64) * 7 % 251).to(torch.uint8)
+    arena = ref.clone() if rank == 0 else torch.zeros(size, dtype=torch.uint8)
+    acc.broadcast_weights(arena, src=0, mode=mode)
+    assert torch.equal(arena, ref), (mode, size)
+    chk = torch.tensor([int(arena.to(torch.int64).sum())])
+    gathered = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(gathered, chk)
+    assert all(int(g) == int(gathered[0]) for g in gathered)
 names = [f"t{(i * 5) % 11}.tif" for i in range(97)]
 class DS(list):
     pass

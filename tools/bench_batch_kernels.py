@@ -17,9 +17,12 @@ from zoomearth_amd.synth import uniform_ints  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 tunes = sys.argv[2:] or [""]
 NAMES = ["qkv", "o_proj", "gate_up", "down", "lm_head", "attention", "rmsnorm", "rope_kv"]
-e = Engine(ModelConfig.zoomearth_3b(), max_seqs=B, max_ctx=2048, max_patches=2048, max_tile_side=1024,
-           max_prefill_rows=16 * 1024)
+cfg = ModelConfig.qwen25vl_7b() if os.environ.get("ZE_MODEL") == "7b" else ModelConfig.zoomearth_3b()
+e = Engine(cfg, max_seqs=B, max_ctx=2048, max_patches=2048, max_tile_side=1024, max_prefill_rows=16 * 1024)
 e.fill_synthetic(0)
+if os.environ.get("ZE_FP8") == "1":  # FP8 decoder weights: the batched step streams fp8 fragments (knob 10 = 1: bf16 copies)
+    e.quantize_fp8()
+print(f"model {cfg.name}, fp8 = {os.environ.get('ZE_FP8') == '1'}", flush=True)
 lens = [800 + int(v) for v in uniform_ints(5, B, 0, 640)]  # ragged: 800 .. 1440 tokens (mean ~1120)
 for g0 in range(0, B, 8):
     gs = list(range(g0, min(B, g0 + 8)))

@@ -66,19 +66,53 @@ class Accelerator:
             dist.init_process_group(backend, rank=self.process_index, world_size=self.num_processes)
             self._pg = True
 
-    def broadcast_weights(self, arena, src: int = 0):
-        """arena: uint8 tensor view of the engine's packed weights (Engine.weights_arena())."""
+    def broadcast_weights(self, arena, src: int = 0, mode: str = "broadcast"):
+        """arena: uint8 tensor view of the engine's packed weights (Engine.weights_arena()); identical afterwards on
+        every rank.  mode "scatter_allgather" (SURVEY.md section 5 / 8e): xGMI is a point-to-point mesh (7 links per GPU),
+        so rank `src` first sends a DIFFERENT 1/N of the arena to every peer -- all of its links busy at once -- and
+        the ranks then all-gather the pieces, every link of every GPU carrying 1/N of the bytes, instead of pushing
+        the whole 7.5 GB down one ring; "broadcast" (default: the form verified on hardware) is the plain collective."""
         if self.num_processes <= 1:
             return
         import torch.distributed as dist
         self.init_process_group("nccl" if arena.is_cuda else "gloo")
-        dist.broadcast(arena, src=src)
+        scatter_allgather_broadcast(arena, src, dist) if mode == "scatter_allgather" else dist.broadcast(arena, src=src)
 
     def wait_for_everyone(self):
         if self.num_processes > 1:
             import torch.distributed as dist
             if dist.is_initialized():
                 dist.barrier()
+
+
+def scatter_allgather_broadcast(arena, src: int, dist, align: int = 256) -> None:
+    """Broadcast of a flat byte tensor as scatter (point-to-point sends of distinct pieces from `src`) + all-gather.
+    Piece size is a multiple of `align` bytes; the tail that does not divide evenly goes by a plain (tiny) broadcast."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = arena.numel()
+    piece = (n // world) // align * align
+    if piece == 0 or world == 1:
+        dist.broadcast(arena, src=src)
+        return
+    body = arena[: piece * world]
+    mine = body[rank * piece:(rank + 1) * piece]
+    # 1. scatter: `src` keeps its own piece in place and sends piece r to rank r
+    if rank == src:
+        ops = [dist.P2POp(dist.isend, body[r * piece:(r + 1) * piece], r) for r in range(world) if r != src]
+    else:
+        ops = [dist.P2POp(dist.irecv, mine, src)]
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    # 2. all-gather the pieces in place (the piece of rank r already sits at offset r * piece of its own arena)
+    if arena.is_cuda:
+        dist.all_gather_into_tensor(body, mine)
+    else:  # gloo: list form; the own slot receives a copy of itself
+        gathered = [body[r * piece:(r + 1) * piece] for r in range(world)]
+        own = mine.clone()
+        dist.all_gather(gathered, own)
+    # 3. the remainder (< world * align bytes)
+    if piece * world < n:
+        dist.broadcast(arena[piece * world:], src=src)
 
 
 class ShardedLoader:
