@@ -3,7 +3,7 @@
 // The single-chain kernel (ze_attn_decode.hip) cuts a context into 64-token slices, one workgroup each: at 64 chains
 // that is ~2300 short-lived workgroups per layer, each paying the chain-state loads, one exposed HBM round trip, a
 // write-through publish + drain + ticket -- 32.8 us for 69 MB of K/V (2.1 TB/s, profiles/r01_batch64_kernel_stats.csv).
-// Here a workgroup owns a PART of AB_CHUNK = 256 tokens of one (chain, kv head): up to eight 32-token rounds whose K / V
+// Here a workgroup owns a PART of a sixth of the context of one (chain, kv head): a handful of 32-token rounds whose K / V
 // tiles arrive by `global_load_lds_dwordx4` into a three-stage ring (no VGPR staging; two rounds are in flight while the
 // current one is on the matrix cores, one barrier per round), so the launch is a few hundred long-lived workgroups,
 // three per CU (48 KB of LDS each: 64 chains at ~1100 tokens are 640 workgroups, all resident at once), every CU keeping
@@ -17,7 +17,6 @@
 #include "ze_kernels.h"
 #include "ze_attn_decode.h"
 
-#define AB_CHUNK 256
 #define AB_TOK 32                        // keys per round
 #define AB_STAGES 3
 #define AB_STAGE (2 * AB_TOK * 256)      // K image + V image of one round, bytes (16 KB)
@@ -53,17 +52,23 @@ __global__ void __launch_bounds__(256) k_attn_decode_stream(const bf16_t* __rest
                                                             const int* __restrict__ seq_ids, int heads, int kv_heads,
                                                             int max_ctx, float scale_log2e, float* __restrict__ ws,
                                                             int max_parts, unsigned* __restrict__ tickets,
-                                                            bf16_t* __restrict__ out, int out_row_stride) {
+                                                            bf16_t* __restrict__ out, int out_row_stride, int chunk_arg) {
     constexpr int D = 128;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // AB_STAGES stages of (K image | V image)
     const int bz = blockIdx.y;
     const int kvh = blockIdx.x % kv_heads, part = blockIdx.x / kv_heads;
     const int seq = seq_ids[bz];
     const int ctx = st_base[seq].ctx + 1;
-    const int nparts = (ctx + AB_CHUNK - 1) / AB_CHUNK;
+    // tokens per part: a sixth of the chain's own context in whole 32-token rounds, at least 128 -- six parts per (chain,
+    // kv head) from 768 tokens on, so 64 chains fill the chip's 768 workgroup slots in ONE round whatever their length
+    // (measured at 64 chains of 804..1436 tokens: 24.5 us, against 29.6 / 31.0 for fixed 256 / 288-token parts whose 576-640
+    // workgroups leave CUs with two or three of them; fixed 384: 22.3 there but 16.1 instead of 12.0 us at 8 chains).
+    // chunk_arg > 0 (measurements): a fixed size.  A function of the chain's own length alone: batch-invariant.
+    const int chunk = chunk_arg > 0 ? chunk_arg : max(128, ((ctx + 5) / 6 + 31) / 32 * 32);
+    const int nparts = (ctx + chunk - 1) / chunk;
     if (part >= nparts) return;  // workgroup-uniform: no part, no ticket
     const int G = heads / kv_heads;
-    const int t0 = part * AB_CHUNK, t1 = min(ctx, t0 + AB_CHUNK);
+    const int t0 = part * chunk, t1 = min(ctx, t0 + chunk);
     const int nr = (t1 - t0 + AB_TOK - 1) / AB_TOK;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -205,7 +210,7 @@ __global__ void __launch_bounds__(256) k_attn_decode_stream(const bf16_t* __rest
 void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_t* kcache, const bf16_t* vcache,
                                   size_t cache_seq_stride, bf16_t* out, int out_row_stride, const ze_seq_dev* st,
                                   const int* seq_ids, int n, int heads, int kv_heads, int max_ctx, float scale,
-                                  float* ws_partial, int max_parts, unsigned* tickets, hipStream_t s) {
+                                  float* ws_partial, int max_parts, unsigned* tickets, hipStream_t s, int chunk) {
     const float sl = scale * 1.4426950408889634f;
     const size_t lds = AB_STAGES * AB_STAGE;
     static bool attr_set = false;
@@ -215,5 +220,5 @@ void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_
     }
     k_attn_decode_stream<8><<<dim3(kv_heads * max_parts, n), 256, lds, s>>>(q, q_row_stride, kcache, vcache, cache_seq_stride, st,
                                                                           seq_ids, heads, kv_heads, max_ctx, sl, ws_partial,
-                                                                          max_parts, tickets, out, out_row_stride);
+                                                                          max_parts, tickets, out, out_row_stride, chunk);
 }

@@ -357,7 +357,7 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     }
     chk(dev_alloc(e, &e->bseq, c.max_seqs));
     chk(dev_alloc(e, &e->blogits, (size_t)c.max_seqs * c.vocab));
-    chk(dev_alloc(e, &e->bpartial, (size_t)c.max_seqs * e->max_splits * c.heads * 132));
+    chk(dev_alloc(e, &e->bpartial, (size_t)c.max_seqs * std::max(e->max_splits, 8) * c.heads * 132));  // >= 8 parts per chain (ze_attn_batch.hip)
     chk(dev_alloc(e, &e->bsample, (size_t)c.max_seqs * 3 * 128 + 8));  // arg-max partials, then chunk sums
     if (r == 0 && hipHostMalloc((void**)&e->bstate_host, sizeof(ze_seq_dev) * c.max_seqs) != hipSuccess)
         r = ze_fail(e, ZE_ERR_HIP, "hipHostMalloc failed");

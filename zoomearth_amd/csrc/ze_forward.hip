@@ -1053,10 +1053,15 @@ static void launch_batch_attention(ze_engine* e, int li, int n, bool frag_out, h
     if (ze_gemv_knobs[8] == 1)
         ze_launch_attn_decode(e->tqkv, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, e->to, frag_out ? -(nq / 32) : nq, e->st_dev,
                               e->bseq, n, c.heads, c.kv_heads, hd, c.max_ctx, scale, e->bpartial, e->max_splits, e->atickets, s);
-    else
+    else {
+        // tokens per part (a multiple of 32; knob 11 for measurements): a function of nothing but the build, so a chain's
+        // partition depends on its own context length alone
+        const int chunk = ze_gemv_knobs[11] >= 64 ? ze_gemv_knobs[11] / 32 * 32 : 0;  // 0: a sixth of the chain's context
+        const int max_parts = chunk ? (c.max_ctx + chunk - 1) / chunk : 8;           // (at most 8 parts: 128-token floor)
         ze_launch_attn_decode_stream(e->tqkv, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, e->to, frag_out ? -(nq / 32) : nq,
-                                     e->st_dev, e->bseq, n, c.heads, c.kv_heads, c.max_ctx, scale, e->bpartial,
-                                     (c.max_ctx + 255) / 256, e->atickets, s);
+                                     e->st_dev, e->bseq, n, c.heads, c.kv_heads, c.max_ctx, scale, e->bpartial, max_parts,
+                                     e->atickets, s, chunk);
+    }
 }
 
 static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_eos, int sample, const ze_sample_opts& so,

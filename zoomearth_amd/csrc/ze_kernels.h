@@ -184,7 +184,7 @@ void ze_launch_attn_decode(const bf16_t* q, int q_row_stride, const bf16_t* kcac
 void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_t* kcache, const bf16_t* vcache,
                                   size_t cache_seq_stride, bf16_t* out, int out_row_stride, const ze_seq_dev* st,
                                   const int* seq_ids, int n, int heads, int kv_heads, int max_ctx, float scale,
-                                  float* ws_partial, int max_parts, unsigned* tickets, hipStream_t s);
+                                  float* ws_partial, int max_parts, unsigned* tickets, hipStream_t s, int chunk = 0);
 
 // ---- sampling
 struct ze_sample_opts {
