@@ -3,7 +3,7 @@
 // The single-chain kernel (ze_attn_decode.hip) cuts a context into 64-token slices, one workgroup each: at 64 chains
 // that is ~2300 short-lived workgroups per layer, each paying the chain-state loads, one exposed HBM round trip, a
 // write-through publish + drain + ticket -- 32.8 us for 69 MB of K/V (2.1 TB/s, profiles/r01_batch64_kernel_stats.csv).
-// Here a workgroup owns a PART of a sixth of the context of one (chain, kv head): a handful of 32-token rounds whose K / V
+// Here a workgroup owns a PART of 192 tokens (more beyond 1536) of one (chain, kv head): six 32-token rounds whose K / V
 // tiles arrive by `global_load_lds_dwordx4` into a three-stage ring (no VGPR staging; two rounds are in flight while the
 // current one is on the matrix cores, one barrier per round), so the launch is a few hundred long-lived workgroups,
 // three per CU (48 KB of LDS each: 64 chains at ~1100 tokens are 640 workgroups, all resident at once), every CU keeping
@@ -59,12 +59,13 @@ __global__ void __launch_bounds__(256) k_attn_decode_stream(const bf16_t* __rest
     const int kvh = blockIdx.x % kv_heads, part = blockIdx.x / kv_heads;
     const int seq = seq_ids[bz];
     const int ctx = st_base[seq].ctx + 1;
-    // tokens per part: a sixth of the chain's own context in whole 32-token rounds, at least 128 -- six parts per (chain,
-    // kv head) from 768 tokens on, so 64 chains fill the chip's 768 workgroup slots in ONE round whatever their length
-    // (measured at 64 chains of 804..1436 tokens: 24.5 us, against 29.6 / 31.0 for fixed 256 / 288-token parts whose 576-640
-    // workgroups leave CUs with two or three of them; fixed 384: 22.3 there but 16.1 instead of 12.0 us at 8 chains).
-    // chunk_arg > 0 (measurements): a fixed size.  A function of the chain's own length alone: batch-invariant.
-    const int chunk = chunk_arg > 0 ? chunk_arg : max(128, ((ctx + 5) / 6 + 31) / 32 * 32);
+    // Tokens per part: 192 (six 32-token rounds), or an eighth of the context once that is longer -- at most 8 parts per
+    // (chain, kv head).  Measured at 64 chains of 804..1436 tokens: 24.7 us (fixed 128: 33.2 -- 1152 workgroups are 1.5
+    // rounds of the 768 resident slots; 256 / 288: 29.6 / 31.0 -- 576-640 workgroups leave CUs with two or three of them;
+    // 384: 22.3 but 16.1 instead of 12.0 us at 8 chains; parts proportional to each chain's length: 27.8 -- the longest
+    // chain's parts set the time).  chunk_arg > 0 (measurements): a fixed size.  A function of the chain's own length
+    // alone, so its result does not depend on the batch.
+    const int chunk = chunk_arg > 0 ? chunk_arg : max(192, ((ctx + 7) / 8 + 31) / 32 * 32);
     const int nparts = (ctx + chunk - 1) / chunk;
     if (part >= nparts) return;  // workgroup-uniform: no part, no ticket
     const int G = heads / kv_heads;
