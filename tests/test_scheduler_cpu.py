@@ -185,6 +185,21 @@ def test_two_stage_follow_up_reuses_slot_and_prefix_and_view_features():
     assert len(vit) == 5                                     # viewA once, viewB once, three crops
 
 
+def test_feature_cache_never_evicts_what_the_round_needs():
+    """A round that encodes more new images than the cache holds must keep the already-cached view it also needs."""
+    model = make_model(max_seqs=6, max_patches=16)
+    sched = ChainScheduler(model, Proc(), burst=2, feature_cache=2)
+    done = {}
+    sched.submit(Request(prompt="41 <img> 60", images=["view"], max_new_tokens=2, on_done=lambda r, t, x: done.__setitem__("a", t)))
+    sched.run()                                              # "view" is cached now
+    for q in range(5):                                       # five prompts: the cached view + a new crop each
+        sched.submit(Request(prompt=f"{43 + 2 * q} <img> 60 <img>", images=["view", f"crop{q}"], max_new_tokens=2,
+                             on_done=lambda r, t, x, q=q: done.__setitem__(q, t)))
+    sched.run()
+    assert sorted(k for k in done if k != "a") == [0, 1, 2, 3, 4]
+    assert sum(len(x[1]) for x in model.engine.log if x[0] == "vit") == 6   # the view once, five crops
+
+
 def test_errors_are_isolated_per_request():
     model = make_model(max_seqs=2, max_ctx=12)
     sched = ChainScheduler(model, Proc(), burst=4)

@@ -113,7 +113,7 @@ class ChainScheduler:
         if not batch:
             return
         # tokenise / preprocess each newcomer; collect the images whose features are not cached
-        prepared, todo = [], OrderedDict()
+        prepared, todo, needed = [], OrderedDict(), set()
         for req in batch:
             try:
                 inp = self.processor(text=[req.prompt], images=list(req.images) or None, return_tensors="pt")
@@ -129,12 +129,15 @@ class ChainScheduler:
                 rows = np.concatenate([[0], np.cumsum([g[0] * g[1] * g[2] for g in grids])]).astype(int)
                 reuse, n_reused = self._reusable(req.slot, ids, keys)
                 for i in range(n_reused, len(grids)):
-                    if keys[i] not in self._features and keys[i] not in todo:
+                    if keys[i] in self._features:
+                        self._features.move_to_end(keys[i])   # needed this round: not an eviction candidate
+                    elif keys[i] not in todo:
                         todo[keys[i]] = (inp["pixel_values"][rows[i]:rows[i + 1]], grids[i])
+                    needed.add(keys[i])
                 prepared.append((req, ids, grids, keys, reuse, n_reused))
             except Exception as ex:  # a malformed request must not take the batch down
                 self._fail(req, ex)
-        self._encode(todo)
+        self._encode(todo, needed)
         # prefill: rows of several chains share every GEMM, up to max_prefill_rows per pass
         group, rows = [], 0
         for item in prepared + [None]:
@@ -157,7 +160,7 @@ class ChainScheduler:
             return n, len(pkeys)
         return 0, 0
 
-    def _encode(self, todo) -> None:
+    def _encode(self, todo, needed=()) -> None:
         """ONE multi-resolution ViT call (per max_patches worth of images) for the uncached images of this round."""
         e = self.engine
         items = list(todo.items())
@@ -178,8 +181,12 @@ class ChainScheduler:
                 self._features[key] = feats[off:off + k]
                 off += k
             i = j
-        while len(self._features) > max(self._feature_cap, len(todo)):
-            self._features.popitem(last=False)
+        # LRU eviction, never of a feature this round's prefills are about to read
+        for key in list(self._features.keys()):
+            if len(self._features) <= max(self._feature_cap, len(needed)):
+                break
+            if key not in needed:
+                del self._features[key]
 
     def _prefill(self, group) -> None:
         e = self.engine
