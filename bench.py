@@ -185,7 +185,7 @@ def batch_step(engine, tiles, q0: int, B: int, stats=None, use_graph=True, slots
     model = Model64(engine)
     proc = SynthProcessor(engine.config, engine)
     sched = ChainScheduler(model, proc, do_sample=False, repetition_penalty=PENALTY, ignore_eos=True, burst=16,
-                           use_graph=use_graph, min_admit=int(os.environ.get("ZE_MIN_ADMIT", "8")),
+                           use_graph=use_graph, min_admit=int(os.environ.get("ZE_MIN_ADMIT", "16")),
                            max_wait_bursts=int(os.environ.get("ZE_MAX_WAIT", "2")), max_batch=slots)
     done = {}
     views = {}
@@ -673,11 +673,12 @@ def main():
         if want64:
             # BASELINE configs[2], driver-timed in the default run: one warm-up step (graph captures, fragment copy), then
             # ONE timed step of 64 questions about 6 tiles through the scheduler, bracketed by device synchronisation
-            # 64 chain slots, a stream of 2 x 64 questions (12 tile-slots: every tile questioned twice over): as in the
-            # LRS-GRO run, a chain that finishes hands its slot to the next question, so the batch stays full until the
-            # stream runs dry (one drain tail per 128 questions instead of one per 64)
+            # 64 chain slots, a stream of 4 x 64 questions (every tile questioned in four passes): as in the LRS-GRO run, a
+            # chain that finishes hands its slot to the next question, so the batch stays full until the stream runs dry
+            # (the drain tail -- ~110 of the decode steps -- is paid once per 256 questions; measured: 64 questions 28.5,
+            # 128 questions 27.9-28.4 questions/s: the middle of the stream gains what its second admission wave costs)
             st = {}
-            NQ = 128
+            NQ = 256
             batch_step(e, tiles64, 7_000_000, 64)
             e.phase_timers(enable=True, reset=True)
             torch.cuda.synchronize()
@@ -691,7 +692,7 @@ def main():
             line["batch64"] = {
                 "workload": ("BASELINE configs[2]: 64 question chains about 6 tiles advanced together on one GPU by the "
                              "continuous-batching scheduler (zoomearth_amd/scheduler.py: the path of src/eval/infer.py), fed a "
-                             "stream of 128 questions (two steps of 64); ragged N1 / N2 (+-25 %), chains leave at their own "
+                             "stream of 256 questions (four steps of 64); ragged N1 / N2 (+-25 %), chains leave at their own "
                              "budget and hand their slot to the next question, stage 2 joins the running batch; one multi-"
                              "resolution ViT call per admission round, the view of a tile encoded once per pass over its questions"),
                 "value": NQ / dt64, "unit": "questions/s", "steps": NQ // 64, "questions": NQ, "chain_slots": 64, "tiles": 6,

@@ -65,7 +65,7 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
     # the rank's questions arrive grouped by tile: decode the next tile while the current one is being questioned
     tiles = TilePrefetcher([tile_path(n) for n in dl.image_names()], model.engine)
     sched = ChainScheduler(model, processor, do_sample=do_sample, temperature=0.01 if do_sample else None, burst=8,
-                           min_admit=max(1, batch_size // 8), max_wait_bursts=2)
+                           min_admit=max(1, batch_size // 4), max_wait_bursts=2)
     done, next_out = {}, [0]
     bar = tqdm(total=len(dl), desc="Evaluating")
 

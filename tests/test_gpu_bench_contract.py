@@ -45,11 +45,11 @@ def test_bench_line_contract():
     assert d["tile_upload_ms"] > 0 and d["weight_broadcast_s"] == 0
     # BASELINE configs[2] in the same line: one timed step of 64 questions about 6 tiles through the scheduler
     b = d["batch64"]
-    assert b["questions"] == 128 and b["chain_slots"] == 64 and b["tiles"] == 6 and b["steps"] == 2
+    assert b["questions"] == 256 and b["chain_slots"] == 64 and b["tiles"] == 6 and b["steps"] == 4
     assert abs(b["value"] - 64000.0 / b["ms_per_step"]) < 1e-6 * b["value"]
     assert b["value"] > 5 * d["value"]
     assert 0.75 * 192 <= b["mean_N1"] <= 1.25 * 192 and 0.75 * 96 <= b["mean_N2"] <= 1.25 * 96 and b["mean_L1"] == 802
-    assert b["scheduler"]["admitted"] == 256 and b["scheduler"]["chain_steps"] > 40 * b["scheduler"]["steps"]
+    assert b["scheduler"]["admitted"] == 512 and b["scheduler"]["chain_steps"] > 40 * b["scheduler"]["steps"]
     rb = b["roofline"]
     assert rb["bound"] == "hbm" and rb["chains"] == 64 and "batched decode" in rb["kernel"]
     assert abs(rb["frac"] - rb["achieved"] / rb["peak"]) < 1e-9 and 0.05 < rb["frac"] < 1.0
