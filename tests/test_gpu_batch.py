@@ -214,3 +214,32 @@ def test_wide_batch_matches_narrow_batch_bitwise():
         assert np.array_equal(wide[:3], narrow)
     finally:
         e.close()
+
+
+def test_more_than_64_chains_fall_back_and_agree():
+    """Beyond 64 chains the fragment / one-shot kernels (M <= 64) do not apply: the step runs on the row-major
+    weight-streaming GEMMs + the stand-alone rope kernel, the streaming attention kernel keeps its chain dimension.  A
+    chain's logits there must agree with the 64-chain path within the bf16 noise of a different summation order, and the
+    step must be batch-invariant within its own path (70 chains vs 66)."""
+    from zoomearth_amd.config import ModelConfig
+    from zoomearth_amd.engine import Engine
+
+    n = 70
+    e = Engine(ModelConfig.tiny(), device=0, max_seqs=n, max_ctx=256, max_patches=256, max_tile_side=512)
+    try:
+        e.fill_synthetic(seed=1, std=0.02, matrix_gain=4.0, bias_std=0.02, norm_jitter=0.1)
+        prompts = [[int(t) for t in prng.uniform_ints(150 + s, 20 + (s % 7) * 9, 10, 1990)] for s in range(n)]
+
+        def run(chains):
+            for s in chains:
+                prefill_text(e, s, prompts[s])
+            return e.decode_batch(chains, [11 + s for s in chains]).cpu().numpy()
+
+        wide = run(list(range(n)))
+        mid = run(list(range(66)))
+        frag = run(list(range(64)))
+        assert np.isfinite(wide).all()
+        assert np.array_equal(wide[:66], mid)
+        assert float(np.abs(wide[:64] - frag).max()) < 0.15, float(np.abs(wide[:64] - frag).max())
+    finally:
+        e.close()

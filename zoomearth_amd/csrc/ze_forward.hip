@@ -73,7 +73,8 @@ static int crop_resize(ze_engine* e, const uint8_t* src, int src_h, int src_w, c
             const int last = std::min(dst_w, c0 + 64) - 1;
             max_span = std::max(max_span, ch.xmin[last] + ch.xcnt[last] - ch.xmin[c0]);
         }
-        ze_launch_resize_h(src, src_h, src_w, bx0, by0, bh, hout, dst_w, d_xmin, d_xcnt, d_xk, ch.ksize, max_span, s);
+        const int inside = bx0 >= 0 && by0 >= 0 && bx0 + bw <= src_w && by0 + bh <= src_h;
+        ze_launch_resize_h(src, src_h, src_w, bx0, by0, bh, hout, dst_w, d_xmin, d_xcnt, d_xk, ch.ksize, max_span, s, inside);
         ZE_KCHECK();
         if (need_v) {
             ze_launch_resize_v(e->fe_tmp, bh, dst_w, 0, 0, dst_w * 3, dst, dst_h, d_ymin, d_ycnt, d_yk, cv.ksize, 0, s);

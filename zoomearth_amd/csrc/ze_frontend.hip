@@ -71,6 +71,83 @@ __global__ void __launch_bounds__(256) k_resize_h(const uint8_t* __restrict__ sr
     d[2] = clip8(s2);
 }
 
+// The same pass for a box that lies INSIDE the image (every view / crop of the zoom chain except crops that leave the
+// tile): the 75-MB tile is the one large HBM read of the front-end, so the span is staged with 16-BYTE loads from the
+// 16-B-aligned address at or below its first byte (the misalignment is carried as an offset into the LDS row), 8 rows per
+// workgroup, and a thread runs its taps for two rows from one read of the coefficient table.  Arithmetic and rounding are
+// those of k_resize_h (bit-exact with Pillow).  5000^2 -> 512^2: 224 us (0.33 TB/s) with the byte-staged kernel.
+#define HV_ROWS 8
+__global__ void __launch_bounds__(256) k_resize_h_vec(const uint8_t* __restrict__ src, int src_h, int src_w, int bx0,
+                                                      int by0, int box_h, uint8_t* __restrict__ dst, int out_w,
+                                                      const int* __restrict__ xmin, const int* __restrict__ xcnt,
+                                                      const int* __restrict__ kk, int ksize, int row_stride) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t hv_lds[];  // HV_ROWS rows of row_stride bytes
+    const int col0 = blockIdx.x * HZ_COLS;
+    const int row0 = blockIdx.y * HV_ROWS;
+    const int ncol = min(HZ_COLS, out_w - col0);
+    const int span_lo = xmin[col0];
+    const int last = col0 + ncol - 1;
+    const int nb = (xmin[last] + xcnt[last] - span_lo) * 3;  // bytes of the span
+    const size_t row_bytes = (size_t)src_w * 3;
+    const uint8_t* end = src + (size_t)src_h * row_bytes;
+    int off0 = 0;
+    for (int r = 0; r < HV_ROWS; ++r) {
+        const int y = row0 + r;
+        if (y >= box_h) break;
+        const uint8_t* a = src + (size_t)(by0 + y) * row_bytes + (size_t)(bx0 + span_lo) * 3;
+        const int off = (int)((uintptr_t)a & 15);
+        const uint8_t* a16 = a - off;
+        if (r == 0) off0 = off;
+        // this row's bytes land at hv_lds[r][off .. off + nb); rows differ in `off` (row_bytes % 16 != 0 in general)
+        const int nvec = (off + nb + 15) >> 4;
+        uint8_t* lrow = hv_lds + (size_t)r * row_stride;
+        if (a16 >= src && a16 + (size_t)nvec * 16 <= end) {
+            for (int v = threadIdx.x; v < nvec; v += 256)
+                *reinterpret_cast<uint4*>(lrow + v * 16) = *reinterpret_cast<const uint4*>(a16 + v * 16);
+        } else {  // first / last bytes of the allocation: no over-read
+            for (int i = threadIdx.x; i < nb; i += 256) lrow[off + i] = a[i];
+        }
+        if (threadIdx.x == 0) reinterpret_cast<int*>(hv_lds + (size_t)HV_ROWS * row_stride)[r] = off;
+    }
+    (void)off0;
+    __syncthreads();
+    const int c = threadIdx.x & (HZ_COLS - 1);
+    const int rg = threadIdx.x >> 6;  // rows rg and rg + 4
+    if (c >= ncol) return;
+    const int xx = col0 + c;
+    const int lo = (xmin[xx] - span_lo) * 3;
+    const int n = xcnt[xx];
+    const int* k = kk + (size_t)xx * ksize;
+    const int* offs = reinterpret_cast<const int*>(hv_lds + (size_t)HV_ROWS * row_stride);
+    const int ya = row0 + rg, yb = ya + 4;
+    const bool has_a = ya < box_h, has_b = yb < box_h;
+    const uint8_t* pa = hv_lds + (size_t)rg * row_stride + (has_a ? offs[rg] : 0) + lo;
+    const uint8_t* pb = hv_lds + (size_t)(rg + 4) * row_stride + (has_b ? offs[rg + 4] : 0) + lo;
+    if (!has_b) pb = pa;  // shadow row a: no branch in the tap loop
+    int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0, b0 = a0, b1 = a0, b2 = a0;
+    for (int j = 0; j < n; ++j) {
+        const int w = k[j];
+        a0 += w * pa[3 * j + 0];
+        a1 += w * pa[3 * j + 1];
+        a2 += w * pa[3 * j + 2];
+        b0 += w * pb[3 * j + 0];
+        b1 += w * pb[3 * j + 1];
+        b2 += w * pb[3 * j + 2];
+    }
+    if (has_a) {
+        uint8_t* d = dst + ((size_t)ya * out_w + xx) * 3;
+        d[0] = clip8(a0);
+        d[1] = clip8(a1);
+        d[2] = clip8(a2);
+    }
+    if (has_b) {
+        uint8_t* d = dst + ((size_t)yb * out_w + xx) * 3;
+        d[0] = clip8(b0);
+        d[1] = clip8(b1);
+        d[2] = clip8(b2);
+    }
+}
+
 // Fallback horizontal pass without LDS staging (span too wide for the staged kernel).
 __global__ void __launch_bounds__(256) k_resize_h_direct(const uint8_t* __restrict__ src, int src_h, int src_w,
                                                          int bx0, int by0, int box_h, uint8_t* __restrict__ dst,
@@ -168,7 +245,16 @@ __global__ void __launch_bounds__(256) k_patchify(const uint8_t* __restrict__ im
 
 void ze_launch_resize_h(const uint8_t* src, int src_h, int src_w, int bx0, int by0, int box_h, uint8_t* dst,
                         int out_w, const int* xmin, const int* xcnt, const int* kk, int ksize, int max_span,
-                        hipStream_t s) {
+                        hipStream_t s, int inside) {
+    // box inside the image: 16-byte staging, 8 rows per workgroup (rows of max_span * 3 bytes + 16 of misalignment + 16
+    // of vector tail, a multiple of 16; up to 160 KB of LDS)
+    const int row_stride = (max_span * 3 + 32 + 15) & ~15;
+    const size_t lds = (size_t)HV_ROWS * row_stride + HV_ROWS * sizeof(int);
+    if (inside && lds <= 64 * 1024) {
+        dim3 gv(ze_cdiv(out_w, 64), ze_cdiv(box_h, HV_ROWS));
+        k_resize_h_vec<<<gv, 256, lds, s>>>(src, src_h, src_w, bx0, by0, box_h, dst, out_w, xmin, xcnt, kk, ksize, row_stride);
+        return;
+    }
     dim3 grid(ze_cdiv(out_w, 64), ze_cdiv(box_h, 4));
     if (max_span <= HZ_MAXSPAN)
         k_resize_h<<<grid, 256, 0, s>>>(src, src_h, src_w, bx0, by0, box_h, dst, out_w, xmin, xcnt, kk, ksize);

@@ -23,7 +23,7 @@ struct ze_seq_dev {
 // ---- front-end
 void ze_launch_resize_h(const uint8_t* src, int src_h, int src_w, int bx0, int by0, int box_h, uint8_t* dst,
                         int out_w, const int* xmin, const int* xcnt, const int* kk, int ksize, int max_span,
-                        hipStream_t s);
+                        hipStream_t s, int inside = 0);  // inside: the box lies inside the image (16-byte staging path)
 void ze_launch_resize_v(const uint8_t* src, int src_h, int src_w, int bx0, int by0, int row_bytes, uint8_t* dst,
                         int out_h, const int* ymin, const int* ycnt, const int* kk, int ksize, int boxed,
                         hipStream_t s);
