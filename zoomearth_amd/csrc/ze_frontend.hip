@@ -75,7 +75,10 @@ __global__ void __launch_bounds__(256) k_resize_h(const uint8_t* __restrict__ sr
 // tile): the 75-MB tile is the one large HBM read of the front-end, so the span is staged with 16-BYTE loads from the
 // 16-B-aligned address at or below its first byte (the misalignment is carried as an offset into the LDS row), 8 rows per
 // workgroup, and a thread runs its taps for two rows from one read of the coefficient table.  Arithmetic and rounding are
-// those of k_resize_h (bit-exact with Pillow).  5000^2 -> 512^2: 224 us (0.33 TB/s) with the byte-staged kernel.
+// those of k_resize_h (bit-exact with Pillow).  5000^2 -> 512^2: 224 us (0.33 TB/s) with the byte-staged kernel, 68-72 us
+// (1.1 TB/s) here; what is left is the unpacking of interleaved RGB bytes on the vector ALUs (~60 instructions per four
+// taps of two rows), not memory: dword taps, 24-bit multiplies, pipelined staging and coefficients in LDS each moved it by
+// a few us only.
 #define HV_ROWS 8
 __global__ void __launch_bounds__(256) k_resize_h_vec(const uint8_t* __restrict__ src, int src_h, int src_w, int bx0,
                                                       int by0, int box_h, uint8_t* __restrict__ dst, int out_w,
@@ -90,26 +93,50 @@ __global__ void __launch_bounds__(256) k_resize_h_vec(const uint8_t* __restrict_
     const int nb = (xmin[last] + xcnt[last] - span_lo) * 3;  // bytes of the span
     const size_t row_bytes = (size_t)src_w * 3;
     const uint8_t* end = src + (size_t)src_h * row_bytes;
-    int off0 = 0;
-    for (int r = 0; r < HV_ROWS; ++r) {
-        const int y = row0 + r;
-        if (y >= box_h) break;
-        const uint8_t* a = src + (size_t)(by0 + y) * row_bytes + (size_t)(bx0 + span_lo) * 3;
-        const int off = (int)((uintptr_t)a & 15);
-        const uint8_t* a16 = a - off;
-        if (r == 0) off0 = off;
-        // this row's bytes land at hv_lds[r][off .. off + nb); rows differ in `off` (row_bytes % 16 != 0 in general)
-        const int nvec = (off + nb + 15) >> 4;
-        uint8_t* lrow = hv_lds + (size_t)r * row_stride;
-        if (a16 >= src && a16 + (size_t)nvec * 16 <= end) {
-            for (int v = threadIdx.x; v < nvec; v += 256)
-                *reinterpret_cast<uint4*>(lrow + v * 16) = *reinterpret_cast<const uint4*>(a16 + v * 16);
-        } else {  // first / last bytes of the allocation: no over-read
-            for (int i = threadIdx.x; i < nb; i += 256) lrow[off + i] = a[i];
-        }
-        if (threadIdx.x == 0) reinterpret_cast<int*>(hv_lds + (size_t)HV_ROWS * row_stride)[r] = off;
+    // staging: the 16-byte pieces of all 8 rows as ONE flat index space, four loads in flight per thread before the
+    // first LDS store (row after row with a load -> store dependency each was eight exposed round trips per workgroup)
+    int* offs_w = reinterpret_cast<int*>(hv_lds + (size_t)HV_ROWS * row_stride);
+    // the 64 columns' coefficient rows (contiguous in the table) go to LDS too: the tap loop then has no global load in it
+    int* kl = offs_w + HV_ROWS;
+    {
+        const int* ksrc = kk + (size_t)col0 * ksize;
+        for (int i = threadIdx.x; i < ncol * ksize; i += 256) kl[i] = ksrc[i];
     }
-    (void)off0;
+    const int nrows = min(HV_ROWS, box_h - row0);
+    const int nvec_max = (15 + nb + 15) >> 4;
+    const int total = nrows * nvec_max;
+    for (int f0 = 0; f0 < total; f0 += 4 * 256) {
+        uint4 val[4];
+        int dsto[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = f0 + u * 256 + (int)threadIdx.x;
+            const int r = min(f / nvec_max, nrows - 1), v = f % nvec_max;
+            const uint8_t* a = src + (size_t)(by0 + row0 + r) * row_bytes + (size_t)(bx0 + span_lo) * 3;
+            const int off = (int)((uintptr_t)a & 15);
+            const uint8_t* p16 = a - off + (size_t)v * 16;
+            const bool need = f < total && v * 16 < off + nb;
+            const bool safe = p16 >= src && p16 + 16 <= end;
+            dsto[u] = need ? (r * row_stride + v * 16) | (safe ? 0 : (1 << 30)) : -1;
+            val[u] = (need && safe) ? *reinterpret_cast<const uint4*>(p16) : make_uint4(0, 0, 0, 0);
+            if (v == 0 && f < total) offs_w[r] = off;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (dsto[u] < 0) continue;
+            if (dsto[u] & (1 << 30)) {  // first / last 16 bytes of the allocation: byte by byte, no over-read
+                const int d = dsto[u] & ~(1 << 30), r = d / row_stride, v = (d % row_stride) >> 4;
+                const uint8_t* a = src + (size_t)(by0 + row0 + r) * row_bytes + (size_t)(bx0 + span_lo) * 3;
+                const int off = (int)((uintptr_t)a & 15);
+                for (int b = 0; b < 16; ++b) {
+                    const int i = v * 16 + b - off;
+                    if (i >= 0 && i < nb) hv_lds[d + b] = a[i];
+                }
+            } else {
+                *reinterpret_cast<uint4*>(hv_lds + dsto[u]) = val[u];
+            }
+        }
+    }
     __syncthreads();
     const int c = threadIdx.x & (HZ_COLS - 1);
     const int rg = threadIdx.x >> 6;  // rows rg and rg + 4
@@ -117,22 +144,49 @@ __global__ void __launch_bounds__(256) k_resize_h_vec(const uint8_t* __restrict_
     const int xx = col0 + c;
     const int lo = (xmin[xx] - span_lo) * 3;
     const int n = xcnt[xx];
-    const int* k = kk + (size_t)xx * ksize;
     const int* offs = reinterpret_cast<const int*>(hv_lds + (size_t)HV_ROWS * row_stride);
+    const int* k = offs + HV_ROWS + c * ksize;
     const int ya = row0 + rg, yb = ya + 4;
     const bool has_a = ya < box_h, has_b = yb < box_h;
     const uint8_t* pa = hv_lds + (size_t)rg * row_stride + (has_a ? offs[rg] : 0) + lo;
     const uint8_t* pb = hv_lds + (size_t)(rg + 4) * row_stride + (has_b ? offs[rg + 4] : 0) + lo;
     if (!has_b) pb = pa;  // shadow row a: no branch in the tap loop
     int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0, b0 = a0, b1 = a0, b2 = a0;
-    for (int j = 0; j < n; ++j) {
+    // Four taps = 12 bytes = three dwords per row: aligned ds_read_b32 + v_alignbyte instead of twelve byte reads (the
+    // byte-read form of this loop was LDS-instruction-bound: 72 us for 5000^2 -> 512^2), and 24-bit multiplies
+    // (|coefficient| < 2^22, pixel < 2^8: v_mad_i32_i24 runs at full rate, v_mul_lo_u32 at a quarter).
+    const uint32_t* qa = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(pa) & ~(uintptr_t)3);
+    const uint32_t* qb = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(pb) & ~(uintptr_t)3);
+    const unsigned sha = (unsigned)(reinterpret_cast<uintptr_t>(pa) & 3), shb = (unsigned)(reinterpret_cast<uintptr_t>(pb) & 3);
+    uint32_t wa0 = qa[0], wb0 = qb[0];
+    int j = 0, di = 1;
+    for (; j + 4 <= n; j += 4, di += 3) {
+        const uint32_t wa1 = qa[di], wa2 = qa[di + 1], wa3 = qa[di + 2];
+        const uint32_t wb1 = qb[di], wb2 = qb[di + 1], wb3 = qb[di + 2];
+        const uint32_t da0 = __builtin_amdgcn_alignbyte(wa1, wa0, sha), da1 = __builtin_amdgcn_alignbyte(wa2, wa1, sha),
+                       da2 = __builtin_amdgcn_alignbyte(wa3, wa2, sha);
+        const uint32_t db0 = __builtin_amdgcn_alignbyte(wb1, wb0, shb), db1 = __builtin_amdgcn_alignbyte(wb2, wb1, shb),
+                       db2 = __builtin_amdgcn_alignbyte(wb3, wb2, shb);
+        wa0 = wa3;
+        wb0 = wb3;
+        const int k0 = k[j], k1 = k[j + 1], k2 = k[j + 2], k3 = k[j + 3];
+#define HV_B(d, i) (int)(((d) >> (8 * (i))) & 255u)
+        a0 += __mul24(k0, HV_B(da0, 0)) + __mul24(k1, HV_B(da0, 3)) + __mul24(k2, HV_B(da1, 2)) + __mul24(k3, HV_B(da2, 1));
+        a1 += __mul24(k0, HV_B(da0, 1)) + __mul24(k1, HV_B(da1, 0)) + __mul24(k2, HV_B(da1, 3)) + __mul24(k3, HV_B(da2, 2));
+        a2 += __mul24(k0, HV_B(da0, 2)) + __mul24(k1, HV_B(da1, 1)) + __mul24(k2, HV_B(da2, 0)) + __mul24(k3, HV_B(da2, 3));
+        b0 += __mul24(k0, HV_B(db0, 0)) + __mul24(k1, HV_B(db0, 3)) + __mul24(k2, HV_B(db1, 2)) + __mul24(k3, HV_B(db2, 1));
+        b1 += __mul24(k0, HV_B(db0, 1)) + __mul24(k1, HV_B(db1, 0)) + __mul24(k2, HV_B(db1, 3)) + __mul24(k3, HV_B(db2, 2));
+        b2 += __mul24(k0, HV_B(db0, 2)) + __mul24(k1, HV_B(db1, 1)) + __mul24(k2, HV_B(db2, 0)) + __mul24(k3, HV_B(db2, 3));
+#undef HV_B
+    }
+    for (; j < n; ++j) {
         const int w = k[j];
-        a0 += w * pa[3 * j + 0];
-        a1 += w * pa[3 * j + 1];
-        a2 += w * pa[3 * j + 2];
-        b0 += w * pb[3 * j + 0];
-        b1 += w * pb[3 * j + 1];
-        b2 += w * pb[3 * j + 2];
+        a0 += __mul24(w, (int)pa[3 * j + 0]);
+        a1 += __mul24(w, (int)pa[3 * j + 1]);
+        a2 += __mul24(w, (int)pa[3 * j + 2]);
+        b0 += __mul24(w, (int)pb[3 * j + 0]);
+        b1 += __mul24(w, (int)pb[3 * j + 1]);
+        b2 += __mul24(w, (int)pb[3 * j + 2]);
     }
     if (has_a) {
         uint8_t* d = dst + ((size_t)ya * out_w + xx) * 3;
@@ -249,7 +303,7 @@ void ze_launch_resize_h(const uint8_t* src, int src_h, int src_w, int bx0, int b
     // box inside the image: 16-byte staging, 8 rows per workgroup (rows of max_span * 3 bytes + 16 of misalignment + 16
     // of vector tail, a multiple of 16; up to 160 KB of LDS)
     const int row_stride = (max_span * 3 + 32 + 15) & ~15;
-    const size_t lds = (size_t)HV_ROWS * row_stride + HV_ROWS * sizeof(int);
+    const size_t lds = (size_t)HV_ROWS * row_stride + HV_ROWS * sizeof(int) + (size_t)64 * ksize * sizeof(int);
     if (inside && lds <= 64 * 1024) {
         dim3 gv(ze_cdiv(out_w, 64), ze_cdiv(box_h, HV_ROWS));
         k_resize_h_vec<<<gv, 256, lds, s>>>(src, src_h, src_w, bx0, by0, box_h, dst, out_w, xmin, xcnt, kk, ksize, row_stride);
