@@ -146,6 +146,13 @@ int ze_vit_forward(ze_engine* e, const float* pixel_values, const int32_t* grid_
 int ze_seq_reset(ze_engine* e, int seq, void* stream);
 int ze_seq_truncate(ze_engine* e, int seq, int keep_len, void* stream);
 int ze_seq_len(ze_engine* e, int seq);
+/* Shared prompt prefixes (the questions about one tile start with the same system turn and the same view's image tokens --
+ * 347 of the 802 tokens of a stage-1 prompt, src/eval/infer.py:180-214): chain `dst_seq` becomes the first `n_tokens`
+ * cached tokens of chain `src_seq` (K/V rows of every layer copied, repetition-penalty set cleared); the caller then
+ * ze_prefill's only the tokens after the prefix.  A prefix's K/V rows depend on the prefix alone and every kernel of the
+ * prefill computes a row independently of what else shares the pass, so this is bit-identical to prefilling the whole
+ * prompt into dst_seq. */
+int ze_seq_copy_prefix(ze_engine* e, int dst_seq, int src_seq, int n_tokens, void* stream);
 
 /* replaces: the prefill forward of Qwen2_5_VLForConditionalGeneration (HF:...:1185-1253,1308-1400): embed,
  * image scatter, M-RoPE, decoder layers, final norm, lm_head on the last position.

@@ -243,3 +243,44 @@ def test_more_than_64_chains_fall_back_and_agree():
         assert float(np.abs(wide[:64] - frag).max()) < 0.15, float(np.abs(wide[:64] - frag).max())
     finally:
         e.close()
+
+
+def test_copied_prompt_prefix_is_bit_identical_to_a_full_prefill(eng):
+    """ze_seq_copy_prefix: chain 2 takes the first 90 cached tokens of chain 0 (another prompt with the same beginning)
+    and prefills only its own tail; logits and the following decode steps equal a full prefill of its prompt bit for
+    bit -- alone and inside a batched prefill pass."""
+    e = eng
+    head = [int(t) for t in prng.uniform_ints(301, 90, 10, 1990)]
+    tails = [[int(t) for t in prng.uniform_ints(302 + s, 25 + 6 * s, 10, 1990)] for s in range(3)]
+    prompts = [head + t for t in tails]
+
+    def after(slot, steps=3):
+        return [e.decode_batch([slot], [17 + i]).cpu().numpy()[0] for i in range(steps)]
+
+    # reference: chain 2's prompt prefilled in full
+    pos, delta = e.rope_index(prompts[2], [])
+    e.seq_reset(2)
+    want0 = e.prefill(2, prompts[2], None, pos, delta).cpu().numpy()
+    want = after(2)
+    # chain 0 holds another prompt with the same head; chain 2 copies the head and prefills its tail
+    prefill_text(e, 0, prompts[0])
+    e.seq_reset(2)
+    e.seq_copy_prefix(2, 0, 90)
+    assert e.seq_len(2) == 90
+    got0 = e.prefill(2, prompts[2][90:], None, pos[:, 90:], delta).cpu().numpy()
+    assert np.array_equal(got0, want0)
+    for a, b in zip(after(2), want):
+        assert np.array_equal(a, b)
+    # the same through one batched pass for two copying chains
+    for s in (1, 2):
+        e.seq_reset(s)
+        e.seq_copy_prefix(s, 0, 90)
+    pl = [e.rope_index(prompts[s], []) for s in (1, 2)]
+    e.prefill_batch([1, 2], [prompts[1][90:], prompts[2][90:]], [None, None], [pl[0][0][:, 90:], pl[1][0][:, 90:]],
+                    [pl[0][1], pl[1][1]])
+    for a, b in zip(after(2), want):
+        assert np.array_equal(a, b)
+    with pytest.raises(Exception):
+        e.seq_copy_prefix(1, 1, 10)
+    with pytest.raises(Exception):
+        e.seq_copy_prefix(1, 0, 10 ** 6)

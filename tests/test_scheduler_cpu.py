@@ -41,6 +41,15 @@ class StubEngine:
     def seq_reset(self, slot):
         self.chains[slot] = dict(ids=[], out=[], fin=False)
 
+    def seq_len(self, slot):
+        c = self.chains.get(slot)
+        return 0 if c is None else len(c["ids"]) + max(len(c["out"]) - 1, 0)
+
+    def seq_copy_prefix(self, dst, src, n):
+        assert n <= len(self.chains[src]["ids"]) and dst != src
+        self.log.append(("copy", dst, src, n))
+        self.chains[dst] = dict(ids=list(self.chains[src]["ids"][:n]), out=[], fin=False)
+
     def seq_truncate(self, slot, keep):
         c = self.chains[slot]
         assert keep <= len(c["ids"]) + max(len(c["out"]) - 1, 0)
@@ -183,6 +192,38 @@ def test_two_stage_follow_up_reuses_slot_and_prefix_and_view_features():
     assert sorted(n for p in pre for n in p[2]) == [6, 6, 6, 8, 8, 8]   # stage 2 prefills only the appended tokens
     vit = [g for x in e.log if x[0] == "vit" for g in x[1]]
     assert len(vit) == 5                                     # viewA once, viewB once, three crops
+
+
+def test_shared_prompt_prefix_is_copied_not_recomputed():
+    """Questions about one tile start alike (system turn + the view's image tokens): the first newcomer's prefix is
+    prefilled alone, the others copy its K/V rows and prefill only their tails; a later question copies from a chain that
+    is still alive; outputs equal those of a scheduler that prefills every prompt in full."""
+    def run(share):
+        model = make_model(max_seqs=4)
+        sched = ChainScheduler(model, Proc(), burst=2, share_prefix=share, min_shared=3)
+        out = {}
+        for q in range(4):                                    # 71 72 73 <img x4> : shared;  then the question
+            sched.submit(Request(prompt=f"71 72 73 <img> {20 + q} 50", images=["viewA"], max_new_tokens=40 if q == 0 else 12,
+                                 on_done=lambda r, t, x, q=q: out.__setitem__(q, (t, r.n_prompt))))
+        sched.step()                                          # all four admitted in one round
+        sched.submit(Request(prompt="71 72 73 <img> 33 50 51", images=["viewA"], max_new_tokens=3,
+                             on_done=lambda r, t, x: out.__setitem__(4, (t, r.n_prompt))))
+        sched.submit(Request(prompt="71 99 <img> 34", images=["viewA"], max_new_tokens=3,   # shares only 1 token: full prefill
+                             on_done=lambda r, t, x: out.__setitem__(5, (t, r.n_prompt))))
+        sched.run()
+        return out, model.engine.log, sched.stats
+
+    shared, log, st = run(True)
+    plain, log0, st0 = run(False)
+    assert shared == plain and sorted(shared) == [0, 1, 2, 3, 4, 5]
+    assert [x for x in log0 if x[0] == "copy"] == []
+    copies = [x for x in log if x[0] == "copy"]
+    assert len(copies) == 4 and all(c[3] == 7 for c in copies)            # 3 text ids + 4 image tokens
+    assert {c[2] for c in copies} == {0} and {c[1] for c in copies[:3]} == {1, 2, 3}   # the later one copies from live chain 0
+    pre = [x for x in log if x[0] == "prefill"]
+    assert pre[0][2] == [7] and sorted(pre[1][2]) == [2, 2, 2, 2]         # pass A: the prefix once; pass B: four tails
+    assert st["shared_rows"] == 28 and st["prefill_rows"] == st0["prefill_rows"] - 28
+    assert sum(len(x[1]) for x in log if x[0] == "vit") == 1              # the view encoded once
 
 
 def test_feature_cache_never_evicts_what_the_round_needs():

@@ -84,6 +84,7 @@ _SIGS = {
     "ze_seq_reset": (C.c_int, [_P, C.c_int, _P]),
     "ze_seq_truncate": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "ze_seq_len": (C.c_int, [_P, C.c_int]),
+    "ze_seq_copy_prefix": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "ze_prefill": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.c_int, _P, C.c_int, C.POINTER(C.c_int32), C.c_int,
                              _P, _P]),
     "ze_score": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.c_int, _P, C.c_int, C.POINTER(C.c_int32), C.c_int,

@@ -423,3 +423,24 @@ void ze_launch_rope_kv_batch(bf16_t* qkv, int n, int heads, int kv_heads, int D,
     k_rope_kv_batch<<<(unsigned)((tot + 255) / 256), 256, 0, s>>>(qkv, n, heads, kv_heads, D, cosT, sinT, st, seq_ids,
                                                                   kcache, vcache, cache_seq_stride, max_ctx);
 }
+
+
+// ------------------------------------------------------------------ KV prefix copy (shared prompt prefixes)
+// The first n cached tokens of chain `src` -> chain `dst`, every layer and kv head, K and V: blockIdx.y = (layer, kv
+// head, K|V) picks one contiguous n x 256-byte run of the cache, blockIdx.x strides over its 16-byte pieces.
+__global__ void __launch_bounds__(256) k_kv_copy_prefix(bf16_t* __restrict__ kcache, bf16_t* __restrict__ vcache,
+                                                        size_t layer_stride, size_t seq_stride, size_t head_stride,
+                                                        int kv_heads, int src, int dst, int n_vec) {
+    const int which = blockIdx.y & 1, kvh = (blockIdx.y >> 1) % kv_heads, layer = (blockIdx.y >> 1) / kv_heads;
+    bf16_t* base = (which ? vcache : kcache) + (size_t)layer * layer_stride + (size_t)kvh * head_stride;
+    const uint4* s = reinterpret_cast<const uint4*>(base + (size_t)src * seq_stride);
+    uint4* d = reinterpret_cast<uint4*>(base + (size_t)dst * seq_stride);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_vec; i += gridDim.x * 256) d[i] = s[i];
+}
+void ze_launch_kv_copy_prefix(bf16_t* kcache, bf16_t* vcache, size_t layer_stride, size_t seq_stride, size_t head_stride,
+                              int layers, int kv_heads, int D, int src, int dst, int n_tokens, hipStream_t s) {
+    if (n_tokens <= 0) return;
+    const int n_vec = n_tokens * D * 2 / 16;
+    k_kv_copy_prefix<<<dim3(std::max(1, std::min(8, (n_vec + 255) / 256)), layers * kv_heads * 2), 256, 0, s>>>(
+        kcache, vcache, layer_stride, seq_stride, head_stride, kv_heads, src, dst, n_vec);
+}

@@ -338,6 +338,24 @@ extern "C" int ze_seq_truncate(ze_engine* e, int seq, int keep_len, void* stream
     return push_state(e, seq, (hipStream_t)stream, 0, 0, 0);
 }
 
+extern "C" int ze_seq_copy_prefix(ze_engine* e, int dst_seq, int src_seq, int n_tokens, void* stream) {
+    ZE_TRY(check_seq(e, dst_seq));
+    ZE_TRY(check_seq(e, src_seq));
+    if (dst_seq == src_seq) return ze_fail(e, ZE_ERR_INVALID, "source and destination chain are the same");
+    if (n_tokens <= 0 || n_tokens > e->ctx_host[src_seq]) return ze_fail(e, ZE_ERR_INVALID, "n_tokens exceeds the source chain's context");
+    const ze_config& c = e->cfg;
+    hipSetDevice(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t head_stride = (size_t)c.max_ctx * e->head_dim, seq_stride = (size_t)c.kv_heads * head_stride;
+    ze_launch_kv_copy_prefix(e->kcache, e->vcache, (size_t)c.max_seqs * seq_stride, seq_stride, head_stride, c.layers, c.kv_heads,
+                             e->head_dim, src_seq, dst_seq, n_tokens, s);
+    ZE_KCHECK();
+    e->ctx_host[dst_seq] = n_tokens;
+    e->delta_host[dst_seq] = 0;
+    ZE_HIP(hipMemsetAsync(e->seen + (size_t)dst_seq * c.vocab, 0, c.vocab, s));
+    return push_state(e, dst_seq, s, 0, 0, 0);
+}
+
 extern "C" int ze_seq_len(ze_engine* e, int seq) {
     if (check_seq(e, seq) != 0) return ZE_ERR_NOTFOUND;
     return e->ctx_host[seq];

@@ -186,6 +186,10 @@ void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_
                                   const int* seq_ids, int n, int heads, int kv_heads, int max_ctx, float scale,
                                   float* ws_partial, int max_parts, unsigned* tickets, hipStream_t s, int chunk = 0);
 
+// first n_tokens cached K/V rows of chain src -> chain dst (all layers / kv heads); strides in elements
+void ze_launch_kv_copy_prefix(bf16_t* kcache, bf16_t* vcache, size_t layer_stride, size_t seq_stride, size_t head_stride,
+                              int layers, int kv_heads, int D, int src, int dst, int n_tokens, hipStream_t s);
+
 // ---- sampling
 struct ze_sample_opts {
     float temperature = 0.f;      // 0: greedy arg-max; > 0: multinomial draw from softmax(score / temperature)

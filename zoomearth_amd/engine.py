@@ -206,6 +206,10 @@ class Engine:
     def seq_truncate(self, seq: int, keep: int):
         self._check(self.lib.ze_seq_truncate(self.h, seq, keep, self._stream()))
 
+    def seq_copy_prefix(self, dst: int, src: int, n_tokens: int):
+        """Chain `dst` becomes the first n_tokens cached tokens of chain `src` (shared prompt prefix: K/V rows copied)."""
+        self._check(self.lib.ze_seq_copy_prefix(self.h, dst, src, n_tokens, self._stream()))
+
     def seq_len(self, seq: int) -> int:
         return self._check(self.lib.ze_seq_len(self.h, seq))
 

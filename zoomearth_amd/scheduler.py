@@ -49,7 +49,8 @@ class _Live:
 class ChainScheduler:
     def __init__(self, model, processor, do_sample: bool = False, temperature=None, repetition_penalty=None, seed: int = 0,
                  burst: int = 8, max_batch: Optional[int] = None, ignore_eos: bool = False, use_graph: bool = True,
-                 feature_cache: int = 64, min_admit: int = 1, max_wait_bursts: int = 2):
+                 feature_cache: int = 64, min_admit: int = 1, max_wait_bursts: int = 2, share_prefix: bool = True,
+                 min_shared: int = 64):
         self.model, self.processor, self.engine = model, processor, model.engine
         gc = model.generation_config
         pen = repetition_penalty if repetition_penalty is not None else (getattr(gc, "repetition_penalty", 1.0) or 1.0)
@@ -64,6 +65,13 @@ class ChainScheduler:
         self.min_admit = max(1, int(min_admit))
         self.max_wait_bursts = max(0, int(max_wait_bursts))
         self._waited = 0
+        # Shared prompt prefixes: the questions about one tile start with the same system turn and the same view's image
+        # tokens (347 of the 802 tokens of a stage-1 prompt).  A fresh chain whose prompt starts like that of a chain that
+        # already holds those K/V rows copies them (ze_seq_copy_prefix) and prefills only its own tail; when a round brings
+        # several such chains and none exists yet, the first one's prefix is prefilled alone (pass A), copied to the
+        # others, and all tails go through one pass (pass B).  Bit-identical to prefilling every prompt in full.
+        self.share_prefix = bool(share_prefix)
+        self.min_shared = max(1, int(min_shared))
         self.burst = max(1, int(burst))
         self.max_batch = min(int(max_batch or self.engine.max_seqs), self.engine.max_seqs)
         self.waiting = deque()
@@ -72,7 +80,7 @@ class ChainScheduler:
         self.free = list(range(self.max_batch))[::-1]
         self._features = OrderedDict()     # image key -> ViT features (LRU)
         self._feature_cap = feature_cache
-        self.stats = dict(bursts=0, steps=0, chain_steps=0, prefill_rows=0, admitted=0, vit_calls=0)
+        self.stats = dict(bursts=0, steps=0, chain_steps=0, prefill_rows=0, admitted=0, vit_calls=0, shared_rows=0)
         model._chains.clear()              # the scheduler owns every chain slot while it runs
 
     # ------------------------------------------------------------------ queue
@@ -134,19 +142,81 @@ class ChainScheduler:
                     elif keys[i] not in todo:
                         todo[keys[i]] = (inp["pixel_values"][rows[i]:rows[i + 1]], grids[i])
                     needed.add(keys[i])
-                prepared.append((req, ids, grids, keys, reuse, n_reused))
+                prepared.append(dict(req=req, ids=ids, grids=grids, keys=keys, reuse=reuse, n_reused=n_reused, copy_from=None,
+                                     upto=len(ids), final=True))
             except Exception as ex:  # a malformed request must not take the batch down
                 self._fail(req, ex)
         self._encode(todo, needed)
-        # prefill: rows of several chains share every GEMM, up to max_prefill_rows per pass
-        group, rows = [], 0
-        for item in prepared + [None]:
-            if group and (item is None or rows + len(item[1]) - item[4] > e.max_prefill_rows):
-                self._prefill(group)
-                group, rows = [], 0
-            if item is not None:
-                group.append(item)
-                rows += len(item[1]) - item[4]
+        anchors = self._plan_sharing(prepared) if self.share_prefix else []
+        # prefill: rows of several chains share every GEMM, up to max_prefill_rows per pass; pass A (the prefixes that
+        # other newcomers of this round will copy) goes first
+        for items in (anchors, prepared):
+            group, rows = [], 0
+            for item in items + [None]:
+                if group and (item is None or rows + item["upto"] - item["reuse"] > e.max_prefill_rows):
+                    self._prefill(group)
+                    group, rows = [], 0
+                if item is not None:
+                    group.append(item)
+                    rows += item["upto"] - item["reuse"]
+
+    # -- shared prompt prefixes
+    def _prefix_len(self, a, b) -> int:
+        """Longest common prefix of two id lists that leaves both a non-empty tail and does not end inside a run of image
+        tokens (a run is fed by one image's feature rows: it is shared whole or not at all)."""
+        n = min(len(a), len(b)) - 1
+        i = 0
+        while i < n and a[i] == b[i]:
+            i += 1
+        img = self.model.config.image_token_id
+        while i > 0 and a[i - 1] == img and a[i] == img:
+            i -= 1
+        return i
+
+    def _images_in(self, ids, n) -> int:
+        img = self.model.config.image_token_id
+        return sum(1 for t in range(n) if ids[t] == img and (t == 0 or ids[t - 1] != img))
+
+    def _plan_sharing(self, prepared):
+        """Decides, for every fresh chain of the round, where its leading K/V rows come from; returns the pass-A items."""
+        fresh = [p for p in prepared if p["reuse"] == 0 and p["keys"] and all(k is not None for k in p["keys"])]
+        if not fresh:
+            return []
+        donors = {}   # first image key -> [(slot, ids, keys)]: chains that hold their prompt's K/V rows right now
+        taken = {p["req"].slot for p in prepared}
+        for slot, l in self.live.items():
+            if l.keys and slot not in taken:
+                donors.setdefault(l.keys[0], []).append((slot, l.ids, l.keys))
+        for slot, (pids, pkeys) in self.parked.items():
+            if pkeys:
+                donors.setdefault(pkeys[0], []).append((slot, pids, pkeys))
+        groups = OrderedDict()
+        for p in fresh:
+            groups.setdefault(p["keys"][0], []).append(p)
+        anchors = []
+        for k0, members in groups.items():
+            rest = members
+            for slot, dids, dkeys in donors.get(k0, []):   # an existing chain: every member that matches it copies from it
+                for p in list(rest):
+                    n = self._prefix_len(p["ids"], dids)
+                    ni = self._images_in(p["ids"], n)
+                    if n >= self.min_shared and tuple(p["keys"][:ni]) == tuple(dkeys[:ni]):
+                        p.update(copy_from=slot, reuse=n, n_reused=ni)
+                        rest = [q for q in rest if q is not p]
+                if not rest:
+                    break
+            if len(rest) < 2:
+                continue
+            ref = rest[0]                                   # no donor yet: the first member's prefix is prefilled alone
+            n = min(self._prefix_len(ref["ids"], p["ids"]) for p in rest[1:])
+            ni = self._images_in(ref["ids"], n)
+            if n < self.min_shared or any(tuple(p["keys"][:ni]) != tuple(ref["keys"][:ni]) for p in rest[1:]):
+                continue
+            anchors.append(dict(ref, upto=n, final=False))
+            ref.update(reuse=n, n_reused=ni, copy_from=-1)   # -1: the rows are already in its own slot after pass A
+            for p in rest[1:]:
+                p.update(copy_from=ref["req"].slot, reuse=n, n_reused=ni)
+        return anchors
 
     def _reusable(self, slot, ids, keys):
         """(cached prefix length, images inside it) when the slot's parked chain is a strict prefix of `ids`."""
@@ -192,23 +262,37 @@ class ChainScheduler:
         e = self.engine
         slots, ids_l, emb_l, pos_l, dl = [], [], [], [], []
         ok = []
-        for req, ids, grids, keys, reuse, n_reused in group:
+        for it in group:
+            req, ids, grids, keys, reuse, n_reused, upto = (it["req"], it["ids"], it["grids"], it["keys"], it["reuse"],
+                                                           it["n_reused"], it["upto"])
+            if req.slot < 0:
+                continue                                       # failed earlier in this round (pass A)
+            if it["copy_from"] is not None and e.seq_len(it["copy_from"] if it["copy_from"] >= 0 else req.slot) < reuse:
+                it["copy_from"], reuse, n_reused = None, 0, 0   # the donor's rows are gone (its pass failed): prefill in full
+                it.update(reuse=0, n_reused=0)
             try:
                 pos, delta = e.rope_index(ids, grids)
-                feats = [self._features[k] for k in keys[n_reused:]]
-                for k in keys[n_reused:]:
+                n_upto = len(keys) if upto == len(ids) else self._images_in(ids, upto)   # pass A stops after the prefix
+                feats = [self._features[k] for k in keys[n_reused:n_upto]]
+                for k in keys[n_reused:n_upto]:
                     self._features.move_to_end(k)
                 emb = (torch.cat(feats) if len(feats) > 1 else feats[0]) if feats else None
-                if reuse:
-                    e.seq_truncate(req.slot, reuse)
-                else:
+                if it["copy_from"] is None:
+                    if reuse:
+                        e.seq_truncate(req.slot, reuse)       # a follow-up on its own slot: keep the cached prompt
+                    else:
+                        e.seq_reset(req.slot)
+                elif it["copy_from"] >= 0:                     # shared prefix: the rows of another chain
                     e.seq_reset(req.slot)
+                    e.seq_copy_prefix(req.slot, it["copy_from"], reuse)
+                    self.stats["shared_rows"] += reuse
+                # (copy_from == -1: pass A left the prefix in this slot)
                 slots.append(req.slot)
-                ids_l.append(ids[reuse:])
+                ids_l.append(ids[reuse:upto])
                 emb_l.append(emb)
-                pos_l.append(pos[:, reuse:])
+                pos_l.append(pos[:, reuse:upto])
                 dl.append(delta)
-                ok.append((req, ids, keys))
+                ok.append(it)
             except Exception as ex:
                 self._fail(req, ex)
         if not ok:
@@ -216,11 +300,14 @@ class ChainScheduler:
         try:
             e.prefill_batch(slots, ids_l, emb_l, pos_l, dl)
         except Exception as ex:
-            for req, _, _ in ok:
-                self._fail(req, ex)
+            for it in ok:
+                self._fail(it["req"], ex)
             return
         self.stats["prefill_rows"] += sum(len(x) for x in ids_l)
-        for req, ids, keys in ok:
+        for it in ok:
+            if not it["final"]:
+                continue                                       # pass A: the chain is completed by pass B
+            req, ids, keys = it["req"], it["ids"], it["keys"]
             if self.penalty != 1.0:
                 e.mark_seen(req.slot, ids)
             e.chain_begin(req.slot, self.params, req.stream_id)
