@@ -45,10 +45,22 @@ BATCH_KERNEL_NAMES = {
 }
 
 
-def question_ids(cfg, q: int, n_img: int):
+L_QUESTION = 18  # of the 455 ids after the image: the question itself; the other 437 are the instruction
+
+
+def text_ids(q: int):
+    """The 476 synthetic text ids of question q with the structure of the reference prompt (src/eval/infer.py:180-214;
+    SURVEY 8d: ~21 system-turn ids, ~18 question ids, ~437 instruction ids): the system turn and the instruction are the
+    same text for every question, only the question differs."""
     from zoomearth_amd.synth import uniform_ints
-    a = uniform_ints(7 + q, L_TEXT_A, 1000, 150000).tolist()
-    b = uniform_ints(7_000_003 + q, L_TEXT_B, 1000, 150000).tolist()
+    a = uniform_ints(7, L_TEXT_A, 1000, 150000).tolist()
+    b = uniform_ints(7_000_003 + q, L_QUESTION, 1000, 150000).tolist() + \
+        uniform_ints(8_000_003, L_TEXT_B - L_QUESTION, 1000, 150000).tolist()
+    return a, b
+
+
+def question_ids(cfg, q: int, n_img: int):
+    a, b = text_ids(q)
     return a + [cfg.vision_start_token_id] + [cfg.image_token_id] * n_img + [cfg.vision_end_token_id] + b
 
 
@@ -135,8 +147,9 @@ class SynthTokenizer:
 class SynthProcessor:
     """The processor surface the scheduler calls (`processor(text=[prompt], images=[...])`, `.tokenizer.decode`) with
     synthetic token ids: the real image path (ZoomEarthProcessor.preprocess_images -> HIP front-end), and for the text
-    the scripted lengths of SURVEY 8d -- 21 ids before the first image, 455 after it (question + instruction), then
-    whatever decimal words follow `assistant\\n` (the re-fed stage-1 output)."""
+    the scripted lengths of SURVEY 8d -- 21 ids before the first image (the system turn: the same for every question),
+    455 after it (18 of the question, 437 of the instruction), then whatever decimal words follow `assistant\\n` (the
+    re-fed stage-1 output)."""
 
     def __init__(self, cfg, engine):
         from zoomearth_amd.processor import ZoomEarthProcessor
@@ -148,18 +161,18 @@ class SynthProcessor:
     def __call__(self, text, images=None, return_tensors="pt", **kw):
         import torch
         from zoomearth_amd.hostloop import VISION_BLOCK
-        from zoomearth_amd.synth import uniform_ints
         cfg = self.cfg
         prompt = text[0]
         q = int(prompt.split("#q", 1)[1].split("#", 1)[0])
         pv, grids, keys = self._img.preprocess_images(list(images))
         parts = prompt.split(VISION_BLOCK)
         assert len(parts) == len(grids) + 1
-        ids = uniform_ints(7 + q, L_TEXT_A, 1000, 150000).tolist()
+        ta, tb = text_ids(q)
+        ids = list(ta)
         for i, g in enumerate(grids):
             ids += [cfg.vision_start_token_id] + [cfg.image_token_id] * (g[0] * g[1] * g[2] // 4) + [cfg.vision_end_token_id]
             if i == 0:
-                ids += uniform_ints(7_000_003 + q, L_TEXT_B, 1000, 150000).tolist()
+                ids += tb
                 tail = parts[1].split("assistant\n", 1)[1]
                 ids += [int(w) for w in tail.split()]
         return dict(input_ids=torch.tensor([ids]), image_grid_thw=torch.tensor(grids), pixel_values=pv, image_keys=keys)
