@@ -7,6 +7,8 @@ in HBM (BASELINE.json configs[1]; workload constants from SURVEY.md section 8d):
   ViT 1296 patches -> 324 image tokens             prefill L1 = 802 tokens, decode N1 = 192 (greedy, penalty 1.05)
   scripted bbox -> 512^2 crop of the FULL-RES tile  ViT on the crop (view features reused: identical bits)
   prefill of the 518 new tokens after the cached 802-token stage-1 prompt (L2 = 1320), decode N2 = 96
+Text ids are synthetic with the structure of the reference prompt: 21 system-turn ids and 437 instruction ids that are
+the same for every question, 18 question ids that differ.
 Weights: Qwen2.5-VL-3B shape, bf16, synthetic N(0, 0.02^2) from the repo PRNG (no checkpoint offline).
 Control flow is scripted (random weights emit neither EOS nor a bbox): lengths fixed, EOS ignored.
 
