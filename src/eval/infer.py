@@ -34,6 +34,14 @@ def collate_fn(examples):
     return examples
 
 
+def stream_of(sample) -> int:
+    """Random stream of a question when sampling: a function of the question alone (its id), so its output does not depend
+    on the rank it landed on, its place in the rank's stream or the batch it shared."""
+    import zlib
+    qid = sample.get("question_id")
+    return int(qid) & 0x3FFFFFFF if isinstance(qid, int) else zlib.crc32(str(qid).encode("utf-8")) & 0x3FFFFFFF
+
+
 def prepare_dataloader(ds_path, collate_fn):
     from datasets import load_from_disk
     return DataLoader(load_from_disk(ds_path), batch_size=1, collate_fn=collate_fn, shuffle=False, num_workers=0)
@@ -92,7 +100,7 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
                     view_of = (path,) + tuple(H.resize_image(tile))
                 H.submit_zoom_chain(sched, sample["question"], tile,
                                     lambda r, idx=idx, sample=sample: done.__setitem__(idx, (sample, r)),
-                                    view=view_of[1], scale=view_of[2], stream_id=int(idx), max_new_tokens=max_new_tokens)
+                                    view=view_of[1], scale=view_of[2], stream_id=stream_of(sample), max_new_tokens=max_new_tokens)
             except Exception as ex:  # keep going; the record marks the failure
                 done[idx] = (sample, dict(output1=f"Error: {ex}", output2="", error=True))
     while sched.busy():

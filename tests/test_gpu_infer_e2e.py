@@ -142,3 +142,24 @@ def test_infer_sh_defaults(workdir):
     recs = load(d / "results" / "sh_0.jsonl")
     assert [r["question_id"] for r in recs] == [r["question_id"] for r in rows]
     assert all(list(r.keys()) == KEYS for r in recs)
+
+
+def test_two_ranks_shard_by_tile_and_merge_to_the_single_rank_result(workdir):
+    """The data-parallel layout of BASELINE configs[3] in miniature: two ranks (RANK / WORLD_SIZE as torchrun sets them;
+    both on this box's one GPU) each take whole tiles (accel.shard_by_tile), write results/{exp}{rank}.jsonl, and the
+    merged file equals the single-rank run record for record (a chain's output depends neither on the batch nor on the
+    rank it ran on)."""
+    d, rows = workdir
+    base = [sys.executable, "src/infer.py", "--model_name", "ckpt", "--max_new_tokens", "14", "--max_ctx", "2048",
+            "--batch_size", "4"]
+    for rank in (0, 1):
+        run(base + ["--exp_name", "dp_"], d, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2")
+    run(base + ["--exp_name", "one_"], d)
+    from zoomearth_amd.accel import merge_results
+    n = merge_results(str(d / "results" / "dp_"), 2, str(d / "results" / "dp_merged.jsonl"))
+    merged, single = load(d / "results" / "dp_merged.jsonl"), load(d / "results" / "one_0.jsonl")
+    parts = [load(d / "results" / f"dp_{r}.jsonl") for r in (0, 1)]
+    assert n == len(rows) == len(merged) and all(len(p) > 0 for p in parts)
+    tiles = [{r["image"] for r in p} for p in parts]
+    assert not (tiles[0] & tiles[1])                     # a tile never splits across ranks
+    assert merged == sorted(single, key=lambda r: r["question_id"])
