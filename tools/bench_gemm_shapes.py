@@ -1,0 +1,26 @@
+import os, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch
+from zoomearth_amd.config import ModelConfig
+from zoomearth_amd.engine import Engine
+e = Engine(ModelConfig.tiny(), max_seqs=1, max_ctx=256, max_patches=1024, max_tile_side=1024)
+shapes = [("vit qkv x16", 20736, 3840, 1280), ("vit proj x16", 20736, 1280, 1280), ("vit gate_up x16", 20736, 6912, 1280),
+          ("vit down x16", 20736, 1280, 3456), ("vit qkv x4", 5184, 3840, 1280), ("vit gate_up x4", 5184, 6912, 1280),
+          ("llm o 16x518", 8288, 2048, 2048), ("llm down 16x518", 8288, 2048, 11008), ("llm qkv 16x518", 8288, 2560, 2048)]
+for name, m, n, k in shapes:
+    a = (torch.randn(m, k, device="cuda") * 0.5).to(torch.bfloat16)
+    w = (torch.randn(n, k, device="cuda") * 0.05).to(torch.bfloat16)
+    row = []
+    for kn in (0, 4, 6):
+        e.lib.ze_tune(7, kn)
+        for _ in range(2):
+            e.op_linear(a, w)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            e.op_linear(a, w)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        row.append(f"knob7={kn}: {dt * 1e6:8.1f} us {2 * m * n * k / dt / 1e12:7.1f} TF")
+    print(f"{name:16s} M={m:6d} N={n:5d} K={k:5d} | " + " | ".join(row), flush=True)
+e.close()
