@@ -97,6 +97,11 @@ int ze_weights_missing(ze_engine* e);
 /* The packed bf16 weight arena (one contiguous device allocation): lets the host broadcast it once over
  * RCCL/xGMI with torch.distributed and checksum it.  Does not transfer ownership. */
 int ze_weights_arena(ze_engine* e, void** dev_ptr, size_t* bytes);
+/* The same broadcast for a host that owns an RCCL communicator (`ncclComm_t`, passed as void*): ncclBroadcast of the whole
+ * arena from rank `root` on `stream`, in place (replaces: accelerator.prepare / every rank's own from_pretrained,
+ * src/eval/infer.py:147-151,171 -- the checkpoint is read from disk once).  RCCL is not linked: the symbol must already be
+ * loaded in the process (ZE_ERR_NOTFOUND otherwise).  Derived weight copies are dropped as after ze_load_weight. */
+int ze_weights_broadcast(ze_engine* e, void* nccl_comm, int root, void* stream);
 
 /* ------------------------------------------------------------------ image front-end (K0-K2) */
 /* replaces: `Image.open(image_fp).convert("RGB")` arriving on the device (src/eval/infer.py:215,237 + the `.to(device)`

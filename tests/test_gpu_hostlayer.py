@@ -303,3 +303,37 @@ def test_openai_server_batches_concurrent_requests(stack):
         got = o.json()["choices"][0]["message"]["content"]
         assert got in (want_batched[i], want_single[i]), (i, got, want_batched[i], want_single[i])
     srv.close()
+
+
+def test_weights_broadcast_through_a_caller_owned_rccl_communicator(stack):
+    """ze_weights_broadcast: the entry point for hosts that own an ncclComm_t.  A one-rank communicator created through
+    RCCL's C API (ctypes) -- the broadcast is then a device-side no-op copy, which still exercises symbol lookup, argument
+    passing and the invalidation of derived weight copies; the arena must be unchanged and generation must still work."""
+    import ctypes as C
+    import glob
+    model, proc, tile, tile_np = stack
+    e = model.engine
+    libs = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + ["/opt/rocm/lib/librccl.so"]
+    rccl = C.CDLL(libs[0], mode=C.RTLD_GLOBAL)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        before = e.weights_arena().to(torch.int64).sum().item()
+        rc = e.lib.ze_weights_broadcast(e.h, comm, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert rc == 0, e.lib.ze_last_error(e.h)
+        assert e.weights_arena().to(torch.int64).sum().item() == before
+        assert e.lib.ze_weights_broadcast(e.h, None, 0, None) < 0          # null communicator: an error, not a crash
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+    view, _ = H.resize_image(tile)
+    out = H.chat_batch([prompt1(words(61, 5))], [view], proc, model, max_new_tokens=4)
+    assert isinstance(out[0], str)

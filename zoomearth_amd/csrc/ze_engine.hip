@@ -501,6 +501,24 @@ extern "C" int ze_weights_arena(ze_engine* e, void** dev_ptr, size_t* bytes) {
     return ZE_OK;
 }
 
+// RCCL broadcast of the arena for hosts that own an ncclComm_t (a C++ launcher; the Python shim goes through
+// torch.distributed, whose communicator is not exposed).  The library does not link RCCL: the symbol is taken from
+// whatever RCCL the process already loaded (dlsym), so there is never a second copy of it in the address space.
+#include <dlfcn.h>
+extern "C" int ze_weights_broadcast(ze_engine* e, void* nccl_comm, int root, void* stream) {
+    if (!e || !nccl_comm || root < 0) return ze_fail(e, ZE_ERR_INVALID, "null engine / communicator or negative root");
+    typedef int (*bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    static bcast_fn fn = nullptr;
+    if (!fn) fn = reinterpret_cast<bcast_fn>(dlsym(RTLD_DEFAULT, "ncclBroadcast"));
+    if (!fn) return ze_fail(e, ZE_ERR_NOTFOUND, "ncclBroadcast is not loaded in this process (load librccl before calling)");
+    hipSetDevice(e->device);
+    ze_weights_changed(e);
+    const size_t bytes = e->arena_used * sizeof(bf16_t);
+    const int rc = fn(e->arena, e->arena, bytes, /*ncclUint8*/ 1, root, nccl_comm, (hipStream_t)stream);
+    if (rc != 0) return ze_fail(e, ZE_ERR_HIP, "ncclBroadcast failed with code " + std::to_string(rc));
+    return ZE_OK;
+}
+
 // ------------------------------------------------------------------ phase timers
 int ze_timer_begin(ze_engine* e, int phase, hipStream_t s) {
     if (!e->timers_on) return -1;
