@@ -63,3 +63,49 @@ def test_7b_layer_shape_text_path_vs_oracle():
     finally:
         e.close()
         torch.cuda.empty_cache()
+
+
+def test_7b_shape_through_the_vit():
+    """configs[4] end to end at reduced depth: a 28 x 28 view through the ViT whose merger projects to the 7B hidden size
+    (out_hidden 3584: merger.mlp.2 is [3584, 5120]), image tokens scattered into a 7B-shape prompt, prefill and three
+    teacher-forced decode steps -- engine vs fp32 oracle within 2x the oracle's own bf16-vs-fp32 error."""
+    from oracle import frontend
+    from zoomearth_amd.config import ModelConfig
+    from zoomearth_amd.engine import Engine
+    mc = ModelConfig.qwen25vl_7b()
+    mc = dataclasses.replace(mc, text=dataclasses.replace(mc.text, num_hidden_layers=2, vocab_size=4096),
+                             vision=dataclasses.replace(mc.vision, depth=2, fullatt_block_indexes=(1,)),
+                             image_token_id=4000, vision_start_token_id=4001, vision_end_token_id=4002,
+                             eos_token_ids=(4003,), pad_token_id=4004)
+    oc = Q.Config(vision=Q.VisionConfig(depth=2, fullatt_block_indexes=(1,), out_hidden_size=3584),
+                  text=Q.TextConfig(hidden_size=3584, num_hidden_layers=2, num_attention_heads=28, num_key_value_heads=4,
+                                    intermediate_size=18944, vocab_size=4096, tie_word_embeddings=False),
+                  image_token_id=4000, vision_start_token_id=4001, vision_end_token_id=4002, eos_token_ids=(4003,),
+                  pad_token_id=4004)
+    w = Q.synthetic_weights(oc, **W7)
+    e = Engine(mc, device=0, max_seqs=1, max_ctx=512, max_patches=1024, max_tile_side=512)
+    try:
+        e.fill_synthetic(**W7)
+        img = prng.synthetic_tile(21, 392, 392)
+        pv, grid = e.preprocess_image(torch.from_numpy(img).cuda())
+        want_pv, want_grid = frontend.image_to_pixel_values(img)
+        assert tuple(grid) == tuple(want_grid) == (1, 28, 28) and np.array_equal(pv.cpu().numpy(), want_pv)
+        emb = e.vit_forward(pv, [grid])
+        o32, o16 = Q.Qwen25VLOracle(oc, w, "fp32"), Q.Qwen25VLOracle(oc, w, "bf16")
+        v32, v16 = o32.vit_forward(want_pv, [want_grid]), o16.vit_forward(want_pv, [want_grid])
+        assert emb.shape == (196, 3584)
+        assert float(np.abs(emb.float().cpu().numpy() - v32).max()) <= 2.0 * float(np.abs(v16 - v32).max())
+        ids = prng.uniform_ints(8, 20, 10, 3990).tolist() + [4001] + [4000] * 196 + [4002] + prng.uniform_ints(9, 60, 10, 3990).tolist()
+        forced = [int(t) for t in prng.uniform_ints(10, 3, 10, 3990)]
+        ref32 = [o32.prefill(ids, pixel_values=want_pv, grid_thw=[want_grid])] + [o32.decode_step(t) for t in forced]
+        ref16 = [o16.prefill(ids, pixel_values=want_pv, grid_thw=[want_grid])] + [o16.decode_step(t) for t in forced]
+        pos, delta = e.rope_index(ids, [grid])
+        e.seq_reset(0)
+        got = [e.prefill(0, ids, emb, pos, delta).cpu().numpy()] + [e.decode_step(0, t).cpu().numpy() for t in forced]
+        yard = max(float(np.abs(a - b).max()) for a, b in zip(ref16, ref32))
+        worst = max(float(np.abs(a - b).max()) for a, b in zip(got, ref32))
+        print(f"7B shape through the ViT: max|engine - fp32 oracle| = {worst:.4f}, oracle bf16-vs-fp32 = {yard:.4f}")
+        assert worst <= 2.0 * yard
+    finally:
+        e.close()
+        torch.cuda.empty_cache()
