@@ -497,12 +497,16 @@ def main():
     ap.add_argument("--fp8", action="store_true",
                     help="FP8 (E4M3) decoder weights (BASELINE configs[4]); NOT the metric's precision: reported as its own "
                          "configuration")
+    ap.add_argument("--fp8-act", action="store_true",
+                    help="--fp8 plus FP8 activations at the qkv / gate-up inputs (ze_set_fp8_activations: fp8 x fp8 MFMA in the "
+                         "batched decode step)")
     ap.add_argument("--batch", type=int, default=1,
                     help="1 = BASELINE configs[1] is the line's value (plus a one-step batch64 object); B > 1 = configs[2] with "
                          "B chains is the line's value")
     ap.add_argument("--no-batch64", action="store_true", help="skip the batch64 object of the default line")
     ap.add_argument("--spawn-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    args.fp8 = args.fp8 or args.fp8_act
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus)
@@ -559,6 +563,8 @@ def main():
         del arena
     if args.fp8:
         e.quantize_fp8()  # after the broadcast: every rank quantises the weights it received
+        if args.fp8_act:
+            e.set_fp8_activations(True)
     # tile upload (PCIe): pinned host buffer -> HBM through the C ABI, timed on its own (never inside `value`)
     host_tiles = [torch.from_numpy(synthetic_tile(1000 + rank * 16 + t, args.tile, args.tile)).pin_memory() for t in range(n_tiles)]
     torch.cuda.synchronize()
@@ -685,6 +691,9 @@ def main():
         if args.fp8:
             line["dtype"] = "fp8-e4m3 decoder weights (per-row power-of-two scales) streamed by the decode GEMVs; bf16 activations, bf16 MFMA prefill on the dequantised copy"
             line["metric"] += " [fp8 weights: reduced precision, not the headline metric]"
+        if args.fp8_act:
+            line["dtype"] = ("fp8-e4m3 decoder weights + fp8-e4m3 qkv / gate-up inputs (dynamic per-row power-of-two scales): "
+                             "fp8 x fp8 MFMA in the batched decode step, the same values as bf16 everywhere else")
         if want64:
             # BASELINE configs[2], driver-timed in the default run: one warm-up step (graph captures, fragment copy), then
             # ONE timed step of 64 questions about 6 tiles through the scheduler, bracketed by device synchronisation

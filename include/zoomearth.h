@@ -257,6 +257,16 @@ int ze_op_sample_temperature(ze_engine* e, int seq, const float* logits, float r
  * values (exactly representable) so that prefill and decode compute with identical weights, and switches the batch-1
  * decode GEMVs to the fp8 stream (half the HBM bytes per token).  Call once, after the weights are loaded. */
 int ze_weights_quantize_fp8(ze_engine* e, void* stream);
+/* FP8 activations on top of the FP8 weights (opt-in; ZE_ERR_INVALID unless ze_weights_quantize_fp8 ran): the inputs of
+ * the qkv and gate/up projections -- the two RMSNorm outputs of every decoder layer -- are quantised to E4M3 with one
+ * dynamic power-of-two scale per token row (k = smallest integer with max|y| / 2^k <= 448, the rule of the weight
+ * rows).  Batched decode (<= 64 chains) then multiplies FP8 x FP8 on v_mfma_f32_16x16x32_fp8_fp8; every other path
+ * (prefill, scoring, single-chain GEMV decode, > 64 chains) computes with the same values, q * 2^k kept as bf16, so
+ * the model is ONE model whichever kernel serves a token.  The o / down / lm_head inputs stay bf16.  A weight
+ * change (load, fill, arena hand-out, broadcast) switches it off together with the FP8 weights.  `on` = 0 returns
+ * to bf16 activations.  There is no counterpart in the reference (its checkpoints run bf16); oracle:
+ * oracle/qwen25vl.py `act_fp8`. */
+int ze_set_fp8_activations(ze_engine* e, int on);
 /* The quantiser on one matrix: w bf16 [rows, cols] (device, overwritten with the dequantised values), q_out u8
  * [rows, cols], scale_out f32 [rows]; cols % 16 == 0. */
 int ze_op_quantize_fp8(ze_engine* e, void* w_bf16, int rows, int cols, void* q_out, void* scale_out, void* stream);

@@ -35,7 +35,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from . import indices, prng
+from . import fp8, indices, prng
 
 
 # ----------------------------------------------------------------------------- numerics helpers
@@ -211,10 +211,14 @@ def synthetic_weights(cfg: Config, seed: int = 0, std: float = 0.02, matrix_gain
 
 # ----------------------------------------------------------------------------- model
 class Qwen25VLOracle:
-    def __init__(self, cfg: Config, weights: dict, mode: str = "bf16"):
+    def __init__(self, cfg: Config, weights: dict, mode: str = "bf16", act_fp8: bool = False):
         assert mode in ("bf16", "fp32")
         self.cfg = cfg
         self.mode = mode
+        # act_fp8: the engine's ze_set_fp8_activations mode (include/zoomearth.h) -- the two RMSNorm outputs of every
+        # decoder layer (the inputs of q/k/v and of gate/up) are replaced by their per-row E4M3 quantisation q * 2^k
+        # (oracle/fp8.py).  No counterpart in the reference, whose checkpoints run bf16.
+        self.act_fp8 = act_fp8
         self.r = bf16_round if mode == "bf16" else _ident
         self.w = {k: (bf16_round(v.astype(np.float32)) if mode == "bf16" else v.astype(np.float32))
                   for k, v in weights.items()}
@@ -344,6 +348,8 @@ class Qwen25VLOracle:
         for li in range(t.num_hidden_layers):
             p = f"model.language_model.layers.{li}."
             y = self.rmsnorm(h, p + "input_layernorm.weight", t.rms_norm_eps)
+            if self.act_fp8:
+                y = fp8.quantize_rows(y)[2]
             q = self.linear(y, p + "self_attn.q_proj.weight", p + "self_attn.q_proj.bias").reshape(tn, nq, hd)
             k = self.linear(y, p + "self_attn.k_proj.weight", p + "self_attn.k_proj.bias").reshape(tn, nkv, hd)
             vv = self.linear(y, p + "self_attn.v_proj.weight", p + "self_attn.v_proj.bias").reshape(tn, nkv, hd)
@@ -370,6 +376,8 @@ class Qwen25VLOracle:
             o = self.r(o).reshape(tn, -1)
             h = self.r(h + self.linear(o, p + "self_attn.o_proj.weight"))
             y = self.rmsnorm(h, p + "post_attention_layernorm.weight", t.rms_norm_eps)
+            if self.act_fp8:
+                y = fp8.quantize_rows(y)[2]
             h = self.r(h + self.swiglu(y, p + "mlp.", bias=False))
             if return_layers:
                 layers.append(h.copy())

@@ -146,3 +146,95 @@ def test_weight_reload_after_quantisation_drops_the_fp8_stream(fresh_tiny):
     e.seq_reset(0)
     e.prefill(0, ids, None, pos, delta, want_logits=False)
     assert len(e.generate(0, 4, ignore_eos=True)) == 4
+
+
+# ----------------------------------------------------------------------------- fp8 activations (ze_set_fp8_activations)
+def _quantised_oracles(oc, w, act_fp8):
+    wq = dict(w)
+    for name, v in w.items():
+        if name.startswith("model.language_model.layers") and name.endswith("proj.weight"):
+            wq[name] = fp8.quantize_rows(v.reshape(v.shape[0], -1))[2].reshape(v.shape)
+    return (Q.Qwen25VLOracle(oc, wq, "fp32", act_fp8=act_fp8), Q.Qwen25VLOracle(oc, wq, "bf16", act_fp8=act_fp8))
+
+
+def test_fp8_activations_need_fp8_weights(fresh_tiny):
+    e = fresh_tiny
+    with pytest.raises(RuntimeError, match="ze_weights_quantize_fp8"):
+        e.set_fp8_activations(True)
+    e.quantize_fp8()
+    e.set_fp8_activations(True)
+    e.set_fp8_activations(False)
+
+
+def test_fp8_activation_model_vs_oracle_and_across_kernels(fresh_tiny):
+    """One model whichever kernel serves a token: prefill (bf16 MFMA on fake-quantised rows), single-chain GEMV decode
+    (fake-quantised row in LDS) and batched decode (FP8 fragments on v_mfma_f32_16x16x32_fp8_fp8) against the oracle
+    with act_fp8 (teacher-forced logits within 2x the oracle's own bf16-vs-fp32 error)."""
+    e = fresh_tiny
+    oc = Q.tiny_config()
+    w = Q.synthetic_weights(oc, **CHAIN_W)
+    ids = text_ids(57, 130)
+    forced = [int(t) for t in text_ids(58, 8)]
+    pos, delta = e.rope_index(ids, [])
+    e.quantize_fp8()
+
+    def gemv_run():
+        e.seq_reset(0)
+        return [e.prefill(0, ids, None, pos, delta).cpu().numpy()] + [e.decode_step(0, t).cpu().numpy() for t in forced]
+
+    def batch_run():
+        e.seq_reset(1)
+        out = [e.prefill(1, ids, None, pos, delta).cpu().numpy()]
+        return out + [e.decode_batch([1], [t]).cpu().numpy()[0] for t in forced]
+
+    w8a16 = gemv_run()
+    e.set_fp8_activations(True)
+    got_gemv, got_batch = gemv_run(), batch_run()
+    o32, o16 = _quantised_oracles(oc, w, True)
+    ref32 = [o32.prefill(ids)] + [o32.decode_step(t) for t in forced]
+    ref16 = [o16.prefill(ids)] + [o16.decode_step(t) for t in forced]
+    yard = max(float(np.abs(a - b).max()) for a, b in zip(ref16, ref32))
+    worst_gemv = max(float(np.abs(a - b).max()) for a, b in zip(got_gemv, ref32))
+    worst_batch = max(float(np.abs(a - b).max()) for a, b in zip(got_batch, ref32))
+    moved = max(float(np.abs(a - b).max()) for a, b in zip(got_gemv, w8a16))
+    print(f"fp8 activations: |gemv - fp32 oracle| = {worst_gemv:.4f}, |batched - fp32 oracle| = {worst_batch:.4f}, "
+          f"oracle bf16-vs-fp32 = {yard:.4f}, moved vs bf16 activations = {moved:.4f}")
+    assert worst_gemv <= 2.0 * yard and worst_batch <= 2.0 * yard
+    assert moved > 0.0                                    # the mode is really in effect
+    # prefill of prompt + first forced token == decode of that token (both kernels), within the same yardstick
+    e.seq_reset(1)
+    full = e.prefill(1, ids + forced[:1], None, *e.rope_index(ids + forced[:1], [])).cpu().numpy()
+    assert float(np.abs(full - got_gemv[1]).max()) <= 2.0 * yard
+    assert float(np.abs(full - got_batch[1]).max()) <= 2.0 * yard
+    # switching the mode off returns the W8A16 model exactly
+    e.set_fp8_activations(False)
+    again = gemv_run()
+    for a, b in zip(again, w8a16):
+        assert np.array_equal(a, b)
+
+
+def test_fp8_activation_batched_step_is_batch_invariant(fresh_tiny):
+    """fp8 x fp8 batched decode keeps the batch-invariance contract: a chain's logits are the same bits alone, in a
+    batch of 2 and in a batch large enough for the balanced gate/up launch (> 32 rows)."""
+    from zoomearth_amd.config import ModelConfig
+    from zoomearth_amd.engine import Engine
+    e = Engine(ModelConfig.tiny(), device=0, max_seqs=40, max_ctx=256, max_patches=256, max_tile_side=256)
+    try:
+        e.fill_synthetic(**CHAIN_W)
+        e.quantize_fp8()
+        e.set_fp8_activations(True)
+        ids = [text_ids(70 + s, 40 + 3 * s) for s in range(40)]
+        tok = [int(text_ids(90 + s, 1)[0]) for s in range(40)]
+
+        def run(slots):
+            for s in slots:
+                e.seq_reset(s)
+                e.prefill(s, ids[s], None, *e.rope_index(ids[s], []), want_logits=False)
+            out = e.decode_batch(list(slots), [tok[s] for s in slots]).cpu().numpy()
+            return {s: out[i] for i, s in enumerate(slots)}
+
+        alone, pair, crowd = run([3]), run([3, 17]), run(list(range(40)))
+        assert np.array_equal(alone[3], pair[3]) and np.array_equal(alone[3], crowd[3])
+        assert np.array_equal(pair[17], crowd[17])
+    finally:
+        e.close()

@@ -37,3 +37,19 @@ def test_row_quantisation_properties():
     # relative error of a normal-range element is at most 2^-4
     big = np.abs(w) > np.exp2(k)[:, None] * 2.0 ** -6
     assert np.all(np.abs(dq - w)[big] <= np.abs(w)[big] * 2.0 ** -4 + 1e-12)
+
+
+def test_act_fp8_oracle_mode_quantises_the_norm_outputs_and_stays_causal():
+    """Oracle act_fp8 (ze_set_fp8_activations): per-row dynamic scales make the quantisation of a token independent of
+    the other rows of the pass, so prefill of n + 1 tokens == prefill of n then one decode step, to fp32 rounding."""
+    from oracle import prng
+    from oracle import qwen25vl as Q
+    oc = Q.tiny_config()
+    w = Q.synthetic_weights(oc, seed=3, std=0.02, matrix_gain=4.0, bias_std=0.02, norm_jitter=0.1)
+    ids = prng.uniform_ints(5, 24, 10, 1990).tolist()
+    plain, quant = Q.Qwen25VLOracle(oc, w, "fp32"), Q.Qwen25VLOracle(oc, w, "fp32", act_fp8=True)
+    a, b = plain.prefill(ids), quant.prefill(ids)
+    assert float(np.abs(a - b).max()) > 1e-3              # the mode does something
+    step = quant.decode_step(ids[0])
+    whole = Q.Qwen25VLOracle(oc, w, "fp32", act_fp8=True).prefill(ids + ids[:1])
+    assert float(np.abs(step - whole).max()) < 2e-3

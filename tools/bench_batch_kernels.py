@@ -20,9 +20,11 @@ NAMES = ["qkv", "o_proj", "gate_up", "down", "lm_head", "attention", "rmsnorm", 
 cfg = ModelConfig.qwen25vl_7b() if os.environ.get("ZE_MODEL") == "7b" else ModelConfig.zoomearth_3b()
 e = Engine(cfg, max_seqs=B, max_ctx=2048, max_patches=2048, max_tile_side=1024, max_prefill_rows=16 * 1024)
 e.fill_synthetic(0)
-if os.environ.get("ZE_FP8") == "1":  # FP8 decoder weights: the batched step streams fp8 fragments (knob 10 = 1: bf16 copies)
+if os.environ.get("ZE_FP8") in ("1", "2"):  # FP8 decoder weights: the batched step streams fp8 fragments (knob 10 = 1: bf16 copies)
     e.quantize_fp8()
-print(f"model {cfg.name}, fp8 = {os.environ.get('ZE_FP8') == '1'}", flush=True)
+if os.environ.get("ZE_FP8") == "2":  # ... and FP8 activations at the two norm sites (fp8 x fp8 MFMA)
+    e.set_fp8_activations(True)
+print(f"model {cfg.name}, fp8 = {os.environ.get('ZE_FP8', '0')} (1 weights, 2 weights + activations)", flush=True)
 lens = [800 + int(v) for v in uniform_ints(5, B, 0, 640)]  # ragged: 800 .. 1440 tokens (mean ~1120)
 for g0 in range(0, B, 8):
     gs = list(range(g0, min(B, g0 + 8)))

@@ -57,9 +57,31 @@ void ze_launch_fill_rows(uint64_t seed, float c_scale, float base, int rows, int
 // frag != 0: y is written MFMA-fragment-major for the batched decode GEMMs (k_gemm_skinny<..., FRAG>):
 //   element (row r, col k) -> (((r / 16) * (cols / 32) + k / 32) * 64 + ((k % 32) / 8) * 16 + r % 16) * 8 + k % 8
 // i.e. a wave's A fragment of 16 rows x 32 columns is one contiguous 1-KiB block (cols % 32 == 0).
+// FP8 activations (ze_set_fp8_activations: BASELINE configs[4], "fp8 weights on fp8 MFMA"): the normalised row -- the
+// input of the qkv and gate/up projections -- is quantised to E4M3 with ONE power-of-two scale per row, the rule of the
+// weight rows (ze_quant.hip, oracle/fp8.py): k = the smallest integer with max|y| / 2^k <= 448, q = e4m3(y / 2^k).
+// q * 2^k is exact in bf16, so a path without an fp8 MFMA kernel (prefill, single-chain GEMV, > 64 chains) computes with
+// the SAME values by writing q * 2^k back as bf16 ("fake quantisation"), and the model stays one model.
+__device__ __forceinline__ int fp8_row_exponent(float amax) {
+    if (!(amax > 0.f)) return 0;
+    int e;
+    const float m = frexpf(amax / 448.0f, &e);  // amax / 448 = m * 2^e, m in [0.5, 1)
+    return (m == 0.5f) ? e - 1 : e;
+}
+typedef float ew_f32x2 __attribute__((ext_vector_type(2)));
+// two bf16 values (one packed word) -> the two E4M3 bytes of value / 2^k (low 16 bits of the result)
+__device__ __forceinline__ uint32_t fp8_pack2(uint32_t w, float inv_s) {
+    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(bf16lo(w) * inv_s, bf16hi(w) * inv_s, 0, false) & 0xffffu;
+}
+// ... and back to a packed bf16 word holding q * 2^k (exact)
+__device__ __forceinline__ uint32_t fp8_fake2(uint32_t w, float inv_s, float s) {
+    const ew_f32x2 back = __builtin_amdgcn_cvt_pk_f32_fp8((int)fp8_pack2(w, inv_s), false);
+    return pack_bf16x2(back.x * s, back.y * s);
+}
+
 __global__ void __launch_bounds__(256) k_rmsnorm(const bf16_t* __restrict__ x, int ldx,
                                                  const bf16_t* __restrict__ w, bf16_t* __restrict__ y, int ldy,
-                                                 int rows, int cols, float eps, int frag) {
+                                                 int rows, int cols, float eps, int frag, int act8) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -78,17 +100,37 @@ __global__ void __launch_bounds__(256) k_rmsnorm(const bf16_t* __restrict__ x, i
     ss = wave_sum(ss);
     const float inv = rsqrtf(ss / (float)cols + eps);
     bf16_t* yr = y + (size_t)row * ldy;
-    for (int v = lane; v < nv; v += 64) {
+    auto norm_vec = [&](int v, uint32_t (&o)[4]) {
         const uint4 q = *reinterpret_cast<const uint4*>(xr + v * 8);
         const uint4 g = *reinterpret_cast<const uint4*>(w + v * 8);
         const uint32_t u[4] = {q.x, q.y, q.z, q.w};
         const uint32_t gw[4] = {g.x, g.y, g.z, g.w};
-        uint32_t o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float a = bf16_round(bf16lo(u[j]) * inv) * bf16lo(gw[j]);
             const float b = bf16_round(bf16hi(u[j]) * inv) * bf16hi(gw[j]);
             o[j] = pack_bf16x2(a, b);
+        }
+    };
+    float s8 = 1.f, inv8 = 1.f;
+    if (act8) {  // a pass for the row's largest magnitude (of the bf16 outputs), then the quantising pass below
+        float amax = 0.f;
+        for (int v = lane; v < nv; v += 64) {
+            uint32_t o[4];
+            norm_vec(v, o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(bf16lo(o[j])), fabsf(bf16hi(o[j]))));
+        }
+        const int k = fp8_row_exponent(wave_max(amax));
+        s8 = ldexpf(1.0f, k);
+        inv8 = ldexpf(1.0f, -k);
+    }
+    for (int v = lane; v < nv; v += 64) {
+        uint32_t o[4];
+        norm_vec(v, o);
+        if (act8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = fp8_fake2(o[j], inv8, s8);
         }
         bf16_t* dst = yr + v * 8;
         if (frag)
@@ -101,9 +143,12 @@ __global__ void __launch_bounds__(256) k_rmsnorm(const bf16_t* __restrict__ x, i
 // (NV 16-B vectors per thread), so the launch is a single memory round trip on 64 CUs instead of a two-pass loop on 16
 // (7.3 -> about 3.5 us at 64 x 2048: the kernel is pure latency).  Sum of squares: lane partials in vector order, the
 // wave sums, then the four waves in order -- a function of the row alone.
+// act8: 0 bf16 output; 1 fake-quantised bf16 output (same layout); 2 FP8 fragment-major output in y8 (fragment = 64
+// lanes x 8 B: this thread's 8 consecutive columns are exactly one lane's bytes) + the row's scale in yscale[row]
 template <int NV>
 __global__ void __launch_bounds__(256) k_rmsnorm_row(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ w,
-                                                     bf16_t* __restrict__ y, int ldy, int cols, float eps, int frag) {
+                                                     bf16_t* __restrict__ y, int ldy, int cols, float eps, int frag,
+                                                     int act8, uint8_t* __restrict__ y8, float* __restrict__ yscale) {
     const int row = blockIdx.x, t = threadIdx.x;
     const int nv = cols >> 3;
     const bf16_t* xr = x + (size_t)row * ldx;
@@ -131,39 +176,66 @@ __global__ void __launch_bounds__(256) k_rmsnorm_row(const bf16_t* __restrict__ 
     if ((t & 63) == 0) part[t >> 6] = ss;
     __syncthreads();
     const float inv = rsqrtf((((part[0] + part[1]) + part[2]) + part[3]) / (float)cols + eps);
+    uint32_t o[NV][4];
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int v = t + i * 256;
-        if (v >= nv) continue;
         const uint32_t u[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
         const uint32_t gw[4] = {g[i].x, g[i].y, g[i].z, g[i].w};
-        uint32_t o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float a = bf16_round(bf16lo(u[j]) * inv) * bf16lo(gw[j]);
             const float b = bf16_round(bf16hi(u[j]) * inv) * bf16hi(gw[j]);
-            o[j] = pack_bf16x2(a, b);
+            o[i][j] = pack_bf16x2(a, b);
+            if (t + i * 256 < nv) amax = fmaxf(amax, fmaxf(fabsf(bf16lo(o[i][j])), fabsf(bf16hi(o[i][j]))));
+        }
+    }
+    float s8 = 1.f, inv8 = 1.f;
+    if (act8) {  // workgroup-uniform
+        amax = wave_max(amax);
+        __shared__ float pmax[4];
+        if ((t & 63) == 0) pmax[t >> 6] = amax;
+        __syncthreads();
+        const int k = fp8_row_exponent(fmaxf(fmaxf(pmax[0], pmax[1]), fmaxf(pmax[2], pmax[3])));
+        s8 = ldexpf(1.0f, k);
+        inv8 = ldexpf(1.0f, -k);
+        if (act8 == 2 && t == 0) yscale[row] = s8;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = t + i * 256;
+        if (v >= nv) continue;
+        const size_t fslot = ((size_t)(row >> 4) * (cols >> 5) + (v >> 2)) * 64 + (v & 3) * 16 + (row & 15);
+        if (act8 == 2) {
+            uint2 b;
+            b.x = fp8_pack2(o[i][0], inv8) | (fp8_pack2(o[i][1], inv8) << 16);
+            b.y = fp8_pack2(o[i][2], inv8) | (fp8_pack2(o[i][3], inv8) << 16);
+            *reinterpret_cast<uint2*>(y8 + (fslot << 3)) = b;
+            continue;
+        }
+        if (act8 == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[i][j] = fp8_fake2(o[i][j], inv8, s8);
         }
         bf16_t* dst = y + (size_t)row * ldy + v * 8;
-        if (frag)
-            dst = y + ((((size_t)(row >> 4) * (cols >> 5) + (v >> 2)) * 64 + (v & 3) * 16 + (row & 15)) << 3);
-        *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+        if (frag) dst = y + (fslot << 3);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(o[i][0], o[i][1], o[i][2], o[i][3]);
     }
 }
 
 void ze_launch_rmsnorm(const bf16_t* x, int ldx, const bf16_t* w, bf16_t* y, int ldy, int rows, int cols, float eps,
-                       hipStream_t s, int frag) {
+                       hipStream_t s, int frag, int act8, uint8_t* y8, float* yscale) {
     if (rows == 0) return;
     // frag != 0 marks the batched decode step (<= 64 rows): its rows take the one-workgroup-per-row form, so that a
     // chain's normalised row is the same bits whatever the batch; every other caller keeps the wave-per-row kernel
     if (frag && rows <= 64 && cols <= 8192 && cols % 8 == 0) {
         const int nv = cols >> 3;
-        if (nv <= 256) k_rmsnorm_row<1><<<rows, 256, 0, s>>>(x, ldx, w, y, ldy, cols, eps, frag);
-        else if (nv <= 512) k_rmsnorm_row<2><<<rows, 256, 0, s>>>(x, ldx, w, y, ldy, cols, eps, frag);
-        else k_rmsnorm_row<4><<<rows, 256, 0, s>>>(x, ldx, w, y, ldy, cols, eps, frag);
+        if (nv <= 256) k_rmsnorm_row<1><<<rows, 256, 0, s>>>(x, ldx, w, y, ldy, cols, eps, frag, act8, y8, yscale);
+        else if (nv <= 512) k_rmsnorm_row<2><<<rows, 256, 0, s>>>(x, ldx, w, y, ldy, cols, eps, frag, act8, y8, yscale);
+        else k_rmsnorm_row<4><<<rows, 256, 0, s>>>(x, ldx, w, y, ldy, cols, eps, frag, act8, y8, yscale);
         return;
     }
-    k_rmsnorm<<<ze_cdiv(rows, 4), 256, 0, s>>>(x, ldx, w, y, ldy, rows, cols, eps, frag);
+    k_rmsnorm<<<ze_cdiv(rows, 4), 256, 0, s>>>(x, ldx, w, y, ldy, rows, cols, eps, frag, act8 ? 1 : 0);
 }
 
 // W [n, k] row-major (leading dimension ldw) -> MFMA-fragment-major copy: fragment (nb, ks) = rows 16 nb .. +15,

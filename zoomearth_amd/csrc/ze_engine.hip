@@ -16,6 +16,7 @@ void ze_weights_changed(ze_engine* e) {
     e->frag_ready = false;
     if (e->fp8_ready) {
         e->fp8_ready = false;
+        e->fp8_act = false;  // goes with the fp8 weights: the caller quantises and switches it on again
         for (auto& L : e->tl)
             for (ze_linear* l : {&L.qkv, &L.o, &L.gate_up, &L.down}) {
                 l->w8 = nullptr;
@@ -329,6 +330,8 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     const int nqkv = (c.heads + 2 * c.kv_heads) * e->head_dim;
     chk(dev_alloc(e, &e->th, tm * c.hidden));
     chk(dev_alloc(e, &e->ty, tm * c.hidden));
+    chk(dev_alloc(e, &e->ty8, (size_t)64 * c.hidden));
+    chk(dev_alloc(e, &e->ty8_scale, 64));
     chk(dev_alloc(e, &e->tqkv, tm * nqkv));
     chk(dev_alloc(e, &e->to, tm * c.heads * e->head_dim));
     chk(dev_alloc(e, &e->ta, tm * e->text_ipad));
@@ -401,7 +404,8 @@ extern "C" int ze_engine_destroy(ze_engine* e) {
                    e->st_dev, e->seen, e->out_tokens, e->fe_tmp, e->fe_img, e->fe_coef, e->vx, e->vh, e->vy, e->vqkv,
                    e->vo, e->va, e->vz, e->vz2, e->vcos, e->vsin, e->vperm, e->vinv, e->vtiles_win, e->vtiles_full,
                    e->th, e->ty, e->tqkv, e->to, e->ta, e->tsrc, e->tpos, e->ttiles, e->ttile_aux, e->trow_aux, e->dh, e->dq, e->dattn, e->dact,
-                   e->dlogits, e->dpartial, e->dsample, e->gbar, e->atickets, e->gslab, e->gtickets, e->bseq, e->blogits, e->bpartial, e->bsample, e->arena8, e->arena_f, e->arena_f8};
+                   e->dlogits, e->dpartial, e->dsample, e->gbar, e->atickets, e->gslab, e->gtickets, e->bseq, e->blogits, e->bpartial, e->bsample, e->arena8, e->arena_f, e->arena_f8,
+                   e->ty8, e->ty8_scale};
     for (void* p : dev)
         if (p) hipFree(p);
     void* host[] = {e->fe_coef_host, e->v_host_ints, e->v_host_f32, e->t_host_ints, e->d_host_ints, e->bstate_host};

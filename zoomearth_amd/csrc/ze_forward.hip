@@ -424,7 +424,7 @@ static int prefill_impl(ze_engine* e, int seq, const int32_t* input_ids, int len
     const float scale = 1.0f / sqrtf((float)hd);
     for (int li = 0; li < c.layers; ++li) {
         const ze_text_layer& L = e->tl[li];
-        ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, len, H, c.rms_eps, s);
+        ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, len, H, c.rms_eps, s, 0, e->fp8_act ? 1 : 0);
         ze_launch_gemm(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, nullptr, len,
                        nqkv, H, s);
         ze_launch_mrope_kv(e->tqkv, len, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->tpos, e->axis_of,
@@ -433,7 +433,7 @@ static int prefill_impl(ze_engine* e, int seq, const int32_t* input_ids, int len
                              c.max_ctx * hd, e->to, nq, hd, e->ttiles, nt, c.heads, c.heads / c.kv_heads, scale, past,
                              s);
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, len, H, nq, s);
-        ze_launch_rmsnorm(e->th, H, L.post_norm, e->ty, H, len, H, c.rms_eps, s);
+        ze_launch_rmsnorm(e->th, H, L.post_norm, e->ty, H, len, H, c.rms_eps, s, 0, e->fp8_act ? 1 : 0);
         ze_launch_gemm(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad,
                        nullptr, len, 2 * e->text_ipad, H, s);
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, nullptr,
@@ -571,7 +571,7 @@ extern "C" int ze_prefill_batch(ze_engine* e, const int32_t* seqs, int n, const 
     const size_t seq_stride = (size_t)c.kv_heads * c.max_ctx * hd;
     for (int li = 0; li < c.layers; ++li) {
         const ze_text_layer& L = e->tl[li];
-        ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, total, H, c.rms_eps, s);
+        ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, total, H, c.rms_eps, s, 0, e->fp8_act ? 1 : 0);
         ze_launch_gemm(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, nullptr, total,
                        nqkv, H, s);
         ze_launch_mrope_kv(e->tqkv, total, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->tpos, e->axis_of, e->kc(li, 0),
@@ -580,7 +580,7 @@ extern "C" int ze_prefill_batch(ze_engine* e, const int32_t* seqs, int n, const 
                              c.max_ctx * hd, e->to, nq, hd, e->ttiles, nt, c.heads, c.heads / c.kv_heads, scale, 0, s,
                              e->ttile_aux, seq_stride);
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, total, H, nq, s);
-        ze_launch_rmsnorm(e->th, H, L.post_norm, e->ty, H, total, H, c.rms_eps, s);
+        ze_launch_rmsnorm(e->th, H, L.post_norm, e->ty, H, total, H, c.rms_eps, s, 0, e->fp8_act ? 1 : 0);
         ze_launch_gemm(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad,
                        nullptr, total, 2 * e->text_ipad, H, s);
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, nullptr,
@@ -707,6 +707,7 @@ int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos,
         a.kv_heads = c.kv_heads;
         a.D = hd;
         a.max_ctx = c.max_ctx;
+        a.act8 = e->fp8_act ? 1 : 0;
         if (li == 0) {
             a.embed = e->embed;
             a.embed_out = e->dh;
@@ -768,6 +769,7 @@ int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos,
         g.eps = c.rms_eps;
         g.out_bf16 = e->dact;
         g.D = hd;
+        g.act8 = e->fp8_act ? 1 : 0;
         ze_launch_gemv(ZE_GV_SWIGLU, g, s);
         ze_gemv_args d;
         memset(&d, 0, sizeof(d));
@@ -1096,12 +1098,18 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
         // attention merge and the SwiGLU epilogue then write their outputs in that layout too
         const bool fr = L.qkv.wf && n <= 64 && ze_gemv_knobs[5] != 1;
         const ze_gemm_ws ws = e->gemm_ws();
-        ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, n, H, c.rms_eps, s, fr ? 1 : 0);
+        // FP8 activations: the fragment path with FP8 weight fragments takes the row as FP8 fragments + a scale (fp8 x
+        // fp8 MFMA); any other path takes the same values as bf16
+        const bool a8q = e->fp8_act && fr && L.qkv.wf8 && ze_gemv_knobs[10] != 1;
+        const bool a8g = e->fp8_act && fr && L.gate_up.wf8 && ze_gemv_knobs[10] != 1;
+        ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, n, H, c.rms_eps, s, fr ? 1 : 0, a8q ? 2 : (e->fp8_act ? 1 : 0), e->ty8,
+                          e->ty8_scale);
         if (fr) {  // projection + M-RoPE + KV append in one launch (the fragment copy of qkv is packed for it)
             const bool w8 = L.qkv.wf8 && ze_gemv_knobs[10] != 1;  // FP8 fragment stream (quantised engine)
-            ze_launch_qkv_rope_oneshot(e->ty, w8 ? (const bf16_t*)L.qkv.wf8 : L.qkv.wf, L.qkv.bias, e->tqkv, nqkv, n, H, c.heads,
-                                       c.kv_heads, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(li, 0), e->vc(li, 0), seq_stride,
-                                       c.max_ctx, s, w8 ? L.qkv.scale8 : nullptr);
+            ze_launch_qkv_rope_oneshot(a8q ? (const bf16_t*)e->ty8 : e->ty, w8 ? (const bf16_t*)L.qkv.wf8 : L.qkv.wf, L.qkv.bias,
+                                       e->tqkv, nqkv, n, H, c.heads, c.kv_heads, e->cosT, e->sinT, e->st_dev, e->bseq,
+                                       e->kc(li, 0), e->vc(li, 0), seq_stride, c.max_ctx, s, w8 ? L.qkv.scale8 : nullptr,
+                                       a8q ? e->ty8_scale : nullptr);
         } else {
             ze_launch_gemm_stream(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, ws, s);
             ze_launch_rope_kv_batch(e->tqkv, n, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(li, 0),
@@ -1116,11 +1124,13 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
             ze_launch_gemm_frag(ZE_EPI_RESIDUAL, e->to, L.o.wf, nullptr, e->th, H, e->th, H, n, H, nq, s);
         else
             ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, n, H, nq, ws, s);
-        ze_launch_rmsnorm(e->th, H, L.post_norm, e->ty, H, n, H, c.rms_eps, s, fr ? 1 : 0);
+        ze_launch_rmsnorm(e->th, H, L.post_norm, e->ty, H, n, H, c.rms_eps, s, fr ? 1 : 0, a8g ? 2 : (e->fp8_act ? 1 : 0), e->ty8,
+                          e->ty8_scale);
         if (fr) {
             const bool w8 = L.gate_up.wf8 && ze_gemv_knobs[10] != 1;
-            ze_launch_gemm_frag(ZE_EPI_SWIGLU, e->ty, w8 ? (const bf16_t*)L.gate_up.wf8 : L.gate_up.wf, nullptr, nullptr, 0, e->ta,
-                                e->text_ipad, n, 2 * e->text_ipad, H, s, w8 ? L.gate_up.scale8 : nullptr);
+            ze_launch_gemm_frag(ZE_EPI_SWIGLU, a8g ? (const bf16_t*)e->ty8 : e->ty, w8 ? (const bf16_t*)L.gate_up.wf8 : L.gate_up.wf,
+                                nullptr, nullptr, 0, e->ta, e->text_ipad, n, 2 * e->text_ipad, H, s,
+                                w8 ? L.gate_up.scale8 : nullptr, a8g ? e->ty8_scale : nullptr);
         } else
             ze_launch_gemm_stream(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad, n,
                                   2 * e->text_ipad, H, ws, s);
@@ -1520,6 +1530,17 @@ extern "C" int ze_weights_quantize_fp8(ze_engine* e, void* stream) {
     e->fp8_ready = true;
     e->frag_ready = false;  // the bf16 copies were replaced by the dequantised values
     ++ze_tune_epoch;  // captured decode steps hold the bf16 streams
+    return ZE_OK;
+}
+
+extern "C" int ze_set_fp8_activations(ze_engine* e, int on) {
+    if (!e) return ze_fail(e, ZE_ERR_INVALID, "null engine");
+    if (on && !e->fp8_ready)
+        return ze_fail(e, ZE_ERR_INVALID, "fp8 activations go with fp8 weights: call ze_weights_quantize_fp8 first");
+    if (e->fp8_act != (on != 0)) {
+        e->fp8_act = on != 0;
+        ++ze_tune_epoch;  // captured decode steps bake the choice of kernels in
+    }
     return ZE_OK;
 }
 

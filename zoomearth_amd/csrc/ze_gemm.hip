@@ -461,9 +461,9 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
 // down projection) then go through the slab / ticket reduction of gemm_finish.  The order of every sum is a function
 // of (K, ksplit) alone, so a chain's result does not depend on how many chains share the step.
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;  // an FP8 weight fragment of one lane: 8 bytes
-template <int TN, int CH, int MT, bool W8 = false>
+template <int TN, int CH, int MT, bool W8 = false, bool A8 = false>
 struct skinny_frag {
-    bf16x8 a[CH][MT];
+    typename std::conditional<A8, u32x2_t, bf16x8>::type a[CH][MT];
     typename std::conditional<W8, u32x2_t, bf16x8>::type b[CH][TN];
 };
 
@@ -494,14 +494,19 @@ __device__ __forceinline__ bf16x8 deq_fp8x8(u32x2_t w, float scale) {
 // the CUs as evenly as the pair count allows while every workgroup passes over the activations ONCE.
 // W8: the fragment-major weights are FP8 (8 B per lane per fragment, k_pack_fragments8) with one power-of-two scale per
 // weight row in `wscale`; they are dequantised in registers (deq_fp8x8) right before the MFMA.
-template <int TN, int EPI, bool FRAG = false, int MT = 4, bool BAL = false, bool W8 = false>
+// A8 (with W8): the activations are FP8 fragments as well (k_rmsnorm_row act8 = 2) and the product runs on
+// v_mfma_f32_16x16x32_fp8_fp8; `ascale` holds one power-of-two scale per activation row, applied with the weight row's to
+// the fp32 sums before the epilogue.
+template <int TN, int EPI, bool FRAG = false, int MT = 4, bool BAL = false, bool W8 = false, bool A8 = false>
 __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
                                                      int ldw, const bf16_t* __restrict__ bias,
                                                      const bf16_t* __restrict__ R, int ldr, bf16_t* __restrict__ C,
                                                      int ldc, int M, int N, int K, int ksplit,
                                                      float* __restrict__ slab, unsigned* __restrict__ tickets,
-                                                     const float* __restrict__ wscale = nullptr) {
+                                                     const float* __restrict__ wscale = nullptr,
+                                                     const float* __restrict__ ascale = nullptr) {
     static_assert(!W8 || FRAG, "fp8 weights come fragment-major");
+    static_assert(!A8 || W8, "fp8 activations go with fp8 weights");
     constexpr int BN = 16 * TN, CH = (TN == 1) ? 4 : 2;  // MFMA slices per prefetch chunk
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     int nwg = (N + BN - 1) / BN;
@@ -528,6 +533,7 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
     // per-slice stride of a fragment pointer, in elements: 32 columns of a row (row-major) or one 1-KiB fragment
     constexpr int SSTR = FRAG ? 512 : 32;
     constexpr int WSTR = W8 ? 256 : SSTR;  // an fp8 fragment is 512 B = 256 bf16-sized elements
+    constexpr int ASTR = A8 ? 256 : SSTR;
     const bf16_t* wp[TN];
     const bf16_t* ap[4];
     float wsc[TN];
@@ -542,7 +548,7 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
             if (W8) wsc[j] = wscale[blk * 16 + fr];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ap[i] = A + ((size_t)min(i, mt - 1) * ns_all * 64 + lane) * 8;
+        for (int i = 0; i < 4; ++i) ap[i] = A + ((size_t)min(i, mt - 1) * ns_all * 64 + lane) * (A8 ? 4 : 8);
     } else {
 #pragma unroll
         for (int j = 0; j < TN; ++j) wp[j] = W + (size_t)min(bn0 + j * 16 + fr, N - 1) * ldw + fq * 8;
@@ -557,39 +563,52 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     typedef typename std::conditional<W8, u32x2_t, bf16x8>::type wfrag_t;
-    auto load = [&](skinny_frag<TN, CH, MT, W8>& f, int s) {
+    typedef typename std::conditional<A8, u32x2_t, bf16x8>::type afrag_t;
+    auto load = [&](skinny_frag<TN, CH, MT, W8, A8>& f, int s) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const int k = (s + c) * SSTR, kw = (s + c) * WSTR;
+            const int k = (s + c) * ASTR, kw = (s + c) * WSTR;
 #pragma unroll
             for (int j = 0; j < TN; ++j)  // streamed once: non-temporal
                 f.b[c][j] = __builtin_nontemporal_load(reinterpret_cast<const wfrag_t*>(wp[j] + kw));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (i < mt) f.a[c][i] = *reinterpret_cast<const bf16x8*>(ap[i] + k);
+                if (i < mt) f.a[c][i] = *reinterpret_cast<const afrag_t*>(ap[i] + k);
         }
     };
-    auto mac = [&](const skinny_frag<TN, CH, MT, W8>& f) {
+    auto mac = [&](const skinny_frag<TN, CH, MT, W8, A8>& f) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            bf16x8 fb[TN];
+            if constexpr (A8) {  // both operands as they came from memory
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if constexpr (W8) fb[j] = deq_fp8x8(f.b[c][j], wsc[j]);
-                else fb[j] = f.b[c][j];
-            }
+                for (int i = 0; i < 4; ++i)
+                    if (i < mt) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < mt) {
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(*reinterpret_cast<const long*>(&f.a[c][i]),
+                                                                                   *reinterpret_cast<const long*>(&f.b[c][j]),
+                                                                                   acc[i][j], 0, 0, 0);
+                    }
+            } else {
+                bf16x8 fb[TN];
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[c][i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (W8) fb[j] = deq_fp8x8(f.b[c][j], wsc[j]);
+                    else fb[j] = f.b[c][j];
                 }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < mt) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[c][i], fb[j], acc[i][j], 0, 0, 0);
+                    }
+            }
         }
     };
     const int nch = ns / CH;
     {
-        skinny_frag<TN, CH, MT, W8> f0, f1;
+        skinny_frag<TN, CH, MT, W8, A8> f0, f1;
         if (nch > 0) load(f0, s0);
         int c = 0;
         for (; c + 2 <= nch; c += 2) {
@@ -601,21 +620,27 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
         if (c < nch) mac(f0);
     }
     for (int s = s0 + nch * CH; s < s0 + ns; ++s) {  // fewer than CH slices left
-        const int k = s * SSTR, kw = s * WSTR;
+        const int k = s * ASTR, kw = s * WSTR;
         bf16x8 fb[TN];
+        wfrag_t raw[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const wfrag_t raw = __builtin_nontemporal_load(reinterpret_cast<const wfrag_t*>(wp[j] + kw));
-            if constexpr (W8) fb[j] = deq_fp8x8(raw, wsc[j]);
-            else fb[j] = raw;
+            raw[j] = __builtin_nontemporal_load(reinterpret_cast<const wfrag_t*>(wp[j] + kw));
+            if constexpr (W8 && !A8) fb[j] = deq_fp8x8(raw[j], wsc[j]);
+            else if constexpr (!W8) fb[j] = raw[j];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i < mt) {
-                const bf16x8 fa = *reinterpret_cast<const bf16x8*>(ap[i] + k);
+                const afrag_t fa = *reinterpret_cast<const afrag_t*>(ap[i] + k);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (A8)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(*reinterpret_cast<const long*>(&fa),
+                                                                               *reinterpret_cast<const long*>(&raw[j]), acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+                }
             }
     }
 
@@ -642,6 +667,10 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
                 v[2] += t[2];
                 v[3] += t[3];
             }
+        }
+        if constexpr (A8) {  // fp8 x fp8 sums -> values: activation-row and weight-row powers of two (exact)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= ascale[min(wid * 16 + fq * 4 + r, M - 1)] * wsc[j];
         }
         out[0][j] = v;
     }
@@ -803,10 +832,10 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
 // the finer grid: 24.1 us (26.8 at 64 rows per workgroup, 25.1 at 128, 27 on the ring).  Narrow matrices (qkv) take
 // 16 rows per workgroup so that their grid still covers the chip: 5.5 / 8.1 us at 8 / 64 chains (9.8 / 13.9 row-major,
 // 15 on the ring).  lm_head: 96 us at 8 chains (120 on the ring), 140 at 64 (145).
-template <int TN, int MT, bool W8 = false>
+template <int TN, int MT, bool W8 = false, bool A8 = false>
 static void launch_frag_mt(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,
                         bf16_t* C, int ldc, int M, int N, int K, hipStream_t s, int ksplit, const ze_gemm_ws& ws,
-                        const float* wscale = nullptr) {
+                        const float* wscale = nullptr, const float* ascale = nullptr) {
     float* g_slab = ws.slab;
     unsigned* g_tickets = ws.tickets;
     const int grid = ze_cdiv(N, 16 * TN) * ksplit;
@@ -824,13 +853,13 @@ static void launch_frag_mt(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf
     do {                                                                                                            \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<TN, E, true, MT, false, W8>),          \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<TN, E, true, MT, false, W8, A8>),      \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);                          \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL((k_gemm_skinny<TN, E, true, MT, false, W8>), dim3(grid), dim3(256), lds, s, Xf, 0, Wf,   \
-                           0, bias, R, ldr,                                                                         \
-                           C, ldc, M, N, K, ksplit, g_slab, g_tickets, wscale);                                     \
+        hipLaunchKernelGGL((k_gemm_skinny<TN, E, true, MT, false, W8, A8>), dim3(grid), dim3(256), lds, s, Xf, 0,   \
+                           Wf, 0, bias, R, ldr,                                                                     \
+                           C, ldc, M, N, K, ksplit, g_slab, g_tickets, wscale, ascale);                             \
     } while (0)
     if constexpr (TN % 2 == 0) {
         if (epi == ZE_EPI_SWIGLU) {
@@ -838,6 +867,7 @@ static void launch_frag_mt(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf
             return;
         }
     }
+    if constexpr (A8) return;  // fp8 activations: gate/up only
     switch (epi) {
         case ZE_EPI_NONE: ZE_FRAG_LAUNCH(ZE_EPI_NONE); break;
         case ZE_EPI_RESIDUAL: ZE_FRAG_LAUNCH(ZE_EPI_RESIDUAL); break;
@@ -850,7 +880,15 @@ static void launch_frag_mt(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf
 template <int TN>
 static void launch_frag(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,
                         bf16_t* C, int ldc, int M, int N, int K, hipStream_t s, int ksplit = 1,
-                        const ze_gemm_ws& ws = ze_gemm_ws(), const float* wscale = nullptr) {
+                        const ze_gemm_ws& ws = ze_gemm_ws(), const float* wscale = nullptr, const float* ascale = nullptr) {
+    if constexpr (TN == 2) {
+        if (wscale && ascale && epi == ZE_EPI_SWIGLU && ksplit == 1) {  // fp8 x fp8
+            if (M <= 16) launch_frag_mt<TN, 1, true, true>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s, 1, ws, wscale, ascale);
+            else if (M <= 32) launch_frag_mt<TN, 2, true, true>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s, 1, ws, wscale, ascale);
+            else launch_frag_mt<TN, 4, true, true>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s, 1, ws, wscale, ascale);
+            return;
+        }
+    }
     if (wscale) {  // fp8 fragment stream
         if (M <= 16) launch_frag_mt<TN, 1, true>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s, ksplit, ws, wscale);
         else if (M <= 32) launch_frag_mt<TN, 2, true>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s, ksplit, ws, wscale);
@@ -864,22 +902,22 @@ static void launch_frag(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_
 
 // gate/up (SwiGLU, wide): one workgroup per CU (or a multiple), each with a balanced range of at most three 32-row
 // pairs and ONE pass over the activations
-template <int MT, bool W8 = false>
+template <int MT, bool W8 = false, bool A8 = false>
 static void launch_frag_balanced(const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, bf16_t* C, int ldc, int M, int N,
-                                 int K, int grid, hipStream_t s, const float* wscale = nullptr) {
+                                 int K, int grid, hipStream_t s, const float* wscale = nullptr, const float* ascale = nullptr) {
     const size_t lds = (size_t)16 * 6 * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<6, ZE_EPI_SWIGLU, true, MT, true, W8>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny<6, ZE_EPI_SWIGLU, true, MT, true, W8, A8>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gemm_skinny<6, ZE_EPI_SWIGLU, true, MT, true, W8>), dim3(grid), dim3(256), lds, s, Xf, 0, Wf, 0, bias,
-                       nullptr, 0, C, ldc, M, N, K, 1, nullptr, nullptr, wscale);
+    hipLaunchKernelGGL((k_gemm_skinny<6, ZE_EPI_SWIGLU, true, MT, true, W8, A8>), dim3(grid), dim3(256), lds, s, Xf, 0, Wf, 0,
+                       bias, nullptr, 0, C, ldc, M, N, K, 1, nullptr, nullptr, wscale, ascale);
 }
 
 void ze_launch_gemm_frag(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,
-                         bf16_t* C, int ldc, int M, int N, int K, hipStream_t s, const float* wscale) {
+                         bf16_t* C, int ldc, int M, int N, int K, hipStream_t s, const float* wscale, const float* ascale) {
     if (M <= 0 || N <= 0) return;
     // (more than 32 chains only: below that the activation pass is small and the finer 32-row grid wins, 2.84 against
     //  2.91 ms per step at 8 chains; at 64 chains 3.86 against 3.95.  Both forms add an output's K quarters in the same
@@ -893,14 +931,15 @@ void ze_launch_gemm_frag(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16
         }
         const int P = N / 32;
         const int grid = cus_b * ze_cdiv(P, 3 * cus_b);  // at most three pairs per workgroup
-        if (wscale) launch_frag_balanced<4, true>(Xf, Wf, bias, C, ldc, M, N, K, grid, s, wscale);
+        if (wscale && ascale) launch_frag_balanced<4, true, true>(Xf, Wf, bias, C, ldc, M, N, K, grid, s, wscale, ascale);
+        else if (wscale) launch_frag_balanced<4, true>(Xf, Wf, bias, C, ldc, M, N, K, grid, s, wscale);
         else launch_frag_balanced<4>(Xf, Wf, bias, C, ldc, M, N, K, grid, s);
         return;
     }
     if (N <= 4096 && epi != ZE_EPI_SWIGLU)
         launch_frag<1>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s, 1, ze_gemm_ws(), wscale);
     else
-        launch_frag<2>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s, 1, ze_gemm_ws(), wscale);
+        launch_frag<2>(epi, Xf, Wf, bias, R, ldr, C, ldc, M, N, K, s, 1, ze_gemm_ws(), wscale, ascale);
 }
 
 // Batched decode: the skinny kernel when the shape allows (M <= 64, whole MFMA slices), else the ring.

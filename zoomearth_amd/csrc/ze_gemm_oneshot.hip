@@ -29,6 +29,7 @@ struct ze_oneshot_args {
     const bf16_t* Wf;      // weights, fragment-major (row-permuted for OS_EPI_QKV)
     const bf16_t* bias;    // [N] in ORIGINAL row order, or null
     const float* wscale;   // W8: per-row power-of-two scales of the FP8 fragment copy, ORIGINAL row order
+    const float* ascale;   // A8: Xf holds FP8 fragments (k_rmsnorm_row act8 = 2), one power-of-two scale per activation row
     const bf16_t* R;       // residual rows (OS_EPI_RESIDUAL)
     bf16_t* C;             // output rows (BIAS / RESIDUAL: [M, ldc]; QKV: the q buffer, row stride ldc)
     int ldr, ldc, M, N, K;
@@ -55,9 +56,13 @@ __device__ __forceinline__ os_bf16x8 os_deq_fp8x8(os_u32x2 w, float scale) {  //
     return u.v;
 }
 
-// W8: Wf is the FP8 fragment copy (8 B per lane per fragment), dequantised in registers with the row's scale
-template <int EPI, int MT, bool W8 = false>
+// W8: Wf is the FP8 fragment copy (8 B per lane per fragment), dequantised in registers with the row's scale.
+// A8 (with W8): the activations are FP8 fragments too and the product runs on v_mfma_f32_16x16x32_fp8_fp8 -- both
+// operands straight from memory into the matrix cores, half the bytes of each; the row and column scales (powers of two)
+// multiply the fp32 sums in the epilogue, exactly.
+template <int EPI, int MT, bool W8 = false, bool A8 = false>
 __global__ void __launch_bounds__(1024) k_gemm_oneshot(const ze_oneshot_args a) {
+    static_assert(!A8 || W8, "fp8 activations go with fp8 weights");
     constexpr int D = 128;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -98,19 +103,22 @@ __global__ void __launch_bounds__(1024) k_gemm_oneshot(const ze_oneshot_args a) 
     const float wsc = W8 ? a.wscale[col] : 1.0f;  // fragment row fr of this block IS output column `col`
     const bf16_t* ap[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) ap[i] = a.Xf + ((size_t)i * ns_all * 64 + lane) * 8;
+    for (int i = 0; i < MT; ++i) ap[i] = a.Xf + ((size_t)i * ns_all * 64 + lane) * (A8 ? 4 : 8);
     for (int c0 = 0; c0 < ns; c0 += 4) {
         os_bf16x8 fb[4], fa[4][MT];
-        os_u32x2 fb8[4];
+        os_u32x2 fb8[4], fa8[4][MT];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const size_t k = (size_t)(s0 + min(c0 + c, ns - 1)) * 512;  // slices past the share re-read its last one
             if constexpr (W8) fb8[c] = __builtin_nontemporal_load(reinterpret_cast<const os_u32x2*>(wp + (k >> 1)));
             else fb[c] = __builtin_nontemporal_load(reinterpret_cast<const os_bf16x8*>(wp + k));
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[c][i] = *reinterpret_cast<const os_bf16x8*>(ap[i] + k);
+            for (int i = 0; i < MT; ++i) {
+                if constexpr (A8) fa8[c][i] = *reinterpret_cast<const os_u32x2*>(ap[i] + (k >> 1));
+                else fa[c][i] = *reinterpret_cast<const os_bf16x8*>(ap[i] + k);
+            }
         }
-        if constexpr (W8) {
+        if constexpr (W8 && !A8) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) fb[c] = os_deq_fp8x8(fb8[c], wsc);
         }
@@ -118,8 +126,13 @@ __global__ void __launch_bounds__(1024) k_gemm_oneshot(const ze_oneshot_args a) 
         for (int c = 0; c < 4; ++c)
             if (c0 + c < ns) {  // wave-uniform
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[c][i], fb[c], acc[i], 0, 0, 0);
+                for (int i = 0; i < MT; ++i) {
+                    if constexpr (A8)
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(*reinterpret_cast<const long*>(&fa8[c][i]),
+                                                                             *reinterpret_cast<const long*>(&fb8[c]), acc[i], 0, 0, 0);
+                    else
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[c][i], fb[c], acc[i], 0, 0, 0);
+                }
             }
     }
 
@@ -167,6 +180,10 @@ __global__ void __launch_bounds__(1024) k_gemm_oneshot(const ze_oneshot_args a) 
         v[3] += u[3];
     }
 
+    if constexpr (A8) {  // fp8 x fp8 sums -> values: the activation row's and the weight row's powers of two
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= a.ascale[min(wid * 16 + fq * 4 + r, a.M - 1)] * wsc;
+    }
     // ---- epilogue: v[r] -> row = wid*16 + fq*4 + r, column `col`
     if (EPI != OS_EPI_QKV) {
 #pragma unroll
@@ -204,7 +221,7 @@ __global__ void __launch_bounds__(1024) k_gemm_oneshot(const ze_oneshot_args a) 
     }
 }
 
-template <int EPI, bool W8>
+template <int EPI, bool W8, bool A8>
 static void launch_oneshot_w(const ze_oneshot_args& a, hipStream_t s) {
     const int grid = a.N / 16;
 #define ZE_OS_LAUNCH(MT)                                                                                              \
@@ -212,11 +229,11 @@ static void launch_oneshot_w(const ze_oneshot_args& a, hipStream_t s) {
         const size_t lds = (size_t)(16 + 4) * MT * 64 * 16;                                                           \
         static bool attr_set = false;                                                                                 \
         if (!attr_set) {                                                                                              \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_oneshot<EPI, MT, W8>),                          \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_oneshot<EPI, MT, W8, A8>),                      \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
             attr_set = true;                                                                                          \
         }                                                                                                             \
-        hipLaunchKernelGGL((k_gemm_oneshot<EPI, MT, W8>), dim3(grid), dim3(1024), lds, s, a);                         \
+        hipLaunchKernelGGL((k_gemm_oneshot<EPI, MT, W8, A8>), dim3(grid), dim3(1024), lds, s, a);                     \
     } while (0)
     if (a.M <= 16) ZE_OS_LAUNCH(1);
     else if (a.M <= 32) ZE_OS_LAUNCH(2);
@@ -225,17 +242,19 @@ static void launch_oneshot_w(const ze_oneshot_args& a, hipStream_t s) {
 }
 template <int EPI>
 static void launch_oneshot(const ze_oneshot_args& a, hipStream_t s) {
-    if (a.wscale) launch_oneshot_w<EPI, true>(a, s);
-    else launch_oneshot_w<EPI, false>(a, s);
+    if (a.wscale && a.ascale) launch_oneshot_w<EPI, true, true>(a, s);
+    else if (a.wscale) launch_oneshot_w<EPI, true, false>(a, s);
+    else launch_oneshot_w<EPI, false, false>(a, s);
 }
 
 // C = X W^T (+ bias) (+ residual): M <= 64, N % 16 == 0, K % 32 == 0
 void ze_launch_gemm_oneshot(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,
-                            bf16_t* C, int ldc, int M, int N, int K, hipStream_t s, const float* wscale) {
+                            bf16_t* C, int ldc, int M, int N, int K, hipStream_t s, const float* wscale, const float* ascale) {
     if (M <= 0 || N <= 0) return;
     ze_oneshot_args a;
     memset(&a, 0, sizeof(a));
     a.wscale = wscale;
+    a.ascale = ascale;
     a.Xf = Xf; a.Wf = Wf; a.bias = bias; a.R = R; a.ldr = ldr; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
     if (epi == ZE_EPI_RESIDUAL) launch_oneshot<OS_EPI_RESIDUAL>(a, s);
     else launch_oneshot<OS_EPI_BIAS>(a, s);
@@ -245,11 +264,12 @@ void ze_launch_gemm_oneshot(int epi, const bf16_t* Xf, const bf16_t* Wf, const b
 void ze_launch_qkv_rope_oneshot(const bf16_t* Xf, const bf16_t* Wf_perm, const bf16_t* bias, bf16_t* q_out, int ldq, int M,
                                 int K, int heads, int kv_heads, const bf16_t* cosT, const bf16_t* sinT,
                                 const ze_seq_dev* st, const int* seq_ids, bf16_t* kcache, bf16_t* vcache,
-                                size_t cache_seq_stride, int max_ctx, hipStream_t s, const float* wscale) {
+                                size_t cache_seq_stride, int max_ctx, hipStream_t s, const float* wscale, const float* ascale) {
     if (M <= 0) return;
     ze_oneshot_args a;
     memset(&a, 0, sizeof(a));
     a.wscale = wscale;
+    a.ascale = ascale;
     a.Xf = Xf; a.Wf = Wf_perm; a.bias = bias; a.C = q_out; a.ldc = ldq; a.M = M; a.N = (heads + 2 * kv_heads) * 128; a.K = K;
     a.st = st; a.seq_ids = seq_ids; a.cosT = cosT; a.sinT = sinT; a.kcache = kcache; a.vcache = vcache;
     a.cache_seq_stride = cache_seq_stride; a.heads = heads; a.kv_heads = kv_heads; a.max_ctx = max_ctx;

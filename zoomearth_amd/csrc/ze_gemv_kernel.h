@@ -177,6 +177,43 @@ __global__ void __launch_bounds__(256) k_gemv(const ze_gemv_args a) {
                                    bf16_round(bf16hi(u[j]) * inv) * bf16hi(gw[j]));
             *reinterpret_cast<uint4*>(xs + v * 8) = make_uint4(o[0], o[1], o[2], o[3]);
         }
+        if constexpr (WB == 8) {
+            if (a.act8) {  // FP8 activations: the row's E4M3 quantisation (per-row power-of-two scale), kept as bf16 in LDS
+                typedef float f32x2_q __attribute__((ext_vector_type(2)));
+                __syncthreads();
+                float amax = 0.f;
+                for (int v = tid; v < (K >> 3); v += 256) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(xs + v * 8);
+                    const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(bf16lo(u[j])), fabsf(bf16hi(u[j]))));
+                }
+                amax = wave_max(amax);
+                if (lane == 0) red[wid] = amax;
+                __syncthreads();
+                amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+                int kx = 0;
+                if (amax > 0.f) {
+                    int ex;
+                    const float m = frexpf(amax / 448.0f, &ex);
+                    kx = (m == 0.5f) ? ex - 1 : ex;
+                }
+                const float s8 = ldexpf(1.0f, kx), inv8 = ldexpf(1.0f, -kx);
+                __syncthreads();
+                for (int v = tid; v < (K >> 3); v += 256) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(xs + v * 8);
+                    const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+                    uint32_t o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo(u[j]) * inv8, bf16hi(u[j]) * inv8, 0, false);
+                        const f32x2_q back = __builtin_amdgcn_cvt_pk_f32_fp8(pk, false);
+                        o[j] = pack_bf16x2(back.x * s8, back.y * s8);
+                    }
+                    *reinterpret_cast<uint4*>(xs + v * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
     }
     __syncthreads();
 

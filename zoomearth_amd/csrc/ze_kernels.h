@@ -44,24 +44,30 @@ struct ze_gemm_ws {
     unsigned* tickets = nullptr;
     int ticket_cap = 0;
 };
+// act8 (FP8 activations, ze_set_fp8_activations): 1 = the output row is replaced by its per-row E4M3 quantisation,
+// written back as bf16 (q * 2^k, exact); 2 (frag only, rows <= 64) = FP8 fragment-major bytes into y8 + the row scales
+// into yscale (the A operand of the fp8 MFMA kernels of the batched step)
 void ze_launch_rmsnorm(const bf16_t* x, int ldx, const bf16_t* w, bf16_t* y, int ldy, int rows, int cols, float eps,
-                       hipStream_t s, int frag = 0);
+                       hipStream_t s, int frag = 0, int act8 = 0, uint8_t* y8 = nullptr, float* yscale = nullptr);
 void ze_launch_pack_fragments(const bf16_t* W, int ldw, int n, int k, bf16_t* Wf, hipStream_t s, int rope_dim = 0);
 // One-shot skinny GEMMs of the batched decode step (ze_gemm_oneshot.hip): sixteen waves per workgroup, one memory round
 // trip per launch.  epi: ZE_EPI_NONE (+bias) or ZE_EPI_RESIDUAL; M <= 64, N % 16 == 0, K % 32 == 0.
 void ze_launch_gemm_oneshot(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,
-                            bf16_t* C, int ldc, int M, int N, int K, hipStream_t s, const float* wscale = nullptr);
+                            bf16_t* C, int ldc, int M, int N, int K, hipStream_t s, const float* wscale = nullptr,
+                            const float* ascale = nullptr);  // ascale: Xf is FP8 fragments (fp8 x fp8 MFMA)
 // qkv projection + M-RoPE + KV append in one launch; Wf_perm = ze_launch_pack_fragments(..., rope_dim = 128); q heads go
 // to q_out rows (stride ldq, original column order), k / v rows into the caches at each chain's position.
 void ze_launch_qkv_rope_oneshot(const bf16_t* Xf, const bf16_t* Wf_perm, const bf16_t* bias, bf16_t* q_out, int ldq, int M,
                                 int K, int heads, int kv_heads, const bf16_t* cosT, const bf16_t* sinT,
                                 const ze_seq_dev* st, const int* seq_ids, bf16_t* kcache, bf16_t* vcache,
-                                size_t cache_seq_stride, int max_ctx, hipStream_t s, const float* wscale = nullptr);
+                                size_t cache_seq_stride, int max_ctx, hipStream_t s, const float* wscale = nullptr,
+                                const float* ascale = nullptr);
 // batched decode on fragment-major operands (k_gemm_skinny<..., FRAG>): Xf from ze_launch_rmsnorm(frag = 1), Wf from
 // ze_launch_pack_fragments; M <= 64, N % 16 == 0, K % 32 == 0, K <= 4096 (no split-K)
 // wscale != null: Wf is the FP8 fragment copy (ze_launch_pack_fragments8) and wscale the per-row power-of-two scales
 void ze_launch_gemm_frag(int epi, const bf16_t* Xf, const bf16_t* Wf, const bf16_t* bias, const bf16_t* R, int ldr,
-                         bf16_t* C, int ldc, int M, int N, int K, hipStream_t s, const float* wscale = nullptr);
+                         bf16_t* C, int ldc, int M, int N, int K, hipStream_t s, const float* wscale = nullptr,
+                         const float* ascale = nullptr);  // ascale (gate/up at > 32 chains only): Xf is FP8 fragments
 // FP8 weights [n, ld8] row-major (ze_launch_quantize_rows) -> fragment-major: fragment (nb, ks) = 64 lanes x 8 B,
 // lane = (col % 32) / 8 * 16 + row % 16 holds columns 8 (lane / 16) .. +7 of its row; rope_dim as ze_launch_pack_fragments
 void ze_launch_pack_fragments8(const uint8_t* W8, int ld8, int n, int k, uint8_t* Wf8, hipStream_t s, int rope_dim = 0);
@@ -112,6 +118,9 @@ struct ze_gemv_args {
     const uint8_t* W8;
     const float* scale8;
     int ldw8;
+    // FP8 activations (fp8 weight stream only, norm prologue only): the normalised x is replaced by its E4M3
+    // quantisation (one power-of-two scale for the row) before the dot products -- the values k_rmsnorm(act8) writes
+    int act8;
 };
 // returns false when x[K] does not fit the LDS stage
 bool ze_launch_gemv(int epi, const ze_gemv_args& a, hipStream_t s);

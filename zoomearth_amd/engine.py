@@ -365,6 +365,11 @@ class Engine:
         """Switch the decoder's linear layers to FP8 (E4M3, per-row power-of-two scales): see ze_weights_quantize_fp8."""
         self._check(self.lib.ze_weights_quantize_fp8(self.h, self._stream()))
 
+    def set_fp8_activations(self, on: bool = True):
+        """FP8 x FP8 batched decode (qkv and gate/up inputs quantised per row): see ze_set_fp8_activations.  Needs
+        quantize_fp8() first; a weight change switches it off again."""
+        self._check(self.lib.ze_set_fp8_activations(self.h, 1 if on else 0))
+
     def op_quantize_fp8(self, w: torch.Tensor):
         """w bf16 [rows, cols] on the device (overwritten with the dequantised values) -> (u8 bits, f32 scales)."""
         rows, cols = w.shape
