@@ -751,6 +751,12 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
     //     the grid is many rounds -- the batched prefill (16 chains x 802 rows): gate/up 1487 -> 1250 us (926
     //     TFLOP/s), down 663 -> 561 (1030), qkv 165 -> 141 (955); 4096^3 1018 -- and loses to quantisation on the
     //     single-chain grids (344 tiles = 1.3 rounds at M = 802).
+    //   * tried on the 256 x 256 tile and dropped (round 2, tools/bench_gemm_shapes.py, random operands): four 32-deep
+    //     stages instead of two 64-deep ones (three K-steps in flight, twice the barriers) 5-10 % slower; the fragment
+    //     reads software-pipelined by hand across the barrier (next half-step's twelve ds_read_b128 ahead of the current
+    //     32 MFMAs) within 1 %; the loop with NO refill DMAs at all 1.30 PFLOP/s at 4096^3 against 1.17 with them: the
+    //     loop is within 10 % of its own no-memory ceiling, the rest of the gap to the 2.5 PFLOP/s peak is clock under
+    //     matrix load (zero-filled operands run 15-20 % faster than random ones: MI355X_MICROARCH.md).
     // All of them accumulate an output element in the same K order: results are bit-identical across the choices.
     // knob 7: 3 = register-staged only, 4 = always 256 x 256, 6 = always 128 x 256.
     if (BM == 128 && BN == 128 && ksplit == 1 && K % GEMM_BK == 0 && K / GEMM_BK >= 4 && ze_gemv_knobs[7] != 3 &&

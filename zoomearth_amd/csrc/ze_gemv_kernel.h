@@ -11,9 +11,14 @@
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 // weights are read exactly once per token by exactly one wave: non-temporal 16-B loads
+// (-DZE_PLAIN_WEIGHT_LOADS: measurement build with default-policy loads, tools/probe_mall.py)
 __device__ __forceinline__ uint4 load_w16(const bf16_t* p) {
+#ifdef ZE_PLAIN_WEIGHT_LOADS
+    return *reinterpret_cast<const uint4*>(p);
+#else
     const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
+#endif
 }
 
 template <int PAIRS>
