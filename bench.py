@@ -6,7 +6,8 @@ in HBM (BASELINE.json configs[1]; workload constants from SURVEY.md section 8d):
   K0  tile 5000^2 -> 512^2 bicubic view            K1/K2 smart_resize 504^2 + patchify (1296 patches)
   ViT 1296 patches -> 324 image tokens             prefill L1 = 802 tokens, decode N1 = 192 (greedy, penalty 1.05)
   scripted bbox -> 512^2 crop of the FULL-RES tile  ViT on the crop (view features reused: identical bits)
-  prefill of the 518 new tokens after the cached 802-token stage-1 prompt (L2 = 1320), decode N2 = 96
+  prefill of the new tokens after the cached stage-1 prompt (L2 = 1320: 802 cached, of the 192 re-inserted ids those
+  that equal the generated ones keep the rows decode wrote, 326 vision-block ids), decode N2 = 96
 Text ids are synthetic with the structure of the reference prompt: 21 system-turn ids and 437 instruction ids that are
 the same for every question, 18 question ids that differ.
 Weights: Qwen2.5-VL-3B shape, bf16, synthetic N(0, 0.02^2) from the repo PRNG (no checkpoint offline).
@@ -119,10 +120,16 @@ class Chain:
         # ---- stage 2: cached stage-1 prompt + re-fed stage-1 output + second vision block
         ids2 = ids1 + refeed(cfg, out1) + [cfg.vision_start_token_id] + [cfg.image_token_id] * (g_c[1] * g_c[2] // 4) + [cfg.vision_end_token_id]
         pos2, delta2 = e.rope_index(ids2, [g_v, g_c])
-        e.seq_truncate(0, len(ids1))
-        e.prefill(0, ids2[len(ids1):], emb_c, pos2[:, len(ids1):], delta2, want_logits=False)
+        # the rows of the generated tokens the prompt repeats id for id stay too (all but the last one sampled, which never
+        # went through the model), as in the scheduler (ChainScheduler.reuse_generated, the path of src/eval/infer.py)
+        keep = len(ids1)
+        while keep - len(ids1) < len(out1) - 1 and ids2[keep] == out1[keep - len(ids1)]:
+            keep += 1
+        e.seq_truncate(0, keep)
+        e.prefill(0, ids2[keep:], emb_c, pos2[:, keep:], delta2, want_logits=False)
         e.mark_seen(0, ids2)
         out2 = e.generate(0, N2, repetition_penalty=PENALTY, ignore_eos=True, use_graph=self.use_graph, sync_every=N2)
+        self.kept_generated = keep - len(ids1)   # rows of generated tokens kept instead of prefilled again
         return out1, out2, len(ids1), len(ids2)
 
 
@@ -641,7 +648,9 @@ def main():
                        "batch": B,
                        "tile": [args.tile, args.tile], "L1": lens[0], "L2": lens[1], "N1": lens[2], "N2": lens[3],
                        "repetition_penalty": PENALTY, "hip_graph": not args.no_graph,
-                       "reuse": "stage-1 prompt KV and view features reused in stage 2 (bit-identical)",
+                       "reuse": ("stage-1 prompt KV and view features reused in stage 2 (bit-identical); the KV rows of the "
+                                 "generated tokens that stage 2 re-inserts id for id are kept as the decode steps wrote them"),
+                       "stage2_rows_kept_from_decode": (chain.kept_generated if B == 1 else None),
                        "parallelism": f"dp{world}", "weight_broadcast_s": round(bcast_s, 4)},
             "weight_broadcast_s": round(bcast_s, 4),
             "tile_upload_ms": round(tile_upload_ms, 3),
@@ -671,7 +680,10 @@ def main():
                 # per-phase roofline fractions: algorithmic work of the as-built question (stage-1 prompt KV
                 # and view features reused) over the measured phase time, against the dense bf16 MFMA peak / the HBM peak
                 pm = line["phase_ms_per_question"]
-                f_vit, f_pre = 3.41e12, 1320 * 5.549e9 + 0.257e12          # FLOP per question
+                # (prefill: the rows actually prefilled -- the stage-1 prompt and what stage 2 appends beyond the kept rows)
+                kept = lens[0] + chain.kept_generated
+                f_vit = 3.41e12                                            # FLOP per question
+                f_pre = (lens[0] + lens[1] - kept) * 5.549e9 + 36 * 4 * 2048 * (lens[0] ** 2 + lens[1] ** 2 - kept ** 2) / 2
                 b_dec = (N1 + N2) * 6.171e9 + 36864.0 * (N1 * (lens[0] + N1 / 2) + N2 * (lens[1] + N2 / 2))  # bytes per question
                 line["roofline_phases"] = {
                     "vit": {"bound": "mfma", "achieved_TFLOPs": f_vit / (pm["vit"] * 1e-3) / 1e12, "peak_TFLOPs": 2500.0,

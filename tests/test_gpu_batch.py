@@ -284,3 +284,35 @@ def test_copied_prompt_prefix_is_bit_identical_to_a_full_prefill(eng):
         e.seq_copy_prefix(1, 1, 10)
     with pytest.raises(Exception):
         e.seq_copy_prefix(1, 0, 10 ** 6)
+
+
+def test_follow_up_on_decode_written_rows_matches_the_oracle(eng):
+    """The scheduler's reuse_generated: a follow-up prompt that repeats the ids its predecessor generated keeps their K/V
+    rows (written by the batched decode steps) and prefills only the tail.  The logits at the end of that tail against the
+    fp32 oracle of the whole sequence, with the oracle's own bf16-vs-fp32 error as the yardstick (x2) -- the same bar as a
+    prefill of everything -- and close to the logits of such a full prefill."""
+    e = eng
+    prompt, gen_n = text_ids(61, 90), 12
+    prefill_text(e, 0, prompt)
+    p = e.gen_params(ignore_eos=True)
+    e.chain_begin(0, p)
+    e.decode_burst([0], gen_n - 1, p)                       # gen_n tokens sampled; gen_n - 1 of them went through the model
+    gen = [int(t) for t in e.chain_tokens(0, gen_n)]
+    assert len(gen) == gen_n and e.seq_len(0) == len(prompt) + gen_n - 1
+    tail = text_ids(62, 7)
+    full = prompt + gen + tail
+    pos, delta = e.rope_index(full, [])
+    keep = len(prompt) + gen_n - 1
+    e.seq_truncate(0, keep)
+    reused = e.prefill(0, full[keep:], None, pos[:, keep:], delta).cpu().numpy()
+    e.seq_reset(1)
+    fresh = e.prefill(1, full, None, pos, delta).cpu().numpy()
+    cfg = Q.tiny_config()
+    w = Q.synthetic_weights(cfg, **CHAIN_W)
+    ref32 = Q.Qwen25VLOracle(cfg, w, "fp32").prefill(full)
+    yard = float(np.abs(Q.Qwen25VLOracle(cfg, w, "bf16").prefill(full) - ref32).max())
+    err_reused, err_fresh = float(np.abs(reused - ref32).max()), float(np.abs(fresh - ref32).max())
+    print(f"follow-up on decode-written rows: |reused - fp32| = {err_reused:.4f}, |full prefill - fp32| = {err_fresh:.4f}, "
+          f"oracle bf16-vs-fp32 = {yard:.4f}")
+    assert err_reused <= 2.0 * yard and err_fresh <= 2.0 * yard
+    assert float(np.abs(reused - fresh).max()) <= 2.0 * yard

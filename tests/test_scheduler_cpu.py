@@ -54,7 +54,7 @@ class StubEngine:
         c = self.chains[slot]
         assert keep <= len(c["ids"]) + max(len(c["out"]) - 1, 0)
         self.log.append(("truncate", slot, keep))
-        c["ids"], c["out"], c["fin"] = c["ids"][:keep], [], False
+        c["ids"], c["out"], c["fin"] = (c["ids"] + c["out"][:-1])[:keep], [], False   # rows of fed tokens stay
 
     def prefill_batch(self, slots, ids_l, emb_l, pos_l, dl):
         self.log.append(("prefill", list(slots), [len(x) for x in ids_l]))
@@ -159,16 +159,24 @@ def test_continuous_batching_more_requests_than_slots(slots):
         assert order.index(1) < order.index(0) or order.index(3) < order.index(2)
 
 
-def test_two_stage_follow_up_reuses_slot_and_prefix_and_view_features():
+@pytest.mark.parametrize("mode", ["generated", "prompt", "edited"])
+def test_two_stage_follow_up_reuses_slot_and_prefix_and_view_features(mode):
+    """mode "generated": the follow-up keeps the rows of the prompt AND of the generated tokens it repeats (all but the last
+    one sampled, which never went through the model); "prompt": reuse_generated=False keeps the prompt rows only;
+    "edited": the re-inserted output differs from the generated ids at its second word -- reuse stops there."""
     model = make_model(max_seqs=2)
     e = model.engine
-    sched = ChainScheduler(model, Proc(), burst=2)
+    sched = ChainScheduler(model, Proc(), burst=2, reuse_generated=mode != "prompt")
     results = {}
 
     def chain(q, first, view, crop):
         p1 = f"{first} <img> 60"
 
         def stage1(req, toks, text):
+            if mode == "edited":
+                words = text.split()
+                words[1] = "99"
+                text = " ".join(words)
             p2 = p1 + " " + text + " <img>"
 
             def stage2(req2, toks2, text2):
@@ -184,12 +192,15 @@ def test_two_stage_follow_up_reuses_slot_and_prefix_and_view_features():
     for q, first in ((0, 21), (1, 23), (2, 25)):
         s1, s2, t1, t2, n2 = results[q]
         assert s1 == s2                                      # stage 2 continued on the slot of stage 1
-        assert t1 == " ".join(str(t) for t in expected(first, 4))
+        if mode != "edited":
+            assert t1 == " ".join(str(t) for t in expected(first, 4))
         assert n2 == 6 + 4 + 4                               # stage-1 prompt + its 4 output words + second image
+    kept = {"generated": 6 + 3, "prompt": 6, "edited": 6 + 1}[mode]   # cached stage-1 prompt = 1 + 4 + 1 tokens
     trunc = [x for x in e.log if x[0] == "truncate"]
-    assert len(trunc) == 3 and all(t[2] == 6 for t in trunc)   # cached stage-1 prompt (1 + 4 + 1 tokens) kept
+    assert len(trunc) == 3 and all(t[2] == kept for t in trunc)
     pre = [x for x in e.log if x[0] == "prefill"]
-    assert sorted(n for p in pre for n in p[2]) == [6, 6, 6, 8, 8, 8]   # stage 2 prefills only the appended tokens
+    assert sorted(n for p in pre for n in p[2]) == sorted([6, 6, 6] + [14 - kept] * 3)   # stage 2 prefills only what is not cached
+    assert sched.stats["reused_generated_rows"] == 3 * (kept - 6)
     vit = [g for x in e.log if x[0] == "vit" for g in x[1]]
     assert len(vit) == 5                                     # viewA once, viewB once, three crops
 

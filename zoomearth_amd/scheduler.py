@@ -50,7 +50,7 @@ class ChainScheduler:
     def __init__(self, model, processor, do_sample: bool = False, temperature=None, repetition_penalty=None, seed: int = 0,
                  burst: int = 8, max_batch: Optional[int] = None, ignore_eos: bool = False, use_graph: bool = True,
                  feature_cache: int = 64, min_admit: int = 1, max_wait_bursts: int = 2, share_prefix: bool = True,
-                 min_shared: int = 64):
+                 min_shared: int = 64, reuse_generated: bool = True):
         self.model, self.processor, self.engine = model, processor, model.engine
         gc = model.generation_config
         pen = repetition_penalty if repetition_penalty is not None else (getattr(gc, "repetition_penalty", 1.0) or 1.0)
@@ -72,15 +72,21 @@ class ChainScheduler:
         # others, and all tails go through one pass (pass B).  Bit-identical to prefilling every prompt in full.
         self.share_prefix = bool(share_prefix)
         self.min_shared = max(1, int(min_shared))
+        # Follow-ups keep the K/V rows of the tokens their predecessor generated while the new prompt repeats those ids
+        # (exact in real arithmetic; in bf16 the rows come from the decode kernels instead of the prefill kernels, both
+        # held to the same tolerance against the oracle).  False: only the predecessor's PROMPT rows are kept, which is
+        # bit-identical to prefilling the new prompt in full.
+        self.reuse_generated = bool(reuse_generated)
         self.burst = max(1, int(burst))
         self.max_batch = min(int(max_batch or self.engine.max_seqs), self.engine.max_seqs)
         self.waiting = deque()
         self.live = OrderedDict()          # slot -> _Live
-        self.parked = {}                   # slot -> (ids tuple, image keys): finished chains whose slot waits for a follow-up
+        self.parked = {}                   # slot -> (prompt ids, image keys, generated ids with K/V rows): finished chains whose slot waits for a follow-up
         self.free = list(range(self.max_batch))[::-1]
         self._features = OrderedDict()     # image key -> ViT features (LRU)
         self._feature_cap = feature_cache
-        self.stats = dict(bursts=0, steps=0, chain_steps=0, prefill_rows=0, admitted=0, vit_calls=0, shared_rows=0)
+        self.stats = dict(bursts=0, steps=0, chain_steps=0, prefill_rows=0, admitted=0, vit_calls=0, shared_rows=0,
+                          reused_generated_rows=0)
         model._chains.clear()              # the scheduler owns every chain slot while it runs
 
     # ------------------------------------------------------------------ queue
@@ -187,7 +193,7 @@ class ChainScheduler:
         for slot, l in self.live.items():
             if l.keys and slot not in taken:
                 donors.setdefault(l.keys[0], []).append((slot, l.ids, l.keys))
-        for slot, (pids, pkeys) in self.parked.items():
+        for slot, (pids, pkeys, _gen) in self.parked.items():
             if pkeys:
                 donors.setdefault(pkeys[0], []).append((slot, pids, pkeys))
         groups = OrderedDict()
@@ -219,15 +225,24 @@ class ChainScheduler:
         return anchors
 
     def _reusable(self, slot, ids, keys):
-        """(cached prefix length, images inside it) when the slot's parked chain is a strict prefix of `ids`."""
+        """(cached prefix length, images inside it) when the slot's parked chain is a strict prefix of `ids`.  With
+        `reuse_generated` the prefix extends over the tokens the parked chain GENERATED for as long as the new prompt
+        repeats them id for id (stage 2 re-inserts the stage-1 output: src/eval/infer.py:222): their K/V rows were written
+        by the decode steps and are kept instead of being prefilled again."""
         rec = self.parked.pop(slot, None)
         if rec is None:
             return 0, 0
-        pids, pkeys = rec
+        pids, pkeys, gen = rec
         n = len(pids)
+        cfg = self.model.config
         if 0 < n < len(ids) and tuple(ids[:n]) == pids and tuple(keys[: len(pkeys)]) == pkeys \
-                and ids[n] != self.model.config.image_token_id and all(k is not None for k in pkeys):
-            return n, len(pkeys)
+                and ids[n] != cfg.image_token_id and all(k is not None for k in pkeys):
+            special = (cfg.image_token_id, getattr(cfg, "vision_start_token_id", None), getattr(cfg, "vision_end_token_id", None))
+            m = 0
+            while m < len(gen) and n + m < len(ids) - 1 and ids[n + m] == gen[m] and gen[m] not in special:
+                m += 1
+            self.stats["reused_generated_rows"] += m
+            return n + m, len(pkeys)
         return 0, 0
 
     def _encode(self, todo, needed=()) -> None:
@@ -346,7 +361,9 @@ class ChainScheduler:
                 raise
         if follow is not None:  # continues on this slot; its cached prompt is reusable
             follow.slot = slot
-            self.parked[slot] = (l.ids, l.keys)
+            # ... and so are the rows of the generated tokens that went through the model (all but the last one sampled)
+            cached = min(self.engine.seq_len(slot) - len(l.ids), len(req.tokens) - 1) if self.reuse_generated else 0
+            self.parked[slot] = (l.ids, l.keys, tuple(req.tokens[:max(0, cached)]))
             self.waiting.appendleft(follow)
         else:
             self.free.append(slot)
