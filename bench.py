@@ -207,8 +207,8 @@ def batch_step(engine, tiles, q0: int, B: int, stats=None, use_graph=True, slots
     model = Model64(engine)
     proc = SynthProcessor(engine.config, engine)
     sched = ChainScheduler(model, proc, do_sample=False, repetition_penalty=PENALTY, ignore_eos=True, burst=16,
-                           use_graph=use_graph, min_admit=int(os.environ.get("ZE_MIN_ADMIT", "16")),
-                           max_wait_bursts=int(os.environ.get("ZE_MAX_WAIT", "2")), max_batch=slots)
+                           use_graph=use_graph, min_admit=int(os.environ.get("ZE_MIN_ADMIT", str(max(1, (slots or B) // 2)))),
+                           max_wait_bursts=int(os.environ.get("ZE_MAX_WAIT", "6")), max_batch=slots)
     done = {}
     views = {}
     for b in range(B):
@@ -510,7 +510,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1,
                     help="1 = BASELINE configs[1] is the line's value (plus a one-step batch64 object); B > 1 = configs[2] with "
                          "B chains is the line's value")
-    ap.add_argument("--no-batch64", action="store_true", help="skip the batch64 object of the default line")
+    ap.add_argument("--no-batch64", action="store_true", help="skip the batch64 and stream256 objects of the default line")
+    ap.add_argument("--no-stream256", action="store_true", help="skip the stream256 object of the default line")
     ap.add_argument("--spawn-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     args.fp8 = args.fp8 or args.fp8_act
@@ -546,7 +547,9 @@ def main():
     BB = 64 if want64 else B          # chains of the batched workload (0 = none)
     n_tiles = max(1, round(BB * 6 / 64)) if BB > 1 else 1
     cfg = ModelConfig.zoomearth_3b() if args.model == "3b" else ModelConfig.qwen25vl_7b()
-    e = Engine(cfg, device=local, max_seqs=max(1, BB), max_ctx=2048, max_patches=max(4096, 1400 * min(BB, 40)),
+    want256 = want64 and not args.no_stream256
+    SLOTS = int(os.environ.get("ZE_STREAM_SLOTS", "256"))  # chain slots of the stream256 object (other values: measurements)
+    e = Engine(cfg, device=local, max_seqs=(SLOTS if want256 else max(1, BB)), max_ctx=2048, max_patches=max(4096, 1400 * min(BB, 40)),
                max_prefill_rows=(16 * 832 if BB > 1 else 0), max_tile_side=max(args.tile, 1024))
     e.fill_synthetic(seed=0, std=0.02)
     for kv in os.environ.get("ZE_TUNE", "").split(","):  # measurement-only A/B knobs, e.g. ZE_TUNE=2:64
@@ -738,6 +741,33 @@ def main():
                 "phase_ms": {k: round(v, 2) for k, v in ph64.items()},
                 "decode_ms_per_step": round(ph64["decode"] / dec_steps, 3), "scheduler": st,
                 "roofline": batch_roofline(64),
+            }
+        if want256:
+            # BASELINE configs[3], one GPU's share of the LRS-GRO stream (9734 questions over 8 GPUs): the same scheduler with
+            # 256 chain slots -- the slot count is the engine's choice there, not part of the workload -- fed 1024 questions
+            # (16 passes over the 6 tiles).  Beyond 64 chains the decode step leaves the fragment kernels for the tiled
+            # GEMMs; a chain's result is batch-invariant within each of the two regimes.
+            st2 = {}
+            NQ2 = 1024
+            batch_step(e, tiles64, 7_500_000, SLOTS, slots=SLOTS)
+            e.phase_timers(enable=True, reset=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            batch_step(e, tiles64, 7_600_000, NQ2, st2, slots=SLOTS)
+            torch.cuda.synchronize()
+            dt256 = time.perf_counter() - t0
+            ph256 = e.phase_timers(enable=False)
+            lens256 = st2.pop("lens")
+            line["stream256"] = {
+                "workload": ("BASELINE configs[3], one GPU's share: a stream of 1024 questions (sixteen passes over 6 tiles) through "
+                             "the continuous-batching scheduler with 256 chain slots; ragged N1 / N2, prompt prefixes shared per "
+                             "tile, stage 2 continues on the slot of stage 1"),
+                "value": NQ2 / dt256, "unit": "questions/s", "questions": NQ2, "chain_slots": SLOTS, "tiles": 6,
+                "seconds": round(dt256, 3),
+                "mean_N1": float(np.mean([l[1] for l in lens256])), "mean_N2": float(np.mean([l[3] for l in lens256])),
+                "phase_ms": {k: round(v, 2) for k, v in ph256.items()},
+                "decode_ms_per_step": round(ph256["decode"] / max(1, st2.get("steps", 1)), 3),
+                "mean_chains_per_step": round(st2.get("chain_steps", 0) / max(1, st2.get("steps", 1)), 1), "scheduler": st2,
             }
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             line["cpu_baseline"] = measure_cpu_baseline(args.cpu_baseline)

@@ -73,7 +73,7 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
     # the rank's questions arrive grouped by tile: decode the next tile while the current one is being questioned
     tiles = TilePrefetcher([tile_path(n) for n in dl.image_names()], model.engine)
     sched = ChainScheduler(model, processor, do_sample=do_sample, temperature=0.01 if do_sample else None, burst=8,
-                           min_admit=max(1, batch_size // 4), max_wait_bursts=2)
+                           min_admit=max(1, batch_size // 2), max_wait_bursts=12)
     done, next_out = {}, [0]
     bar = tqdm(total=len(dl), desc="Evaluating")
 
@@ -122,7 +122,8 @@ if __name__ == "__main__":
     parser.add_argument("--dataset", type=str, default="./LRS_GRO/test")
     parser.add_argument("--image_dir", type=str, default="./image/")
     parser.add_argument("--max_new_tokens", type=int, default=1024)
-    parser.add_argument("--batch_size", type=int, default=BATCH_SIZE, help="question chains advanced together per GPU")
+    parser.add_argument("--batch_size", type=int, default=BATCH_SIZE, help="question chains advanced together per GPU (up to 64: a chain's output does not depend on the "
+                                                                           "batch; 256 gives about 1.5x the questions/s, DESIGN.md 7b)")
     parser.add_argument("--max_ctx", type=int, default=4096, help="tokens per chain (KV capacity)")
     parser.add_argument("--greedy", action="store_true", help="arg-max instead of the reference's T=0.01 sampling")
     args = parser.parse_args()

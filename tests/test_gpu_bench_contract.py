@@ -53,5 +53,10 @@ def test_bench_line_contract():
     rb = b["roofline"]
     assert rb["bound"] == "hbm" and rb["chains"] == 64 and "batched decode" in rb["kernel"]
     assert abs(rb["frac"] - rb["achieved"] / rb["peak"]) < 1e-9 and 0.05 < rb["frac"] < 1.0
+    # BASELINE configs[3], one GPU's share of the stream: 1024 questions through 256 chain slots
+    w = d["stream256"]
+    assert w["questions"] == 1024 and w["chain_slots"] == 256 and w["scheduler"]["admitted"] == 2048
+    assert abs(w["value"] - 1024 / w["seconds"]) < 1e-2 * w["value"] and w["value"] > b["value"]
+    assert 64 < w["mean_chains_per_step"] <= 256
     ph = d["roofline_phases"]
     assert ph["decode"]["bound"] == "hbm" and ph["vit"]["bound"] == "mfma" and 0 < ph["question"]["frac"] < 1

@@ -1098,6 +1098,11 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
         // attention merge and the SwiGLU epilogue then write their outputs in that layout too
         const bool fr = L.qkv.wf && n <= 64 && ze_gemv_knobs[5] != 1;
         const ze_gemm_ws ws = e->gemm_ws();
+        // Beyond 64 chains (no fragment kernels): the prefill tile policy for qkv / o / gate-up / lm_head (one pass over K
+        // per output tile, no split: at 256 chains qkv 12.0 against 24.7 us on the split-K streaming launcher, o 11.9 /
+        // 17.7, gate/up 43.6 / 56.9, lm_head 250 / 336; tools/bench_midm.py), the streaming launcher for down (32.4 / 44.3).
+        // Every one of them sums an output's K range in an order fixed by (N, K): batch invariance within this path.
+        const bool tiled = n > 64 && ze_gemv_knobs[13] != 1;
         // FP8 activations: the fragment path with FP8 weight fragments takes the row as FP8 fragments + a scale (fp8 x
         // fp8 MFMA); any other path takes the same values as bf16
         const bool a8q = e->fp8_act && fr && L.qkv.wf8 && ze_gemv_knobs[10] != 1;
@@ -1111,7 +1116,8 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
                                        e->kc(li, 0), e->vc(li, 0), seq_stride, c.max_ctx, s, w8 ? L.qkv.scale8 : nullptr,
                                        a8q ? e->ty8_scale : nullptr);
         } else {
-            ze_launch_gemm_stream(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, ws, s);
+            if (tiled) ze_launch_gemm(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, nullptr, n, nqkv, H, s);
+            else ze_launch_gemm_stream(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, ws, s);
             ze_launch_rope_kv_batch(e->tqkv, n, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(li, 0),
                                     e->vc(li, 0), seq_stride, c.max_ctx, s);
         }
@@ -1122,6 +1128,8 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
                                    nq, s, w8 ? L.o.scale8 : nullptr);
         } else if (fr)
             ze_launch_gemm_frag(ZE_EPI_RESIDUAL, e->to, L.o.wf, nullptr, e->th, H, e->th, H, n, H, nq, s);
+        else if (tiled)
+            ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, n, H, nq, s);
         else
             ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, n, H, nq, ws, s);
         ze_launch_rmsnorm(e->th, H, L.post_norm, e->ty, H, n, H, c.rms_eps, s, fr ? 1 : 0, a8g ? 2 : (e->fp8_act ? 1 : 0), e->ty8,
@@ -1131,7 +1139,10 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
             ze_launch_gemm_frag(ZE_EPI_SWIGLU, a8g ? (const bf16_t*)e->ty8 : e->ty, w8 ? (const bf16_t*)L.gate_up.wf8 : L.gate_up.wf,
                                 nullptr, nullptr, 0, e->ta, e->text_ipad, n, 2 * e->text_ipad, H, s,
                                 w8 ? L.gate_up.scale8 : nullptr, a8g ? e->ty8_scale : nullptr);
-        } else
+        } else if (tiled)
+            ze_launch_gemm(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad, nullptr, n,
+                           2 * e->text_ipad, H, s);
+        else
             ze_launch_gemm_stream(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad, n,
                                   2 * e->text_ipad, H, ws, s);
         // the down projection (K = 11008) stays on the split-K ring: the fragment kernel with K split over 8 x 32
@@ -1145,7 +1156,10 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
         const bool w8 = e->lm_head8.wf8 && ze_gemv_knobs[10] != 1;
         ze_launch_gemm_frag(ZE_EPI_F32, e->ty, w8 ? (const bf16_t*)e->lm_head8.wf8 : e->lm_head_f, nullptr, nullptr, 0,
                             (bf16_t*)e->blogits, c.vocab, n, c.vocab, H, s, w8 ? e->lm_head8.scale8 : nullptr);
-    } else
+    } else if (n > 160 && ze_gemv_knobs[13] != 1)  // (lm_head: 200 / 260 / 336 us streaming against 241 / 243 / 250 tiled at 128 / 192 / 256 chains)
+        ze_launch_gemm(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, nullptr, n, c.vocab,
+                       H, s);
+    else
         ze_launch_gemm_stream(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n,
                               c.vocab, H, e->gemm_ws(), s);
     ze_launch_sample_batch(e->blogits, c.vocab, e->seen, penalty, e->st_dev, e->bseq, n, e->eos_dev, c.n_eos,
@@ -1658,22 +1672,26 @@ extern "C" int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters
         const int li = it % c.layers;
         const ze_text_layer& L = e->tl[li];
         const bool fr = L.qkv.wf && n <= 64;
+        const bool tiled = n > 64 && ze_gemv_knobs[13] != 1;  // (as enqueue_decode_batch)
         const ze_gemm_ws ws = e->gemm_ws();
         switch (which) {
             case 0:
                 if (fr) ze_launch_qkv_rope_oneshot(e->ty, L.qkv.wf, L.qkv.bias, e->tqkv, nqkv, n, H, c.heads, c.kv_heads, e->cosT, e->sinT,
                                                    e->st_dev, e->bseq, e->kc(li, 0), e->vc(li, 0), seq_stride, c.max_ctx, s);
+                else if (tiled) ze_launch_gemm(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, nullptr, n, nqkv, H, s);
                 else ze_launch_gemm_stream(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, ws, s);
                 bytes = (double)nqkv * H * 2;
                 break;
             case 1:
                 if (fr && ze_gemv_knobs[9] != 1) ze_launch_gemm_oneshot(ZE_EPI_RESIDUAL, e->to, L.o.wf, nullptr, e->th, H, e->th, H, n, H, nq, s);
                 else if (fr) ze_launch_gemm_frag(ZE_EPI_RESIDUAL, e->to, L.o.wf, nullptr, e->th, H, e->th, H, n, H, nq, s);
+                else if (tiled) ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, n, H, nq, s);
                 else ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, n, H, nq, ws, s);
                 bytes = (double)H * nq * 2;
                 break;
             case 2:
                 if (fr) ze_launch_gemm_frag(ZE_EPI_SWIGLU, e->ty, L.gate_up.wf, nullptr, nullptr, 0, e->ta, e->text_ipad, n, 2 * e->text_ipad, H, s);
+                else if (tiled) ze_launch_gemm(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad, nullptr, n, 2 * e->text_ipad, H, s);
                 else ze_launch_gemm_stream(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad, n, 2 * e->text_ipad, H, ws, s);
                 bytes = 2.0 * c.intermediate * H * 2;
                 break;
@@ -1683,6 +1701,7 @@ extern "C" int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters
                 break;
             case 4:
                 if (e->lm_head_f && n <= 64) ze_launch_gemm_frag(ZE_EPI_F32, e->ty, e->lm_head_f, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab, H, s);
+                else if (tiled && n > 160) ze_launch_gemm(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, nullptr, n, c.vocab, H, s);
                 else ze_launch_gemm_stream(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab, H, ws, s);
                 bytes = (double)c.vocab * H * 2;
                 break;
