@@ -58,9 +58,17 @@ def write_tokenizer(path):
 
 @pytest.fixture(scope="module")
 def workdir(tmp_path_factory):
+    return build_workdir(tmp_path_factory.mktemp("lrsgro"), 11)
+
+
+@pytest.fixture(scope="module")
+def workdir_wide(tmp_path_factory):
+    return build_workdir(tmp_path_factory.mktemp("lrsgro_wide"), 90)
+
+
+def build_workdir(d, n_questions):
     from datasets import Dataset
     from PIL import Image
-    d = tmp_path_factory.mktemp("lrsgro")
     ck = d / "ckpt"
     os.makedirs(ck)
     hf_cfg = {"vision_config": dict(depth=4, hidden_size=160, num_heads=2, intermediate_size=220, out_hidden_size=512,
@@ -81,8 +89,8 @@ def workdir(tmp_path_factory):
     for t, (w, h) in enumerate(sizes):
         Image.fromarray(prng.synthetic_tile(300 + t, h, w)).save(d / "image" / f"tile{t}.png")
     rows = []
-    for q in range(11):
-        t = (0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 0)[q]  # grouped by tile, with one straggler at the end
+    for q in range(n_questions):
+        t = (0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 0)[q % 11]  # grouped by tile, with one straggler at the end
         rows.append({"question": " ".join(word(int(v)) for v in prng.uniform_ints(500 + q, 4 + q % 3, 0, 1999)),
                      "image_name": f"some/dir/tile{t}.png", "question_id": 1000 + q, "ground_truth": word(3 * q),
                      "category": "cat%d" % (q % 2), "type": ("count", "object", "relation")[q % 3],
@@ -163,3 +171,22 @@ def test_two_ranks_shard_by_tile_and_merge_to_the_single_rank_result(workdir):
     tiles = [{r["image"] for r in p} for p in parts]
     assert not (tiles[0] & tiles[1])                     # a tile never splits across ranks
     assert merged == sorted(single, key=lambda r: r["question_id"])
+
+
+def test_infer_with_more_than_64_chains(workdir_wide):
+    """--batch_size 96: the decode steps run beyond the 64-row fragment kernels (tiled GEMMs, stand-alone rope kernel) and
+    fall back into them as the stream drains.  Every question is answered in dataset order with the reference schema, the
+    run is reproducible, and it agrees with the 8-chain run wherever bf16 rounding does not flip a token (the two regimes
+    sum in different orders: DESIGN.md 7b) -- with these random weights most records."""
+    d, rows = workdir_wide
+    base = [sys.executable, "src/infer.py", "--model_name", "ckpt", "--max_new_tokens", "10", "--max_ctx", "1024", "--greedy"]
+    run(base + ["--exp_name", "w96a_", "--batch_size", "96"], d)
+    run(base + ["--exp_name", "w96b_", "--batch_size", "96"], d)
+    run(base + ["--exp_name", "w8_", "--batch_size", "8"], d)
+    a, b, n = load(d / "results" / "w96a_0.jsonl"), load(d / "results" / "w96b_0.jsonl"), load(d / "results" / "w8_0.jsonl")
+    assert len(a) == len(rows) == len(n) and a == b
+    for got, row in zip(a, rows):
+        assert list(got.keys()) == KEYS and got["question_id"] == row["question_id"] and got["stage1"]
+    same = sum(1 for x, y in zip(a, n) if x == y)
+    print(f"96 chains vs 8 chains: {same} of {len(a)} records identical")
+    assert same >= len(a) // 2
