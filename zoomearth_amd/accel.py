@@ -43,7 +43,10 @@ class Accelerator:
         self.num_processes = int(os.environ.get("WORLD_SIZE", "1"))
         self.mixed_precision = mixed_precision
         import torch
-        self.device = torch.device("cuda", self.local_process_index)
+        # more local ranks than GPUs is allowed (ranks r and r + n_gpus share a GPU): two ranks of 128 chains interleave
+        # their prefill and decode phases on one GPU and answer 52.5 questions/s where one rank of 256 chains answers 47.6
+        # (DESIGN.md section 8).  Every rank then loads the checkpoint itself: RCCL takes one rank per GPU.
+        self.device = torch.device("cuda", self.local_process_index % max(1, torch.cuda.device_count()))
         self._pg = False
 
     @property
