@@ -228,13 +228,16 @@ void ze_launch_rmsnorm(const bf16_t* x, int ldx, const bf16_t* w, bf16_t* y, int
     if (rows == 0) return;
     // frag != 0 marks the batched decode step (<= 64 rows): its rows take the one-workgroup-per-row form, so that a
     // chain's normalised row is the same bits whatever the batch; every other caller keeps the wave-per-row kernel
-    if (frag && rows <= 64 && cols <= 8192 && cols % 8 == 0) {
-        const int nv = cols >> 3;
-        if (nv <= 256) k_rmsnorm_row<1><<<rows, 256, 0, s>>>(x, ldx, w, y, ldy, cols, eps, frag, act8, y8, yscale);
-        else if (nv <= 512) k_rmsnorm_row<2><<<rows, 256, 0, s>>>(x, ldx, w, y, ldy, cols, eps, frag, act8, y8, yscale);
-        else k_rmsnorm_row<4><<<rows, 256, 0, s>>>(x, ldx, w, y, ldy, cols, eps, frag, act8, y8, yscale);
+    // frag == 2: a batched decode step beyond the fragment kernels (row-major output, any number of chains): the same
+    // one-workgroup-per-row kernel (5.5 -> 3.6 us at 256 rows x 2048)
+    if (((frag == 1 && rows <= 64) || frag == 2) && cols <= 8192 && cols % 8 == 0) {
+        const int nv = cols >> 3, fm = frag == 1 ? 1 : 0;
+        if (nv <= 256) k_rmsnorm_row<1><<<rows, 256, 0, s>>>(x, ldx, w, y, ldy, cols, eps, fm, act8, y8, yscale);
+        else if (nv <= 512) k_rmsnorm_row<2><<<rows, 256, 0, s>>>(x, ldx, w, y, ldy, cols, eps, fm, act8, y8, yscale);
+        else k_rmsnorm_row<4><<<rows, 256, 0, s>>>(x, ldx, w, y, ldy, cols, eps, fm, act8, y8, yscale);
         return;
     }
+    if (frag == 2) frag = 0;
     k_rmsnorm<<<ze_cdiv(rows, 4), 256, 0, s>>>(x, ldx, w, y, ldy, rows, cols, eps, frag, act8 ? 1 : 0);
 }
 

@@ -1107,7 +1107,7 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
         // fp8 MFMA); any other path takes the same values as bf16
         const bool a8q = e->fp8_act && fr && L.qkv.wf8 && ze_gemv_knobs[10] != 1;
         const bool a8g = e->fp8_act && fr && L.gate_up.wf8 && ze_gemv_knobs[10] != 1;
-        ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, n, H, c.rms_eps, s, fr ? 1 : 0, a8q ? 2 : (e->fp8_act ? 1 : 0), e->ty8,
+        ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, n, H, c.rms_eps, s, fr ? 1 : 2, a8q ? 2 : (e->fp8_act ? 1 : 0), e->ty8,
                           e->ty8_scale);
         if (fr) {  // projection + M-RoPE + KV append in one launch (the fragment copy of qkv is packed for it)
             const bool w8 = L.qkv.wf8 && ze_gemv_knobs[10] != 1;  // FP8 fragment stream (quantised engine)
@@ -1132,7 +1132,7 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
             ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, n, H, nq, s);
         else
             ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, n, H, nq, ws, s);
-        ze_launch_rmsnorm(e->th, H, L.post_norm, e->ty, H, n, H, c.rms_eps, s, fr ? 1 : 0, a8g ? 2 : (e->fp8_act ? 1 : 0), e->ty8,
+        ze_launch_rmsnorm(e->th, H, L.post_norm, e->ty, H, n, H, c.rms_eps, s, fr ? 1 : 2, a8g ? 2 : (e->fp8_act ? 1 : 0), e->ty8,
                           e->ty8_scale);
         if (fr) {
             const bool w8 = L.gate_up.wf8 && ze_gemv_knobs[10] != 1;
@@ -1151,7 +1151,7 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
                               e->text_ipad, ws, s);
     }
     const bool fl = e->lm_head_f && n <= 64 && ze_gemv_knobs[5] != 1;
-    ze_launch_rmsnorm(e->th, H, e->final_norm, e->ty, H, n, H, c.rms_eps, s, fl ? 1 : 0);
+    ze_launch_rmsnorm(e->th, H, e->final_norm, e->ty, H, n, H, c.rms_eps, s, fl ? 1 : 2);
     if (fl) {
         const bool w8 = e->lm_head8.wf8 && ze_gemv_knobs[10] != 1;
         ze_launch_gemm_frag(ZE_EPI_F32, e->ty, w8 ? (const bf16_t*)e->lm_head8.wf8 : e->lm_head_f, nullptr, nullptr, 0,
@@ -1710,7 +1710,7 @@ extern "C" int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters
                 bytes = kv_bytes;
                 break;
             case 6:
-                ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, n, H, c.rms_eps, s, fr ? 1 : 0);
+                ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, n, H, c.rms_eps, s, fr ? 1 : 2);
                 bytes = (double)n * H * 2 * 2;
                 break;
             default:
