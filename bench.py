@@ -703,6 +703,19 @@ def main():
             else:
                 line["roofline"] = batch_roofline(B)
                 line["scheduler"] = {k: v for k, v in bstats.items() if k != "lens"}
+        elif B == 1:
+            # configs[4] shapes (7B backbone and / or FP8 decoder weights): the same object for this configuration's own
+            # dominant kernel -- the decode gate/up weight stream at this shape and weight width -- measured the same way
+            us, by = e.profile_decode_kernel(2, iters=144)
+            others = {}
+            for which, name in ((0, "qkv"), (1, "o_proj"), (3, "down"), (4, "lm_head")):
+                u, b = e.profile_decode_kernel(which, iters=72)
+                others[name] = {"us": round(u, 2), "GBps": round(b / (u * 1e-6) / 1e9, 1)}
+            ach = by / (us * 1e-6) / 1e9
+            line["roofline"] = {"bound": "hbm", "kernel": ("k_gemv<SWIGLU, fp8 weights> " if args.fp8 else "k_gemv<SWIGLU> ") +
+                                f"(decode gate/up weight stream of the {cfg.name} shape, {cfg.text.num_hidden_layers} launches per token)",
+                                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                                "avg_us": us, "bytes_per_launch": by, "other_decode_kernels": others}
         if args.fp8:
             line["dtype"] = "fp8-e4m3 decoder weights (per-row power-of-two scales) streamed by the decode GEMVs; bf16 activations, bf16 MFMA prefill on the dequantised copy"
             line["metric"] += " [fp8 weights: reduced precision, not the headline metric]"

@@ -1594,36 +1594,46 @@ extern "C" int ze_profile_decode_kernel(ze_engine* e, int which, int iters, floa
         ze_gemv_args g;
         memset(&g, 0, sizeof(g));
         g.D = hd;
+        // a quantised engine streams the FP8 copy (1 byte per weight + one fp32 scale per row), as its decode step does
+        auto fp8 = [&](const ze_linear& l, double rows, double cols) {
+            if (e->fp8_ready && l.w8) {
+                g.W8 = l.w8;
+                g.scale8 = l.scale8;
+                g.ldw8 = l.ld8;
+                return rows * cols + rows * 4.0;
+            }
+            return rows * cols * 2.0;
+        };
         switch (which) {
             case 0:
                 g.W = L.qkv.w; g.ldw = L.qkv.ld; g.N = nqkv; g.K = H; g.x = e->dh; g.norm_w = L.in_norm;
                 g.eps = c.rms_eps; g.bias = L.qkv.bias; g.out_bf16 = e->dq; g.st = e->st_dev; g.cosT = e->cosT;
                 g.sinT = e->sinT; g.kcache = e->kc(it % c.layers, 0); g.vcache = e->vc(it % c.layers, 0);
                 g.heads = c.heads; g.kv_heads = c.kv_heads; g.max_ctx = c.max_ctx;
+                bytes = fp8(L.qkv, nqkv, H);
                 ze_launch_gemv(ZE_GV_QKV_ROPE, g, s);
-                bytes = (double)nqkv * H * 2;
                 break;
             case 1:
                 g.W = L.o.w; g.ldw = L.o.ld; g.N = H; g.K = nq; g.x = e->dattn; g.out_bf16 = e->dh;
+                bytes = fp8(L.o, H, nq);
                 ze_launch_gemv(ZE_GV_RESIDUAL, g, s);
-                bytes = (double)H * nq * 2;
                 break;
             case 2:
                 g.W = L.gate_up.w; g.ldw = L.gate_up.ld; g.N = 2 * e->text_ipad; g.K = H; g.x = e->dh;
                 g.norm_w = L.post_norm; g.eps = c.rms_eps; g.out_bf16 = e->dact;
+                bytes = fp8(L.gate_up, 2.0 * c.intermediate, H);
                 ze_launch_gemv(ZE_GV_SWIGLU, g, s);
-                bytes = 2.0 * c.intermediate * H * 2;
                 break;
             case 3:
                 g.W = L.down.w; g.ldw = L.down.ld; g.N = H; g.K = e->text_ipad; g.x = e->dact; g.out_bf16 = e->dh;
+                bytes = fp8(L.down, H, c.intermediate);
                 ze_launch_gemv(ZE_GV_RESIDUAL, g, s);
-                bytes = (double)H * c.intermediate * 2;
                 break;
             default:
                 g.W = e->lm_head; g.ldw = H; g.N = c.vocab; g.K = H; g.x = e->dh; g.norm_w = e->final_norm;
                 g.eps = c.rms_eps; g.out_f32 = e->dlogits;
+                bytes = fp8(e->lm_head8, c.vocab, H);
                 ze_launch_gemv(ZE_GV_LOGITS, g, s);
-                bytes = (double)c.vocab * H * 2;
                 break;
         }
     };
