@@ -550,7 +550,7 @@ def main():
     want256 = want64 and not args.no_stream256
     SLOTS = int(os.environ.get("ZE_STREAM_SLOTS", "256"))  # chain slots of the stream256 object (other values: measurements)
     e = Engine(cfg, device=local, max_seqs=(SLOTS if want256 else max(1, BB)), max_ctx=2048, max_patches=max(4096, 1400 * min(BB, 40)),
-               max_prefill_rows=(16 * 832 if BB > 1 else 0), max_tile_side=max(args.tile, 1024))
+               max_prefill_rows=(int(os.environ.get("ZE_PREFILL_ROWS", str(16 * 832))) if BB > 1 else 0), max_tile_side=max(args.tile, 1024))
     e.fill_synthetic(seed=0, std=0.02)
     for kv in os.environ.get("ZE_TUNE", "").split(","):  # measurement-only A/B knobs, e.g. ZE_TUNE=2:64
         if ":" in kv:
