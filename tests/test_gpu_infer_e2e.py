@@ -161,7 +161,8 @@ def test_two_ranks_shard_by_tile_and_merge_to_the_single_rank_result(workdir):
     base = [sys.executable, "src/infer.py", "--model_name", "ckpt", "--max_new_tokens", "14", "--max_ctx", "2048",
             "--batch_size", "4"]
     for rank in (0, 1):
-        run(base + ["--exp_name", "dp_"], d, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2")
+        # LOCAL_RANK 1 on a one-GPU box: local ranks beyond the GPU count share GPUs (rank r -> GPU r mod n_gpus)
+        run(base + ["--exp_name", "dp_"], d, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2")
     run(base + ["--exp_name", "one_"], d)
     from zoomearth_amd.accel import merge_results
     n = merge_results(str(d / "results" / "dp_"), 2, str(d / "results" / "dp_merged.jsonl"))

@@ -46,8 +46,8 @@ class ZoomEarthForConditionalGeneration:
                         max_patches: int = 8192, max_tile_side: int = 8192, max_prefill_rows: int = 0, **kw):
         config = ModelConfig.from_pretrained(path)
         dev = 0 if device is None else (device.index or 0 if isinstance(device, torch.device) else int(device))
-        if device is None and "LOCAL_RANK" in os.environ:
-            dev = int(os.environ["LOCAL_RANK"])
+        if device is None and "LOCAL_RANK" in os.environ:  # (more local ranks than GPUs: ranks share GPUs, accel.Accelerator)
+            dev = int(os.environ["LOCAL_RANK"]) % max(1, torch.cuda.device_count())
         engine = Engine(config, device=dev, max_seqs=max_seqs, max_ctx=max_ctx, max_patches=max_patches,
                         max_tile_side=max_tile_side, max_prefill_rows=max_prefill_rows)
         try:
