@@ -129,3 +129,27 @@ def test_greedy_pick_is_memory_safe_on_nan_logits(tiny_engine):
     assert e.sample_greedy(0, lg, 1.0) == int(torch.argmax(lg.cpu())) == 0
     lg[7] = 1.0  # a comparable value wins over NaNs
     assert e.sample_greedy(0, lg, 1.0) == 7
+
+
+@pytest.mark.parametrize("penalty", [1.0, 1.3])
+def test_arg_max_folded_into_the_lm_head_launch_picks_the_same_tokens(tiny_engine, penalty):
+    """Greedy single-chain decode takes its arg-max partials from the lm_head GEMV's workgroups (ze_gemv_args::amax_ws)
+    instead of a separate pass over the logits (ze_tune knob 14 = 1): same penalty arithmetic, same lowest-index
+    tie-break, so the same tokens -- graph and eager, with and without the repetition penalty."""
+    e = tiny_engine
+    e.fill_synthetic(**CHAIN_W)
+    ids = prng.uniform_ints(77, 60, 10, 1990).tolist()
+    pos, delta = e.rope_index(ids, [])
+    runs = {}
+    try:
+        for knob in (0, 1):
+            e.lib.ze_tune(14, knob)
+            for graph in (True, False):
+                e.seq_reset(0)
+                e.prefill(0, ids, None, pos, delta, want_logits=False)
+                e.mark_seen(0, ids)
+                runs[(knob, graph)] = e.generate(0, 24, repetition_penalty=penalty, ignore_eos=True, use_graph=graph)
+    finally:
+        e.lib.ze_tune(14, 0)
+    assert len(set(map(tuple, runs.values()))) == 1, runs
+    assert len(set(runs[(0, True)])) > 4

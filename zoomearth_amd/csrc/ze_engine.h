@@ -70,6 +70,7 @@ struct ze_engine {
     uint8_t* arena8 = nullptr;    // fp8 decode weights (0 until ze_weights_quantize_fp8)
     bool fp8_ready = false;
     bool fp8_act = false;         // ze_set_fp8_activations: qkv / gate-up inputs quantised to E4M3 per row (needs fp8_ready)
+    float* damax = nullptr;       // single-chain decode: arg-max partials of the lm_head GEMV's workgroups (count, pairs)
     uint8_t* ty8 = nullptr;       // batched decode: the normalised rows as FP8 fragments (64 rows x hidden bytes)
     float* ty8_scale = nullptr;   // ... and their per-row scales (64)
     // second, fragment-major copy of the wide decode projections (qkv, gate/up, lm_head) for batched decode: built on

@@ -803,8 +803,18 @@ int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos,
     a.eps = c.rms_eps;
     a.out_f32 = e->dlogits + (size_t)seq * c.vocab;
     a.D = hd;
-    ze_launch_gemv(ZE_GV_LOGITS, a, s);
-    if (sample)
+    // greedy: the arg-max partials come out of the lm_head launch itself (knob 14 = 1: the separate partial kernel)
+    const bool folded = sample && so.temperature <= 0.f && ze_gemv_knobs[14] != 1;
+    if (folded) {
+        a.seen = e->seen + (size_t)seq * c.vocab;
+        a.penalty = penalty;
+        a.amax_ws = e->damax;
+    }
+    const bool gemv_ok = ze_launch_gemv(ZE_GV_LOGITS, a, s);
+    if (folded && gemv_ok)
+        ze_launch_sample_folded(e->damax, c.vocab, e->seen + (size_t)seq * c.vocab, e->st_dev + seq, e->eos_dev, c.n_eos,
+                                c.pad_token_id, ignore_eos, /*advance_ctx=*/1, e->out_tokens + (size_t)seq * c.max_ctx, s);
+    else if (sample)
         ze_launch_sample(e->dlogits + (size_t)seq * c.vocab, c.vocab, e->seen + (size_t)seq * c.vocab, penalty, e->st_dev + seq, e->eos_dev,
                          c.n_eos, c.pad_token_id, ignore_eos, /*advance_ctx=*/1,
                          e->out_tokens + (size_t)seq * c.max_ctx, e->dsample, so, s);

@@ -112,6 +112,11 @@ __global__ void __launch_bounds__(256) k_gemv(const ze_gemv_args a) {
                 const int j = r1[i] % a.D;
                 e.x1[i] = bf16_to_f32(a.cosT[(size_t)pos * halfD + j]);
                 e.x2[i] = bf16_to_f32(a.sinT[(size_t)pos * halfD + j]);
+            } else if (EPI == ZE_GV_LOGITS) {  // folded arg-max: the seen flags travel with the first weight trip
+                if (a.amax_ws && a.penalty != 1.0f) {
+                    e.x1[i] = (float)a.seen[r1[i]];
+                    e.x2[i] = (float)a.seen[r2[i]];
+                }
             }
         }
     };
@@ -222,6 +227,8 @@ __global__ void __launch_bounds__(256) k_gemv(const ze_gemv_args a) {
     }
     __syncthreads();
 
+    float best_v = -INFINITY;  // LOGITS + amax_ws: lane 0 of a wave keeps the best of the rows it finished
+    int best_i = 0x7fffffff;
     // one pair set (2*PAIRS rows); `w0` / `ein` optionally hold its already-issued first trip and epilogue operands
     auto pair_set = [&](int p0, const uint8_t* const (&wrow)[2 * PAIRS], const int (&r1)[PAIRS], const int (&r2)[PAIRS],
                         auto have_first, uint4 (&w0)[CH][2 * PAIRS], epi_in<PAIRS>& ein) {
@@ -358,6 +365,13 @@ __global__ void __launch_bounds__(256) k_gemv(const ze_gemv_args a) {
             } else if (EPI == ZE_GV_LOGITS) {
                 a.out_f32[r1[i]] = v1;
                 a.out_f32[r2[i]] = v2;
+                if (a.amax_ws) {  // k_argmax_partial's arithmetic: penalty on seen ids, larger value, then lower index
+                    float p1 = v1, p2 = v2;
+                    if (ein.x1[i] != 0.f) p1 = p1 < 0.f ? p1 * a.penalty : p1 / a.penalty;
+                    if (ein.x2[i] != 0.f) p2 = p2 < 0.f ? p2 * a.penalty : p2 / a.penalty;
+                    if (p1 > best_v || (p1 == best_v && r1[i] < best_i)) { best_v = p1; best_i = r1[i]; }
+                    if (p2 > best_v || (p2 == best_v && r2[i] < best_i)) { best_v = p2; best_i = r2[i]; }
+                }
             } else {
                 a.out_bf16[r1[i]] = f32_to_bf16(v1);
                 a.out_bf16[r2[i]] = f32_to_bf16(v2);
@@ -372,6 +386,30 @@ __global__ void __launch_bounds__(256) k_gemv(const ze_gemv_args a) {
         epi_in<PAIRS> e;
         rows_of(p0, wrow, r1, r2);
         pair_set(p0, wrow, r1, r2, std::false_type{}, wpre, e);
+    }
+    if constexpr (EPI == ZE_GV_LOGITS && KSPLIT == 1) {
+        if (a.amax_ws) {  // workgroup-uniform
+            __syncthreads();  // `red` is free again
+            if (lane == 0) {
+                red[2 * wid] = best_v;
+                red[2 * wid + 1] = __int_as_float(best_i);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < 4; ++w) {
+                    const float v = red[2 * w];
+                    const int i = __float_as_int(red[2 * w + 1]);
+                    if (v > best_v || (v == best_v && i < best_i)) { best_v = v; best_i = i; }
+                }
+                a.amax_ws[2 * blockIdx.x] = best_v;
+                reinterpret_cast<int*>(a.amax_ws)[2 * blockIdx.x + 1] = best_i;
+                // slots beyond this launch's grid (a smaller grid than an earlier launch's) go back to "nothing"
+                for (int sl = blockIdx.x + gridDim.x; sl < 2048; sl += gridDim.x) {
+                    a.amax_ws[2 * sl] = -INFINITY;
+                    reinterpret_cast<int*>(a.amax_ws)[2 * sl + 1] = 0x7fffffff;
+                }
+            }
+        }
     }
 }
 

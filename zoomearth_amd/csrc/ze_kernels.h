@@ -121,6 +121,12 @@ struct ze_gemv_args {
     // FP8 activations (fp8 weight stream only, norm prologue only): the normalised x is replaced by its E4M3
     // quantisation (one power-of-two scale for the row) before the dot products -- the values k_rmsnorm(act8) writes
     int act8;
+    // LOGITS with the greedy arg-max folded in (amax_ws non-null): every workgroup also leaves the best (penalised value,
+    // index) of its rows in amax_ws[2 b], amax_ws[2 b + 1] (at most 2048 workgroups: the launch grid's cap);
+    // k_argmax_final_folded reduces the 2048 slots -- no k_argmax_partial pass over the 600-KB logits row
+    const uint8_t* seen;
+    float penalty;
+    float* amax_ws;
 };
 // returns false when x[K] does not fit the LDS stage
 bool ze_launch_gemv(int epi, const ze_gemv_args& a, hipStream_t s);
@@ -209,6 +215,9 @@ struct ze_sample_opts {
 void ze_launch_sample(const float* logits, int vocab, uint8_t* seen, float penalty, ze_seq_dev* st,
                       const int* eos_ids, int n_eos, int pad_id, int ignore_eos, int advance_ctx,
                       int32_t* out_tokens, float* ws, const ze_sample_opts& so, hipStream_t s);
+void ze_launch_sample_folded(const float* amax_ws, int vocab, uint8_t* seen, ze_seq_dev* st, const int* eos_ids, int n_eos,
+                             int pad_id, int ignore_eos, int advance_ctx, int32_t* out_tokens, hipStream_t s);
+void ze_launch_amax_init(float* amax_ws, hipStream_t s);  // 2048 (value, index) slots
 void ze_launch_advance_ctx(ze_seq_dev* st, hipStream_t s);
 // batched decode helpers (one token for each of n chains)
 void ze_launch_embed_tokens_batch(const ze_seq_dev* st, const int* seq_ids, int n, const bf16_t* embed, bf16_t* out,

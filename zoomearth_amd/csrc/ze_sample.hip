@@ -44,6 +44,11 @@ __global__ void __launch_bounds__(256) k_argmax_partial(const float* __restrict_
     }
 }
 
+// the chosen token enters the chain state (one thread)
+__device__ __forceinline__ void accept_token(int bi, uint8_t* __restrict__ seen, ze_seq_dev* __restrict__ st,
+                                             const int* __restrict__ eos_ids, int n_eos, int pad_id, int ignore_eos,
+                                             int advance_ctx, int32_t* __restrict__ out_tokens, int vocab);
+
 __global__ void __launch_bounds__(64) k_argmax_final(const float* __restrict__ ws, uint8_t* __restrict__ seen,
                                                      ze_seq_dev* __restrict__ st, const int* __restrict__ eos_ids,
                                                      int n_eos, int pad_id, int ignore_eos, int advance_ctx,
@@ -57,7 +62,47 @@ __global__ void __launch_bounds__(64) k_argmax_final(const float* __restrict__ w
         const int oi = __shfl_xor(bi, off, 64);
         better(bv, bi, ov, oi);
     }
+    if (threadIdx.x == 0) accept_token(bi, seen, st, eos_ids, n_eos, pad_id, ignore_eos, advance_ctx, out_tokens, vocab);
+}
+
+// The partials of the lm_head GEMV's workgroups (ze_gemv_args::amax_ws: AMAX_SLOTS (value, index) pairs; slots no
+// workgroup writes keep the (-inf, INT_MAX) they were created with): every thread requests its eight pairs at once --
+// one memory round trip for the whole reduction.
+#define AMAX_SLOTS 2048
+__global__ void __launch_bounds__(256) k_argmax_final_folded(const float2* __restrict__ ws, uint8_t* __restrict__ seen,
+                                                            ze_seq_dev* __restrict__ st, const int* __restrict__ eos_ids,
+                                                            int n_eos, int pad_id, int ignore_eos, int advance_ctx,
+                                                            int32_t* __restrict__ out_tokens, int vocab) {
+    float2 p[AMAX_SLOTS / 256];
+#pragma unroll
+    for (int u = 0; u < AMAX_SLOTS / 256; ++u) p[u] = ws[threadIdx.x + u * 256];
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int u = 0; u < AMAX_SLOTS / 256; ++u) better(bv, bi, p[u].x, __float_as_int(p[u].y));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(bv, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        better(bv, bi, ov, oi);
+    }
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    if ((threadIdx.x & 63) == 0) {
+        sv[threadIdx.x >> 6] = bv;
+        si[threadIdx.x >> 6] = bi;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) better(bv, bi, sv[w], si[w]);
+        accept_token(bi, seen, st, eos_ids, n_eos, pad_id, ignore_eos, advance_ctx, out_tokens, vocab);
+    }
+}
+
+__device__ __forceinline__ void accept_token(int bi, uint8_t* __restrict__ seen, ze_seq_dev* __restrict__ st,
+                                             const int* __restrict__ eos_ids, int n_eos, int pad_id, int ignore_eos,
+                                             int advance_ctx, int32_t* __restrict__ out_tokens, int vocab) {
+    {
         int tok = bi;
         if ((unsigned)tok >= (unsigned)vocab) tok = 0;  // no comparable logit at all (every one NaN): torch.argmax gives 0
         if (st->finished) tok = pad_id;  // finished rows emit pad (HF:generation/utils.py:2927-2929)
@@ -86,6 +131,20 @@ void ze_launch_sample(const float* logits, int vocab, uint8_t* seen, float penal
                               ws + 2 * SAMPLE_BLOCKS + 64, s);
     k_argmax_final<<<1, 64, 0, s>>>(ws, seen, st, eos_ids, n_eos, pad_id, ignore_eos, advance_ctx, out_tokens, vocab);
 }
+
+// greedy token when the lm_head GEMV already left its workgroups' partial maxima in amax_ws
+void ze_launch_sample_folded(const float* amax_ws, int vocab, uint8_t* seen, ze_seq_dev* st, const int* eos_ids, int n_eos,
+                             int pad_id, int ignore_eos, int advance_ctx, int32_t* out_tokens, hipStream_t s) {
+    k_argmax_final_folded<<<1, 256, 0, s>>>(reinterpret_cast<const float2*>(amax_ws), seen, st, eos_ids, n_eos, pad_id,
+                                            ignore_eos, advance_ctx, out_tokens, vocab);
+}
+
+// amax_ws as the engine creates it: every slot (-inf, INT_MAX)
+__global__ void k_amax_init(float2* ws) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < AMAX_SLOTS) ws[i] = make_float2(-INFINITY, __int_as_float(0x7fffffff));
+}
+void ze_launch_amax_init(float* amax_ws, hipStream_t s) { k_amax_init<<<AMAX_SLOTS / 256, 256, 0, s>>>(reinterpret_cast<float2*>(amax_ws)); }
 
 __global__ void k_advance_ctx(ze_seq_dev* st) { st->ctx += 1; }
 void ze_launch_advance_ctx(ze_seq_dev* st, hipStream_t s) { k_advance_ctx<<<1, 1, 0, s>>>(st); }
