@@ -44,7 +44,7 @@ BATCH_KERNEL_NAMES = {
     2: "k_gemm_skinny<6,SWIGLU,FRAG,BAL> (batched decode gate/up weight stream, one workgroup per CU)",
     3: "k_gemm_ring<64,64,4,RESIDUAL> split-K (batched decode down projection)",
     4: "k_gemm_skinny<2,F32,FRAG> (batched decode lm_head)",
-    5: "k_attn_decode_stream<8> (batched decode attention: K/V rows of every chain through an LDS-DMA ring)",
+    5: "k_attn_decode_wave<8> (batched decode attention: every wave streams 16 keys of each 64-key round, K rows straight into MFMA registers, V rows through its own LDS stages)",
 }
 
 

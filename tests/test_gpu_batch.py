@@ -316,3 +316,41 @@ def test_follow_up_on_decode_written_rows_matches_the_oracle(eng):
           f"oracle bf16-vs-fp32 = {yard:.4f}")
     assert err_reused <= 2.0 * yard and err_fresh <= 2.0 * yard
     assert float(np.abs(reused - fresh).max()) <= 2.0 * yard
+
+
+def test_per_wave_attention_kernel_is_batch_invariant_and_agrees_with_the_ring_kernel():
+    """k_attn_decode_wave (the default of the batched step) against k_attn_decode_stream (ze_tune knob 8 = 2): ragged
+    contexts whose last 192-key part is anything from one key to full -- rounds past the end of a part re-read its last row
+    and are masked -- logits within bf16 noise of the ring kernel's, reproducible, and a chain's logits the same bits alone,
+    in a pair and among forty."""
+    from zoomearth_amd.config import ModelConfig
+    from zoomearth_amd.engine import Engine
+    n = 40
+    e = Engine(ModelConfig.tiny(), device=0, max_seqs=n, max_ctx=1024, max_patches=256, max_tile_side=256)
+    try:
+        e.fill_synthetic(seed=1, std=0.02, matrix_gain=4.0, bias_std=0.02, norm_jitter=0.1)
+        lens = [5 + (37 * s) % 700 for s in range(n)]
+        lens[3], lens[4], lens[5] = 191, 192, 193          # the part boundary itself (context = prompt + 1 at the first step)
+        ids = [prng.uniform_ints(70 + s, lens[s], 10, 1990).tolist() for s in range(n)]
+        tok = [int(prng.uniform_ints(90 + s, 1, 10, 1990)[0]) for s in range(n)]
+
+        def run(slots, knob):
+            e.lib.ze_tune(8, knob)
+            for s in slots:
+                e.seq_reset(s)
+                e.prefill(s, ids[s], None, *e.rope_index(ids[s], []), want_logits=False)
+            return [e.decode_batch(list(slots), [tok[s] + k for s in slots]).cpu().numpy() for k in (0, 1)]
+
+        ring, wave, again = run(list(range(n)), 2), run(list(range(n)), 0), run(list(range(n)), 0)
+        assert all(np.isfinite(a).all() for a in wave)
+        assert all(np.array_equal(a, b) for a, b in zip(wave, again))
+        err = max(float(np.abs(a - b).max()) for a, b in zip(ring, wave))
+        assert err < 0.06, err
+        for solo in (7, 31, 0, 4):
+            alone = run([solo], 0)
+            assert all(np.array_equal(alone[k][0], wave[k][solo]) for k in (0, 1)), solo
+        pair = run([7, 31], 0)
+        assert all(np.array_equal(pair[k][0], wave[k][7]) and np.array_equal(pair[k][1], wave[k][31]) for k in (0, 1))
+    finally:
+        e.lib.ze_tune(8, 0)
+        e.close()

@@ -208,10 +208,256 @@ __global__ void __launch_bounds__(256) k_attn_decode_stream(const bf16_t* __rest
                              out + (size_t)bz * out_row_stride, 0, 0, nparts);
 }
 
+template <int N>
+__device__ __forceinline__ void ab_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Every WAVE a stream of its own.  What bounds k_attn_decode_stream is not its arithmetic (compiled out, the launch is 7 %
+// shorter at 256 chains) but its per-workgroup fixed cost against a ring that holds two 16-KB rounds behind a workgroup
+// barrier.  Here a part is 192 keys = three rounds of 64, and wave w owns keys 16 w .. 16 w + 15 of every round, start to
+// finish:
+//   * its K rows go straight from global memory into MFMA A-operand registers (lane (fr, fq): key fr, 16 B of d -- no LDS);
+//     its V rows arrive by LDS-DMA in three 4-KB stages of the wave's own, read back transposed by ds_read_b64_tr_b16;
+//     ALL three rounds are requested at t = 0 and ordered by the wave's own counted vmcnt -- no barrier, no loop, no refill;
+//   * S^T = K Q^T is ONE 16-key tile per wave and round (4 MFMAs instead of every wave forming every tile), the softmax
+//     statistics of the wave's keys stay lane-local plus two shuffles, and P^T feeds the B operand of O^T += V^T P^T
+//     (v_mfma_f32_16x16x16_bf16: the accumulator lane that holds S^T[4 fq + r][fr] is the lane that needs those four keys);
+//   * every wave keeps its own running (m, l, O^T) -- a flash-decoding split inside the workgroup -- and the four are
+//     merged in wave order once (LDS, one barrier), then published and merged across parts as before.
+// The loads of Q / K and the MFMAs that consume them are inline asm: a load the compiler knows of gets its own s_waitcnt,
+// computed without the DMAs in the queue (too strict: it drains everything), and a register the compiler merely sees
+// DEFINED by an asm load may be copied before the data has landed (seen: tied operands of a separate wait statement made
+// hipcc copy the K registers ahead of the wait on two of three paths).  So the code is straight-line -- always three
+// rounds; rounds past the end of a short last part re-read the last row and are masked -- and every load result is first
+// touched by the asm statement that waits for it.
+// Parts are 192 keys whatever the context (up to max_ctx / 192 of them): a function of the chain's own length alone, like
+// every sum order here (batch invariance).  The sums are ordered differently from k_attn_decode_stream's, so the two
+// kernels agree within rounding, not bit for bit.
+#define AW_TOK 64
+#define AW_ROUNDS 3
+#define AW_PART (AW_TOK * AW_ROUNDS)
+#define AW_VSTAGE 4096
+#define AW_VSTAGES 3                     // V stages per wave (2: round 2's tile takes round 0's stage once that has been read --
+                                         // four workgroups per CU instead of three: 24.5 against 23.2 us at 64 chains, equal at 256)
+
+typedef __attribute__((ext_vector_type(4))) unsigned int aw_u32x4;
+
+// S^T tile of one round: wait until all but the N youngest memory operations of the wave have retired, then K Q^T
+template <int N>
+__device__ __forceinline__ ad_f32x4 aw_wait_qk(const aw_u32x4 (&k4)[4], const aw_u32x4 (&q4)[4]) {
+    ad_f32x4 sacc;
+    asm volatile(
+        "s_waitcnt vmcnt(%9)\n\t"
+        "v_mfma_f32_16x16x32_bf16 %0, %1, %5, 0\n\t"
+        "v_mfma_f32_16x16x32_bf16 %0, %2, %6, %0\n\t"
+        "v_mfma_f32_16x16x32_bf16 %0, %3, %7, %0\n\t"
+        "v_mfma_f32_16x16x32_bf16 %0, %4, %8, %0\n\t"
+        "s_nop 15\n\ts_nop 7"
+        : "=&v"(sacc)
+        : "v"(k4[0]), "v"(k4[1]), "v"(k4[2]), "v"(k4[3]), "v"(q4[0]), "v"(q4[1]), "v"(q4[2]), "v"(q4[3]), "n"(N)
+        : "memory");
+    return sacc;
+}
+
+template <int MB>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AW_VSTAGES == 2 ? 4 : 3))) k_attn_decode_wave(
+    const bf16_t* __restrict__ q, int q_row_stride, const bf16_t* __restrict__ kcache, const bf16_t* __restrict__ vcache,
+    size_t cache_seq_stride, const ze_seq_dev* __restrict__ st_base, const int* __restrict__ seq_ids, int heads, int kv_heads,
+    int max_ctx, float scale_log2e, float* __restrict__ ws, int max_parts, unsigned* __restrict__ tickets,
+    bf16_t* __restrict__ out, int out_row_stride) {
+    constexpr int D = 128;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 4 waves x AW_VSTAGES V stages of 4 KB
+    __shared__ float s_ml[4][32];                                   // the waves' (m, l) per head column
+    const int bz = blockIdx.y;
+    const int kvh = blockIdx.x % kv_heads, part = blockIdx.x / kv_heads;
+    const int seq = seq_ids[bz];
+    const int ctx = st_base[seq].ctx + 1;
+    const int nparts = (ctx + AW_PART - 1) / AW_PART;
+    if (part >= nparts) return;  // workgroup-uniform: no part, no ticket
+    const int G = heads / kv_heads;
+    const int t0 = part * AW_PART, t1 = min(ctx, t0 + AW_PART);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const bf16_t* kb = kcache + (size_t)seq * cache_seq_stride + (size_t)kvh * max_ctx * D;
+    const bf16_t* vb = vcache + (size_t)seq * cache_seq_stride + (size_t)kvh * max_ctx * D;
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem) +
+                              (unsigned)wid * (AW_VSTAGES * AW_VSTAGE);
+    const uint8_t* ring = smem + wid * (AW_VSTAGES * AW_VSTAGE);
+
+    // ---- every request of the wave, in the order it will be waited for: Q (4), then per round K (4 loads) + V (4 DMA pieces)
+    // (Q: lane = head column fr, d = ks*32 + fq*8 .. +7; columns >= G repeat head G - 1: finite, never stored)
+    aw_u32x4 qf4[4], kreg[AW_ROUNDS][4];
+    {
+        const bf16_t* qsrc = q + (size_t)bz * q_row_stride + (kvh * G + min(fr, G - 1)) * D + fq * 8;
+        asm volatile(
+            "global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:64\n\t"
+            "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:192"
+            : "=&v"(qf4[0]), "=&v"(qf4[1]), "=&v"(qf4[2]), "=&v"(qf4[3])
+            : "v"(qsrc)
+            : "memory");
+    }
+    const int r4 = lane >> 4, pos = lane & 15;
+    auto issue_v = [&](int u) {  // the V tile of round u into stage u % 2: four 1-KB pieces (no register results)
+        const int tok0 = t0 + u * AW_TOK + wid * 16;
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {  // piece pp = rows 4pp .. 4pp + 3; the ad_off swizzle on the source chunk (ab_issue)
+            const int row = 4 * pp + r4;
+            const int ch = pos ^ ((r4 << 2) | (pp & 3));
+            const bf16_t* src = vb + (size_t)min(tok0 + row, t1 - 1) * D + ch * 8;
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(src), "s"(ring_lds + (unsigned)(u % AW_VSTAGES) * AW_VSTAGE + (unsigned)pp * 1024u)
+                : "memory");
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < AW_ROUNDS; ++u) {
+        const int tok0 = t0 + u * AW_TOK + wid * 16;  // rows past t1 re-read row t1 - 1 (finite; masked below)
+        const bf16_t* ksrc = kb + (size_t)min(tok0 + fr, t1 - 1) * D + fq * 8;
+        asm volatile(
+            "global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:64\n\t"
+            "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:192"
+            : "=&v"(kreg[u][0]), "=&v"(kreg[u][1]), "=&v"(kreg[u][2]), "=&v"(kreg[u][3])
+            : "v"(ksrc)
+            : "memory");
+        if (u < AW_VSTAGES) issue_v(u);
+    }
+
+    ad_f32x4 oacc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) oacc[j] = ad_f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const int tq = fr >> 2, tp = fr & 3;
+#pragma unroll
+    for (int u = 0; u < AW_ROUNDS; ++u) {
+        // operations retire in issue order -- Q, K0, V0, K1, V1, K2, V2 (with two stages V2 goes out behind round 0): round 0
+        // has landed when the 16 (12) behind V0 are left, round 1 when K2, V2 (8) are
+        ad_f32x4 sacc;
+        if (u == 0) sacc = aw_wait_qk<(AW_VSTAGES == 2 ? 12 : 16)>(kreg[0], qf4);
+        else if (u == 1) sacc = aw_wait_qk<8>(kreg[1], qf4);
+        else sacc = aw_wait_qk<0>(kreg[2], qf4);
+        const int kbase = t0 + u * AW_TOK + wid * 16 + fq * 4;
+        float p[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const float sv = (kbase + rr < t1) ? sacc[rr] * scale_log2e : -INFINITY;
+            p[rr] = sv;
+            mx = fmaxf(mx, sv);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = exp2f(m_run - m_use);  // m_run = -inf -> 0
+        float rs = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            p[rr] = __builtin_amdgcn_exp2f(p[rr] - m_use);  // arguments <= 0
+            rs += p[rr];
+        }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+        // O^T += V^T P^T over the wave's 16 keys (P rounded to bf16, as HF's eager attention rounds it)
+        const uint2 pq = make_uint2(ad_pack_bf16(p[0], p[1]), ad_pack_bf16(p[2], p[3]));
+        const ad_v4s pb = *reinterpret_cast<const ad_v4s*>(&pq);
+        const uint8_t* sV = ring + (u % AW_VSTAGES) * AW_VSTAGE;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const ad_v4s va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) ad_v4s*)(sV + ad_off(fq * 4 + tq, j * 2 + (tp >> 1)) + 8 * (tp & 1)));
+            oacc[j][0] *= alpha;
+            oacc[j][1] *= alpha;
+            oacc[j][2] *= alpha;
+            oacc[j][3] *= alpha;
+            oacc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, pb, oacc[j], 0, 0, 0);
+        }
+        if (AW_VSTAGES == 2 && u == 0) {  // stage 0 has been read (the transposed reads have returned): it takes round 2's tile
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue_v(2);
+        }
+    }
+    // ---- the four waves' results meet in LDS (their stages are idle now): wave w, [8 tiles][64 lanes] float4 in its own
+    // stages + its (m, l) per head column; then wave w merges d-tiles 2w, 2w + 1 of the four in wave order
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+        ad_f32x4* mine = reinterpret_cast<ad_f32x4*>(smem + wid * (AW_VSTAGES * AW_VSTAGE));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mine[j * 64 + lane] = oacc[j];
+        if (fq == 0) {
+            s_ml[wid][fr] = m_run;
+            s_ml[wid][16 + fr] = l_run;
+        }
+    }
+    __syncthreads();
+    float mw[4], lw[4];
+    float m_all = -INFINITY;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        mw[x] = s_ml[x][fr];
+        lw[x] = s_ml[x][16 + fr];
+        m_all = fmaxf(m_all, mw[x]);
+    }
+    float l_all = 0.f;
+    ad_f32x4 om[2];
+    om[0] = om[1] = ad_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const float w = (mw[x] == -INFINITY) ? 0.f : exp2f(mw[x] - m_all);
+        l_all += w * lw[x];
+        const ad_f32x4* theirs = reinterpret_cast<const ad_f32x4*>(smem + x * (AW_VSTAGES * AW_VSTAGE));
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const ad_f32x4 t = theirs[(2 * wid + jj) * 64 + lane];
+            om[jj][0] += w * t[0];
+            om[jj][1] += w * t[1];
+            om[jj][2] += w * t[2];
+            om[jj][3] += w * t[3];
+        }
+    }
+    __syncthreads();  // the tail reuses the LDS
+
+    // partial of head fr for this part, published write-through (the layout and the merge of k_attn_decode_stream)
+    float* wsb = ws + (size_t)bz * max_parts * heads * AD_STRIDE;
+    if (fr < G) {
+        const uint32_t dst = (uint32_t)((part * heads + kvh * G + fr) * AD_STRIDE * 4);
+        if (wid == 0 && fq == 0) ad_store16<true>(wsb, dst, m_all, l_all, 0.f, 0.f);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+            ad_store16<true>(wsb, dst + (uint32_t)((4 + (2 * wid + jj) * 16 + fq * 4) * 4), om[jj][0], om[jj][1], om[jj][2], om[jj][3]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned* flag = reinterpret_cast<unsigned*>(smem + 16 * 1024);
+    if (threadIdx.x == 0) {
+        unsigned* t = tickets + (size_t)bz * kv_heads + kvh;
+        const unsigned old = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned last = old == (unsigned)nparts - 1u;
+        if (last) __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = last;
+    }
+    __syncthreads();
+    if (*flag == 0u) return;
+    __syncthreads();
+    float* sW = reinterpret_cast<float*>(smem);
+    if (out_row_stride < 0)
+        attn_merge_group<MB>(sW, sW + AD_GMAX * 64, wsb, ctx, kvh, heads, kv_heads, max_parts, out, -out_row_stride, bz, nparts);
+    else
+        attn_merge_group<MB>(sW, sW + AD_GMAX * 64, wsb, ctx, kvh, heads, kv_heads, max_parts,
+                             out + (size_t)bz * out_row_stride, 0, 0, nparts);
+}
+
 void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_t* kcache, const bf16_t* vcache,
                                   size_t cache_seq_stride, bf16_t* out, int out_row_stride, const ze_seq_dev* st,
                                   const int* seq_ids, int n, int heads, int kv_heads, int max_ctx, float scale,
-                                  float* ws_partial, int max_parts, unsigned* tickets, hipStream_t s, int chunk) {
+                                  float* ws_partial, int max_parts, unsigned* tickets, hipStream_t s, int chunk, int per_wave) {
     const float sl = scale * 1.4426950408889634f;
     const size_t lds = AB_STAGES * AB_STAGE;
     static bool attr_set = false;
@@ -219,7 +465,14 @@ void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_decode_stream<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    k_attn_decode_stream<8><<<dim3(kv_heads * max_parts, n), 256, lds, s>>>(q, q_row_stride, kcache, vcache, cache_seq_stride, st,
-                                                                          seq_ids, heads, kv_heads, max_ctx, sl, ws_partial,
-                                                                          max_parts, tickets, out, out_row_stride, chunk);
+    if (per_wave) {  // 192-key parts whatever the context: max_parts here = ceil(max_ctx / 192)
+        const int wparts = (max_ctx + AW_PART - 1) / AW_PART;
+        k_attn_decode_wave<8><<<dim3(kv_heads * wparts, n), 256, 4 * AW_VSTAGES * AW_VSTAGE, s>>>(
+            q, q_row_stride, kcache, vcache, cache_seq_stride, st, seq_ids, heads, kv_heads, max_ctx, sl, ws_partial, wparts, tickets,
+            out, out_row_stride);
+    }
+    else
+        k_attn_decode_stream<8><<<dim3(kv_heads * max_parts, n), 256, lds, s>>>(q, q_row_stride, kcache, vcache, cache_seq_stride, st,
+                                                                              seq_ids, heads, kv_heads, max_ctx, sl, ws_partial,
+                                                                              max_parts, tickets, out, out_row_stride, chunk);
 }

@@ -1074,8 +1074,9 @@ static int upload_batch(ze_engine* e, const int32_t* seqs, int n, hipStream_t s)
     return ZE_OK;
 }
 
-// decode attention of the batched step: the LDS-DMA streaming kernel (ze_attn_batch.hip); knob 8 = 1: the 64-token-slice
-// kernel of the single-chain step with a chain dimension (the round-1 form, kept for A/B measurements)
+// decode attention of the batched step: the per-wave streaming kernel k_attn_decode_wave (ze_attn_batch.hip); knob 8 = 2:
+// its predecessor k_attn_decode_stream (a workgroup-wide LDS-DMA ring); knob 8 = 1: the 64-token-slice kernel of the
+// single-chain step with a chain dimension (the round-1 form) -- both kept for A/B measurements
 static void launch_batch_attention(ze_engine* e, int li, int n, bool frag_out, hipStream_t s) {
     const ze_config& c = e->cfg;
     const int hd = e->head_dim, nq = c.heads * hd, nqkv = nq + 2 * c.kv_heads * hd;
@@ -1087,11 +1088,15 @@ static void launch_batch_attention(ze_engine* e, int li, int n, bool frag_out, h
     else {
         // tokens per part (a multiple of 32; knob 11 for measurements): a function of nothing but the build, so a chain's
         // partition depends on its own context length alone
+        // the per-wave kernel cuts 192-key parts whatever the context: ceil(max_ctx / 192) of them must fit the partial buffer
+        // (max(max_splits, 8) parts per chain) and the merge's 64 lanes
+        const int wparts = (c.max_ctx + 191) / 192;
+        const bool per_wave = ze_gemv_knobs[8] != 2 && ze_gemv_knobs[11] == 0 && wparts <= std::max(e->max_splits, 8) && wparts <= 64;
         const int chunk = ze_gemv_knobs[11] >= 64 ? ze_gemv_knobs[11] / 32 * 32 : 0;  // 0: a sixth of the chain's context
         const int max_parts = chunk ? (c.max_ctx + chunk - 1) / chunk : 8;           // (at most 8 parts: 128-token floor)
         ze_launch_attn_decode_stream(e->tqkv, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, e->to, frag_out ? -(nq / 32) : nq,
                                      e->st_dev, e->bseq, n, c.heads, c.kv_heads, c.max_ctx, scale, e->bpartial, max_parts,
-                                     e->atickets, s, chunk);
+                                     e->atickets, s, chunk, per_wave ? 1 : 0);
     }
 }
 

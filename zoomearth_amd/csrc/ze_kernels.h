@@ -199,7 +199,8 @@ void ze_launch_attn_decode(const bf16_t* q, int q_row_stride, const bf16_t* kcac
 void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_t* kcache, const bf16_t* vcache,
                                   size_t cache_seq_stride, bf16_t* out, int out_row_stride, const ze_seq_dev* st,
                                   const int* seq_ids, int n, int heads, int kv_heads, int max_ctx, float scale,
-                                  float* ws_partial, int max_parts, unsigned* tickets, hipStream_t s, int chunk = 0);
+                                  float* ws_partial, int max_parts, unsigned* tickets, hipStream_t s, int chunk = 0,
+                                  int per_wave = 0);  // per_wave: k_attn_decode_wave (every wave a stream of its own)
 
 // first n_tokens cached K/V rows of chain src -> chain dst (all layers / kv heads); strides in elements
 void ze_launch_kv_copy_prefix(bf16_t* kcache, bf16_t* vcache, size_t layer_stride, size_t seq_stride, size_t head_stride,
