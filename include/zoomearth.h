@@ -304,8 +304,16 @@ int ze_profile_decode_kernel(ze_engine* e, int which, int iters, float* avg_us, 
  * 6 RMSNorm, 7 rope + KV append. */
 int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters, float* avg_us, double* bytes_per_launch,
                             void* stream);
-/* Measurement-only kernel-configuration override (A/B of launch shapes inside one process): knob 0 = down-proj
- * GEMV variant, knob 1 = gate/up GEMV variant; value 0 = shipped default. */
+/* Measurement-only kernel-configuration override (A/B of kernels and launch shapes inside one process; value 0 is always
+ * the shipped default, every alternative computes the same function -- bit for bit unless noted).  Knobs (0..15):
+ *   0, 1  variants of the single-chain down / gate-up GEMVs          2   grid cap of the GEMV family
+ *   3, 4  the experimental fused per-layer launches (ze_mega.hip)    5   1: no fragment / skinny kernels in the batched step
+ *   6, 7  GEMM policy (register-staged vs LDS-DMA ring; forced tile) 8   batched decode attention: 2 = ring kernel,
+ *                                                                        1 = 64-key slice kernel (agree within rounding)
+ *   9     1: skinny instead of one-shot o projection                 10  1: bf16 fragments on a quantised engine
+ *   11    fixed part size (keys) of the ring attention kernel        13  1: streaming launcher beyond 64 chains
+ *   14    1: separate arg-max pass in single-chain greedy decode
+ * Changing a knob invalidates captured decode graphs (they are re-captured on the next step). */
 int ze_tune(int knob, int value);
 /* Per-phase device time (ms) accumulated by HIP events since the last reset: [0] front-end, [1] ViT,
  * [2] prefill, [3] decode, [4] sampling.  Only recorded while enabled. */
