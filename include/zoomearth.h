@@ -270,6 +270,12 @@ int ze_set_fp8_activations(ze_engine* e, int on);
 /* The quantiser on one matrix: w bf16 [rows, cols] (device, overwritten with the dequantised values), q_out u8
  * [rows, cols], scale_out f32 [rows]; cols % 16 == 0. */
 int ze_op_quantize_fp8(ze_engine* e, void* w_bf16, int rows, int cols, void* q_out, void* scale_out, void* stream);
+/* The block-scaled FP8 GEMM of the prefill path (v_mfma_scale_f32_16x16x128_f8f6f4), one call: C[M, N] (bf16; [M, N / 2]
+ * with swiglu != 0: interleaved gate / up rows as in the packed weights) = (A8 2^ka) (W8 2^kw)^T + bias, A8 u8 [M, K] and
+ * W8 u8 [N, K] E4M3 bytes with one power-of-two scale per row each (sa f32 [M], sw f32 [N]: what ze_op_quantize_fp8
+ * writes); K % 128 == 0.  Unit-test / measurement entry: the prefill uses the same kernel behind ze_set_fp8_activations. */
+int ze_op_linear_mx(ze_engine* e, const void* a8, const void* sa, const void* w8, const void* sw, const void* bias, void* c,
+                    int M, int N, int K, int swiglu, void* stream);
 
 /* ------------------------------------------------------------------ unit ops for parity tests (K3-K22) */
 /* C[M,N] = A[M,K] * W[N,K]^T (+bias[N]) ; bf16 in, fp32 accumulate, bf16 out (one rounding).  act: 0 none, 1 exact GELU,
@@ -311,6 +317,7 @@ int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters, float* av
  *   6, 7  GEMM policy (register-staged vs LDS-DMA ring; forced tile) 8   batched decode attention: 2 = ring kernel,
  *                                                                        1 = 64-key slice kernel (agree within rounding)
  *   9     1: skinny instead of one-shot o projection                 10  1: bf16 fragments on a quantised engine
+ *   12    1: bf16 GEMMs instead of the block-scaled FP8 MFMA in a prefill with FP8 activations (agree within rounding)
  *   11    fixed part size (keys) of the ring attention kernel        13  1: streaming launcher beyond 64 chains
  *   14    1: separate arg-max pass in single-chain greedy decode
  * Changing a knob invalidates captured decode graphs (they are re-captured on the next step). */

@@ -238,3 +238,36 @@ def test_fp8_activation_batched_step_is_batch_invariant(fresh_tiny):
         assert np.array_equal(pair[17], crowd[17])
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("m,n,k,swiglu", [(37, 96, 256, False), (802, 2560, 2048, False), (300, 2 * 1376, 512, True),
+                                         (2100, 4096, 3584, False), (1296, 22016, 2048, True)])
+def test_block_scaled_fp8_gemm_vs_fp64(fresh_tiny, m, n, k, swiglu):
+    """ze_op_linear_mx (k_gemm_ring_mx: v_mfma_scale_f32_16x16x128_f8f6f4, both tile shapes, ragged M / N tails) against
+    fp64 arithmetic on the SAME quantised operands: every product q_a 2^ka q_w 2^kw is exact in fp32, so only the fp32
+    accumulation order and the final bf16 rounding separate the two."""
+    e = fresh_tiny
+    rng = np.random.default_rng(m + n)
+    a = (rng.normal(size=(m, k)) * rng.uniform(0.2, 3.0, size=(m, 1))).astype(np.float32)
+    w = (rng.normal(size=(n, k)) * 0.05 * rng.uniform(0.5, 2.0, size=(n, 1))).astype(np.float32)
+    bias = None if swiglu else (rng.normal(size=n) * 0.1).astype(np.float32)
+    ab = torch.from_numpy(a).cuda().to(torch.bfloat16).contiguous()
+    wb = torch.from_numpy(w).cuda().to(torch.bfloat16).contiguous()
+    a8, sa = e.op_quantize_fp8(ab)                      # ab / wb now hold the dequantised values q 2^k
+    w8, sw = e.op_quantize_fp8(wb)
+    bb = None if bias is None else torch.from_numpy(bias).cuda().to(torch.bfloat16).contiguous()
+    got = e.op_linear_mx(a8, sa, w8, sw, bias=bb, swiglu=swiglu).float().cpu().numpy()
+    ref = ab.double().cpu().numpy() @ wb.double().cpu().numpy().T
+    if bb is not None:
+        ref = ref + bb.double().cpu().numpy()[None, :]
+    if swiglu:                                          # packed rows: blocks of 16 gate rows then 16 up rows
+        r = ref.reshape(m, n // 32, 2, 16)
+        g, u = r[:, :, 0, :].reshape(m, -1), r[:, :, 1, :].reshape(m, -1)
+        gb = torch.from_numpy(g).to(torch.bfloat16).double().numpy()
+        ub = torch.from_numpy(u).to(torch.bfloat16).double().numpy()
+        sil = torch.from_numpy(gb / (1.0 + np.exp(-gb))).to(torch.bfloat16).double().numpy()
+        ref = sil * ub
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(got - ref).max())
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    assert err <= 0.012 * scale + 1e-3, (err, scale)    # bf16 output rounding (2^-8 relative) + fp32 accumulation

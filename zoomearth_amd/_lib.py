@@ -109,6 +109,7 @@ _SIGS = {
     "ze_weights_quantize_fp8": (C.c_int, [_P, _P]),
     "ze_set_fp8_activations": (C.c_int, [_P, C.c_int]),
     "ze_op_quantize_fp8": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
+    "ze_op_linear_mx": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ze_op_linear": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ze_op_rmsnorm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     "ze_op_attention": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32),

@@ -79,9 +79,12 @@ __device__ __forceinline__ uint32_t fp8_fake2(uint32_t w, float inv_s, float s) 
     return pack_bf16x2(back.x * s, back.y * s);
 }
 
+// act8 == 3 (prefill on the block-scaled fp8 MFMA, ze_gemm_mx.hip): the row goes out as E4M3 BYTES, row-major in y8 (leading
+// dimension cols), with its scale 2^k in yscale[row]; nothing is written to y
 __global__ void __launch_bounds__(256) k_rmsnorm(const bf16_t* __restrict__ x, int ldx,
                                                  const bf16_t* __restrict__ w, bf16_t* __restrict__ y, int ldy,
-                                                 int rows, int cols, float eps, int frag, int act8) {
+                                                 int rows, int cols, float eps, int frag, int act8,
+                                                 uint8_t* __restrict__ y8, float* __restrict__ yscale) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -124,10 +127,18 @@ __global__ void __launch_bounds__(256) k_rmsnorm(const bf16_t* __restrict__ x, i
         const int k = fp8_row_exponent(wave_max(amax));
         s8 = ldexpf(1.0f, k);
         inv8 = ldexpf(1.0f, -k);
+        if (act8 == 3 && lane == 0) yscale[row] = s8;
     }
     for (int v = lane; v < nv; v += 64) {
         uint32_t o[4];
         norm_vec(v, o);
+        if (act8 == 3) {
+            uint2 b;
+            b.x = fp8_pack2(o[0], inv8) | (fp8_pack2(o[1], inv8) << 16);
+            b.y = fp8_pack2(o[2], inv8) | (fp8_pack2(o[3], inv8) << 16);
+            *reinterpret_cast<uint2*>(y8 + (size_t)row * cols + v * 8) = b;
+            continue;
+        }
         if (act8) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = fp8_fake2(o[j], inv8, s8);
@@ -238,7 +249,7 @@ void ze_launch_rmsnorm(const bf16_t* x, int ldx, const bf16_t* w, bf16_t* y, int
         return;
     }
     if (frag == 2) frag = 0;
-    k_rmsnorm<<<ze_cdiv(rows, 4), 256, 0, s>>>(x, ldx, w, y, ldy, rows, cols, eps, frag, act8 ? 1 : 0);
+    k_rmsnorm<<<ze_cdiv(rows, 4), 256, 0, s>>>(x, ldx, w, y, ldy, rows, cols, eps, frag, act8 == 3 ? 3 : (act8 ? 1 : 0), y8, yscale);
 }
 
 // W [n, k] row-major (leading dimension ldw) -> MFMA-fragment-major copy: fragment (nb, ks) = rows 16 nb .. +15,

@@ -70,6 +70,8 @@ struct ze_engine {
     uint8_t* arena8 = nullptr;    // fp8 decode weights (0 until ze_weights_quantize_fp8)
     bool fp8_ready = false;
     bool fp8_act = false;         // ze_set_fp8_activations: qkv / gate-up inputs quantised to E4M3 per row (needs fp8_ready)
+    uint8_t* ty8p = nullptr;      // prefill with FP8 activations: the normalised rows as E4M3 bytes, row-major [rows, hidden]
+    float* ty8p_scale = nullptr;  // ... and their scales (block-scaled MFMA GEMM, ze_gemm.hip: k_gemm_ring_mx)
     float* damax = nullptr;       // single-chain decode: arg-max partials of the lm_head GEMV's workgroups (count, pairs)
     uint8_t* ty8 = nullptr;       // batched decode: the normalised rows as FP8 fragments (64 rows x hidden bytes)
     float* ty8_scale = nullptr;   // ... and their per-row scales (64)

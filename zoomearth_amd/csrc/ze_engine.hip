@@ -330,6 +330,8 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     const int nqkv = (c.heads + 2 * c.kv_heads) * e->head_dim;
     chk(dev_alloc(e, &e->th, tm * c.hidden));
     chk(dev_alloc(e, &e->ty, tm * c.hidden));
+    chk(dev_alloc(e, &e->ty8p, tm * c.hidden, false));
+    chk(dev_alloc(e, &e->ty8p_scale, tm, false));
     chk(dev_alloc(e, &e->damax, 2 * 2048));
     ze_launch_amax_init(e->damax, nullptr);
     chk(dev_alloc(e, &e->ty8, (size_t)64 * c.hidden));
@@ -407,7 +409,7 @@ extern "C" int ze_engine_destroy(ze_engine* e) {
                    e->vo, e->va, e->vz, e->vz2, e->vcos, e->vsin, e->vperm, e->vinv, e->vtiles_win, e->vtiles_full,
                    e->th, e->ty, e->tqkv, e->to, e->ta, e->tsrc, e->tpos, e->ttiles, e->ttile_aux, e->trow_aux, e->dh, e->dq, e->dattn, e->dact,
                    e->dlogits, e->dpartial, e->dsample, e->gbar, e->atickets, e->gslab, e->gtickets, e->bseq, e->blogits, e->bpartial, e->bsample, e->arena8, e->arena_f, e->arena_f8,
-                   e->ty8, e->ty8_scale, e->damax};
+                   e->ty8, e->ty8_scale, e->damax, e->ty8p, e->ty8p_scale};
     for (void* p : dev)
         if (p) hipFree(p);
     void* host[] = {e->fe_coef_host, e->v_host_ints, e->v_host_f32, e->t_host_ints, e->d_host_ints, e->bstate_host};

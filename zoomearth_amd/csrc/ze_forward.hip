@@ -378,6 +378,21 @@ extern "C" int ze_seq_mark_seen(ze_engine* e, int seq, const int32_t* ids, int n
 }
 
 // ================================================================== prefill
+// RMSNorm + the projection behind it, on `rows` prefill rows of e->th.  With FP8 activations on a quantised engine the row
+// goes out as E4M3 bytes + one scale and the product runs on the block-scaled FP8 MFMA against the FP8 weight rows
+// (k_gemm_ring_mx: the values of the fake-quantised bf16 path, another summation order; ze_tune knob 12 = 1 keeps that path).
+static void prefill_norm_gemm(ze_engine* e, const bf16_t* norm_w, const ze_linear& lin, const bf16_t* bias, int epi, bf16_t* out,
+                              int ldo, int rows, int N, hipStream_t s) {
+    const ze_config& c = e->cfg;
+    const int H = c.hidden;
+    if (e->fp8_act && lin.w8 && ze_gemv_knobs[12] != 1 && H % 128 == 0 && H >= 256 && lin.ld8 % 16 == 0) {
+        ze_launch_rmsnorm(e->th, H, norm_w, e->ty, H, rows, H, c.rms_eps, s, 0, 3, e->ty8p, e->ty8p_scale);
+        if (ze_launch_gemm_mx(epi, e->ty8p, H, e->ty8p_scale, lin.w8, lin.ld8, lin.scale8, bias, out, ldo, rows, N, H, s)) return;
+    }
+    ze_launch_rmsnorm(e->th, H, norm_w, e->ty, H, rows, H, c.rms_eps, s, 0, e->fp8_act ? 1 : 0);
+    ze_launch_gemm(epi, e->ty, H, lin.w, lin.ld, bias, nullptr, 0, out, ldo, nullptr, rows, N, H, s);
+}
+
 static int prefill_impl(ze_engine* e, int seq, const int32_t* input_ids, int len, const void* image_embeds,
                         int n_image_rows, const int32_t* position_ids, int rope_delta, float* out_logits,
                         float* out_logps, void* stream) {
@@ -424,18 +439,14 @@ static int prefill_impl(ze_engine* e, int seq, const int32_t* input_ids, int len
     const float scale = 1.0f / sqrtf((float)hd);
     for (int li = 0; li < c.layers; ++li) {
         const ze_text_layer& L = e->tl[li];
-        ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, len, H, c.rms_eps, s, 0, e->fp8_act ? 1 : 0);
-        ze_launch_gemm(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, nullptr, len,
-                       nqkv, H, s);
+        prefill_norm_gemm(e, L.in_norm, L.qkv, L.qkv.bias, ZE_EPI_NONE, e->tqkv, nqkv, len, nqkv, s);
         ze_launch_mrope_kv(e->tqkv, len, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->tpos, e->axis_of,
                            e->kc(li, seq), e->vc(li, seq), c.max_ctx, past, nullptr, 0, s);
         ze_launch_flash_attn(hd, 1, e->tqkv, nqkv, hd, e->kc(li, seq), hd, c.max_ctx * hd, e->vc(li, seq), hd,
                              c.max_ctx * hd, e->to, nq, hd, e->ttiles, nt, c.heads, c.heads / c.kv_heads, scale, past,
                              s);
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, len, H, nq, s);
-        ze_launch_rmsnorm(e->th, H, L.post_norm, e->ty, H, len, H, c.rms_eps, s, 0, e->fp8_act ? 1 : 0);
-        ze_launch_gemm(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad,
-                       nullptr, len, 2 * e->text_ipad, H, s);
+        prefill_norm_gemm(e, L.post_norm, L.gate_up, nullptr, ZE_EPI_SWIGLU, e->ta, e->text_ipad, len, 2 * e->text_ipad, s);
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, nullptr,
                        len, H, e->text_ipad, s);
     }
@@ -571,18 +582,14 @@ extern "C" int ze_prefill_batch(ze_engine* e, const int32_t* seqs, int n, const 
     const size_t seq_stride = (size_t)c.kv_heads * c.max_ctx * hd;
     for (int li = 0; li < c.layers; ++li) {
         const ze_text_layer& L = e->tl[li];
-        ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, total, H, c.rms_eps, s, 0, e->fp8_act ? 1 : 0);
-        ze_launch_gemm(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, nullptr, total,
-                       nqkv, H, s);
+        prefill_norm_gemm(e, L.in_norm, L.qkv, L.qkv.bias, ZE_EPI_NONE, e->tqkv, nqkv, total, nqkv, s);
         ze_launch_mrope_kv(e->tqkv, total, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->tpos, e->axis_of, e->kc(li, 0),
                            e->vc(li, 0), c.max_ctx, 0, e->trow_aux, seq_stride, s);
         ze_launch_flash_attn(hd, 1, e->tqkv, nqkv, hd, e->kc(li, 0), hd, c.max_ctx * hd, e->vc(li, 0), hd,
                              c.max_ctx * hd, e->to, nq, hd, e->ttiles, nt, c.heads, c.heads / c.kv_heads, scale, 0, s,
                              e->ttile_aux, seq_stride);
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, total, H, nq, s);
-        ze_launch_rmsnorm(e->th, H, L.post_norm, e->ty, H, total, H, c.rms_eps, s, 0, e->fp8_act ? 1 : 0);
-        ze_launch_gemm(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad,
-                       nullptr, total, 2 * e->text_ipad, H, s);
+        prefill_norm_gemm(e, L.post_norm, L.gate_up, nullptr, ZE_EPI_SWIGLU, e->ta, e->text_ipad, total, 2 * e->text_ipad, s);
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, nullptr,
                        total, H, e->text_ipad, s);
     }
@@ -1570,6 +1577,20 @@ extern "C" int ze_set_fp8_activations(ze_engine* e, int on) {
         e->fp8_act = on != 0;
         ++ze_tune_epoch;  // captured decode steps bake the choice of kernels in
     }
+    return ZE_OK;
+}
+
+extern "C" int ze_op_linear_mx(ze_engine* e, const void* a8, const void* sa, const void* w8, const void* sw, const void* bias,
+                               void* cmat, int M, int N, int K, int swiglu, void* stream) {
+    if (!e || !a8 || !sa || !w8 || !sw || !cmat || M <= 0 || N <= 0 || K <= 0)
+        return ze_fail(e, ZE_ERR_INVALID, "null pointer or empty shape");
+    if (K % 128 != 0 || K < 256 || (swiglu && N % 32 != 0))
+        return ze_fail(e, ZE_ERR_INVALID, "K must be a multiple of 128 (>= 256); with swiglu N a multiple of 32");
+    hipSetDevice(e->device);
+    if (!ze_launch_gemm_mx(swiglu ? ZE_EPI_SWIGLU : ZE_EPI_NONE, (const uint8_t*)a8, K, (const float*)sa, (const uint8_t*)w8, K,
+                           (const float*)sw, (const bf16_t*)bias, (bf16_t*)cmat, swiglu ? N / 2 : N, M, N, K, (hipStream_t)stream))
+        return ze_fail(e, ZE_ERR_INVALID, "shape not supported by the block-scaled kernel");
+    ZE_KCHECK();
     return ZE_OK;
 }
 

@@ -452,6 +452,191 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
 
 
 // ----------------------------------------------------------------------------------------------------------------
+// The ring on the block-scaled FP8 matrix instruction (BASELINE configs[4]: "fp8 weights on CDNA4 fp8 MFMA", prefill side;
+// ze_set_fp8_activations): C = (A8 * 2^ka) (W8 * 2^kw)^T with A8 [M, K] and W8 [N, K] E4M3 bytes, K contiguous, and ONE
+// power-of-two scale per row of each -- the activations' from k_rmsnorm(act8 = 3), the weights' from k_quantize_rows.
+// v_mfma_scale_f32_16x16x128_f8f6f4 multiplies 16 x 128 by 128 x 16 bytes per instruction (twice the MACs per cycle of
+// the bf16 form) and takes an E8M0 scale per lane and operand: a lane holds 32 consecutive K bytes of its row, and the MX
+// format's scale per 32-element block is simply the row's scale here -- the exponent field of the fp32 power of two --
+// so the instruction computes exactly the products the bf16 kernels form from the dequantised copies (q_a 2^ka x q_w 2^kw
+// is exact in fp32), in another summation order.  Staging is k_gemm_ring's, byte for byte: a 128-element K-step is the same
+// 128-B LDS row as 64 bf16, swizzle and all; a fragment is two 16-B chunks (32 bytes) per lane.
+typedef __attribute__((ext_vector_type(8))) int mx_i32x8;
+// the scale bytes are packed four to a register and picked by op_sel, which has to be a literal: dispatch over the 16
+// (byte of A, byte of B) pairs -- the selectors are loop counters of fully unrolled loops, so one case survives
+template <int OA, int OB>
+__device__ __forceinline__ f32x4 mx_mfma(const mx_i32x8& a, const mx_i32x8& b, const f32x4& c, int ea, int eb) {
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, OA, ea, OB, eb);
+}
+__device__ __forceinline__ f32x4 mx_mfma_sel(const mx_i32x8& a, const mx_i32x8& b, const f32x4& c, int oa, int ea, int ob, int eb) {
+    switch (oa * 4 + ob) {
+        case 0: return mx_mfma<0, 0>(a, b, c, ea, eb);
+        case 1: return mx_mfma<0, 1>(a, b, c, ea, eb);
+        case 2: return mx_mfma<0, 2>(a, b, c, ea, eb);
+        case 3: return mx_mfma<0, 3>(a, b, c, ea, eb);
+        case 4: return mx_mfma<1, 0>(a, b, c, ea, eb);
+        case 5: return mx_mfma<1, 1>(a, b, c, ea, eb);
+        case 6: return mx_mfma<1, 2>(a, b, c, ea, eb);
+        case 7: return mx_mfma<1, 3>(a, b, c, ea, eb);
+        case 8: return mx_mfma<2, 0>(a, b, c, ea, eb);
+        case 9: return mx_mfma<2, 1>(a, b, c, ea, eb);
+        case 10: return mx_mfma<2, 2>(a, b, c, ea, eb);
+        case 11: return mx_mfma<2, 3>(a, b, c, ea, eb);
+        case 12: return mx_mfma<3, 0>(a, b, c, ea, eb);
+        case 13: return mx_mfma<3, 1>(a, b, c, ea, eb);
+        case 14: return mx_mfma<3, 2>(a, b, c, ea, eb);
+        default: return mx_mfma<3, 3>(a, b, c, ea, eb);
+    }
+}
+
+template <int BM, int BN, int STAGES, int EPI, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring_mx(const uint8_t* __restrict__ A, int lda, const float* __restrict__ sa,
+                                                      const uint8_t* __restrict__ W, int ldw, const float* __restrict__ sw,
+                                                      const bf16_t* __restrict__ bias, const bf16_t* __restrict__ R, int ldr,
+                                                      bf16_t* __restrict__ C, int ldc, int M, int N, int K) {
+    constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN), NT = 64 * WM * WN;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    constexpr int LPA = BM / 8 / (WM * WN), LPW = (BM + BN) / 8 / (WM * WN);  // DMA instructions per wave per stage
+    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
+    const int nwg = nbx * nby;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const bool col_major = N > M;  // (see k_gemm_ring)
+    const int bm0 = (col_major ? bid % nby : bid / nbx) * BM, bn0 = (col_major ? bid / nby : bid % nbx) * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wid / WN) * (BM / WM), wn0 = (wid % WN) * (BN / WN);
+    const int fr = lane & 15, fq = lane >> 4;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // E8M0 scales of this lane's operand rows: the exponent field of the fp32 power of two
+    // (four to a register: the instruction's op_sel picks the byte)
+    static_assert(TM % 4 == 0 || TM < 4, "scale packing");
+    int ea[(TM + 3) / 4], eb[(TN + 3) / 4];
+#pragma unroll
+    for (int i = 0; i < (TM + 3) / 4; ++i) ea[i] = 0;
+#pragma unroll
+    for (int j = 0; j < (TN + 3) / 4; ++j) eb[j] = 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+        ea[i >> 2] |= (int)(((__float_as_uint(sa[min(bm0 + wm0 + i * 16 + fr, M - 1)]) >> 23) & 0xffu) << (8 * (i & 3)));
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+        eb[j >> 2] |= (int)(((__float_as_uint(sw[min(bn0 + wn0 + j * 16 + fr, N - 1)]) >> 23) & 0xffu) << (8 * (j & 3)));
+
+    const int nk = K / 128;
+    const unsigned smem_lds = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem);
+    // (the byte matrices go through the bf16 issue helpers as [rows][ld / 2] "elements": the same 16-B chunks)
+    const bf16_t* A16 = reinterpret_cast<const bf16_t*>(A);
+    const bf16_t* W16 = reinterpret_cast<const bf16_t*>(W);
+    const int lda16 = lda >> 1, ldw16 = ldw >> 1;
+    auto issue = [&](int kt) {
+        const unsigned img = smem_lds + (kt % STAGES) * STAGE_BYTES;
+        ring_issue<BM, NT>(A16, lda16, bm0, M - 1, kt * 64, img, wid, lane);
+        ring_issue<BN, NT>(W16, ldw16, bn0, N - 1, kt * 64, img + BM * 128, wid, lane);
+    };
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) issue(s);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ahead = min(STAGES - 2, nk - 1 - kt);
+        if (ahead >= 2) ring_wait<2 * LPW>();
+        else if (ahead == 1) ring_wait<LPW>();
+        else ring_wait<0>();
+        __builtin_amdgcn_s_barrier();
+        const bool more = kt + STAGES - 1 < nk;
+        const unsigned img_next = smem_lds + ((kt + STAGES - 1) % STAGES) * STAGE_BYTES;
+        const int k_next = (kt + STAGES - 1) * 64;
+        const uint8_t* imgA = smem + (kt % STAGES) * STAGE_BYTES;
+        const uint8_t* imgB = imgA + BM * 128;
+        mx_i32x8 fb[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row = wn0 + j * 16 + fr, sz = (row >> 1) & 7;
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(imgB + row * 128 + (((2 * fq) ^ sz) << 4));
+            const u32x4 hi = *reinterpret_cast<const u32x4*>(imgB + row * 128 + (((2 * fq + 1) ^ sz) << 4));
+            fb[j] = mx_i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wm0 + i * 16 + fr, sz = (row >> 1) & 7;
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(imgA + row * 128 + (((2 * fq) ^ sz) << 4));
+            const u32x4 hi = *reinterpret_cast<const u32x4*>(imgA + row * 128 + (((2 * fq + 1) ^ sz) << 4));
+            const mx_i32x8 fa = mx_i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = mx_mfma_sel(fa, fb[j], acc[i][j], i & 3, ea[i >> 2], j & 3, eb[j >> 2]);
+            if (more) {  // the refill of this K-step goes out between the rows of MFMAs (k_gemm_ring, SPREAD)
+#pragma unroll
+                for (int pc = 0; pc < LPW; ++pc)
+                    if ((STAGES == 2 ? min(pc, TM - 1) : pc * TM / LPW) == i) {
+                        if (pc < LPA) ring_issue_one(A16, lda16, bm0, M - 1, k_next, img_next, wid + pc * (NT / 64), lane);
+                        else ring_issue_one(W16, ldw16, bn0, N - 1, k_next, img_next + BM * 128, wid + (pc - LPA) * (NT / 64), lane);
+                    }
+            }
+        }
+    }
+    __syncthreads();  // the tail reuses the staging LDS
+    gemm_finish<BM, BN, EPI, WM, WN>(acc, smem, bias, R, ldr, C, ldc, nullptr, M, N, 1, 0, bid, nwg, bm0, bn0, nullptr, nullptr);
+}
+
+template <int BM, int BN, int ST>
+static void launch_ring_mx(int epi, const uint8_t* A, int lda, const float* sa, const uint8_t* W, int ldw, const float* sw,
+                           const bf16_t* bias, const bf16_t* R, int ldr, bf16_t* C, int ldc, int M, int N, int K, hipStream_t s) {
+    const int grid = ze_cdiv(M, BM) * ze_cdiv(N, BN);
+    const size_t lds = (size_t)(BM + BN) * 128 * ST;
+#define ZE_MX_LAUNCH(E)                                                                                              \
+    do {                                                                                                             \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring_mx<BM, BN, ST, E, 2, 4>),                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL((k_gemm_ring_mx<BM, BN, ST, E, 2, 4>), dim3(grid), dim3(512), lds, s, A, lda, sa, W, ldw, \
+                           sw, bias, R, ldr, C, ldc, M, N, K);                                                       \
+    } while (0)
+    switch (epi) {
+        case ZE_EPI_NONE: ZE_MX_LAUNCH(ZE_EPI_NONE); break;
+        case ZE_EPI_SWIGLU: ZE_MX_LAUNCH(ZE_EPI_SWIGLU); break;
+        default: break;
+    }
+#undef ZE_MX_LAUNCH
+}
+
+// C = (A8 2^ka) (W8 2^kw)^T (+ bias) (+ SwiGLU): epi NONE or SWIGLU; K a multiple of 128, lda / ldw even.  Tiles as in the
+// bf16 policy for many-tile grids: 256 x 256 when the grid is many rounds or a nearly full one, else 128 x 256.
+bool ze_launch_gemm_mx(int epi, const uint8_t* A, int lda, const float* sa, const uint8_t* W, int ldw, const float* sw,
+                       const bf16_t* bias, bf16_t* C, int ldc, int M, int N, int K, hipStream_t s) {
+    if (M <= 0 || N <= 0) return true;
+    if (K % 128 != 0 || K / 128 < 2 || (lda & 15) || (ldw & 15) || (epi != ZE_EPI_NONE && epi != ZE_EPI_SWIGLU)) return false;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    const int grid4 = ze_cdiv(M, 256) * ze_cdiv(N, 256);
+    const bool big = (2 * grid4 >= 3 * cus) || (grid4 <= cus && 10 * grid4 >= 9 * cus);
+    if (big) launch_ring_mx<256, 256, 2>(epi, A, lda, sa, W, ldw, sw, bias, nullptr, 0, C, ldc, M, N, K, s);
+    else launch_ring_mx<128, 256, 3>(epi, A, lda, sa, W, ldw, sw, bias, nullptr, 0, C, ldc, M, N, K, s);
+    return true;
+}
+
+
+// ----------------------------------------------------------------------------------------------------------------
 // Skinny GEMM of the batched decode step: M <= 64 rows (one per chain), every weight byte read ONCE, straight from
 // HBM into MFMA operand registers (no LDS staging, no barrier in the loop -- the GEMV of the single-chain step with
 // the matrix cores doing the 64 dot products).  A workgroup owns BN = 16 * TN weight rows over its K range; its four

@@ -62,6 +62,10 @@ void ze_launch_qkv_rope_oneshot(const bf16_t* Xf, const bf16_t* Wf_perm, const b
                                 const ze_seq_dev* st, const int* seq_ids, bf16_t* kcache, bf16_t* vcache,
                                 size_t cache_seq_stride, int max_ctx, hipStream_t s, const float* wscale = nullptr,
                                 const float* ascale = nullptr);
+// block-scaled FP8 GEMM (k_gemm_ring_mx): A8 [M, K] / W8 [N, K] E4M3 bytes with one power-of-two scale per row each; epi
+// ZE_EPI_NONE or ZE_EPI_SWIGLU; false when the shape does not qualify (K % 128, leading dimensions % 16)
+bool ze_launch_gemm_mx(int epi, const uint8_t* A, int lda, const float* sa, const uint8_t* W, int ldw, const float* sw,
+                       const bf16_t* bias, bf16_t* C, int ldc, int M, int N, int K, hipStream_t s);
 // batched decode on fragment-major operands (k_gemm_skinny<..., FRAG>): Xf from ze_launch_rmsnorm(frag = 1), Wf from
 // ze_launch_pack_fragments; M <= 64, N % 16 == 0, K % 32 == 0, K <= 4096 (no split-K)
 // wscale != null: Wf is the FP8 fragment copy (ze_launch_pack_fragments8) and wscale the per-row power-of-two scales

@@ -370,6 +370,16 @@ class Engine:
         quantize_fp8() first; a weight change switches it off again."""
         self._check(self.lib.ze_set_fp8_activations(self.h, 1 if on else 0))
 
+    def op_linear_mx(self, a8: torch.Tensor, sa: torch.Tensor, w8: torch.Tensor, sw: torch.Tensor, bias=None, swiglu: bool = False):
+        """(a8 * sa[:, None]) @ (w8 * sw[:, None]).T on the block-scaled FP8 MFMA: a8 u8 [M, K], w8 u8 [N, K] (E4M3 bytes),
+        sa / sw f32 powers of two per row (what op_quantize_fp8 returns) -> bf16 [M, N] ([M, N / 2] with swiglu)."""
+        m, k = a8.shape
+        n = w8.shape[0]
+        out = torch.empty((m, n // 2 if swiglu else n), dtype=torch.bfloat16, device=self.device)
+        self._check(self.lib.ze_op_linear_mx(self.h, _ptr(a8), _ptr(sa), _ptr(w8), _ptr(sw), _ptr(bias), _ptr(out), m, n, k,
+                                             1 if swiglu else 0, self._stream()))
+        return out
+
     def op_quantize_fp8(self, w: torch.Tensor):
         """w bf16 [rows, cols] on the device (overwritten with the dequantised values) -> (u8 bits, f32 scales)."""
         rows, cols = w.shape
