@@ -11,6 +11,13 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define FA_BQ 64
+#ifndef ZE_FA_CAUSAL_BKV
+// keys per iteration of the causal (prefill) kernel.  128 halves the barriers of a long single-chain prefill but its 128 KB
+// of LDS leave ONE workgroup per CU; 64 (two per CU) wins wherever the grid is many rounds: batched prefill of the 64-slot
+// question stream 1874 -> 1790 ms (33.4 against 32.8 questions/s), single chain 17.75 -> 18.06 ms per question.  One value
+// for every caller: a chain's prefill must not depend on what shares the pass (prefix reuse is bit-exact).
+#define ZE_FA_CAUSAL_BKV 64
+#endif
 #define FA_BK 64
 
 typedef short v4s __attribute__((ext_vector_type(4)));
@@ -240,7 +247,7 @@ void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_rs, int q_hs
     dim3 grid(n_tiles, heads);
 #define FA_LAUNCH(DD, CC)                                                                                      \
     do {                                                                                                          \
-        constexpr int BKV_ = (CC) ? 128 : 64;                                                                     \
+        constexpr int BKV_ = (CC) ? ZE_FA_CAUSAL_BKV : 64;                                                        \
         constexpr int LDS_ = 4 * BKV_ * 256;                                                                      \
         static bool attr_set = false;                                                                             \
         if (!attr_set) {                                                                                          \
