@@ -1098,7 +1098,8 @@ static void launch_batch_attention(ze_engine* e, int li, int n, bool frag_out, h
         // the per-wave kernel cuts 192-key parts whatever the context: ceil(max_ctx / 192) of them must fit the partial buffer
         // (max(max_splits, 8) parts per chain) and the merge's 64 lanes
         const int wparts = (c.max_ctx + 191) / 192;
-        const bool per_wave = ze_gemv_knobs[8] != 2 && ze_gemv_knobs[11] == 0 && wparts <= std::max(e->max_splits, 8) && wparts <= 64;
+        const bool per_wave = ze_gemv_knobs[8] != 2 && ze_gemv_knobs[11] == 0 && wparts <= std::max(e->max_splits, 8) && wparts <= 64 &&
+                              hd == 128 && c.heads / c.kv_heads <= 16;  // (128-wide heads, the q heads of a kv head as MFMA columns)
         const int chunk = ze_gemv_knobs[11] >= 64 ? ze_gemv_knobs[11] / 32 * 32 : 0;  // 0: a sixth of the chain's context
         const int max_parts = chunk ? (c.max_ctx + chunk - 1) / chunk : 8;           // (at most 8 parts: 128-token floor)
         ze_launch_attn_decode_stream(e->tqkv, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, e->to, frag_out ? -(nq / 32) : nq,

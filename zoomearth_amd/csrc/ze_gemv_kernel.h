@@ -439,6 +439,7 @@ static void launch_gemv_cfg(const ze_gemv_args& a, hipStream_t s) {
         if (KSPLIT > 1 && natural > 2 * cus && natural <= 4 * cus) grid = ze_cdiv(natural, 2);
     }
     if (ze_gemv_knobs[2] > 0) grid = std::min(ze_cdiv(P, PAIRS * (KSPLIT == 1 ? 4 : 1)), ze_gemv_knobs[2]);
+    if (EPI == ZE_GV_LOGITS && a.amax_ws && grid > 2048) grid = 2048;  // one arg-max slot per workgroup (k_argmax_final_folded)
     hipLaunchKernelGGL((k_gemv<EPI, PAIRS, KSPLIT, CH, WB>), dim3(grid), dim3(256), lds, s, a);
 }
 
