@@ -1,25 +1,29 @@
 #!/usr/bin/env python3
-"""Headline benchmark: questions/sec end-to-end for the ZoomEarth-3B zoom chain on 5000-px tiles.
+"""Headline benchmark: questions/sec end-to-end for the ZoomEarth-3B zoom chain on 5000-px tiles, at N MI355X.
 
-One "step" = one question = one full two-stage zoom chain on a synthetic 5000x5000 tile that is already resident
-in HBM (BASELINE.json configs[1]; workload constants from SURVEY.md section 8d):
+`python bench.py --gpus N --steps K --warmup W` runs the LRS-GRO question stream of BASELINE configs[3] at EVERY N
+(1 included): a synthetic question table (tiles of 5000 x 5000 px with 3..18 questions each, 10.7 on average as LRS-GRO's
+9734 questions about 908 images) is assigned to the N ranks tile by tile (`accel.shard_by_tile`: a tile never splits,
+longest-processing-time packing), and every rank drives its share through the continuous-batching scheduler
+(`zoomearth_amd/scheduler.py`, the code path of `src/eval/infer.py`) with 256 chain slots.  One "step" = 64 questions per
+GPU entering the stream; the K timed steps are ONE stream of K x 64 questions per GPU (filled at the start, drained at the
+end, both inside the timed region), bracketed by barrier + device synchronisation; `value` = all questions of all ranks
+over the slowest rank's time.  A question = one full two-stage zoom chain:
   K0  tile 5000^2 -> 512^2 bicubic view            K1/K2 smart_resize 504^2 + patchify (1296 patches)
-  ViT 1296 patches -> 324 image tokens             prefill L1 = 802 tokens, decode N1 = 192 (greedy, penalty 1.05)
+  ViT 1296 patches -> 324 image tokens             prefill L1 = 802 tokens, decode N1 ~ 192 (greedy, penalty 1.05)
   scripted bbox -> 512^2 crop of the FULL-RES tile  ViT on the crop (view features reused: identical bits)
-  prefill of the new tokens after the cached stage-1 prompt (L2 = 1320: 802 cached, of the 192 re-inserted ids those
-  that equal the generated ones keep the rows decode wrote, 326 vision-block ids), decode N2 = 96
-Text ids are synthetic with the structure of the reference prompt: 21 system-turn ids and 437 instruction ids that are
-the same for every question, 18 question ids that differ.
-Weights: Qwen2.5-VL-3B shape, bf16, synthetic N(0, 0.02^2) from the repo PRNG (no checkpoint offline).
-Control flow is scripted (random weights emit neither EOS nor a bbox): lengths fixed, EOS ignored.
+  prefill of the new tokens after the cached stage-1 prompt (L2 ~ 1320), decode N2 ~ 96; N1 / N2 ragged (+-25 %)
+Tiles are resident in HBM when the timed region starts (uploaded from pinned host memory before it; the upload rate is
+reported).  Text ids are synthetic with the structure of the reference prompt: 21 system-turn ids and 437 instruction
+ids that are the same for every question, 18 question ids that differ.  Weights: Qwen2.5-VL-3B shape, bf16, synthetic
+N(0, 0.02^2) from the repo PRNG (no checkpoint offline), generated on rank 0 and broadcast once (RCCL over xGMI) to the
+other ranks -- the path's only collective.  Control flow is scripted (random weights emit neither EOS nor a bbox).
 
-The same line carries `batch64`: BASELINE configs[2] -- 64 questions about 6 tiles advanced together by the
-continuous-batching scheduler (zoomearth_amd/scheduler.py, the code path of src/eval/infer.py), ragged lengths
-(+-25 % around N1 / N2 per question), dynamic-resolution ViT batch, timed over one step of 64 questions.
-
-Multi-GPU: one process per GPU (torch.distributed/RCCL); the question stream shards with no data-path collective;
-the only collective is the one-time broadcast of the packed weight arena from rank 0.  `--gpus N` without a
-torchrun environment spawns the N ranks itself (before anything touches the GPU).
+At N = 1 the same line carries, as named sub-objects with their own rooflines: `configs1` (BASELINE configs[1]: one
+chain, batch 1, the single-chain GEMV decode path), `batch64` (BASELINE configs[2]: 64 chain slots) and `cpu_baseline`
+(the reference's own transformers CPU path on this box's host cores).  `--batch 1` makes configs[1] the line's value,
+`--batch B` configs[2] with B chains.  `--gpus N` without a torchrun environment spawns the N ranks itself (before
+anything touches the GPU).
 """
 from __future__ import annotations
 
@@ -38,6 +42,15 @@ sys.path.insert(0, ROOT)
 L_TEXT_A, L_TEXT_B, N1, N2, PENALTY = 21, 455, 192, 96, 1.05  # 21 + 455 = 476 text ids
 HBM_PEAK_GBS = 8000.0
 BATCH_KERNELS = {0: "qkv", 1: "o_proj", 2: "gate_up", 3: "down", 4: "lm_head", 5: "attention", 6: "rmsnorm", 7: "rope_kv"}
+BATCH_KERNEL_NAMES_WIDE = {
+    0: "k_gemm_ring (row-streaming decode qkv projection, rows = chains)",
+    1: "k_gemm_ring (row-streaming decode o projection + residual)",
+    2: "k_gemm_ring<SWIGLU> (row-streaming decode gate/up projection, all chains' rows per workgroup, weights streamed once)",
+    3: "k_gemm_ring<RESIDUAL> split-K x 8 (row-streaming decode down projection)",
+    4: "k_gemm_ring<F32> (row-streaming decode lm_head)",
+    5: "k_attn_decode_wave<8> (batched decode attention: every wave streams 16 keys of each 64-key round, K rows straight into MFMA registers, V rows through its own LDS stages)",
+    7: "k_rope_kv_batch (M-RoPE + KV append of the row-streaming family)",
+}
 BATCH_KERNEL_NAMES = {
     0: "k_gemm_oneshot<QKV,4> (batched decode qkv projection + M-RoPE + KV append, sixteen waves per workgroup)",
     1: "k_gemm_oneshot<RESIDUAL,4> (batched decode o projection)",
@@ -197,43 +210,69 @@ class Model64:
         self._chains = {}
 
 
-def batch_step(engine, tiles, q0: int, B: int, stats=None, use_graph=True, slots=None):
-    """B questions about len(tiles) tiles (6 : 64 as LRS-GRO's 908 : 9734) through the continuous-batching scheduler and
-    the host code of src/eval/infer.py (hostloop.submit_zoom_chain: views, crops, prompts); the "parsed" box is
-    scripted, lengths are ragged and EOS is ignored (random weights emit neither)."""
+Q_STEP = 64          # questions per step per GPU of the stream workload
+STREAM_SLOTS = 256   # chain slots per GPU of the stream workload (the engine's choice in configs[3])
+
+
+def question_table(n_questions: int, seed: int = 0):
+    """Tile index of every question of a synthetic LRS-GRO-like table: tile t has 3..18 questions (10.5 on average; LRS-GRO:
+    9734 questions about 908 images = 10.7), questions grouped by tile as the dataset lists them."""
+    from zoomearth_amd.synth import uniform_ints
+    counts, total, t = [], 0, 0
+    while total < n_questions:
+        c = 3 + int(uniform_ints(424_242 + seed * 7919 + t, 1, 0, 16)[0])
+        c = min(c, n_questions - total)
+        counts.append(c)
+        total += c
+        t += 1
+    return [t for t, c in enumerate(counts) for _ in range(c)]
+
+
+def run_stream(engine, table, q0: int, slots: int, stats=None, use_graph=True):
+    """The questions `table` = [(question number offset, tile DeviceImage, view key)] through the continuous-batching
+    scheduler and the host code of src/eval/infer.py (hostloop: views, crops, prompts); the "parsed" box is scripted,
+    lengths are ragged and EOS is ignored (random weights emit neither).  Every question of a (tile, view key) looks at
+    the same <=512-px view, encoded once."""
     from zoomearth_amd import hostloop as H
     from zoomearth_amd.scheduler import ChainScheduler, Request
 
     model = Model64(engine)
     proc = SynthProcessor(engine.config, engine)
     sched = ChainScheduler(model, proc, do_sample=False, repetition_penalty=PENALTY, ignore_eos=True, burst=16,
-                           use_graph=use_graph, min_admit=int(os.environ.get("ZE_MIN_ADMIT", str(max(1, (slots or B) // 2)))),
+                           use_graph=use_graph, min_admit=int(os.environ.get("ZE_MIN_ADMIT", str(max(1, slots // 2)))),
                            max_wait_bursts=int(os.environ.get("ZE_MAX_WAIT", "6")), max_batch=slots)
     done = {}
     views = {}
-    for b in range(B):
+    for b, tile, vkey in table:
         q = q0 + b
-        t = b * len(tiles) // min(B, 64) if B <= 64 else (b // 64) * len(tiles) + (b % 64) * len(tiles) // 64
-        tile = tiles[t % len(tiles)]
-        if t not in views:  # every question of a tile looks at the same <=512-px view: encoded once per pass over the tile
-            views[t] = H.resize_image(tile)
+        if vkey not in views:
+            views[vkey] = H.resize_image(tile)
         n1, n2 = ragged_lengths(q)
         text = H.stage1_prompt(f"#q{q}#")
 
-        def stage1(req, toks, out1, q=q, tile=tile, view=views[t][0], n2=n2, text=text):
+        def stage1(req, toks, out1, q=q, tile=tile, view=views[vkey][0], n2=n2, text=text):
             crop, _ = H.resize_image(H.cut_image(tile, scripted_bbox(q, tile.width)))
 
             def stage2(req2, toks2, out2, q=q, n_p1=req.n_prompt, n_o1=len(toks)):
                 done[q] = (n_p1, n_o1, req2.n_prompt, len(toks2))
             return Request(prompt=H.stage2_prompt(text, out1), images=[view, crop], max_new_tokens=n2, on_done=stage2)
 
-        sched.submit(Request(prompt=text, images=[views[t][0]], max_new_tokens=n1, on_done=stage1))
+        sched.submit(Request(prompt=text, images=[views[vkey][0]], max_new_tokens=n1, on_done=stage1))
     sched.run()
-    assert len(done) == B
+    assert len(done) == len(table)
     if stats is not None:
         stats.update(sched.stats)
-        stats["lens"] = [done[q0 + b] for b in range(B)]
+        stats["lens"] = [done[q0 + b] for b, _, _ in table]
     return done
+
+
+def batch_step(engine, tiles, q0: int, B: int, stats=None, use_graph=True, slots=None):
+    """B questions about len(tiles) tiles (6 : 64 as LRS-GRO's 908 : 9734), passes of 64 questions over the tiles."""
+    table = []
+    for b in range(B):
+        t = b * len(tiles) // min(B, 64) if B <= 64 else (b // 64) * len(tiles) + (b % 64) * len(tiles) // 64
+        table.append((b, tiles[t % len(tiles)], t))
+    return run_stream(engine, table, q0, slots or B, stats, use_graph)
 
 
 # ----------------------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
@@ -490,8 +529,8 @@ def main():
         return 0
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 16 stream steps of 64 questions per GPU; 4 with --batch)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 4; 1 with --batch)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", choices=("auto", "hf", "port"), default="auto",
@@ -507,14 +546,21 @@ def main():
     ap.add_argument("--fp8-act", action="store_true",
                     help="--fp8 plus FP8 activations at the qkv / gate-up inputs (ze_set_fp8_activations: fp8 x fp8 MFMA in the "
                          "batched decode step)")
-    ap.add_argument("--batch", type=int, default=1,
-                    help="1 = BASELINE configs[1] is the line's value (plus a one-step batch64 object); B > 1 = configs[2] with "
-                         "B chains is the line's value")
-    ap.add_argument("--no-batch64", action="store_true", help="skip the batch64 and stream256 objects of the default line")
-    ap.add_argument("--no-stream256", action="store_true", help="skip the stream256 object of the default line")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="0 (default) = the configs[3] question stream is the line's value; 1 = BASELINE configs[1] (one chain, "
+                         "one question per step); B > 1 = configs[2] with B chains (one step = B questions)")
+    ap.add_argument("--slots", type=int, default=int(os.environ.get("ZE_STREAM_SLOTS", str(STREAM_SLOTS))),
+                    help="chain slots per GPU of the stream workload")
+    ap.add_argument("--no-batch64", action="store_true", help="skip the batch64 object of the default N = 1 line")
+    ap.add_argument("--no-configs1", action="store_true", help="skip the configs1 object of the default N = 1 line")
     ap.add_argument("--spawn-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     args.fp8 = args.fp8 or args.fp8_act
+    stream = args.batch == 0
+    if args.steps is None:
+        args.steps = 16 if stream else 4
+    if args.warmup is None:
+        args.warmup = 4 if stream else 1
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus)
@@ -537,54 +583,34 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
 
+    from zoomearth_amd.accel import broadcast_engine_weights, shard_by_tile
     from zoomearth_amd.config import ModelConfig
     from zoomearth_amd.engine import Engine
     from zoomearth_amd.image import DeviceImage
     from zoomearth_amd.synth import synthetic_tile
 
     B = max(1, args.batch)
-    want64 = B == 1 and world == 1 and args.model == "3b" and not args.fp8 and not args.no_batch64
-    BB = 64 if want64 else B          # chains of the batched workload (0 = none)
-    n_tiles = max(1, round(BB * 6 / 64)) if BB > 1 else 1
+    SLOTS = max(1, args.slots)
+    want1 = stream and world == 1 and args.model == "3b" and not args.fp8 and not args.no_configs1
+    want64 = stream and world == 1 and args.model == "3b" and not args.fp8 and not args.no_batch64
     cfg = ModelConfig.zoomearth_3b() if args.model == "3b" else ModelConfig.qwen25vl_7b()
-    want256 = want64 and not args.no_stream256
-    SLOTS = int(os.environ.get("ZE_STREAM_SLOTS", "256"))  # chain slots of the stream256 object (other values: measurements)
-    e = Engine(cfg, device=local, max_seqs=(SLOTS if want256 else max(1, BB)), max_ctx=2048, max_patches=max(4096, 1400 * min(BB, 40)),
-               max_prefill_rows=(int(os.environ.get("ZE_PREFILL_ROWS", str(16 * 832))) if BB > 1 else 0), max_tile_side=max(args.tile, 1024))
-    e.fill_synthetic(seed=0, std=0.02)
+    chains = SLOTS if stream else B
+    e = Engine(cfg, device=local, max_seqs=chains, max_ctx=2048, max_patches=max(4096, 1400 * min(max(chains, 64 if want64 else 1), 40)),
+               max_prefill_rows=(int(os.environ.get("ZE_PREFILL_ROWS", str(16 * 832))) if chains > 1 else 0), max_tile_side=max(args.tile, 1024))
+    if rank == 0 or os.environ.get("ZE_BENCH_EVERY_RANK_FILLS") == "1":
+        e.fill_synthetic(seed=0, std=0.02)
     for kv in os.environ.get("ZE_TUNE", "").split(","):  # measurement-only A/B knobs, e.g. ZE_TUNE=2:64
         if ":" in kv:
             e.lib.ze_tune(int(kv.split(":")[0]), int(kv.split(":")[1]))
-    bcast_s = 0.0
-    if use_dist:
-        arena = e.weights_arena()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        # the path's only collective: one-time weight broadcast over RCCL/xGMI.  Default: the plain collective (the form
-        # verified on hardware); ZE_BCAST=scatter_allgather: scatter + all-gather, every link of the point-to-point mesh
-        # carrying 1/N of the arena (tested with 2 gloo processes; no multi-GPU box was available to this build)
-        from zoomearth_amd.accel import scatter_allgather_broadcast
-        if os.environ.get("ZE_BCAST", "broadcast") == "scatter_allgather":
-            scatter_allgather_broadcast(arena, 0, dist)
-        else:
-            dist.broadcast(arena, src=0)
-        torch.cuda.synchronize()
-        bcast_s = time.perf_counter() - t0
-        del arena
+    # the path's only collective: rank 0 holds the weights (a checkpoint read in production, the synthetic fill here), the
+    # other ranks receive the packed arena once over RCCL / xGMI (accel.broadcast_engine_weights, what
+    # ZoomEarthForConditionalGeneration.from_pretrained(..., broadcast=True) and src/eval/infer.py run)
+    bcast_s = broadcast_engine_weights(e, rank, world, src=0, force=True) if use_dist else 0.0
+    e.assert_ready()
     if args.fp8:
         e.quantize_fp8()  # after the broadcast: every rank quantises the weights it received
         if args.fp8_act:
             e.set_fp8_activations(True)
-    # tile upload (PCIe): pinned host buffer -> HBM through the C ABI, timed on its own (never inside `value`)
-    host_tiles = [torch.from_numpy(synthetic_tile(1000 + rank * 16 + t, args.tile, args.tile)).pin_memory() for t in range(n_tiles)]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    dev_tiles = [e.tile_upload(h) for h in host_tiles]
-    torch.cuda.synchronize()
-    tile_upload_ms = 1000.0 * (time.perf_counter() - t0) / n_tiles
-    tile = dev_tiles[0]
-    chain = Chain(e, tile, use_graph=not args.no_graph)
-    tiles64 = [DeviceImage(t, e) for t in dev_tiles]
 
     def barrier():
         torch.cuda.synchronize()
@@ -592,118 +618,238 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    q0 = rank * 100000
+    # ---- the workload's tiles: a small pool of distinct synthetic host tiles (generating one takes ~1 s of host time),
+    # every logical tile of the rank uploaded from the pool to its own HBM buffer (pinned host memory -> HBM through the C
+    # ABI, timed on its own, never inside `value`: tiles are resident when the timed region starts)
+    n_pool = 6 if (stream or B > 1 or want64) else 1
+    host_pool = [torch.from_numpy(synthetic_tile(1000 + rank * 16 + t, args.tile, args.tile)).pin_memory() for t in range(n_pool)]
+
+    upload_stats = {"n": 0, "s": 0.0}
+
+    def upload(t):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        d = e.tile_upload(host_pool[t % n_pool])
+        torch.cuda.synchronize()
+        upload_stats["n"] += 1
+        upload_stats["s"] += time.perf_counter() - t0
+        return d
+
+    line = {}
     bstats = {}
+    use_graph = not args.no_graph
+    if stream:
+        # global question table of the timed region: world x steps x 64 questions, tiles assigned to ranks whole
+        n_total = world * args.steps * Q_STEP
+        tile_of = question_table(n_total, seed=1)
+        mine = shard_by_tile([f"tile{t:05d}.tif" for t in tile_of], rank, world)
+        warm_tile_of = question_table(args.warmup * Q_STEP, seed=2)
+        my_tiles = sorted({tile_of[i] for i in mine})
+        dev = {t: DeviceImage(upload(t), e) for t in my_tiles}
+        warm_dev = {t: dev[my_tiles[t % len(my_tiles)]] for t in set(warm_tile_of)} if my_tiles else {}
+        table = [(i, dev[tile_of[i]], tile_of[i]) for i in mine]
+        warm_table = [(i, warm_dev[t], ("w", t)) for i, t in enumerate(warm_tile_of)]
+        if warm_table:
+            run_stream(e, warm_table, 9_000_000 + rank * 100_000, SLOTS, use_graph=use_graph)
+        e.phase_timers(enable=True, reset=True)
+        barrier()
+        t0 = time.perf_counter()
+        run_stream(e, table, 1_000_000, SLOTS, bstats, use_graph=use_graph)
+        torch.cuda.synchronize()
+        my_dt = time.perf_counter() - t0
+        barrier()
+        dt = time.perf_counter() - t0
+        n_questions = n_total
+        lens_all = bstats.pop("lens")
+        lens = (int(np.mean([l[0] for l in lens_all])), int(np.mean([l[2] for l in lens_all])),
+                float(np.mean([l[1] for l in lens_all])), float(np.mean([l[3] for l in lens_all])))
+    else:
+        dev_tiles = [upload(t) for t in range(max(1, round(B * 6 / 64)) if B > 1 else 1)]
+        tiles64 = [DeviceImage(t, e) for t in dev_tiles]
+        chain = Chain(e, dev_tiles[0], use_graph=use_graph)
+        q0 = rank * 100000
 
-    def run_step(q):
-        if B == 1:
-            return chain.question(q)
-        d = batch_step(e, tiles64, q * B, B, bstats, use_graph=not args.no_graph)
-        l = d[q * B]
-        return [0] * l[1], [0] * l[3], l[0], l[2]
+        def run_step(q):
+            if B == 1:
+                return chain.question(q)
+            d = batch_step(e, tiles64, q * B, B, bstats, use_graph=use_graph)
+            l = d[q * B]
+            return [0] * l[1], [0] * l[3], l[0], l[2]
 
-    for i in range(args.warmup):
-        run_step(q0 + i)
-    e.phase_timers(enable=True, reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    lens = None
-    for i in range(args.steps):
-        out1, out2, l1, l2 = run_step(q0 + args.warmup + i)
-        lens = (l1, l2, len(out1), len(out2))
-    barrier()
-    dt = time.perf_counter() - t0
+        for i in range(args.warmup):
+            run_step(q0 + i)
+        e.phase_timers(enable=True, reset=True)
+        barrier()
+        t0 = time.perf_counter()
+        lens = None
+        for i in range(args.steps):
+            out1, out2, l1, l2 = run_step(q0 + args.warmup + i)
+            lens = (l1, l2, len(out1), len(out2))
+        torch.cuda.synchronize()
+        my_dt = time.perf_counter() - t0
+        barrier()
+        dt = time.perf_counter() - t0
+        n_questions = world * args.steps * B
+        mine = list(range(args.steps * B))
     phases = e.phase_timers(enable=False)
+    per_rank = [[len(mine), my_dt]]
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        g = torch.zeros((world, 2), dtype=torch.float64, device=f"cuda:{local}")
+        g[rank, 0], g[rank, 1] = len(mine), my_dt
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        per_rank = g.cpu().tolist()
 
     def batch_roofline(n):
         """dominant kernel of the batched decode step at n chains (largest device time per step among its launches),
         measured live with HIP events on the launch stream; the chains hold the contexts the run left behind"""
+        wide = e.set_decode_regime(1 if n > 64 else 0) == 1
+        names = BATCH_KERNEL_NAMES_WIDE if wide else BATCH_KERNEL_NAMES
         rows = {}
         for which in sorted(BATCH_KERNELS):
+            if which == 7 and not wide:
+                continue  # (the fragment family folds rope + KV append into the qkv launch)
             u, by = e.profile_batch_kernel(which, n, iters=72)
             rows[BATCH_KERNELS[which]] = {"us": round(u, 2), "GBps": round(by / (u * 1e-6) / 1e9, 1), "bytes": by}
         per_step = {k: v["us"] * (2 if k == "rmsnorm" else 1) for k, v in rows.items() if k != "lm_head"}
-        dom = max((w for w in BATCH_KERNELS if BATCH_KERNELS[w] in per_step and w in BATCH_KERNEL_NAMES), key=lambda w: per_step[BATCH_KERNELS[w]])
+        dom = max((w for w in BATCH_KERNELS if BATCH_KERNELS[w] in per_step and w in names), key=lambda w: per_step[BATCH_KERNELS[w]])
         r = rows[BATCH_KERNELS[dom]]
         ach = r["bytes"] / (r["us"] * 1e-6) / 1e9
         layer_us = sum(per_step.values())
-        return {"bound": "hbm", "kernel": BATCH_KERNEL_NAMES[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_us": r["us"], "bytes_per_launch": r["bytes"],
-                "chains": n, "layer_us": round(layer_us, 1),
+        traffic, traffic_src = committed_traffic("stream" if wide else "batch64", BATCH_KERNELS[dom])
+        e.set_decode_regime(-1)
+        return {"bound": "hbm", "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "avg_us": r["us"],
+                "bytes_per_launch": r["bytes"], "chains": n, "layer_us": round(layer_us, 1),
                 "step_kernels": {k: {"us": v["us"], "GBps": v["GBps"]} for k, v in rows.items()}}
 
+    def committed_traffic(section, kernel):
+        """HBM bytes per launch from the PMC passes of the latest committed profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        cannot run inside this process): profiles/traffic_latest.json, written by tools/profile_round.sh"""
+        tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        try:
+            with open(tp) as f:
+                tj = json.load(f)
+            ent = tj[section][kernel] if section in tj else None
+            if ent is None and section == "configs1":
+                ent = tj
+            return ent["hbm_bytes_per_launch"], f"profiles/traffic_latest.json (rocprofv3 --pmc, round {tj.get('round')})"
+        except Exception:
+            return None, None
+
+    def configs1_object(steps, warmup):
+        """BASELINE configs[1]: one chain, batch 1 -- `steps` questions through the single-chain path (GEMV decode under a
+        captured hipGraph), with the roofline of ITS dominant kernel and the per-phase fractions"""
+        tile = next(iter(dev.values())).base if stream else dev_tiles[0]
+        ch = Chain(e, tile, use_graph=use_graph)
+        for i in range(warmup):
+            ch.question(5_000_000 + i)
+        e.phase_timers(enable=True, reset=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        l = None
+        for i in range(steps):
+            o1, o2, l1, l2 = ch.question(5_000_100 + i)
+            l = (l1, l2, len(o1), len(o2))
+        torch.cuda.synchronize()
+        d = time.perf_counter() - t0
+        ph = e.phase_timers(enable=False)
+        obj = {"workload": "BASELINE configs[1]: ZoomEarth-3B shape, one 5000x5000 tile, full two-stage zoom chain per question, "
+                           "greedy, batch 1 (single-chain GEMV decode path, captured hipGraph)",
+               "value": steps / d, "unit": "questions/s", "steps": steps, "warmup": warmup, "ms_per_question": 1000.0 * d / steps,
+               "L1": l[0], "L2": l[1], "N1": l[2], "N2": l[3], "stage2_rows_kept_from_decode": ch.kept_generated,
+               "phase_ms_per_question": {k: round(v / steps, 3) for k, v in ph.items()}}
+        obj.update(decode_rooflines(obj["phase_ms_per_question"], l, ch.kept_generated, obj["ms_per_question"]))
+        return obj
+
+    def decode_rooflines(pm, l, kept_generated, ms_question):
+        # roofline of the dominant kernel (decode gate/up weight stream), measured live with HIP events on the stream
+        # the kernel runs on; bytes = algorithmic weight bytes of one launch (2 * 11008 * 2048 * 2 B)
+        us, by = e.profile_decode_kernel(2, iters=144)
+        ach = by / (us * 1e-6) / 1e9
+        others = {}
+        for which, name in ((0, "qkv"), (1, "o_proj"), (3, "down"), (4, "lm_head")):
+            u, b = e.profile_decode_kernel(which, iters=72)
+            others[name] = {"us": round(u, 2), "GBps": round(b / (u * 1e-6) / 1e9, 1)}
+        traffic, traffic_src = committed_traffic("configs1", "gate_up")
+        out = {"roofline": {"bound": "hbm", "kernel": "k_gemv<EPI=SWIGLU,PAIRS=1,KSPLIT=1,CH=4> = k_gemv<2, 1, 1, 4> (decode gate/up weight stream, 36 launches per token)",
+                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                            "traffic_source": traffic_src, "avg_us": us, "bytes_per_launch": by, "other_decode_kernels": others}}
+        # per-phase roofline fractions (SURVEY.md 8d): algorithmic work of the as-built question (stage-1 prompt KV and view
+        # features reused) over the measured phase time, against the dense bf16 MFMA peak / the HBM peak
+        # (prefill: the rows actually prefilled -- the stage-1 prompt and what stage 2 appends beyond the kept rows)
+        kept = l[0] + kept_generated
+        f_vit = 3.41e12                                            # FLOP per question
+        f_pre = (l[0] + l[1] - kept) * 5.549e9 + 36 * 4 * 2048 * (l[0] ** 2 + l[1] ** 2 - kept ** 2) / 2
+        b_dec = (N1 + N2) * 6.171e9 + 36864.0 * (N1 * (l[0] + N1 / 2) + N2 * (l[1] + N2 / 2))  # bytes per question
+        ph = {
+            "vit": {"bound": "mfma", "achieved_TFLOPs": f_vit / (pm["vit"] * 1e-3) / 1e12, "peak_TFLOPs": 2500.0,
+                    "frac": f_vit / (pm["vit"] * 1e-3) / 2.5e15},
+            "prefill": {"bound": "mfma", "achieved_TFLOPs": f_pre / (pm["prefill"] * 1e-3) / 1e12, "peak_TFLOPs": 2500.0,
+                        "frac": f_pre / (pm["prefill"] * 1e-3) / 2.5e15},
+            "decode": {"bound": "hbm", "achieved_GBs": b_dec / (pm["decode"] * 1e-3) / 1e9, "peak_GBs": HBM_PEAK_GBS,
+                       "frac": b_dec / (pm["decode"] * 1e-3) / (HBM_PEAK_GBS * 1e9)},
+            "question": {"roofline_ms": (f_vit + f_pre + (N1 + N2) * 6.171e9) / 2.5e15 * 1e3 + b_dec / (HBM_PEAK_GBS * 1e9) * 1e3,
+                         "measured_ms": ms_question},
+        }
+        ph["question"]["frac"] = ph["question"]["roofline_ms"] / ph["question"]["measured_ms"]
+        out["roofline_phases"] = ph
+        return out
+
     if rank == 0:
+        n_up = max(1, upload_stats["n"])
         line = {
             "metric": "questions/sec end-to-end, ZoomEarth-3B on 5000px tiles" if args.model == "3b" else
-                      "questions/sec end-to-end, Qwen2.5-VL-7B shape (bf16) on 5000px tiles", "value": world * args.steps * B / dt,
+                      "questions/sec end-to-end, Qwen2.5-VL-7B shape (bf16) on 5000px tiles", "value": n_questions / dt,
             "unit": "questions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: ZoomEarth-3B shape, one 5000x5000 tile per GPU, full two-stage "
+            "config": {"workload": (f"BASELINE configs[3] (LRS-GRO question stream, sharded by tile across the GPUs; ZoomEarth-3B shape): "
+                                    f"{n_questions} questions about {len(set(tile_of))} tiles of {args.tile}x{args.tile} px ({Q_STEP} questions per GPU "
+                                    f"per step), full two-stage zoom chain per question, greedy, {SLOTS} chain slots per GPU on the "
+                                    f"continuous-batching scheduler (the path of src/eval/infer.py)") if stream else
+                                   ("BASELINE configs[1]: ZoomEarth-3B shape, one 5000x5000 tile per GPU, full two-stage "
                                     "zoom chain per question, greedy, batch 1") if B == 1 else
-                                   (f"BASELINE configs[2]: ZoomEarth-3B shape, {B} question chains about {n_tiles} tiles advanced "
+                                   (f"BASELINE configs[2]: ZoomEarth-3B shape, {B} question chains about {len(dev_tiles)} tiles advanced "
                                     f"together per GPU by the continuous-batching scheduler (ragged lengths +-25 %, dynamic-"
                                     f"resolution ViT batch), one step = {B} questions"),
-                       "batch": B,
+                       "questions_per_step_per_gpu": Q_STEP if stream else B, "chain_slots_per_gpu": chains,
                        "tile": [args.tile, args.tile], "L1": lens[0], "L2": lens[1], "N1": lens[2], "N2": lens[3],
-                       "repetition_penalty": PENALTY, "hip_graph": not args.no_graph,
+                       "repetition_penalty": PENALTY, "hip_graph": use_graph,
                        "reuse": ("stage-1 prompt KV and view features reused in stage 2 (bit-identical); the KV rows of the "
-                                 "generated tokens that stage 2 re-inserts id for id are kept as the decode steps wrote them"),
-                       "stage2_rows_kept_from_decode": (chain.kept_generated if B == 1 else None),
-                       "parallelism": f"dp{world}", "weight_broadcast_s": round(bcast_s, 4)},
+                                 "generated tokens that stage 2 re-inserts id for id are kept as the decode steps wrote them; "
+                                 "prompt prefixes shared between the questions of a tile (bit-identical)"),
+                       "parallelism": f"dp{world}", "sharding": "accel.shard_by_tile (tile-level LPT, no data-path collective)",
+                       "weight_broadcast_s": round(bcast_s, 4)},
             "weight_broadcast_s": round(bcast_s, 4),
-            "tile_upload_ms": round(tile_upload_ms, 3),
+            "per_rank": {"questions": [int(r[0]) for r in per_rank], "seconds": [round(r[1], 3) for r in per_rank],
+                         "imbalance": round(max(r[1] for r in per_rank) / max(1e-9, float(np.mean([r[1] for r in per_rank]))), 4)},
+            "tile_upload_ms": round(1000.0 * upload_stats["s"] / n_up, 3),
             "tile_upload_note": (f"one {args.tile}x{args.tile}x3 u8 tile, pinned host memory -> HBM (ze_tile_upload), per TILE, "
-                                 "outside the timed region (tiles are resident when a step starts)"),
-            "phase_ms_per_question": {k: round(v / (args.steps * B), 3) for k, v in phases.items()},
+                                 f"{upload_stats['n']} tiles uploaded on this rank outside the timed region (tiles are resident when "
+                                 "it starts)"),
+            "phase_ms_per_question": {k: round(v / max(1, len(mine)), 3) for k, v in phases.items()},
         }
-        if args.model == "3b" and not args.fp8:
+        if stream:
+            st = dict(bstats)
+            steps_run = max(1, st.get("steps", 1))
+            line["decode_ms_per_step"] = round(phases["decode"] / steps_run, 3)
+            line["mean_chains_per_step"] = round(st.get("chain_steps", 0) / steps_run, 1)
+            line["scheduler"] = st
+            if args.model == "3b" and not args.fp8:
+                live = int(min(SLOTS, max(1, round(line["mean_chains_per_step"]))))
+                line["roofline"] = batch_roofline(live)
+        if args.model == "3b" and not args.fp8 and not stream:
             if B == 1:
-                # roofline of the dominant kernel (decode gate/up weight stream), measured live with HIP events on the
-                # stream the kernel runs on; bytes = algorithmic weight bytes of one launch (2 * 11008 * 2048 * 2 B)
-                us, by = e.profile_decode_kernel(2, iters=144)
-                ach = by / (us * 1e-6) / 1e9
-                others = {}
-                for which, name in ((0, "qkv"), (1, "o_proj"), (3, "down"), (4, "lm_head")):
-                    u, b = e.profile_decode_kernel(which, iters=72)
-                    others[name] = {"us": round(u, 2), "GBps": round(b / (u * 1e-6) / 1e9, 1)}
-                traffic, traffic_src = None, None
-                tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
-                if os.path.exists(tp):  # PMC passes cannot run inside this process: the latest committed measurement
-                    with open(tp) as f:
-                        tj = json.load(f)
-                    traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/traffic_latest.json (rocprofv3 --pmc, round %d)" % tj["round"]
-                line["roofline"] = {"bound": "hbm", "kernel": "k_gemv<EPI=SWIGLU,PAIRS=1,KSPLIT=1,CH=4> = k_gemv<2, 1, 1, 4> (decode gate/up weight stream, 36 launches per token)", "achieved": ach,
-                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                                    "avg_us": us, "bytes_per_launch": by, "other_decode_kernels": others}
-                # per-phase roofline fractions (SURVEY.md 8d): algorithmic work of the as-built question (stage-1 prompt KV
-                # and view features reused) over the measured phase time, against the dense bf16 MFMA peak / the HBM peak
                 pm = line["phase_ms_per_question"]
-                # (prefill: the rows actually prefilled -- the stage-1 prompt and what stage 2 appends beyond the kept rows)
-                kept = lens[0] + chain.kept_generated
-                f_vit = 3.41e12                                            # FLOP per question
-                f_pre = (lens[0] + lens[1] - kept) * 5.549e9 + 36 * 4 * 2048 * (lens[0] ** 2 + lens[1] ** 2 - kept ** 2) / 2
-                b_dec = (N1 + N2) * 6.171e9 + 36864.0 * (N1 * (lens[0] + N1 / 2) + N2 * (lens[1] + N2 / 2))  # bytes per question
-                line["roofline_phases"] = {
-                    "vit": {"bound": "mfma", "achieved_TFLOPs": f_vit / (pm["vit"] * 1e-3) / 1e12, "peak_TFLOPs": 2500.0,
-                            "frac": f_vit / (pm["vit"] * 1e-3) / 2.5e15},
-                    "prefill": {"bound": "mfma", "achieved_TFLOPs": f_pre / (pm["prefill"] * 1e-3) / 1e12, "peak_TFLOPs": 2500.0,
-                                "frac": f_pre / (pm["prefill"] * 1e-3) / 2.5e15},
-                    "decode": {"bound": "hbm", "achieved_GBs": b_dec / (pm["decode"] * 1e-3) / 1e9, "peak_GBs": HBM_PEAK_GBS,
-                               "frac": b_dec / (pm["decode"] * 1e-3) / (HBM_PEAK_GBS * 1e9)},
-                    "question": {"roofline_ms": (f_vit + f_pre + (N1 + N2) * 6.171e9) / 2.5e15 * 1e3 + b_dec / (HBM_PEAK_GBS * 1e9) * 1e3,
-                                 "measured_ms": line["ms_per_step"]},
-                }
-                line["roofline_phases"]["question"]["frac"] = (line["roofline_phases"]["question"]["roofline_ms"] /
-                                                               line["roofline_phases"]["question"]["measured_ms"])
+                line.update(decode_rooflines(pm, lens, chain.kept_generated, line["ms_per_step"]))
+                line["config"]["stage2_rows_kept_from_decode"] = chain.kept_generated
             else:
                 line["roofline"] = batch_roofline(B)
                 line["scheduler"] = {k: v for k, v in bstats.items() if k != "lens"}
-        elif B == 1:
+        elif B == 1 and not stream:
             # configs[4] shapes (7B backbone and / or FP8 decoder weights): the same object for this configuration's own
             # dominant kernel -- the decode gate/up weight stream at this shape and weight width -- measured the same way
             us, by = e.profile_decode_kernel(2, iters=144)
@@ -723,15 +869,13 @@ def main():
             line["dtype"] = ("fp8-e4m3 decoder weights + fp8-e4m3 qkv / gate-up inputs (dynamic per-row power-of-two scales): "
                              "fp8 x fp8 MFMA in the batched decode step, the same values as bf16 everywhere else")
         if want64:
-            # BASELINE configs[2], driver-timed in the default run: one warm-up step (graph captures, fragment copy), then
-            # ONE timed step of 64 questions about 6 tiles through the scheduler, bracketed by device synchronisation
-            # 64 chain slots, a stream of 4 x 64 questions (every tile questioned in four passes): as in the LRS-GRO run, a
-            # chain that finishes hands its slot to the next question, so the batch stays full until the stream runs dry
-            # (the drain tail -- ~110 of the decode steps -- is paid once per 256 questions; measured: 64 questions 28.5,
-            # 128 questions 27.9-28.4 questions/s: the middle of the stream gains what its second admission wave costs)
+            # BASELINE configs[2]: 64 chain slots (the fragment-kernel family of the decode step), a stream of 4 x 64 questions
+            # about 6 tiles (every tile questioned in four passes): a chain that finishes hands its slot to the next question,
+            # so the batch stays full until the stream runs dry (the drain tail is paid once per 256 questions)
             st = {}
             NQ = 256
-            batch_step(e, tiles64, 7_000_000, 64)
+            tiles64 = [dev[t] for t in my_tiles[:6]]
+            batch_step(e, tiles64, 7_000_000, 64, slots=64)
             e.phase_timers(enable=True, reset=True)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -747,7 +891,7 @@ def main():
                              "stream of 256 questions (four steps of 64); ragged N1 / N2 (+-25 %), chains leave at their own "
                              "budget and hand their slot to the next question, stage 2 joins the running batch; one multi-"
                              "resolution ViT call per admission round, the view of a tile encoded once per pass over its questions"),
-                "value": NQ / dt64, "unit": "questions/s", "steps": NQ // 64, "questions": NQ, "chain_slots": 64, "tiles": 6,
+                "value": NQ / dt64, "unit": "questions/s", "steps": NQ // 64, "questions": NQ, "chain_slots": 64, "tiles": len(tiles64),
                 "ms_per_step": 1000.0 * dt64 / (NQ // 64),
                 "mean_N1": float(np.mean([l[1] for l in lens64])), "mean_N2": float(np.mean([l[3] for l in lens64])),
                 "mean_L1": float(np.mean([l[0] for l in lens64])), "mean_L2": float(np.mean([l[2] for l in lens64])),
@@ -755,33 +899,8 @@ def main():
                 "decode_ms_per_step": round(ph64["decode"] / dec_steps, 3), "scheduler": st,
                 "roofline": batch_roofline(64),
             }
-        if want256:
-            # BASELINE configs[3], one GPU's share of the LRS-GRO stream (9734 questions over 8 GPUs): the same scheduler with
-            # 256 chain slots -- the slot count is the engine's choice there, not part of the workload -- fed 1024 questions
-            # (16 passes over the 6 tiles).  Beyond 64 chains the decode step leaves the fragment kernels for the tiled
-            # GEMMs; a chain's result is batch-invariant within each of the two regimes.
-            st2 = {}
-            NQ2 = 1024
-            batch_step(e, tiles64, 7_500_000, SLOTS, slots=SLOTS)
-            e.phase_timers(enable=True, reset=True)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            batch_step(e, tiles64, 7_600_000, NQ2, st2, slots=SLOTS)
-            torch.cuda.synchronize()
-            dt256 = time.perf_counter() - t0
-            ph256 = e.phase_timers(enable=False)
-            lens256 = st2.pop("lens")
-            line["stream256"] = {
-                "workload": ("BASELINE configs[3], one GPU's share: a stream of 1024 questions (sixteen passes over 6 tiles) through "
-                             "the continuous-batching scheduler with 256 chain slots; ragged N1 / N2, prompt prefixes shared per "
-                             "tile, stage 2 continues on the slot of stage 1"),
-                "value": NQ2 / dt256, "unit": "questions/s", "questions": NQ2, "chain_slots": SLOTS, "tiles": 6,
-                "seconds": round(dt256, 3),
-                "mean_N1": float(np.mean([l[1] for l in lens256])), "mean_N2": float(np.mean([l[3] for l in lens256])),
-                "phase_ms": {k: round(v, 2) for k, v in ph256.items()},
-                "decode_ms_per_step": round(ph256["decode"] / max(1, st2.get("steps", 1)), 3),
-                "mean_chains_per_step": round(st2.get("chain_steps", 0) / max(1, st2.get("steps", 1)), 1), "scheduler": st2,
-            }
+        if want1:
+            line["configs1"] = configs1_object(4, 1)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             line["cpu_baseline"] = measure_cpu_baseline(args.cpu_baseline)
         print(json.dumps(line), flush=True)

@@ -97,6 +97,12 @@ int ze_weights_missing(ze_engine* e);
 /* The packed bf16 weight arena (one contiguous device allocation): lets the host broadcast it once over
  * RCCL/xGMI with torch.distributed and checksum it.  Does not transfer ownership. */
 int ze_weights_arena(ze_engine* e, void** dev_ptr, size_t* bytes);
+/* To be called after the host WROTE the whole arena through that pointer (the torch.distributed broadcast that replaces
+ * every rank's own from_pretrained, src/eval/infer.py:147-151: rank 0 reads the checkpoint, the others receive the packed
+ * arena; a weight refresh of the rollout engine): every tensor counts as loaded, the derived copies (fragment-major, FP8)
+ * and the captured graphs are dropped and rebuilt from the new values on their next use.  ze_weights_arena itself has no
+ * side effect. */
+int ze_weights_invalidate(ze_engine* e);
 /* The same broadcast for a host that owns an RCCL communicator (`ncclComm_t`, passed as void*): ncclBroadcast of the whole
  * arena from rank `root` on `stream`, in place (replaces: accelerator.prepare / every rank's own from_pretrained,
  * src/eval/infer.py:147-151,171 -- the checkpoint is read from disk once).  RCCL is not linked: the symbol must already be
@@ -211,6 +217,11 @@ int ze_prefill_batch(ze_engine* e, const int32_t* seqs, int n, const int32_t* le
  * out_logits: f32 [n, vocab] device or NULL.  ze_generate_batch: greedy loop for all chains after their prefills
  * (continuous batching: chains that hit EOS leave the batch); out_tokens host int32 [n, max_new_tokens], n_out [n]. */
 int ze_decode_batch(ze_engine* e, const int32_t* seqs, int n, const int32_t* tokens, float* out_logits, void* stream);
+/* Kernel family of the batched decode step: 0 = the fragment kernels (at most 64 chains per step; more is an error),
+ * 1 = the row-streaming kernels (any count), -1 (default) = by the engine's capacity: max_seqs > 64 -> 1.  The family is a
+ * property of the engine, never of how many chains are live, so a chain's tokens do not depend on the batch it shares
+ * (within a family bit for bit; the two families agree within bf16 rounding).  Returns the family in force (0 / 1). */
+int ze_set_decode_regime(ze_engine* e, int regime);
 int ze_generate_batch(ze_engine* e, const int32_t* seqs, int n, const ze_gen_params* p, int32_t* out_tokens,
                       int32_t* n_out, void* stream);
 /* Continuous batching (replaces: the request stream the reference keeps in flight against its serving back-end,
@@ -284,7 +295,8 @@ int ze_op_linear_mx(ze_engine* e, const void* a8, const void* sa, const void* w8
  *   K % 32 == 0, K <= 4096); 5 the same operands through the sixteen-wave one-shot kernel of the qkv / o projections,
  * 4 the SwiGLU epilogue of the MLP (HF:...modeling_qwen2_5_vl.py:85-96,541-554): W holds gate and up rows interleaved
  *   in blocks of 16 ([gate 0..15 | up 0..15 | gate 16..31 | ...], N = 2 * width, width % 16 == 0), bias likewise;
- *   C is [M, N/2] = bf16(bf16(silu(bf16(gate))) * bf16(up)). */
+ *   C is [M, N/2] = bf16(bf16(silu(bf16(gate))) * bf16(up));
+ * 6 / 7 none / SwiGLU through the launcher of the row-streaming decode regime (ze_set_decode_regime = 1; rows = chains). */
 int ze_op_linear(ze_engine* e, const void* a_bf16, const void* w_bf16, const void* bias_bf16, void* c_bf16, int M,
                  int N, int K, int act, void* stream);
 /* y = weight * bf16(x * rsqrt(mean(x^2)+eps))  (HF:...modeling_qwen2_5_vl.py:64-79), rows x cols bf16. */

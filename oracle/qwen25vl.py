@@ -211,7 +211,10 @@ def synthetic_weights(cfg: Config, seed: int = 0, std: float = 0.02, matrix_gain
 
 # ----------------------------------------------------------------------------- model
 class Qwen25VLOracle:
-    def __init__(self, cfg: Config, weights: dict, mode: str = "bf16", act_fp8: bool = False):
+    def __init__(self, cfg: Config, weights: dict, mode: str = "bf16", act_fp8: bool = False, share_weights: bool = False):
+        """share_weights: `weights` are float32 arrays that already hold bf16-representable values (what the engine
+        stores) and are used as they are, without the per-oracle copy -- the full-depth checks keep ONE 14-GB set for
+        the fp32 and the bf16 oracle."""
         assert mode in ("bf16", "fp32")
         self.cfg = cfg
         self.mode = mode
@@ -220,8 +223,12 @@ class Qwen25VLOracle:
         # (oracle/fp8.py).  No counterpart in the reference, whose checkpoints run bf16.
         self.act_fp8 = act_fp8
         self.r = bf16_round if mode == "bf16" else _ident
-        self.w = {k: (bf16_round(v.astype(np.float32)) if mode == "bf16" else v.astype(np.float32))
-                  for k, v in weights.items()}
+        if share_weights:
+            assert all(v.dtype == np.float32 for v in weights.values())
+            self.w = dict(weights)
+        else:
+            self.w = {k: (bf16_round(v.astype(np.float32)) if mode == "bf16" else v.astype(np.float32))
+                      for k, v in weights.items()}
         if "lm_head.weight" not in self.w:
             self.w["lm_head.weight"] = self.w["model.language_model.embed_tokens.weight"]
         self.reset()

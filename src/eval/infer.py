@@ -5,7 +5,8 @@ same two-stage chain, same `results/{exp_name}{rank}.jsonl` records in the rank'
 
 Differences, all documented in DESIGN.md: up to `--batch_size` question chains advance together on the GPU (continuous
 batching, `zoomearth_amd/scheduler.py`; the reference runs `BATCH_SIZE = 1`, :27) -- a chain's output does not depend
-on the batch size; a 5000-px tile is decoded ONCE per tile by a prefetch thread, uploaded to HBM and cropped / resized
+on which chains share its steps, and is the same for every `--batch_size` up to 64 (above 64 the decode step runs on
+another kernel family: same for every size above 64, equal to the first within bf16 rounding); a 5000-px tile is decoded ONCE per tile by a prefetch thread, uploaded to HBM and cropped / resized
 by the HIP front-end (the reference decodes it twice per question on the CPU), and the <=512-px view of a tile is
 encoded once for all its questions; sampling at T=0.01 draws from the same distribution with the engine's own random
 stream; bf16 arithmetic; questions are sharded by tile across ranks; a question whose box does not parse into four
@@ -51,9 +52,18 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
                     batch_size=BATCH_SIZE, max_ctx=4096, do_sample=True):
     # capacity: the stage-2 prompt holds the stage-1 prompt, its output and a second image (<= ~3200 tokens at the
     # default budgets); prefill passes of up to 16 prompts share their GEMMs
+    # one rank per GPU (torchrun / accelerate launch): rank 0 reads the checkpoint, the others receive the packed weight
+    # arena in one RCCL broadcast over xGMI (the reference: every rank reads it, :147-151).  ZE_WEIGHT_BROADCAST=0, or more
+    # ranks than GPUs (ranks sharing a GPU cannot form an RCCL communicator): every rank loads the checkpoint itself.
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    share = world > 1 and os.environ.get("ZE_WEIGHT_BROADCAST", "1") != "0" and \
+        (os.environ.get("ZE_DIST_BACKEND", "nccl") != "nccl" or world <= torch.cuda.device_count())
     model = ZoomEarthForConditionalGeneration.from_pretrained(
         model_name, max_seqs=batch_size, max_ctx=max_ctx, max_prefill_rows=max(max_ctx, min(batch_size, 16) * 1024),
-        max_patches=max(8192, min(batch_size, 32) * 1400))
+        max_patches=max(8192, min(batch_size, 32) * 1400), broadcast=share)
+    if share and int(os.environ.get("RANK", "0")) == 0:
+        print(f"weights broadcast to {world} ranks in {model.weight_broadcast_s:.2f} s")
     model.eval()
     processor = ZoomEarthProcessor.from_pretrained(model_name, trust_remote_code=True, max_pixels=128 * 128 * 28 * 28)
     processor.tokenizer.padding_side = "left"
@@ -112,6 +122,9 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
     accelerator.wait_for_everyone()
     if accelerator.is_main_process:
         print("Done! Predictions has been written to: ", out_path)
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
     return sched.stats
 
 

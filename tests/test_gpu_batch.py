@@ -217,10 +217,12 @@ def test_wide_batch_matches_narrow_batch_bitwise():
 
 
 def test_more_than_64_chains_fall_back_and_agree():
-    """Beyond 64 chains the fragment / one-shot kernels (M <= 64) do not apply: the step runs on the row-major
-    weight-streaming GEMMs + the stand-alone rope kernel, the streaming attention kernel keeps its chain dimension.  A
-    chain's logits there must agree with the 64-chain path within the bf16 noise of a different summation order, and the
-    step must be batch-invariant within its own path (70 chains vs 66)."""
+    """An engine with more than 64 chain slots runs its decode step on the row-streaming kernel family (row-major
+    weight-streaming GEMMs + the stand-alone rope kernel; the streaming attention kernel keeps its chain dimension) for
+    EVERY batch size, so a chain's logits are the same bits among 70, among 66 and among 3 chains (the family is
+    pinned by capacity, never by the live count); pinned to the fragment kernels (`set_decode_regime(0)`, at most 64 chains
+    per step) the same engine agrees with them within the bf16 noise of a different summation order; more than 64 chains
+    there is an error, not a silent switch."""
     from zoomearth_amd.config import ModelConfig
     from zoomearth_amd.engine import Engine
 
@@ -235,12 +237,20 @@ def test_more_than_64_chains_fall_back_and_agree():
                 prefill_text(e, s, prompts[s])
             return e.decode_batch(chains, [11 + s for s in chains]).cpu().numpy()
 
+        assert e.set_decode_regime(-1) == 1          # by capacity: 70 slots -> row streaming
         wide = run(list(range(n)))
         mid = run(list(range(66)))
-        frag = run(list(range(64)))
+        few = run([0, 1, 2])
         assert np.isfinite(wide).all()
         assert np.array_equal(wide[:66], mid)
+        assert np.array_equal(wide[:3], few)
+        assert e.set_decode_regime(0) == 0
+        frag = run(list(range(64)))
         assert float(np.abs(wide[:64] - frag).max()) < 0.15, float(np.abs(wide[:64] - frag).max())
+        with pytest.raises(Exception):
+            e.decode_batch(list(range(65)), [11] * 65)
+        assert e.set_decode_regime(1) == 1
+        assert np.array_equal(run(list(range(n))), wide)
     finally:
         e.close()
 

@@ -1,5 +1,5 @@
 """GPU: the one-line JSON contract of bench.py (what the driver parses): keys, types, the roofline and cpu_baseline
-objects, and internal consistency (value = steps / time, frac = achieved / peak)."""
+objects, and internal consistency (value = questions / time, frac = achieved / peak)."""
 import json
 import os
 import subprocess
@@ -11,31 +11,40 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*args, timeout=1500):
+def run_bench(*args, timeout=1500, **env):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
-                       timeout=timeout, cwd=ROOT)
+                       timeout=timeout, cwd=ROOT, env=dict(os.environ, **env))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     return json.loads(lines[0])
 
 
+def check_roofline(r, lo=0.05):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and lo < r["frac"] < 1.0
+    assert r["traffic"] is None or 0.9 < r["traffic"] / r["bytes_per_launch"] < 1.6
+
+
 def test_bench_line_contract():
+    """The default workload: BASELINE configs[3], the question stream (here 2 timed steps of 64 questions), with the
+    configs[1] / configs[2] / cpu_baseline sub-objects of an N = 1 run."""
     d = run_bench("--gpus", "1", "--steps", "2", "--warmup", "1")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "per_rank"):
         assert k in d, k
     assert d["unit"] == "questions/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
-    assert abs(d["value"] - 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]          # batch 1: one question per step
-    assert 0.5 < d["value"] < 10.0
-    r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
-        assert k in r, k
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.3 < r["frac"] < 1.0
-    assert r["traffic"] is None or 0.9 < r["traffic"] / r["bytes_per_launch"] < 1.5
+    assert "configs[3]" in d["config"]["workload"] and d["config"]["questions_per_step_per_gpu"] == 64
+    assert abs(d["value"] - 64 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]     # 64 questions per step per GPU
+    assert d["per_rank"]["questions"] == [128] and d["scheduler"]["admitted"] == 256  # two stages per question
+    assert 64 < d["mean_chains_per_step"] <= 256 or d["steps"] < 4
+    assert d["value"] > 10.0
+    check_roofline(d["roofline"])
+    assert d["roofline"]["chains"] >= 1 and "decode" in d["roofline"]["kernel"]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "threads", "kind", "sample"):
         assert k in c, k
@@ -43,20 +52,37 @@ def test_bench_line_contract():
     assert c["cores"] == os.cpu_count() and (c["threads"] is None or 1 <= c["threads"] <= c["cores"])
     assert c["value"] is None or 0 < c["value"] < d["value"]
     assert d["tile_upload_ms"] > 0 and d["weight_broadcast_s"] == 0
-    # BASELINE configs[2] in the same line: one timed step of 64 questions about 6 tiles through the scheduler
+    # BASELINE configs[1] in the same line: the single-chain path with its own roofline (the decode gate/up GEMV)
+    s = d["configs1"]
+    assert s["steps"] == 4 and abs(s["value"] - 1000.0 / s["ms_per_question"]) < 1e-6 * s["value"] and 0.5 < s["value"] < 10.0
+    assert (s["L1"], s["N1"], s["N2"]) == (802, 192, 96)
+    check_roofline(s["roofline"], lo=0.3)
+    ph = s["roofline_phases"]
+    assert ph["decode"]["bound"] == "hbm" and ph["vit"]["bound"] == "mfma" and 0 < ph["question"]["frac"] < 1
+    # BASELINE configs[2] in the same line: 256 questions about 6 tiles through 64 chain slots
     b = d["batch64"]
-    assert b["questions"] == 256 and b["chain_slots"] == 64 and b["tiles"] == 6 and b["steps"] == 4
+    assert b["questions"] == 256 and b["chain_slots"] == 64 and b["steps"] == 4
     assert abs(b["value"] - 64000.0 / b["ms_per_step"]) < 1e-6 * b["value"]
-    assert b["value"] > 5 * d["value"]
+    assert b["value"] > 5 * s["value"]
     assert 0.75 * 192 <= b["mean_N1"] <= 1.25 * 192 and 0.75 * 96 <= b["mean_N2"] <= 1.25 * 96 and b["mean_L1"] == 802
     assert b["scheduler"]["admitted"] == 512 and b["scheduler"]["chain_steps"] > 40 * b["scheduler"]["steps"]
-    rb = b["roofline"]
-    assert rb["bound"] == "hbm" and rb["chains"] == 64 and "batched decode" in rb["kernel"]
-    assert abs(rb["frac"] - rb["achieved"] / rb["peak"]) < 1e-9 and 0.05 < rb["frac"] < 1.0
-    # BASELINE configs[3], one GPU's share of the stream: 1024 questions through 256 chain slots
-    w = d["stream256"]
-    assert w["questions"] == 1024 and w["chain_slots"] == 256 and w["scheduler"]["admitted"] == 2048
-    assert abs(w["value"] - 1024 / w["seconds"]) < 1e-2 * w["value"] and w["value"] > b["value"]
-    assert 64 < w["mean_chains_per_step"] <= 256
-    ph = d["roofline_phases"]
-    assert ph["decode"]["bound"] == "hbm" and ph["vit"]["bound"] == "mfma" and 0 < ph["question"]["frac"] < 1
+    check_roofline(b["roofline"])
+    assert b["roofline"]["chains"] == 64 and "batched decode" in b["roofline"]["kernel"]
+
+
+def test_bench_batch1_is_configs1():
+    """`--batch 1`: BASELINE configs[1] as the line's own value (one question per step), no sub-objects."""
+    d = run_bench("--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "1", "--no-cpu-baseline")
+    assert "configs[1]" in d["config"]["workload"] and d["config"]["questions_per_step_per_gpu"] == 1
+    assert abs(d["value"] - 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"] and 0.5 < d["value"] < 10.0
+    check_roofline(d["roofline"], lo=0.3)
+    assert "batch64" not in d and "configs1" not in d and "cpu_baseline" not in d
+
+
+def test_bench_runs_the_collective_path_on_one_rank():
+    """ZE_BENCH_FORCE_DIST=1: a one-rank RCCL communicator -- init, the weight broadcast (accel.broadcast_engine_weights), the
+    barriers and the max-over-ranks reductions of the N > 1 path, on this box's one GPU."""
+    d = run_bench("--gpus", "1", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-batch64", "--no-configs1",
+                  ZE_BENCH_FORCE_DIST="1", MASTER_PORT="29577")
+    assert d["n_gpus"] == 1 and d["weight_broadcast_s"] > 0 and d["per_rank"]["questions"] == [64]
+    assert d["value"] > 5.0

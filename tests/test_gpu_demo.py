@@ -1,0 +1,97 @@
+"""GPU: BASELINE configs[0] -- `src/demo.py`: one question about one 448-px image, greedy, through the drop-in entry
+point itself (/root/reference/src/demo.py:126-154: `chat(prompt, image_fp)` = view <= 1024 px -> stage 1 -> int box
+parsing -> crop -> stage 2 on [view, crop]).  VERDICT r2: the entry point was never executed by any test.
+
+The checkpoint directory is the tiny one of test_gpu_infer_e2e.py (config.json, model.safetensors, tokenizer.json whose
+words ARE `"bbox_2d":[...]` fragments, so that stage 2 really runs on random weights).  Checked: the script runs as
+`python src/demo.py <image>` with ZOOMEARTH_MODEL set and prints the answer; `chat()` returns the same string as the two
+stages driven by hand through the host helpers; the stage-1 token ids equal the oracle's greedy continuation wherever
+the oracle's top-1 / top-2 margin is decidable."""
+import importlib.util
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from gpu_util import CHAIN_W
+from oracle import frontend, prng
+from oracle import qwen25vl as Q
+from test_gpu_infer_e2e import ROOT, build_workdir
+
+pytestmark = pytest.mark.gpu
+QUESTION = "Are there any building on the top-right island?"  # the question of /root/reference/src/demo.py:150
+
+
+@pytest.fixture(scope="module")
+def demo_dir(tmp_path_factory):
+    from PIL import Image
+    d, _ = build_workdir(tmp_path_factory.mktemp("demo"), 1)
+    os.makedirs(d / "images")
+    Image.fromarray(prng.synthetic_tile(77, 448, 448)).save(d / "images" / "demo3.png")
+    return d
+
+
+def test_demo_script_runs_as_shipped(demo_dir):
+    r = subprocess.run([sys.executable, "src/demo.py"], cwd=demo_dir, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, PYTHONPATH=ROOT, ZOOMEARTH_MODEL=str(demo_dir / "ckpt")))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.strip(), "demo.py printed nothing"
+
+
+def test_demo_chat_is_the_two_stage_chain(demo_dir, monkeypatch):
+    monkeypatch.setenv("ZOOMEARTH_MODEL", str(demo_dir / "ckpt"))
+    spec = importlib.util.spec_from_file_location("ze_demo", os.path.join(ROOT, "src", "demo.py"))
+    demo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo)
+    image_fp = str(demo_dir / "images" / "demo3.png")
+    answer = demo.chat(prompt=QUESTION, image_fp=image_fp)
+    assert isinstance(answer, str) and answer
+    assert demo.chat(prompt=QUESTION, image_fp=image_fp) == answer          # the model is loaded once; greedy is reproducible
+
+    # the same chain by hand through the host helpers (names of the reference: resize_image / extract_bbox / cut_image)
+    from zoomearth_amd import hostloop as H
+    from zoomearth_amd.image import DeviceImage
+    processor, model = demo._load()
+    image = DeviceImage.open(image_fp, model.engine)
+    assert (image.width, image.height) == (448, 448)
+    view = H.resize_image_demo(image)                                        # 448 <= 1024: unchanged
+    assert view.size == (448, 448)
+    text = H.PREFIX + QUESTION + H.INSTRUCTION
+    out1 = H.chat_batch([text], [view], processor, model, do_sample=False)[0]
+    boxes = H.extract_bbox_int(out1, 1)
+    if boxes:
+        crop = H.resize_image_demo(H.cut_image(image, boxes[0]))
+        want = H.chat_batch([text + out1.split("<answer>")[0] + H.VISION_BLOCK], [[view, crop]], processor, model,
+                            do_sample=False)[0]
+    else:
+        want = out1
+    assert answer == want
+    print(f"demo: stage 1 wrote {len(out1.split())} words, {len(boxes)} parsable boxes; answer = {answer[:80]!r}")
+
+    # stage-1 token ids against the oracle's greedy continuation of the same prompt (teacher-forced along the oracle's
+    # path; compared wherever the oracle's margin exceeds 2 x 2 x its own bf16-vs-fp32 error)
+    inputs = processor(text=[text], images=[view], return_tensors="pt", padding="longest")
+    ids = inputs["input_ids"][0].tolist()
+    grid = tuple(int(v) for v in inputs["image_grid_thw"][0])
+    assert grid == (1, 32, 32) and ids.count(model.config.image_token_id) == 256   # configs[0]: 1024 patches, 256 tokens
+    want_pv, want_grid = frontend.image_to_pixel_values(prng.synthetic_tile(77, 448, 448))
+    assert tuple(want_grid) == grid and np.array_equal(inputs["pixel_values"].cpu().numpy(), want_pv)
+    cfg = Q.tiny_config()
+    w = Q.synthetic_weights(cfg, **CHAIN_W)
+    o32, o16 = Q.Qwen25VLOracle(cfg, w, "fp32"), Q.Qwen25VLOracle(cfg, w, "bf16")
+    n_new = 12
+    gen = model.generate(**inputs.to(model.device), max_new_tokens=n_new, do_sample=False, num_beams=1)[0, len(ids):].tolist()
+    l32, l16 = o32.prefill(ids, pixel_values=want_pv, grid_thw=[want_grid]), o16.prefill(ids, pixel_values=want_pv, grid_thw=[want_grid])
+    decided = 0
+    for t in range(len(gen)):
+        yard = float(np.abs(l16 - l32).max())
+        top2 = np.partition(l32, -2)[-2:]
+        if top2[1] - top2[0] > 4.0 * yard:
+            assert gen[t] == int(np.argmax(l32)), (t, gen[t], int(np.argmax(l32)))
+            decided += 1
+        if gen[t] in cfg.eos_token_ids or gen[t] != int(np.argmax(l32)):
+            break  # past an undecidable step the two paths may differ: stop comparing
+        l32, l16 = o32.decode_step(gen[t]), o16.decode_step(gen[t])
+    print(f"demo stage 1 vs oracle: {decided} decidable steps equal")

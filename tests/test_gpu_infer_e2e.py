@@ -162,7 +162,8 @@ def test_two_ranks_shard_by_tile_and_merge_to_the_single_rank_result(workdir):
             "--batch_size", "4"]
     for rank in (0, 1):
         # LOCAL_RANK 1 on a one-GPU box: local ranks beyond the GPU count share GPUs (rank r -> GPU r mod n_gpus)
-        run(base + ["--exp_name", "dp_"], d, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2")
+        # (the two ranks run one after the other here, so each loads the checkpoint itself: ZE_WEIGHT_BROADCAST=0)
+        run(base + ["--exp_name", "dp_"], d, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", ZE_WEIGHT_BROADCAST="0")
     run(base + ["--exp_name", "one_"], d)
     from zoomearth_amd.accel import merge_results
     n = merge_results(str(d / "results" / "dp_"), 2, str(d / "results" / "dp_merged.jsonl"))
@@ -174,18 +175,62 @@ def test_two_ranks_shard_by_tile_and_merge_to_the_single_rank_result(workdir):
     assert merged == sorted(single, key=lambda r: r["question_id"])
 
 
+def test_two_concurrent_ranks_receive_the_weights_by_broadcast(workdir):
+    """The entry point's weight broadcast (BASELINE configs[3] / north_star: "one-time RCCL broadcast of weights"): two
+    ranks run AT ONCE; rank 0 reads the safetensors, rank 1 is pointed at a checkpoint directory WITHOUT the weight file
+    and can only get them from the collective (`from_pretrained(..., broadcast=True)` -> accel.broadcast_engine_weights).
+    Both ranks share this box's one GPU, where RCCL cannot form a communicator, so the collective goes through gloo
+    (ZE_DIST_BACKEND; on a multi-GPU node the default is nccl = RCCL); the merged records equal the single-rank run."""
+    import socket
+    d, rows = workdir
+    bare = d / "ckpt_bare"
+    os.makedirs(bare, exist_ok=True)
+    for f in os.listdir(d / "ckpt"):
+        if not f.endswith(".safetensors") and not os.path.exists(bare / f):
+            os.symlink(d / "ckpt" / f, bare / f)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank, ck in ((0, "ckpt"), (1, "ckpt_bare")):
+        cmd = [sys.executable, "src/infer.py", "--model_name", ck, "--exp_name", "bc_", "--max_new_tokens", "14",
+               "--max_ctx", "2048", "--batch_size", "4"]
+        env = dict(os.environ, PYTHONPATH=ROOT, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), ZE_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen(cmd, cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-2000:] + se[-4000:]
+    assert "weights broadcast to 2 ranks" in outs[0][0]
+    from zoomearth_amd.accel import merge_results
+    n = merge_results(str(d / "results" / "bc_"), 2, str(d / "results" / "bc_merged.jsonl"))
+    run([sys.executable, "src/infer.py", "--model_name", "ckpt", "--exp_name", "bcone_", "--max_new_tokens", "14", "--max_ctx",
+         "2048", "--batch_size", "4"], d)
+    merged, single = load(d / "results" / "bc_merged.jsonl"), load(d / "results" / "bcone_0.jsonl")
+    assert n == len(rows) and len(load(d / "results" / "bc_1.jsonl")) > 0
+    assert merged == sorted(single, key=lambda r: r["question_id"])
+    # a rank without the weight file and without the broadcast fails loudly
+    r = subprocess.run([sys.executable, "src/infer.py", "--model_name", "ckpt_bare", "--exp_name", "x_"], cwd=d,
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode != 0
+
+
 def test_infer_with_more_than_64_chains(workdir_wide):
-    """--batch_size 96: the decode steps run beyond the 64-row fragment kernels (tiled GEMMs, stand-alone rope kernel) and
-    fall back into them as the stream drains.  Every question is answered in dataset order with the reference schema, the
-    run is reproducible, and it agrees with the 8-chain run wherever bf16 rounding does not flip a token (the two regimes
-    sum in different orders: DESIGN.md 7b) -- with these random weights most records."""
+    """--batch_size 96: an engine with more than 64 chain slots runs every decode step on the row-streaming kernel family
+    (tiled GEMMs, stand-alone rope kernel), also while the stream drains below 64 live chains.  Every question is answered
+    in dataset order with the reference schema, the run is reproducible, --batch_size 128 writes the SAME file (a chain's
+    tokens do not depend on the batch within a family), and it agrees with the 8-chain run (the fragment family) wherever
+    bf16 rounding does not flip a token (the two families sum in different orders: DESIGN.md 7b) -- with these random
+    weights most records."""
     d, rows = workdir_wide
     base = [sys.executable, "src/infer.py", "--model_name", "ckpt", "--max_new_tokens", "10", "--max_ctx", "1024", "--greedy"]
     run(base + ["--exp_name", "w96a_", "--batch_size", "96"], d)
     run(base + ["--exp_name", "w96b_", "--batch_size", "96"], d)
     run(base + ["--exp_name", "w8_", "--batch_size", "8"], d)
+    run(base + ["--exp_name", "w128_", "--batch_size", "128"], d)
     a, b, n = load(d / "results" / "w96a_0.jsonl"), load(d / "results" / "w96b_0.jsonl"), load(d / "results" / "w8_0.jsonl")
     assert len(a) == len(rows) == len(n) and a == b
+    assert load(d / "results" / "w128_0.jsonl") == a
     for got, row in zip(a, rows):
         assert list(got.keys()) == KEYS and got["question_id"] == row["question_id"] and got["stage1"]
     same = sum(1 for x, y in zip(a, n) if x == y)

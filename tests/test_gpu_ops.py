@@ -103,6 +103,41 @@ def test_linear_weight_streaming(tiny_engine, m, n, k, bias):
         assert torch.equal(alone[0], got_t[r]), r
 
 
+# The row-streaming family of the batched decode step (engines with more than 64 chain slots): the projections of the 3B
+# layer (gate/up with the SwiGLU epilogue, down with its eight K slices, qkv with bias, a 4096-wide one) at the row counts
+# of the wide regime -- 65, 128, the 217 live chains of the benchmark stream's average step, 256 -- plus a drained batch.
+@pytest.mark.parametrize("m", [9, 65, 128, 217, 256])
+@pytest.mark.parametrize("n,k,bias,swiglu", [(22016, 2048, False, True), (2048, 11008, False, False),
+                                             (2560, 2048, True, False), (4096, 2048, False, False)])
+def test_linear_wide_decode(tiny_engine, m, n, k, bias, swiglu):
+    """ze_launch_gemm_wide against float64 (one bf16 rounding; SwiGLU: four), a row's result independent of the rows that
+    share the launch -- alone, in a 64-row batch and in the full batch: the same bits -- and repeats bit-identical."""
+    a, w = rnd(31, (m, k)), rnd(32, (n, k), 0.05)
+    b = rnd(33, (n,), 0.5) if bias else None
+    da, dw, db = to_dev_bf16(a), to_dev_bf16(w), to_dev_bf16(b) if bias else None
+    act = 7 if swiglu else 6
+    got_t = tiny_engine.op_linear(da, dw, db, act)
+    got = got_t.float().cpu().numpy()
+    full = a.astype(np.float64) @ w.astype(np.float64).T + (b.astype(np.float64) if bias else 0.0)
+    sc = 0.05 * np.sqrt(k) * 0.05
+    if swiglu:
+        blk = full.reshape(m, n // 32, 2, 16)
+        g, u = blk[:, :, 0, :].reshape(m, -1), blk[:, :, 1, :].reshape(m, -1)
+        want = g / (1.0 + np.exp(-g)) * u
+        tol = 2.0 ** -8 * (3.0 * np.abs(want) + 1.2 * np.maximum(np.abs(g), sc) * np.abs(u) + sc * sc)
+        bad = np.abs(got - want) > tol
+        assert not bad.any(), (int(bad.sum()), float((np.abs(got - want) / tol).max()))
+    else:
+        close_bf16(got, full, scale=sc)
+    assert torch.equal(got_t, tiny_engine.op_linear(da, dw, db, act))
+    for r in {0, m // 2, m - 1}:
+        alone = tiny_engine.op_linear(da[r:r + 1].contiguous(), dw, db, act)
+        assert torch.equal(alone[0], got_t[r]), r
+    if m > 64:
+        part = tiny_engine.op_linear(da[m - 64:].contiguous(), dw, db, act)
+        assert torch.equal(part, got_t[m - 64:])
+
+
 @pytest.mark.parametrize("m,n,k,bias", [
     (1, 2560, 2048, True), (8, 2048, 2048, False), (17, 208, 128, True), (33, 80, 352, True), (64, 2560, 2048, True),
     (64, 3584, 3584, False), (40, 22016, 2048, False), (64, 4608, 3584, True), (3, 16, 32, False),

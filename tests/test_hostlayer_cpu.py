@@ -117,6 +117,22 @@ for mode, size in (("scatter_allgather", 4096 + 777), ("broadcast", 4096), ("sca
     gathered = [torch.zeros_like(chk) for _ in range(world)]
     dist.all_gather(gathered, chk)
     assert all(int(g) == int(gathered[0]) for g in gathered)
+# ... and the engine-level form the entry points call (from_pretrained(broadcast=True), bench.py): rank 0 holds the
+# weights, the other rank receives them and is told that its arena was rewritten (weights_invalidate)
+class StubEngine:
+    device = torch.device("cpu")
+    def __init__(self, fill):
+        self.arena = (torch.arange(5000, dtype=torch.int64) * 13 % 241).to(torch.uint8) if fill else torch.zeros(5000, dtype=torch.uint8)
+        self.invalidated = 0
+    def weights_arena(self):
+        return self.arena
+    def weights_invalidate(self):
+        self.invalidated += 1
+for mode in ("broadcast", "scatter_allgather"):
+    eng = StubEngine(rank == 0)
+    secs = accel.broadcast_engine_weights(eng, rank, world, src=0, mode=mode, backend="gloo")
+    assert secs > 0 and eng.invalidated == 1 and torch.equal(eng.arena, StubEngine(True).arena), mode
+assert accel.broadcast_engine_weights(StubEngine(True), 0, 1) == 0.0
 names = [f"t{(i * 5) % 11}.tif" for i in range(97)]
 class DS(list):
     pass

@@ -268,6 +268,54 @@ def test_errors_are_isolated_per_request():
     assert sorted(sched.free) == [0, 1]
 
 
+def test_a_failing_vit_call_or_prefill_pass_orphans_nobody():
+    """a ViT error (or any failure after the round's requests left `waiting`) must fail every request
+    of that round that is not live yet -- on_error called, slot back in `free` and reset -- instead of escaping step() with
+    them in neither queue; an oversized image is rejected per request, before the ViT call; the scheduler keeps serving."""
+    model = make_model(max_seqs=3, max_patches=16)
+    e = model.engine
+    sched = ChainScheduler(model, Proc(), burst=4)
+    ok, bad = {}, {}
+
+    def req(i, prompt, images):
+        return Request(prompt=prompt, images=images, max_new_tokens=3, on_done=lambda r, t, x: ok.__setitem__(i, t),
+                       on_error=lambda r, ex: bad.__setitem__(i, str(ex)))
+
+    real_vit = e.vit_forward
+    e.vit_forward = lambda pv, grids: (_ for _ in ()).throw(RuntimeError("too many patches"))
+    sched.submit(req(0, "41 <img> 60", ["a"]))
+    sched.submit(req(1, "43 44", []))
+    sched.step()                                             # must not raise: both requests carry an on_error
+    assert set(bad) == {0, 1} and "too many patches" in bad[0] and not sched.live and not sched.waiting
+    assert sorted(sched.free) == [0, 1, 2]
+    e.vit_forward = real_vit
+    e.prefill_batch = lambda *a: (_ for _ in ()).throw(RuntimeError("prefill exploded"))
+    sched.submit(req(2, "45 46", []))
+    sched.step()
+    assert "prefill exploded" in bad[2] and sorted(sched.free) == [0, 1, 2]
+    del e.prefill_batch                                      # back to the class method
+    # an image with more patches than the engine's ViT workspace: this request only
+    class BigProc(Proc):
+        def __call__(self, text, images=None, **kw):
+            d = super().__call__(text, images, **kw)
+            if images and images[0] == "huge":
+                d["image_grid_thw"] = torch.tensor([[1, 8, 8]])
+                d["pixel_values"] = torch.zeros((64, 3))
+                d["input_ids"] = torch.tensor([[47] + [IMG] * 16 + [60]])
+            return d
+    sched.processor = BigProc()
+    sched.submit(req(3, "47 <img> 60", ["huge"]))
+    sched.submit(req(4, "49 50", []))
+    sched.run()
+    assert "max_patches" in bad[3] and ok[4] == expected(49, 3) and sorted(sched.free) == [0, 1, 2]
+    # without an on_error the failure still surfaces as an exception, with every slot back
+    e.vit_forward = lambda pv, grids: (_ for _ in ()).throw(RuntimeError("boom"))
+    sched.submit(Request(prompt="51 <img> 60", images=["b"], max_new_tokens=2))
+    with pytest.raises(RuntimeError):
+        sched.step()
+    assert sorted(sched.free) == [0, 1, 2] and not sched.waiting
+
+
 def test_submit_zoom_chain_on_the_scheduler():
     """hostloop.submit_zoom_chain: the reference's per-question control flow (no box -> error record after stage 1,
     malformed box -> error record, box -> stage 2) as linked requests."""

@@ -81,11 +81,51 @@ class Accelerator:
         self.init_process_group("nccl" if arena.is_cuda else "gloo")
         scatter_allgather_broadcast(arena, src, dist) if mode == "scatter_allgather" else dist.broadcast(arena, src=src)
 
+    def broadcast_engine(self, engine, src: int = 0, mode=None, backend=None) -> float:
+        """The whole packed weight arena of `engine` from rank `src` to every rank (in place) and the bookkeeping that goes
+        with a rewritten arena (Engine.weights_invalidate); returns the seconds the collective took."""
+        return broadcast_engine_weights(engine, self.process_index, self.num_processes, src, mode, backend)
+
     def wait_for_everyone(self):
         if self.num_processes > 1:
             import torch.distributed as dist
             if dist.is_initialized():
                 dist.barrier()
+
+
+def broadcast_engine_weights(engine, rank: int, world: int, src: int = 0, mode=None, backend=None, force: bool = False) -> float:
+    """replaces: every rank's own `from_pretrained` (/root/reference/src/eval/infer.py:147-151 under
+    `accelerate launch`): rank `src` has read the checkpoint, the other ranks receive the packed arena -- the path's one
+    collective (RCCL over xGMI; `ZE_DIST_BACKEND=gloo` stages through the host, for boxes where ranks share a GPU).
+    mode: "broadcast" (default) or "scatter_allgather" (`ZE_BCAST`).  Returns the seconds of the collective."""
+    import time
+
+    import torch
+    import torch.distributed as dist
+    if world <= 1 and not force:  # (force: a one-rank communicator still runs the collective -- the RCCL path at N = 1)
+        return 0.0
+    backend = backend or os.environ.get("ZE_DIST_BACKEND", "nccl")
+    mode = mode or os.environ.get("ZE_BCAST", "broadcast")
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = dict(device_id=engine.device) if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    arena = engine.weights_arena()
+    if arena.is_cuda:
+        torch.cuda.synchronize(arena.device)
+    dist.barrier()
+    t0 = time.perf_counter()
+    if mode == "scatter_allgather":
+        scatter_allgather_broadcast(arena, src, dist)
+    else:
+        dist.broadcast(arena, src=src)
+    if arena.is_cuda:
+        torch.cuda.synchronize(arena.device)
+    dt = time.perf_counter() - t0
+    del arena
+    engine.weights_invalidate()
+    return dt
 
 
 def scatter_allgather_broadcast(arena, src: int, dist, align: int = 256) -> None:

@@ -81,6 +81,11 @@ struct ze_engine {
     uint8_t* arena_f8 = nullptr;  // FP8 fragment copies (fp8_ready only)
     bf16_t* lm_head_f = nullptr;
     bool frag_ready = false;
+    // Kernel family of the batched decode step (ze_set_decode_regime): 0 = fragment kernels (at most 64 chains per step),
+    // 1 = row-streaming kernels (any count), -1 = by the engine's capacity (max_seqs > 64 -> 1).  Never a function of how
+    // many chains are live: a chain's tokens do not depend on the batch it happens to share.
+    int decode_regime = -1;
+    bool wide_regime() const { return decode_regime == 1 || (decode_regime < 0 && cfg.max_seqs > 64); }
     std::vector<ze_text_layer> tl;
 
     // tables

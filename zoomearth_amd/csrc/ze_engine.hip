@@ -333,7 +333,7 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     chk(dev_alloc(e, &e->ty8p, tm * c.hidden, false));
     chk(dev_alloc(e, &e->ty8p_scale, tm, false));
     chk(dev_alloc(e, &e->damax, 2 * 2048));
-    ze_launch_amax_init(e->damax, nullptr);
+    if (r == 0 && e->damax) ze_launch_amax_init(e->damax, nullptr);
     chk(dev_alloc(e, &e->ty8, (size_t)64 * c.hidden));
     chk(dev_alloc(e, &e->ty8_scale, 64));
     chk(dev_alloc(e, &e->tqkv, tm * nqkv));
@@ -502,10 +502,20 @@ extern "C" int ze_weights_missing(ze_engine* e) {
 }
 
 extern "C" int ze_weights_arena(ze_engine* e, void** dev_ptr, size_t* bytes) {
-    if (e) ze_weights_changed(e);  // the caller is about to overwrite the arena (broadcast / weight refresh)
     if (!e || !dev_ptr || !bytes) return ze_fail(e, ZE_ERR_INVALID, "null argument");
     *dev_ptr = e->arena;
     *bytes = e->arena_used * sizeof(bf16_t);
+    return ZE_OK;
+}
+
+// A caller that WROTE the whole arena through the pointer above (the broadcast that replaces the other ranks' own
+// from_pretrained, a weight refresh) says so here: every tensor counts as loaded (a receiving rank never called
+// ze_load_weight), the derived copies (fragment-major, FP8) and the captured graphs are dropped and rebuilt from the new
+// values on the next use.
+extern "C" int ze_weights_invalidate(ze_engine* e) {
+    if (!e) return ze_fail(e, ZE_ERR_INVALID, "null engine");
+    for (auto& kv : e->dests) e->loaded.insert(kv.first);
+    ze_weights_changed(e);
     return ZE_OK;
 }
 

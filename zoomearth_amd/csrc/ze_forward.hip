@@ -1069,6 +1069,8 @@ static int ensure_fragments(ze_engine* e, hipStream_t s) {
 
 static int upload_batch(ze_engine* e, const int32_t* seqs, int n, hipStream_t s) {
     if (n <= 0 || n > e->cfg.max_seqs) return ze_fail(e, ZE_ERR_INVALID, "batch size out of range");
+    if (n > 64 && !e->wide_regime())
+        return ze_fail(e, ZE_ERR_INVALID, "more than 64 chains in a step of an engine pinned to the fragment kernels (ze_set_decode_regime)");
     for (int i = 0; i < n; ++i) {
         if (seqs[i] < 0 || seqs[i] >= e->cfg.max_seqs) return ze_fail(e, ZE_ERR_NOTFOUND, "sequence id out of range");
         for (int j = 0; j < i; ++j)
@@ -1119,13 +1121,13 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
         const ze_text_layer& L = e->tl[li];
         // every projection on fragment-major operands when the copy exists (ensure_fragments) and n <= 64: the norms, the
         // attention merge and the SwiGLU epilogue then write their outputs in that layout too
-        const bool fr = L.qkv.wf && n <= 64 && ze_gemv_knobs[5] != 1;
+        const bool fr = L.qkv.wf && !e->wide_regime() && ze_gemv_knobs[5] != 1;
         const ze_gemm_ws ws = e->gemm_ws();
         // Beyond 64 chains (no fragment kernels): the prefill tile policy for qkv / o / gate-up / lm_head (one pass over K
         // per output tile, no split: at 256 chains qkv 12.0 against 24.7 us on the split-K streaming launcher, o 11.9 /
         // 17.7, gate/up 43.6 / 56.9, lm_head 250 / 336; tools/bench_midm.py), the streaming launcher for down (32.4 / 44.3).
         // Every one of them sums an output's K range in an order fixed by (N, K): batch invariance within this path.
-        const bool tiled = n > 64 && ze_gemv_knobs[13] != 1;
+        const bool tiled = e->wide_regime() && ze_gemv_knobs[13] != 1;
         // FP8 activations: the fragment path with FP8 weight fragments takes the row as FP8 fragments + a scale (fp8 x
         // fp8 MFMA); any other path takes the same values as bf16
         const bool a8q = e->fp8_act && fr && L.qkv.wf8 && ze_gemv_knobs[10] != 1;
@@ -1139,7 +1141,7 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
                                        e->kc(li, 0), e->vc(li, 0), seq_stride, c.max_ctx, s, w8 ? L.qkv.scale8 : nullptr,
                                        a8q ? e->ty8_scale : nullptr);
         } else {
-            if (tiled) ze_launch_gemm(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, nullptr, n, nqkv, H, s);
+            if (tiled) ze_launch_gemm_wide(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, ws, s);
             else ze_launch_gemm_stream(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, ws, s);
             ze_launch_rope_kv_batch(e->tqkv, n, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(li, 0),
                                     e->vc(li, 0), seq_stride, c.max_ctx, s);
@@ -1152,7 +1154,7 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
         } else if (fr)
             ze_launch_gemm_frag(ZE_EPI_RESIDUAL, e->to, L.o.wf, nullptr, e->th, H, e->th, H, n, H, nq, s);
         else if (tiled)
-            ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, n, H, nq, s);
+            ze_launch_gemm_wide(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, n, H, nq, ws, s);
         else
             ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, n, H, nq, ws, s);
         ze_launch_rmsnorm(e->th, H, L.post_norm, e->ty, H, n, H, c.rms_eps, s, fr ? 1 : 2, a8g ? 2 : (e->fp8_act ? 1 : 0), e->ty8,
@@ -1163,23 +1165,28 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
                                 nullptr, nullptr, 0, e->ta, e->text_ipad, n, 2 * e->text_ipad, H, s,
                                 w8 ? L.gate_up.scale8 : nullptr, a8g ? e->ty8_scale : nullptr);
         } else if (tiled)
-            ze_launch_gemm(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad, nullptr, n,
-                           2 * e->text_ipad, H, s);
+            ze_launch_gemm_wide(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad, n,
+                                2 * e->text_ipad, H, ws, s);
         else
             ze_launch_gemm_stream(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad, n,
                                   2 * e->text_ipad, H, ws, s);
         // the down projection (K = 11008) stays on the split-K ring: the fragment kernel with K split over 8 x 32
         // workgroups measured 22.6-25.3 us against 17.9 (slab reduction included in both)
-        ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, n, H,
-                              e->text_ipad, ws, s);
+        if (tiled)
+            ze_launch_gemm_wide(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, n, H,
+                                e->text_ipad, ws, s);
+        else
+            ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, n, H,
+                                  e->text_ipad, ws, s);
     }
-    const bool fl = e->lm_head_f && n <= 64 && ze_gemv_knobs[5] != 1;
+    const bool fl = e->lm_head_f && !e->wide_regime() && ze_gemv_knobs[5] != 1;
     ze_launch_rmsnorm(e->th, H, e->final_norm, e->ty, H, n, H, c.rms_eps, s, fl ? 1 : 2);
     if (fl) {
         const bool w8 = e->lm_head8.wf8 && ze_gemv_knobs[10] != 1;
         ze_launch_gemm_frag(ZE_EPI_F32, e->ty, w8 ? (const bf16_t*)e->lm_head8.wf8 : e->lm_head_f, nullptr, nullptr, 0,
                             (bf16_t*)e->blogits, c.vocab, n, c.vocab, H, s, w8 ? e->lm_head8.scale8 : nullptr);
-    } else if (n > 160 && ze_gemv_knobs[13] != 1)  // (lm_head: 200 / 260 / 336 us streaming against 241 / 243 / 250 tiled at 128 / 192 / 256 chains)
+    } else if (n > 160 && ze_gemv_knobs[13] != 1)  // (lm_head: 200 / 260 / 336 us streaming against 241 / 243 / 250 tiled at 128 / 192 / 256 chains; both
+                                                   //  launchers sum an output's K range in one order -- neither splits K at this N --: the choice does not change a result)
         ze_launch_gemm(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, nullptr, n, c.vocab,
                        H, s);
     else
@@ -1461,6 +1468,10 @@ extern "C" int ze_op_linear(ze_engine* e, const void* a, const void* w, const vo
         if (N % 32) return ze_fail(e, ZE_ERR_INVALID, "SwiGLU: N = 2 * width with width % 16 == 0");
         ze_launch_gemm(ZE_EPI_SWIGLU, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias, nullptr, 0,
                        (bf16_t*)cmat, N / 2, nullptr, M, N, K, s);
+    } else if (act == 6 || act == 7) {  // the launcher of the row-streaming decode regime (7: SwiGLU, C is [M, N/2])
+        if (act == 7 && N % 32) return ze_fail(e, ZE_ERR_INVALID, "SwiGLU: N = 2 * width with width % 16 == 0");
+        ze_launch_gemm_wide(act == 7 ? ZE_EPI_SWIGLU : ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias,
+                            nullptr, 0, (bf16_t*)cmat, act == 7 ? N / 2 : N, M, N, K, e->gemm_ws(), s);
     } else if (act == 2) {  // weight-streaming mode of the batched decode step (rows = chains), for measurements
         ze_launch_gemm_stream(ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias, nullptr, 0,
                               (bf16_t*)cmat, N, M, N, K, e->gemm_ws(), s);
@@ -1605,6 +1616,15 @@ extern "C" int ze_op_quantize_fp8(ze_engine* e, void* w_bf16, int rows, int cols
     return ZE_OK;
 }
 
+extern "C" int ze_set_decode_regime(ze_engine* e, int regime) {
+    if (!e || regime < -1 || regime > 1) return ze_fail(e, ZE_ERR_INVALID, "regime is -1 (by capacity), 0 (fragment kernels) or 1 (row streaming)");
+    if (regime != e->decode_regime) {
+        e->decode_regime = regime;
+        ++ze_tune_epoch;  // captured batched steps bake the kernel family in
+    }
+    return e->wide_regime() ? 1 : 0;
+}
+
 // ================================================================== measurement
 extern "C" int ze_tune(int knob, int value) {
     if (knob < 0 || knob >= 16) return ze_fail(nullptr, ZE_ERR_INVALID, "unknown knob");
@@ -1696,7 +1716,7 @@ extern "C" int ze_profile_decode_kernel(ze_engine* e, int which, int iters, floa
 // the activation rows read + written (6, 7).
 extern "C" int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters, float* avg_us, double* bytes_per_launch,
                                        void* stream) {
-    if (!e || !avg_us || !bytes_per_launch || iters <= 0 || n <= 0 || n > e->cfg.max_seqs)
+    if (!e || !avg_us || !bytes_per_launch || iters <= 0 || n <= 0 || n > e->cfg.max_seqs || (n > 64 && !e->wide_regime()))
         return ze_fail(e, ZE_ERR_INVALID, "bad argument");
     const ze_config& c = e->cfg;
     hipStream_t s = (hipStream_t)stream;
@@ -1718,36 +1738,37 @@ extern "C" int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters
     auto launch = [&](int it) {
         const int li = it % c.layers;
         const ze_text_layer& L = e->tl[li];
-        const bool fr = L.qkv.wf && n <= 64;
-        const bool tiled = n > 64 && ze_gemv_knobs[13] != 1;  // (as enqueue_decode_batch)
+        const bool fr = L.qkv.wf && !e->wide_regime() && ze_gemv_knobs[5] != 1;  // (as enqueue_decode_batch)
+        const bool tiled = e->wide_regime() && ze_gemv_knobs[13] != 1;
         const ze_gemm_ws ws = e->gemm_ws();
         switch (which) {
             case 0:
                 if (fr) ze_launch_qkv_rope_oneshot(e->ty, L.qkv.wf, L.qkv.bias, e->tqkv, nqkv, n, H, c.heads, c.kv_heads, e->cosT, e->sinT,
                                                    e->st_dev, e->bseq, e->kc(li, 0), e->vc(li, 0), seq_stride, c.max_ctx, s);
-                else if (tiled) ze_launch_gemm(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, nullptr, n, nqkv, H, s);
+                else if (tiled) ze_launch_gemm_wide(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, ws, s);
                 else ze_launch_gemm_stream(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, ws, s);
                 bytes = (double)nqkv * H * 2;
                 break;
             case 1:
                 if (fr && ze_gemv_knobs[9] != 1) ze_launch_gemm_oneshot(ZE_EPI_RESIDUAL, e->to, L.o.wf, nullptr, e->th, H, e->th, H, n, H, nq, s);
                 else if (fr) ze_launch_gemm_frag(ZE_EPI_RESIDUAL, e->to, L.o.wf, nullptr, e->th, H, e->th, H, n, H, nq, s);
-                else if (tiled) ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, n, H, nq, s);
+                else if (tiled) ze_launch_gemm_wide(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, n, H, nq, ws, s);
                 else ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, n, H, nq, ws, s);
                 bytes = (double)H * nq * 2;
                 break;
             case 2:
                 if (fr) ze_launch_gemm_frag(ZE_EPI_SWIGLU, e->ty, L.gate_up.wf, nullptr, nullptr, 0, e->ta, e->text_ipad, n, 2 * e->text_ipad, H, s);
-                else if (tiled) ze_launch_gemm(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad, nullptr, n, 2 * e->text_ipad, H, s);
+                else if (tiled) ze_launch_gemm_wide(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad, n, 2 * e->text_ipad, H, ws, s);
                 else ze_launch_gemm_stream(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad, n, 2 * e->text_ipad, H, ws, s);
                 bytes = 2.0 * c.intermediate * H * 2;
                 break;
             case 3:
-                ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, n, H, e->text_ipad, ws, s);
+                if (tiled) ze_launch_gemm_wide(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, n, H, e->text_ipad, ws, s);
+                else ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, n, H, e->text_ipad, ws, s);
                 bytes = (double)H * c.intermediate * 2;
                 break;
             case 4:
-                if (e->lm_head_f && n <= 64) ze_launch_gemm_frag(ZE_EPI_F32, e->ty, e->lm_head_f, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab, H, s);
+                if (e->lm_head_f && fr) ze_launch_gemm_frag(ZE_EPI_F32, e->ty, e->lm_head_f, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab, H, s);
                 else if (tiled && n > 160) ze_launch_gemm(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, nullptr, n, c.vocab, H, s);
                 else ze_launch_gemm_stream(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab, H, ws, s);
                 bytes = (double)c.vocab * H * 2;

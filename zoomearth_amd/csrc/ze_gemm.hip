@@ -1191,6 +1191,15 @@ void ze_launch_gemm_stream(int epi, const bf16_t* A, int lda, const bf16_t* W, i
     launch_cfg<64, 64>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s, true, ws);
 }
 
+void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
+                         int ldr, bf16_t* C, int ldc, int M, int N, int K, const ze_gemm_ws& ws, hipStream_t s) {
+    if (M <= 0 || N <= 0) return;
+    // long K (the down projection): eight K slices, reduced in slice order (the split-K ring of the streaming launcher);
+    // everything else: one pass over K on whichever tile fits the row count (all tiles sum K in sequence)
+    if (K > 4096) ze_launch_gemm_stream(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s);
+    else ze_launch_gemm(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s);
+}
+
 void ze_launch_gemm(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
                     int ldr, bf16_t* C, int ldc, const int* c_rows, int M, int N, int K, hipStream_t s) {
     if (M <= 0 || N <= 0) return;

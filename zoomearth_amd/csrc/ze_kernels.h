@@ -95,6 +95,12 @@ void ze_launch_gemm_stream(int epi, const bf16_t* A, int lda, const bf16_t* W, i
                            const bf16_t* R, int ldr, bf16_t* C, int ldc, int M, int N, int K, const ze_gemm_ws& ws,
                            hipStream_t s);
 // split-K workspace: fp32 slabs (>= ksplit * tiles * BM * BN floats) and zero-initialised per-tile tickets
+// The projections of the batched decode step in the row-streaming regime (ze_set_decode_regime: engines with more than 64
+// chain slots), rows = chains, 1 <= M <= max_seqs.  Every output element is summed in an order fixed by (N, K) alone --
+// K in sequence where K <= 4096, eight K slices added in slice order for the long down projection -- whatever tile the
+// row count selects: a chain's result does not depend on the batch it shares.
+void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
+                         int ldr, bf16_t* C, int ldc, int M, int N, int K, const ze_gemm_ws& ws, hipStream_t s);
 
 // ---- decode GEMV family (batch-1 weight streaming)
 struct ze_gemv_args {

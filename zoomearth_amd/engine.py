@@ -132,6 +132,10 @@ class Engine:
         t._ze_keepalive = self  # the engine owns the memory
         return t
 
+    def weights_invalidate(self) -> None:
+        """After writing through weights_arena() (broadcast, weight refresh): derived copies and graphs are rebuilt."""
+        self._check(self.lib.ze_weights_invalidate(self.h))
+
     # ------------------------------------------------------------------ front-end
     def crop_resize(self, tile: torch.Tensor, box: Sequence[int], out_wh: Sequence[int]) -> torch.Tensor:
         """PIL `tile.crop(box).resize(out_wh, BICUBIC)` on a device u8 [H, W, 3] tensor."""
@@ -294,6 +298,11 @@ class Engine:
         self._check(self.lib.ze_generate(self.h, seq, C.byref(p), out, C.byref(n), self._stream()))
         return [int(out[i]) for i in range(n.value)]
 
+    def set_decode_regime(self, regime: int = -1) -> int:
+        """Kernel family of the batched decode step: 0 fragment kernels (<= 64 chains per step), 1 row streaming (any
+        count), -1 by capacity (max_seqs > 64 -> 1).  Returns the family in force."""
+        return self._check(self.lib.ze_set_decode_regime(self.h, int(regime)))
+
     def decode_batch(self, seqs, tokens=None, want_logits: bool = True):
         sq, sp = _i32(seqs)
         tk, tp = _i32(tokens) if tokens is not None else (None, None)
@@ -392,7 +401,7 @@ class Engine:
     def op_linear(self, a, w, bias=None, act: int = 0):
         m, k = a.shape
         n = w.shape[0]
-        out = torch.empty((m, n // 2 if act == 4 else n), dtype=torch.bfloat16, device=self.device)
+        out = torch.empty((m, n // 2 if act in (4, 7) else n), dtype=torch.bfloat16, device=self.device)
         self._check(self.lib.ze_op_linear(self.h, _ptr(a), _ptr(w), _ptr(bias), _ptr(out), m, n, k, act, self._stream()))
         return out
 

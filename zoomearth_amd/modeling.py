@@ -43,15 +43,27 @@ class ZoomEarthForConditionalGeneration:
     # ------------------------------------------------------------------ construction
     @classmethod
     def from_pretrained(cls, path: str, torch_dtype=None, device=None, max_seqs: int = 4, max_ctx: int = 4096,
-                        max_patches: int = 8192, max_tile_side: int = 8192, max_prefill_rows: int = 0, **kw):
+                        max_patches: int = 8192, max_tile_side: int = 8192, max_prefill_rows: int = 0, broadcast=False, **kw):
+        """broadcast=True under WORLD_SIZE > 1 (one rank per GPU): only rank 0 reads the safetensors, the other ranks
+        receive the packed weight arena in ONE collective (accel.broadcast_engine_weights: RCCL over xGMI) -- where the
+        reference has every rank read the checkpoint itself (/root/reference/src/eval/infer.py:147-151).  The seconds the
+        collective took are left in `model.weight_broadcast_s`."""
         config = ModelConfig.from_pretrained(path)
         dev = 0 if device is None else (device.index or 0 if isinstance(device, torch.device) else int(device))
         if device is None and "LOCAL_RANK" in os.environ:  # (more local ranks than GPUs: ranks share GPUs, accel.Accelerator)
             dev = int(os.environ["LOCAL_RANK"]) % max(1, torch.cuda.device_count())
         engine = Engine(config, device=dev, max_seqs=max_seqs, max_ctx=max_ctx, max_patches=max_patches,
                         max_tile_side=max_tile_side, max_prefill_rows=max_prefill_rows)
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        broadcast = bool(broadcast) and world > 1
+        bcast_s = 0.0
         try:
-            engine.load_state_dict(iter_checkpoint(path))
+            if not broadcast or rank == 0:
+                engine.load_state_dict(iter_checkpoint(path))
+            if broadcast:
+                from .accel import broadcast_engine_weights
+                bcast_s = broadcast_engine_weights(engine, rank, world, src=0)
+                engine.assert_ready()
         except Exception:
             engine.close()
             raise
@@ -62,7 +74,9 @@ class ZoomEarthForConditionalGeneration:
             with open(gp, encoding="utf-8") as f:
                 for k, v in json.load(f).items():
                     setattr(gen, k, v)
-        return cls(config, engine, gen)
+        model = cls(config, engine, gen)
+        model.weight_broadcast_s = bcast_s
+        return model
 
     @classmethod
     def from_synthetic(cls, config: ModelConfig, seed: int = 0, std: float = 0.02, matrix_gain: float = 1.0,
@@ -180,6 +194,7 @@ class ZoomEarthForConditionalGeneration:
         if batched:  # every row gets its own chain slot; the decode steps then run as one batch
             self._chains.clear()
             self._next_slot = 0
+            e.set_decode_regime(-1)  # (a scheduler may have pinned the family to its own capacity)
         slots = []
         pending = []
         for b in range(nrows):

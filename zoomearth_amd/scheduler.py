@@ -11,7 +11,10 @@ multi-resolution ViT call over all their images.
 
 A chain's tokens do not depend on which chains share its bursts (the batched kernels accumulate every output element in
 an order that is a function of the layer shape alone -- tests/test_gpu_batch.py), and its sampling stream is the
-request's own `stream_id`: results are the same for any `max_seqs`, including 1.
+request's own `stream_id`.  The decode step has one kernel family per engine (`Engine.decode_regime`: the fragment kernels
+of an engine with at most 64 chain slots, the row-streaming kernels of a larger one), chosen by the engine's CAPACITY and
+never by how many chains happen to be live, so results are the same for any `max_batch` of one engine, including 1, and
+for every engine of one regime; engines of different regimes agree within bf16 rounding (tests/test_gpu_3b_shape.py).
 """
 from __future__ import annotations
 
@@ -79,6 +82,9 @@ class ChainScheduler:
         self.reuse_generated = bool(reuse_generated)
         self.burst = max(1, int(burst))
         self.max_batch = min(int(max_batch or self.engine.max_seqs), self.engine.max_seqs)
+        # the decode step's kernel family follows the scheduler's CAPACITY, never the live count (see the module docstring)
+        if hasattr(self.engine, "set_decode_regime"):
+            self.engine.set_decode_regime(1 if self.max_batch > 64 else 0)
         self.waiting = deque()
         self.live = OrderedDict()          # slot -> _Live
         self.parked = {}                   # slot -> (prompt ids, image keys, generated ids with K/V rows): finished chains whose slot waits for a follow-up
@@ -141,6 +147,8 @@ class ChainScheduler:
                 if len(ids) + 1 > e.max_ctx:
                     raise ValueError(f"prompt of {len(ids)} tokens exceeds max_ctx = {e.max_ctx}")
                 rows = np.concatenate([[0], np.cumsum([g[0] * g[1] * g[2] for g in grids])]).astype(int)
+                if len(grids) and int(np.diff(rows).max()) > e.max_patches:
+                    raise ValueError(f"image of {int(np.diff(rows).max())} patches exceeds max_patches = {e.max_patches}")
                 reuse, n_reused = self._reusable(req.slot, ids, keys)
                 for i in range(n_reused, len(grids)):
                     if keys[i] in self._features:
@@ -152,19 +160,24 @@ class ChainScheduler:
                                      upto=len(ids), final=True))
             except Exception as ex:  # a malformed request must not take the batch down
                 self._fail(req, ex)
-        self._encode(todo, needed)
-        anchors = self._plan_sharing(prepared) if self.share_prefix else []
-        # prefill: rows of several chains share every GEMM, up to max_prefill_rows per pass; pass A (the prefixes that
-        # other newcomers of this round will copy) goes first
-        for items in (anchors, prepared):
-            group, rows = [], 0
-            for item in items + [None]:
-                if group and (item is None or rows + item["upto"] - item["reuse"] > e.max_prefill_rows):
-                    self._prefill(group)
-                    group, rows = [], 0
-                if item is not None:
-                    group.append(item)
-                    rows += item["upto"] - item["reuse"]
+        # From here on a failure (the ViT call, a prefill pass) must not orphan a request that already left `waiting`:
+        # whatever escapes fails every request of the round that is not live yet -- slots freed, on_error called.
+        try:
+            self._encode(todo, needed)
+            anchors = self._plan_sharing(prepared) if self.share_prefix else []
+            # prefill: rows of several chains share every GEMM, up to max_prefill_rows per pass; pass A (the prefixes
+            # that other newcomers of this round will copy) goes first
+            for items in (anchors, prepared):
+                group, rows = [], 0
+                for item in items + [None]:
+                    if group and (item is None or rows + item["upto"] - item["reuse"] > e.max_prefill_rows):
+                        self._prefill(group)
+                        group, rows = [], 0
+                    if item is not None:
+                        group.append(item)
+                        rows += item["upto"] - item["reuse"]
+        except Exception as ex:
+            self._fail_all([p["req"] for p in prepared if p["req"].slot >= 0 and p["req"].slot not in self.live], ex)
 
     # -- shared prompt prefixes
     def _prefix_len(self, a, b) -> int:
@@ -283,7 +296,9 @@ class ChainScheduler:
             if req.slot < 0:
                 continue                                       # failed earlier in this round (pass A)
             if it["copy_from"] is not None and e.seq_len(it["copy_from"] if it["copy_from"] >= 0 else req.slot) < reuse:
-                it["copy_from"], reuse, n_reused = None, 0, 0   # the donor's rows are gone (its pass failed): prefill in full
+                # the donor's rows are gone (its pass failed; _fail resets the slot, so a stale context of the slot's
+                # previous occupant cannot pass for them): prefill in full
+                it["copy_from"], reuse, n_reused = None, 0, 0
                 it.update(reuse=0, n_reused=0)
             try:
                 pos, delta = e.rope_index(ids, grids)
@@ -315,8 +330,7 @@ class ChainScheduler:
         try:
             e.prefill_batch(slots, ids_l, emb_l, pos_l, dl)
         except Exception as ex:
-            for it in ok:
-                self._fail(it["req"], ex)
+            self._fail_all([it["req"] for it in ok], ex)
             return
         self.stats["prefill_rows"] += sum(len(x) for x in ids_l)
         for it in ok:
@@ -368,14 +382,33 @@ class ChainScheduler:
         else:
             self.free.append(slot)
 
-    def _fail(self, req: Request, ex: Exception) -> None:
+    def _release(self, req: Request) -> None:
         if req.slot >= 0:
             self.parked.pop(req.slot, None)
+            try:
+                self.engine.seq_reset(req.slot)   # nothing may copy a prefix from what the slot held before
+            except Exception:
+                pass
             self.free.append(req.slot)
             req.slot = -1
+
+    def _fail(self, req: Request, ex: Exception) -> None:
+        self._release(req)
         if req.on_error:
             req.on_error(req, ex)
         else:
+            raise ex
+
+    def _fail_all(self, reqs, ex: Exception) -> None:
+        """Every request of `reqs` gets the error; the ones without an `on_error` re-raise it once all slots are back."""
+        unhandled = False
+        for req in reqs:
+            self._release(req)
+            if req.on_error:
+                req.on_error(req, ex)
+            else:
+                unhandled = True
+        if unhandled:
             raise ex
 
 
