@@ -1185,10 +1185,9 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
         const bool w8 = e->lm_head8.wf8 && ze_gemv_knobs[10] != 1;
         ze_launch_gemm_frag(ZE_EPI_F32, e->ty, w8 ? (const bf16_t*)e->lm_head8.wf8 : e->lm_head_f, nullptr, nullptr, 0,
                             (bf16_t*)e->blogits, c.vocab, n, c.vocab, H, s, w8 ? e->lm_head8.scale8 : nullptr);
-    } else if (n > 160 && ze_gemv_knobs[13] != 1)  // (lm_head: 200 / 260 / 336 us streaming against 241 / 243 / 250 tiled at 128 / 192 / 256 chains; both
-                                                   //  launchers sum an output's K range in one order -- neither splits K at this N --: the choice does not change a result)
-        ze_launch_gemm(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, nullptr, n, c.vocab,
-                       H, s);
+    } else if (e->wide_regime() && ze_gemv_knobs[13] != 1)  // (one pass over K whatever the row count: batch invariance)
+        ze_launch_gemm_wide(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab, H,
+                            e->gemm_ws(), s);
     else
         ze_launch_gemm_stream(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n,
                               c.vocab, H, e->gemm_ws(), s);
@@ -1769,7 +1768,7 @@ extern "C" int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters
                 break;
             case 4:
                 if (e->lm_head_f && fr) ze_launch_gemm_frag(ZE_EPI_F32, e->ty, e->lm_head_f, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab, H, s);
-                else if (tiled && n > 160) ze_launch_gemm(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, nullptr, n, c.vocab, H, s);
+                else if (tiled) ze_launch_gemm_wide(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab, H, ws, s);
                 else ze_launch_gemm_stream(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab, H, ws, s);
                 bytes = (double)c.vocab * H * 2;
                 break;

@@ -105,6 +105,33 @@ __device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / (16 * WM)][BN / (1
                                 acc[i][j][3] += __uint_as_float(v[q][i * TN + j].w);
                             }
                     }
+            } else if constexpr (TM * TN <= 8) {
+                // larger tiles per thread: the slabs of FOUR slices requested together (32 loads in flight per thread: two
+                // memory round trips for eight slices instead of eight), still added in slice order
+                for (int q0 = 0; q0 < ksplit; q0 += 4) {
+                    u32x4 v[4][TM * TN];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned base =
+                            (unsigned)((((size_t)(min(q0 + q, ksplit - 1) * nwg + bid) * NT + tid) * (TM * TN)) * 16);
+#pragma unroll
+                        for (int t = 0; t < TM * TN; ++t)
+                            v[q][t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + (unsigned)t * 16, 0, 16);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (q0 + q < ksplit) {
+#pragma unroll
+                            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                for (int j = 0; j < TN; ++j) {
+                                    acc[i][j][0] += __uint_as_float(v[q][i * TN + j].x);
+                                    acc[i][j][1] += __uint_as_float(v[q][i * TN + j].y);
+                                    acc[i][j][2] += __uint_as_float(v[q][i * TN + j].z);
+                                    acc[i][j][3] += __uint_as_float(v[q][i * TN + j].w);
+                                }
+                        }
+                }
             } else {
                 for (int q = 0; q < ksplit; ++q) {
                     const unsigned base = (unsigned)((((size_t)(q * nwg + bid) * NT + tid) * (TM * TN)) * 16);
@@ -450,6 +477,224 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
     gemm_finish<BM, BN, EPI, WM, WN>(acc, smem, bias, R, ldr, C, ldc, c_rows, M, N, ksplit, ks, bid, nwg, bm0, bn0, slab, tickets);
 }
 
+
+// ----------------------------------------------------------------------------------------------------------------
+// Weight-streaming GEMM of the batched decode step in the row-streaming regime (65..256 chains; ze_launch_gemm_wide).
+// Rows = chains: a workgroup takes ALL rows (BM = 128 or 256, rows past M re-read the last one) and BN weight columns, so
+// the weights cross the chip once; the activations (M x K, L2-resident) are what every workgroup re-reads.  What bounds the
+// ring kernel above on this shape is BYTES IN FLIGHT: its stages hold activations and weights alike, three of them fill the
+// LDS, and two stages of weights in flight per CU against the ~2.5 us of an HBM miss are 25 GB/s per CU (gate/up at 256
+// chains: 43.6 us for 90 MB).  Here the two operands are pipelined separately, each by its own waves and to its own depth:
+//   * waves 4..7 stage the ACTIVATIONS with the LDS-DMA ring of k_gemm_ring (SA stages of BM x 64; L2 latency: two stages
+//     in flight suffice), counted vmcnt on their own queue;
+//   * waves 0..3 stream the WEIGHTS into REGISTERS, DW K-steps ahead (non-temporal 16-B loads of full 128-B row pieces,
+//     DW x BN x 128 B in flight per workgroup: 96 KB for gate/up), and write the step after next into one of two small LDS
+//     stages with the ring's swizzle (ds_write_b128) -- the compiler's counted vmcnt covers exactly these loads, since
+//     these waves issue no DMA;
+//   * all eight waves run the MFMAs (8 x 1 layout: 16 or 32 rows x BN columns per wave), ONE raw barrier per K-step.
+// Accumulation order per output element = k_gemm_ring's (same MFMA, K in sequence; split-K slices through gemm_finish), so
+// the results are bit-identical to the ring / register-staged kernels whatever tile serves a row count.
+template <int BM, int BN, int SA, int DW, int NK, int EPI>
+__global__ void __launch_bounds__(512) k_gemm_wstream(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
+                                                      int ldw, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ R,
+                                                      int ldr, bf16_t* __restrict__ C, int ldc, int M, int N, int K, int ksplit,
+                                                      float* __restrict__ slab, unsigned* __restrict__ tickets) {
+    constexpr int WM = 8, WN = 1, NT = 512;
+    constexpr int TM = BM / (16 * WM), TN = BN / 16;
+    constexpr int A_STAGE = BM * 128, W_STAGE = BN * 128;
+    constexpr int LA = BM / 8 / 4;   // activation pieces (8 rows x 128 B) per loader wave per K-step
+    constexpr int PW = BN / 8 / 4;   // weight pieces per loader wave per K-step
+    static_assert(BM % 128 == 0 && BN % 32 == 0 && SA >= 2 && SA <= 4 && DW >= 2 && DW <= 8 && LA * (SA - 1) < 64 && PW * DW < 64, "tile");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* const smemW = smem + SA * A_STAGE;
+
+    const int nwg = (N + BN - 1) / BN;  // one row tile: all M rows
+    // K slices of a tile on consecutive block ids: they run on different XCDs, the workgroups of ONE slice (ids equal
+    // mod ksplit = 8) share an XCD and with it the slice of the activations they all read
+    const int ks = blockIdx.x % ksplit, bid = blockIdx.x / ksplit;
+    const int bn0 = bid * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = wid * (BM / WM);
+    const int fr = lane & 15, fq = lane >> 4;
+    const bool wload = wid < 4;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk_all = K / GEMM_BK;
+    const int nk_per = (nk_all + ksplit - 1) / ksplit;
+    const int kt0 = ks * nk_per;
+    const int nk = max(0, min(nk_all - kt0, nk_per));
+
+    const unsigned smem_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem);
+    // activation loader: piece g of the stage image = rows 8g..8g+7
+    auto issue_a = [&](int kt) {
+        const unsigned img = smem_lds + (kt % SA) * A_STAGE;
+        const int k0 = (kt0 + kt) * GEMM_BK;
+#pragma unroll
+        for (int g = 0; g < LA; ++g) ring_issue_one(A, lda, 0, M - 1, k0, img, (wid - 4) + g * 4, lane);
+    };
+    // weight loader: this lane's 16 bytes of piece p (row 8p + lane / 8, chunk lane % 8) of K-step kt: buffer loads with a
+    // loop-invariant per-lane offset and the K offset in a scalar register, issued and awaited from inline asm with a
+    // COUNTED s_waitcnt (the load and the LDS write that waits for it are one asm statement each: hipcc's own counting
+    // degrades to a two-step prefetch around any branch or loop -- it put vmcnt(0) / vmcnt(5) where vmcnt(21) is exact).
+    // A weight-loader wave issues nothing else while the loop runs, so its queue holds PW loads per step in flight.
+    const int wrow = lane >> 3, wchunk = lane & 7;
+    u32x4 wrsrc;
+    {
+        const unsigned long long wp = (unsigned long long)(size_t)W;
+        wrsrc.x = __builtin_amdgcn_readfirstlane((unsigned)wp);
+        wrsrc.y = __builtin_amdgcn_readfirstlane((unsigned)(wp >> 32) & 0xffffu);  // stride 0
+        wrsrc.z = 0x7fffffffu;
+        wrsrc.w = 0x00020000u;
+    }
+    unsigned woff[PW], wlds[PW];
+#pragma unroll
+    for (int p = 0; p < PW; ++p) {
+        const int row = (wid + p * 4) * 8 + wrow;
+        woff[p] = (unsigned)(((size_t)min(bn0 + row, N - 1) * ldw + wchunk * 8) * sizeof(bf16_t));
+        wlds[p] = smem_lds + SA * A_STAGE + row * 128 + ((wchunk ^ ((row >> 1) & 7)) << 4);
+    }
+    u32x4 wreg[DW][PW];
+    auto load_w = [&](u32x4 (&dst)[PW], int kt) {
+        const int koff = __builtin_amdgcn_readfirstlane((kt0 + min(kt, nk - 1)) * GEMM_BK * (int)sizeof(bf16_t));
+#pragma unroll
+        for (int p = 0; p < PW; ++p)
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "=v"(dst[p]) : "v"(woff[p]), "s"(wrsrc), "s"(koff) : "memory");
+    };
+    // waits until at most `left` of this wave's loads are outstanding (the step's PW loads are the oldest in the queue),
+    // then writes the step into weight stage (kt & 1)
+#define ZE_WS_STORE(SRC, KT, LEFT)                                                                                          \
+    do {                                                                                                                    \
+        _Pragma("unroll") for (int p = 0; p < PW; ++p)                                                                      \
+            asm volatile("s_waitcnt vmcnt(%2)\n\tds_write_b128 %0, %1"                                                      \
+                         :: "v"(wlds[p] + ((KT) & 1) * W_STAGE), "v"((SRC)[p]), "n"(LEFT) : "memory");                       \
+    } while (0)
+
+    // MFMAs of K-step kt on activation stage kt % SA and weight stage kt & 1
+    auto compute = [&](int kt) {
+        const uint8_t* imgA = smem + (kt % SA) * A_STAGE;
+        const uint8_t* imgB = smemW + (kt & 1) * W_STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int chunk = kk * 4 + fq;
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm0 + i * 16 + fr;
+                fa[i] = *reinterpret_cast<const bf16x8*>(imgA + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = j * 16 + fr;
+                fb[j] = *reinterpret_cast<const bf16x8*>(imgB + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // The K loop is unrolled IN FULL and runs NK steps on every workgroup (NK = the K-steps of a slice, a template parameter;
+    // the last slice of an uneven split owns fewer: its surplus steps stage clamped re-reads and skip the MFMAs), so every
+    // wait count is a compile-time constant.  The two kinds of waves run their own copy of the loop (one barrier per step in
+    // each: the counts match), which keeps the weight path one straight-line region -- tools/check_wstream_asm.py verifies
+    // in the assembly that nothing touches a weight register between its load and the wait that retires it.
+    if (wload) {
+#pragma unroll
+        for (int j = 0; j < DW; ++j)
+            if (j < NK) load_w(wreg[j], j);
+        ZE_WS_STORE(wreg[0], 0, PW * ((DW < NK ? DW : NK) - 1));
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) {
+            constexpr int dw_ = DW;
+            const int u = kt % dw_;
+            __builtin_amdgcn_s_barrier();
+            // wreg[u] held step kt (written to LDS one iteration ago): refill it DW steps ahead, then put step kt + 1 into
+            // the weight stage nobody reads any more; steps kt + 2 .. min(kt + DW, NK - 1) stay in flight
+            if (kt + DW < NK) load_w(wreg[u], kt + DW);
+            if (kt + 1 < NK) {
+                const int last = kt + DW < NK - 1 ? kt + DW : NK - 1;  // newest step requested so far
+                switch (last - (kt + 1)) {  // (a literal per case: the asm operand has to be an immediate)
+                    case 0: ZE_WS_STORE(wreg[(u + 1) % dw_], kt + 1, 0); break;
+                    case 1: ZE_WS_STORE(wreg[(u + 1) % dw_], kt + 1, PW * 1); break;
+                    case 2: ZE_WS_STORE(wreg[(u + 1) % dw_], kt + 1, PW * 2); break;
+                    case 3: ZE_WS_STORE(wreg[(u + 1) % dw_], kt + 1, PW * 3); break;
+                    case 4: ZE_WS_STORE(wreg[(u + 1) % dw_], kt + 1, PW * 4); break;
+                    case 5: ZE_WS_STORE(wreg[(u + 1) % dw_], kt + 1, PW * 5); break;
+                    case 6: ZE_WS_STORE(wreg[(u + 1) % dw_], kt + 1, PW * 6); break;
+                    default: ZE_WS_STORE(wreg[(u + 1) % dw_], kt + 1, PW * 7); break;
+                }
+            }
+            if (kt < nk) compute(kt);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (nothing of the loop's queue survives into the epilogue)
+    } else {
+#pragma unroll
+        for (int s = 0; s < SA - 1; ++s)
+            if (s < nk) issue_a(s);
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) {
+            // this wave's DMAs of activation stage kt have landed
+            const int ahead = min(SA - 2, nk - 1 - kt);
+            if (ahead >= 2) ring_wait<2 * LA>();
+            else if (ahead == 1) ring_wait<LA>();
+            else ring_wait<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + SA - 1 < nk) issue_a(kt + SA - 1);
+            if (kt < nk) compute(kt);
+        }
+    }
+#undef ZE_WS_STORE
+    __syncthreads();  // the tail reuses the staging LDS
+    gemm_finish<BM, BN, EPI, WM, WN>(acc, smem, bias, R, ldr, C, ldc, nullptr, M, N, ksplit, ks, bid, nwg, 0, bn0, slab, tickets);
+}
+
+template <int BM, int BN, int SA, int DW, int NK, int E>
+static void launch_wstream_one(const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R, int ldr,
+                               bf16_t* C, int ldc, int M, int N, int K, int ksplit, const ze_gemm_ws& ws, hipStream_t s) {
+    const int grid = ze_cdiv(N, BN) * ksplit;
+    const size_t lds = (size_t)SA * BM * 128 + (size_t)2 * BN * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_wstream<BM, BN, SA, DW, NK, E>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_gemm_wstream<BM, BN, SA, DW, NK, E>), dim3(grid), dim3(512), lds, s, A, lda, W, ldw, bias, R, ldr, C,
+                       ldc, M, N, K, ksplit, ws.slab, ws.tickets);
+}
+
+// WIDE: the one-pass instances (gate/up with SwiGLU, the lm_head, plain) at the K-step counts of the 3B / 7B hidden sizes;
+// else the split-K instances of the down projection (K-steps per slice of 11008 / 8 and 18944 / 8).  false = no instance.
+template <int BM, int BN, int SA, int DW, bool WIDE>
+static bool launch_wstream(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
+                           int ldr, bf16_t* C, int ldc, int M, int N, int K, int ksplit, const ze_gemm_ws& ws, hipStream_t s) {
+    const int nk_per = ze_cdiv(K / GEMM_BK, ksplit);
+#define ZE_WS_ONE(NK, E) \
+    launch_wstream_one<BM, BN, SA, DW, NK, E>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ksplit, ws, s); \
+    return true
+    if constexpr (WIDE) {
+        if (nk_per == 32) {
+            if (epi == ZE_EPI_SWIGLU) { ZE_WS_ONE(32, ZE_EPI_SWIGLU); }
+            if (epi == ZE_EPI_F32) { ZE_WS_ONE(32, ZE_EPI_F32); }
+            if (epi == ZE_EPI_NONE) { ZE_WS_ONE(32, ZE_EPI_NONE); }
+        }
+    } else {
+        if (nk_per == 22) {
+            if (epi == ZE_EPI_RESIDUAL) { ZE_WS_ONE(22, ZE_EPI_RESIDUAL); }
+            if (epi == ZE_EPI_NONE) { ZE_WS_ONE(22, ZE_EPI_NONE); }
+        }
+    }
+#undef ZE_WS_ONE
+    return false;
+}
 
 // ----------------------------------------------------------------------------------------------------------------
 // The ring on the block-scaled FP8 matrix instruction (BASELINE configs[4]: "fp8 weights on CDNA4 fp8 MFMA", prefill side;
@@ -1191,13 +1436,48 @@ void ze_launch_gemm_stream(int epi, const bf16_t* A, int lda, const bf16_t* W, i
     launch_cfg<64, 64>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s, true, ws);
 }
 
+// K slices of the long-K weight-streaming GEMMs (the down projection): a function of (N, K) alone, shared by every tile
+// that serves them (the 64 x 64 ring of ze_launch_gemm_stream computes the same count for its own grid)
+static int wide_ksplit(int N, int K) {
+    const int nk = ze_cdiv(K, GEMM_BK), tiles_n = ze_cdiv(N, 64);
+    int ksplit = 1;
+    while (tiles_n * ksplit < 200 && ksplit < 8 && nk / (ksplit * 2) >= 4) ksplit *= 2;
+    return ksplit;
+}
+
 void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
                          int ldr, bf16_t* C, int ldc, int M, int N, int K, const ze_gemm_ws& ws, hipStream_t s) {
     if (M <= 0 || N <= 0) return;
-    // long K (the down projection): eight K slices, reduced in slice order (the split-K ring of the streaming launcher);
-    // everything else: one pass over K on whichever tile fits the row count (all tiles sum K in sequence)
-    if (K > 4096) ze_launch_gemm_stream(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s);
-    else ze_launch_gemm(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s);
+    // knob 15 (measurements): ones digit = wide matrices (gate/up, lm_head), tens digit = long-K (down); 0 = shipped,
+    // 9 = the tile policy of round 2 (ring kernels only)
+    const int vw = ze_gemv_knobs[15] % 10, vd = (ze_gemv_knobs[15] / 10) % 10;
+    const bool ok = K % GEMM_BK == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && M <= 256 && (size_t)N * ldw * sizeof(bf16_t) < ((size_t)1 << 31);
+    bool done = false;
+    if (K > 4096) {
+        // long K (the down projection): eight K slices, reduced in slice order
+        const int ksplit = wide_ksplit(N, K);
+        const bool fits = ws.slab && (size_t)ksplit * ze_cdiv(N, 64) * 256 * 64 <= ws.slab_floats && ze_cdiv(N, 64) <= ws.ticket_cap;
+        if (ok && fits && ksplit > 1 && epi != ZE_EPI_SWIGLU && vd != 9 && K / GEMM_BK / ksplit >= 4) {
+            if (M > 128) {
+                done = launch_wstream<256, 64, 3, 8, false>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ksplit, ws, s);
+            } else {
+                done = launch_wstream<128, 64, 3, 8, false>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ksplit, ws, s);
+            }
+        }
+        if (!done) ze_launch_gemm_stream(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s);
+        return;
+    }
+    // one pass over K (K in sequence on every tile: the choice of tile never changes a result)
+    if (ok && N >= 8192 && vw != 9 && K / GEMM_BK >= 8 && (epi == ZE_EPI_SWIGLU || epi == ZE_EPI_NONE || epi == ZE_EPI_F32)) {
+        if (M > 128) {
+            if (vw == 3) done = launch_wstream<256, 128, 3, 6, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, 1, ws, s);
+            else done = launch_wstream<256, 96, 3, 8, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, 1, ws, s);
+        } else {
+            if (vw == 3) done = launch_wstream<128, 128, 3, 6, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, 1, ws, s);
+            else done = launch_wstream<128, 96, 3, 8, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, 1, ws, s);
+        }
+    }
+    if (!done) ze_launch_gemm(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s);
 }
 
 void ze_launch_gemm(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
