@@ -25,7 +25,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 
 // Tail shared by the GEMM kernels: optional split-K reduction (deterministic, by the last-arriving slice of the tile)
 // and the epilogue.  acc[i][j][r] -> row = wm0 + i*16 + fq*4 + r, col = wn0 + j*16 + fr.
-template <int BM, int BN, int EPI, int WM = 2, int WN = 2>
+template <int BM, int BN, int EPI, int WM = 2, int WN = 2, bool LDS_EPI = false>
 __device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / (16 * WM)][BN / (16 * WN)], uint8_t* smem, const bf16_t* __restrict__ bias,
                                             const bf16_t* __restrict__ R, int ldr, bf16_t* __restrict__ C, int ldc,
                                             const int* __restrict__ c_rows, int M, int N, int ksplit, int ks, int bid,
@@ -46,7 +46,10 @@ __device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / (16 * WM)][BN / (1
         {
             const size_t slab_bytes = (size_t)ksplit * nwg * NT * (TM * TN) * 16;
             auto rsrc = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)min(slab_bytes, (size_t)0x7fffffff), 0x00020000);
-            const unsigned base = (unsigned)((((size_t)(ks * nwg + bid) * NT + tid) * (TM * TN)) * 16);
+            // slab of (slice, tile): [MFMA tile t][thread]: a wave-instruction moves 1 KiB of consecutive bytes (with the
+            // thread-major order of round 2 -- TM * TN float4 per thread back to back -- every lane of a store or load hit
+            // a line of its own: at 8 tiles per thread the reduction of the 256-row down projection took 43 us)
+            const unsigned base = (unsigned)(((size_t)(ks * nwg + bid) * (TM * TN) * NT + tid) * 16);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -56,7 +59,7 @@ __device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / (16 * WM)][BN / (1
                     v.y = __float_as_uint(acc[i][j][1]);
                     v.z = __float_as_uint(acc[i][j][2]);
                     v.w = __float_as_uint(acc[i][j][3]);
-                    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, base + (unsigned)(i * TN + j) * 16, 0, 16 /* sc1 */);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, base + (unsigned)(i * TN + j) * NT * 16, 0, 16 /* sc1 */);
                 }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the ticket
@@ -87,10 +90,10 @@ __device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / (16 * WM)][BN / (1
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const unsigned base =
-                        (unsigned)((((size_t)(min(q, ksplit - 1) * nwg + bid) * NT + tid) * (TM * TN)) * 16);
+                        (unsigned)(((size_t)(min(q, ksplit - 1) * nwg + bid) * (TM * TN) * NT + tid) * 16);
 #pragma unroll
                     for (int t = 0; t < TM * TN; ++t)
-                        v[q][t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + (unsigned)t * 16, 0, 16);
+                        v[q][t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + (unsigned)t * NT * 16, 0, 16);
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
@@ -113,10 +116,10 @@ __device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / (16 * WM)][BN / (1
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const unsigned base =
-                            (unsigned)((((size_t)(min(q0 + q, ksplit - 1) * nwg + bid) * NT + tid) * (TM * TN)) * 16);
+                            (unsigned)(((size_t)(min(q0 + q, ksplit - 1) * nwg + bid) * (TM * TN) * NT + tid) * 16);
 #pragma unroll
                         for (int t = 0; t < TM * TN; ++t)
-                            v[q][t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + (unsigned)t * 16, 0, 16);
+                            v[q][t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + (unsigned)t * NT * 16, 0, 16);
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
@@ -134,12 +137,12 @@ __device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / (16 * WM)][BN / (1
                 }
             } else {
                 for (int q = 0; q < ksplit; ++q) {
-                    const unsigned base = (unsigned)((((size_t)(q * nwg + bid) * NT + tid) * (TM * TN)) * 16);
+                    const unsigned base = (unsigned)(((size_t)(q * nwg + bid) * (TM * TN) * NT + tid) * 16);
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j) {
-                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + (unsigned)(i * TN + j) * 16, 0, 16);
+                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + (unsigned)(i * TN + j) * NT * 16, 0, 16);
                             acc[i][j][0] += __uint_as_float(v.x);
                             acc[i][j][1] += __uint_as_float(v.y);
                             acc[i][j][2] += __uint_as_float(v.z);
@@ -150,6 +153,69 @@ __device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / (16 * WM)][BN / (1
         }
     }
 
+    // ---------------- wide-store epilogue (LDS_EPI; bm0 = 0, c_rows unused): the MFMA result layout gives a lane four ROWS of
+    // one column, so the plain epilogue below stores 2-byte values 32 B at a time (and loads the residual the same way): at
+    // 256 rows it cost the decode projections 6-10 us.  Here the rounded values cross the (idle) staging LDS once and leave
+    // as 16-byte row pieces; the arithmetic and its order of roundings are those of the plain epilogue, value for value.
+    if constexpr (LDS_EPI) {
+        constexpr int OW = (EPI == ZE_EPI_SWIGLU) ? BN / 2 : BN;           // output columns of the tile
+        constexpr int EB = (EPI == ZE_EPI_F32) ? 4 : 2;                    // bytes per staged element
+        constexpr int ROWB = OW * EB + 16;                                 // row pitch in LDS: 16 B of padding spread the banks
+        static_assert((OW * EB) % 16 == 0, "tile width");
+        __syncthreads();  // (split-K: the ticket flag lives in this LDS)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; j += (EPI == ZE_EPI_SWIGLU ? 2 : 1)) {
+                const int ncol = bn0 + wn0 + j * 16 + fr;
+                float b0 = 0.f, b1 = 0.f;
+                if (bias && ncol < N) {
+                    b0 = bf16_to_f32(bias[ncol]);
+                    if (EPI == ZE_EPI_SWIGLU) b1 = bf16_to_f32(bias[ncol + 16]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm0 + i * 16 + fq * 4 + r;
+                    if (EPI == ZE_EPI_SWIGLU) {
+                        const float g = bf16_round(acc[i][j][r] + b0);
+                        const float u = bf16_round(acc[i][j + 1][r] + b1);
+                        *reinterpret_cast<bf16_t*>(smem + row * ROWB + ((wn0 + j * 16) / 2 + fr) * 2) = f32_to_bf16(bf16_round(silu_f(g)) * u);
+                    } else if (EPI == ZE_EPI_F32) {
+                        *reinterpret_cast<float*>(smem + row * ROWB + (wn0 + j * 16 + fr) * 4) = bf16_round(acc[i][j][r] + b0);
+                    } else {
+                        float v = bf16_round(acc[i][j][r] + b0);
+                        if (EPI == ZE_EPI_GELU) v = gelu_erf(v);
+                        *reinterpret_cast<bf16_t*>(smem + row * ROWB + (wn0 + j * 16 + fr) * 2) = f32_to_bf16(v);
+                    }
+                }
+            }
+        __syncthreads();
+        constexpr int PPR = OW * EB / 16;  // 16-byte pieces per row
+        const int oc0 = (EPI == ZE_EPI_SWIGLU) ? bn0 / 2 : bn0, on = (EPI == ZE_EPI_SWIGLU) ? N / 2 : N;
+        for (int pc = tid; pc < BM * PPR; pc += NT) {
+            const int row = pc / PPR, c16 = pc % PPR;
+            if (row >= M) continue;
+            const int col = oc0 + c16 * (16 / EB);  // first output column of the piece
+            if (col >= on) continue;
+            uint4 v = *reinterpret_cast<const uint4*>(smem + row * ROWB + c16 * 16);
+            if (EPI == ZE_EPI_RESIDUAL) {  // out = bf16(residual + value), per element as the plain epilogue
+                const uint4 rr = *reinterpret_cast<const uint4*>(R + (size_t)row * ldr + col);
+                const uint32_t* pv = reinterpret_cast<const uint32_t*>(&v);
+                const uint32_t* pr = reinterpret_cast<const uint32_t*>(&rr);
+                uint32_t o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float lo = __uint_as_float(pr[q] << 16) + __uint_as_float(pv[q] << 16);
+                    const float hi = __uint_as_float(pr[q] & 0xffff0000u) + __uint_as_float(pv[q] & 0xffff0000u);
+                    o[q] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+                }
+                v = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+            if (EPI == ZE_EPI_F32) *reinterpret_cast<uint4*>(reinterpret_cast<float*>(C) + (size_t)row * ldc + col) = v;
+            else *reinterpret_cast<uint4*>(C + (size_t)row * ldc + col) = v;
+        }
+        return;
+    }
     // ---------------- epilogue: acc[i][j][r] -> row = wm0 + i*16 + fq*4 + r, col = wn0 + j*16 + fr
     if (EPI == ZE_EPI_SWIGLU) {
         static_assert(EPI != ZE_EPI_SWIGLU || TN % 2 == 0, "SwiGLU pairs two 16-column tiles of a wave");
@@ -373,7 +439,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
     constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN), NT = 64 * WM * WN;
     constexpr int STAGE_BYTES = (BM + BN) * 128;
     constexpr int LPW = (BM + BN) / 8 / (WM * WN);  // DMA instructions per wave per stage
-    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
+    static_assert(STAGES >= 2 && STAGES <= 8 && 6 * LPW < 64, "ring depth");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
@@ -422,9 +488,21 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
     for (int kt = 0; kt < nk; ++kt) {
         // stages still allowed in flight behind stage kt: min(STAGES - 2, nk - 1 - kt)
         const int ahead = min(STAGES - 2, nk - 1 - kt);
-        if (ahead >= 2) ring_wait<2 * LPW>();
-        else if (ahead == 1) ring_wait<LPW>();
-        else ring_wait<0>();
+        if constexpr (STAGES > 4) {
+            switch (ahead) {
+                case 6: ring_wait<6 * LPW>(); break;
+                case 5: ring_wait<5 * LPW>(); break;
+                case 4: ring_wait<4 * LPW>(); break;
+                case 3: ring_wait<3 * LPW>(); break;
+                case 2: ring_wait<2 * LPW>(); break;
+                case 1: ring_wait<LPW>(); break;
+                default: ring_wait<0>(); break;
+            }
+        } else {
+            if (ahead >= 2) ring_wait<2 * LPW>();
+            else if (ahead == 1) ring_wait<LPW>();
+            else ring_wait<0>();
+        }
         __builtin_amdgcn_s_barrier();
         // SPREAD: the refill DMAs of this K-step go out between the rows of MFMAs below instead of in one burst
         // behind the barrier (every wave of the workgroup issuing its pieces at once leaves the matrix pipe idle
@@ -653,7 +731,7 @@ __global__ void __launch_bounds__(512) k_gemm_wstream(const bf16_t* __restrict__
     }
 #undef ZE_WS_STORE
     __syncthreads();  // the tail reuses the staging LDS
-    gemm_finish<BM, BN, EPI, WM, WN>(acc, smem, bias, R, ldr, C, ldc, nullptr, M, N, ksplit, ks, bid, nwg, 0, bn0, slab, tickets);
+    gemm_finish<BM, BN, EPI, WM, WN, true>(acc, smem, bias, R, ldr, C, ldc, nullptr, M, N, ksplit, ks, bid, nwg, 0, bn0, slab, tickets);
 }
 
 template <int BM, int BN, int SA, int DW, int NK, int E>
@@ -671,27 +749,18 @@ static void launch_wstream_one(const bf16_t* A, int lda, const bf16_t* W, int ld
                        ldc, M, N, K, ksplit, ws.slab, ws.tickets);
 }
 
-// WIDE: the one-pass instances (gate/up with SwiGLU, the lm_head, plain) at the K-step counts of the 3B / 7B hidden sizes;
-// else the split-K instances of the down projection (K-steps per slice of 11008 / 8 and 18944 / 8).  false = no instance.
-template <int BM, int BN, int SA, int DW, bool WIDE>
+// The one-pass instances (gate/up with SwiGLU, the lm_head, plain) at the K-step count of the 3B hidden size (K = 2048);
+// false = no instance for this shape (the caller falls back to the ring kernels, which give the same bits).
+template <int BM, int BN, int SA, int DW>
 static bool launch_wstream(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
-                           int ldr, bf16_t* C, int ldc, int M, int N, int K, int ksplit, const ze_gemm_ws& ws, hipStream_t s) {
-    const int nk_per = ze_cdiv(K / GEMM_BK, ksplit);
+                           int ldr, bf16_t* C, int ldc, int M, int N, int K, const ze_gemm_ws& ws, hipStream_t s) {
+    if (K / GEMM_BK != 32) return false;
 #define ZE_WS_ONE(NK, E) \
-    launch_wstream_one<BM, BN, SA, DW, NK, E>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ksplit, ws, s); \
+    launch_wstream_one<BM, BN, SA, DW, NK, E>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, 1, ws, s); \
     return true
-    if constexpr (WIDE) {
-        if (nk_per == 32) {
-            if (epi == ZE_EPI_SWIGLU) { ZE_WS_ONE(32, ZE_EPI_SWIGLU); }
-            if (epi == ZE_EPI_F32) { ZE_WS_ONE(32, ZE_EPI_F32); }
-            if (epi == ZE_EPI_NONE) { ZE_WS_ONE(32, ZE_EPI_NONE); }
-        }
-    } else {
-        if (nk_per == 22) {
-            if (epi == ZE_EPI_RESIDUAL) { ZE_WS_ONE(22, ZE_EPI_RESIDUAL); }
-            if (epi == ZE_EPI_NONE) { ZE_WS_ONE(22, ZE_EPI_NONE); }
-        }
-    }
+    if (epi == ZE_EPI_SWIGLU) { ZE_WS_ONE(32, ZE_EPI_SWIGLU); }
+    if (epi == ZE_EPI_F32) { ZE_WS_ONE(32, ZE_EPI_F32); }
+    if (epi == ZE_EPI_NONE) { ZE_WS_ONE(32, ZE_EPI_NONE); }
 #undef ZE_WS_ONE
     return false;
 }
@@ -1222,6 +1291,8 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
         // wave), split-K included: merger 26.8 -> 23.3 us; the weight-streaming
         // GEMMs of the batched decode step 4.48 -> 4.33 ms per 64-chain step, 3.27 -> 3.14 at 8 chains
         if (BM == 64 && BN == 64 && ze_gemv_knobs[7] != 3) {
+            // (round 3, the split-K stream of the down projection, us at 64 / 256 rows: this tile 17.4 / 35.2; eight or six
+            //  stages 17.8 / 44.1 and 17.7 / 42.9; 128 x 64 tiles 21.3 / 36.7; 256 x 64 tiles, three stages 32.8 / 39.1)
             launch_ring_variant<64, 64, 4, 4, 2, false>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, ksplit, ws);
             return;
         }
@@ -1436,46 +1507,29 @@ void ze_launch_gemm_stream(int epi, const bf16_t* A, int lda, const bf16_t* W, i
     launch_cfg<64, 64>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s, true, ws);
 }
 
-// K slices of the long-K weight-streaming GEMMs (the down projection): a function of (N, K) alone, shared by every tile
-// that serves them (the 64 x 64 ring of ze_launch_gemm_stream computes the same count for its own grid)
-static int wide_ksplit(int N, int K) {
-    const int nk = ze_cdiv(K, GEMM_BK), tiles_n = ze_cdiv(N, 64);
-    int ksplit = 1;
-    while (tiles_n * ksplit < 200 && ksplit < 8 && nk / (ksplit * 2) >= 4) ksplit *= 2;
-    return ksplit;
-}
-
 void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
                          int ldr, bf16_t* C, int ldc, int M, int N, int K, const ze_gemm_ws& ws, hipStream_t s) {
     if (M <= 0 || N <= 0) return;
-    // knob 15 (measurements): ones digit = wide matrices (gate/up, lm_head), tens digit = long-K (down); 0 = shipped,
-    // 9 = the tile policy of round 2 (ring kernels only)
-    const int vw = ze_gemv_knobs[15] % 10, vd = (ze_gemv_knobs[15] / 10) % 10;
-    const bool ok = K % GEMM_BK == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && M <= 256 && (size_t)N * ldw * sizeof(bf16_t) < ((size_t)1 << 31);
-    bool done = false;
+    // long K (the down projection): eight K slices, reduced in slice order, on the split-K ring (k_gemm_wstream with a
+    // split K loses to it at every row count: 36.7 against 34.1 us at 256 rows, 23.4 against 17.4 at 64 -- its K loop alone
+    // takes 19 us there, but 256-row tiles make the slab reduction eight times the bytes per reducer)
     if (K > 4096) {
-        // long K (the down projection): eight K slices, reduced in slice order
-        const int ksplit = wide_ksplit(N, K);
-        const bool fits = ws.slab && (size_t)ksplit * ze_cdiv(N, 64) * 256 * 64 <= ws.slab_floats && ze_cdiv(N, 64) <= ws.ticket_cap;
-        if (ok && fits && ksplit > 1 && epi != ZE_EPI_SWIGLU && vd != 9 && K / GEMM_BK / ksplit >= 4) {
-            if (M > 128) {
-                done = launch_wstream<256, 64, 3, 8, false>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ksplit, ws, s);
-            } else {
-                done = launch_wstream<128, 64, 3, 8, false>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ksplit, ws, s);
-            }
-        }
-        if (!done) ze_launch_gemm_stream(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s);
+        ze_launch_gemm_stream(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s);
         return;
     }
-    // one pass over K (K in sequence on every tile: the choice of tile never changes a result)
-    if (ok && N >= 8192 && vw != 9 && K / GEMM_BK >= 8 && (epi == ZE_EPI_SWIGLU || epi == ZE_EPI_NONE || epi == ZE_EPI_F32)) {
-        if (M > 128) {
-            if (vw == 3) done = launch_wstream<256, 128, 3, 6, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, 1, ws, s);
-            else done = launch_wstream<256, 96, 3, 8, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, 1, ws, s);
-        } else {
-            if (vw == 3) done = launch_wstream<128, 128, 3, 6, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, 1, ws, s);
-            else done = launch_wstream<128, 96, 3, 8, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, 1, ws, s);
-        }
+    // One pass over K: K in sequence on every tile, so the choice of tile never changes a result and may follow the row
+    // count.  Wide matrices (gate/up, lm_head) take k_gemm_wstream where it is faster (3B shape, us per launch at 64 / 128 /
+    // 217 / 256 rows: gate/up 26.6 / 28.1 / 37.9 / 38.0 against 24.3 / 29.7 / 39.9 / 41.3 on the ring tiles, lm_head 168 /
+    // 181 / 240 / 245 against 192 / 215 / 226 / 228); knob 15 = 9: ring tiles only, 1: k_gemm_wstream wherever it applies.
+    // (the wide-store epilogue of k_gemm_wstream moves whole 16-byte row pieces: aligned rows, N a multiple of 32)
+    const bool ok = K % GEMM_BK == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && M <= 256 && (size_t)N * ldw * sizeof(bf16_t) < ((size_t)1 << 31) &&
+                    N % 32 == 0 && (ldc % 8) == 0 && ((size_t)A % 16) == 0 && ((size_t)C % 16) == 0;
+    const int v = ze_gemv_knobs[15];
+    const bool want = v == 1 || (v != 9 && ((epi == ZE_EPI_SWIGLU && M > 96) || (epi == ZE_EPI_F32 && M <= 160)));
+    bool done = false;
+    if (ok && want && N >= 8192) {
+        if (M > 128) done = launch_wstream<256, 96, 3, 8>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s);
+        else done = launch_wstream<128, 96, 3, 8>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s);
     }
     if (!done) ze_launch_gemm(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s);
 }
