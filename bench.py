@@ -266,6 +266,57 @@ def run_stream(engine, table, q0: int, slots: int, stats=None, use_graph=True):
     return done
 
 
+def run_stream_lanes(engines, table, q0: int, slots: int, stats=None, use_graph=True):
+    """The same stream on several LANES of one GPU: every lane is an engine of its own (weights, KV cache, workspaces) with
+    its own scheduler, host thread and HIP stream; tiles are dealt to the lanes whole (a tile's questions share its view and
+    its prompt prefix).  While one lane is in a prefill / ViT round (matrix-bound) the other one decodes (bandwidth- and
+    latency-bound): the GPU overlaps them, and the host work of one lane hides behind the device work of the other."""
+    import threading
+
+    import torch
+    from zoomearth_amd.image import DeviceImage
+    if len(engines) == 1:
+        return run_stream(engines[0], table, q0, slots, stats, use_graph)
+    lane_of, parts = {}, [[] for _ in engines]
+    for b, tile, vkey in table:
+        ln = lane_of.setdefault(vkey, len(lane_of) % len(engines))
+        parts[ln].append((b, tile, vkey))
+    outs, errs, sts = [None] * len(engines), [], [dict() for _ in engines]
+
+    def work(ln):
+        try:
+            e = engines[ln]
+            mine, own = [], {}
+            for b, tile, vkey in parts[ln]:  # the lane's engine runs the tile's front-end launches
+                if vkey not in own:
+                    own[vkey] = tile if tile.engine is e else DeviceImage(tile.base, e)
+                mine.append((b, own[vkey], vkey))
+            with torch.cuda.stream(torch.cuda.Stream(device=e.device)):
+                outs[ln] = run_stream(e, mine, q0, slots, sts[ln], use_graph)
+                torch.cuda.current_stream().synchronize()
+        except BaseException as ex:  # noqa: BLE001
+            errs.append(ex)
+
+    threads = [threading.Thread(target=work, args=(ln,)) for ln in range(len(engines))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errs:
+        raise errs[0]
+    done = {}
+    for o in outs:
+        done.update(o)
+    if stats is not None:
+        for st in sts:
+            for k, v in st.items():
+                if k != "lens":
+                    stats[k] = stats.get(k, 0) + v
+        stats["lens"] = [done[q0 + b] for b, _, _ in table]
+        stats["lanes"] = len(engines)
+    return done
+
+
 def batch_step(engine, tiles, q0: int, B: int, stats=None, use_graph=True, slots=None):
     """B questions about len(tiles) tiles (6 : 64 as LRS-GRO's 908 : 9734), passes of 64 questions over the tiles."""
     table = []
@@ -551,6 +602,9 @@ def main():
                          "one question per step); B > 1 = configs[2] with B chains (one step = B questions)")
     ap.add_argument("--slots", type=int, default=int(os.environ.get("ZE_STREAM_SLOTS", str(STREAM_SLOTS))),
                     help="chain slots per GPU of the stream workload")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("ZE_LANES", "1")),
+                    help="engines per GPU of the stream workload, each with its own scheduler thread and HIP stream (prefill of one "
+                         "overlaps decode of the other); --slots chain slots EACH")
     ap.add_argument("--no-batch64", action="store_true", help="skip the batch64 object of the default N = 1 line")
     ap.add_argument("--no-configs1", action="store_true", help="skip the configs1 object of the default N = 1 line")
     ap.add_argument("--spawn-check", action="store_true", help=argparse.SUPPRESS)
@@ -611,6 +665,14 @@ def main():
         e.quantize_fp8()  # after the broadcast: every rank quantises the weights it received
         if args.fp8_act:
             e.set_fp8_activations(True)
+    engines = [e]
+    for _ in range(1, max(1, args.lanes) if stream else 1):  # further lanes: engines of their own, weights copied on the device
+        e2 = Engine(cfg, device=local, max_seqs=chains, max_ctx=2048, max_patches=max(4096, 1400 * min(chains, 40)),
+                    max_prefill_rows=int(os.environ.get("ZE_PREFILL_ROWS", str(16 * 832))), max_tile_side=max(args.tile, 1024))
+        e2.weights_arena().copy_(e.weights_arena())
+        torch.cuda.synchronize()
+        e2.weights_invalidate()
+        engines.append(e2)
 
     def barrier():
         torch.cuda.synchronize()
@@ -650,11 +712,12 @@ def main():
         table = [(i, dev[tile_of[i]], tile_of[i]) for i in mine]
         warm_table = [(i, warm_dev[t], ("w", t)) for i, t in enumerate(warm_tile_of)]
         if warm_table:
-            run_stream(e, warm_table, 9_000_000 + rank * 100_000, SLOTS, use_graph=use_graph)
-        e.phase_timers(enable=True, reset=True)
+            run_stream_lanes(engines, warm_table, 9_000_000 + rank * 100_000, SLOTS, use_graph=use_graph)
+        for en in engines:
+            en.phase_timers(enable=True, reset=True)
         barrier()
         t0 = time.perf_counter()
-        run_stream(e, table, 1_000_000, SLOTS, bstats, use_graph=use_graph)
+        run_stream_lanes(engines, table, 1_000_000, SLOTS, bstats, use_graph=use_graph)
         torch.cuda.synchronize()
         my_dt = time.perf_counter() - t0
         barrier()
@@ -692,6 +755,9 @@ def main():
         n_questions = world * args.steps * B
         mine = list(range(args.steps * B))
     phases = e.phase_timers(enable=False)
+    for en in engines[1:]:
+        for k, v in en.phase_timers(enable=False).items():
+            phases[k] += v
     per_rank = [[len(mine), my_dt]]
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
@@ -815,7 +881,8 @@ def main():
                                    (f"BASELINE configs[2]: ZoomEarth-3B shape, {B} question chains about {len(dev_tiles)} tiles advanced "
                                     f"together per GPU by the continuous-batching scheduler (ragged lengths +-25 %, dynamic-"
                                     f"resolution ViT batch), one step = {B} questions"),
-                       "questions_per_step_per_gpu": Q_STEP if stream else B, "chain_slots_per_gpu": chains,
+                       "questions_per_step_per_gpu": Q_STEP if stream else B, "chain_slots_per_gpu": chains * len(engines),
+                       "lanes_per_gpu": len(engines),
                        "tile": [args.tile, args.tile], "L1": lens[0], "L2": lens[1], "N1": lens[2], "N2": lens[3],
                        "repetition_penalty": PENALTY, "hip_graph": use_graph,
                        "reuse": ("stage-1 prompt KV and view features reused in stage 2 (bit-identical); the KV rows of the "
@@ -904,7 +971,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             line["cpu_baseline"] = measure_cpu_baseline(args.cpu_baseline)
         print(json.dumps(line), flush=True)
-    e.close()
+    for en in engines:
+        en.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -239,6 +239,14 @@ int ze_generate_batch(ze_engine* e, const int32_t* seqs, int n, const ze_gen_par
 int ze_chain_begin(ze_engine* e, int seq, const ze_gen_params* p, int sample_stream, void* stream);
 int ze_decode_burst(ze_engine* e, const int32_t* seqs, int n, int steps, const ze_gen_params* p, int32_t* n_generated,
                     int32_t* finished, void* stream);
+/* The same burst in two halves, for a host that overlaps it with other work: _begin enqueues the steps on `stream` and
+ * returns at once (the number of steps enqueued, or a negative ze_status); the host may now enqueue the ViT / prefill
+ * round of the NEXT newcomers on ANOTHER stream (the batched step has activation buffers of its own; chains being
+ * prefilled are not part of the burst, so no state is shared) -- the GPU overlaps the matrix-bound prefill with the
+ * bandwidth-bound decode steps; _end waits for the burst and reports as ze_decode_burst does.  No other call may touch the
+ * burst's chains or use the burst's stream between the two halves. */
+int ze_decode_burst_begin(ze_engine* e, const int32_t* seqs, int n, int steps, const ze_gen_params* p, void* stream);
+int ze_decode_burst_end(ze_engine* e, const int32_t* seqs, int n, int32_t* n_generated, int32_t* finished, void* stream);
 int ze_chain_tokens(ze_engine* e, int seq, int32_t* out_tokens, int capacity, int* n_out, void* stream);
 /* Rollout scoring (replaces _get_per_token_logps, src/train/RL/src/open-r1-multimodal/src/open_r1/trainer/
  * grpo_trainer.py:494-504, as the trainer calls it under torch.no_grad for the old policy and the reference model,

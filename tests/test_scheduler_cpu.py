@@ -268,6 +268,85 @@ def test_errors_are_isolated_per_request():
     assert sorted(sched.free) == [0, 1]
 
 
+class OverlapEngine(StubEngine):
+    """The stub with the two-half burst of the real engine (ze_decode_burst_begin / _end): what is enqueued by _begin only
+    becomes visible at _end, and touching a chain of the burst in between is a bug the stub reports."""
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.in_flight = None
+
+    def decode_burst_begin(self, slots, steps, params):
+        assert self.in_flight is None
+        for s in slots:
+            steps = min(steps, self.max_ctx - (len(self.chains[s]["ids"]) + len(self.chains[s]["out"]) - 1))
+        self.in_flight = (list(slots), steps)
+        self.log.append(("begin", len(slots), steps))
+        return steps
+
+    def decode_burst_end(self, slots):
+        live, steps = self.in_flight
+        assert list(slots) == live
+        self.in_flight = None
+        for _ in range(steps):
+            for s in live:
+                self._next(self.chains[s])
+        self.log.append(("end", len(live), steps))
+        return [len(self.chains[s]["out"]) for s in live], [self.chains[s]["fin"] for s in live]
+
+    def _guard(self, slot):
+        assert self.in_flight is None or slot not in self.in_flight[0], f"slot {slot} touched while its burst is in flight"
+
+    def seq_reset(self, slot):
+        self._guard(slot)
+        super().seq_reset(slot)
+
+    def seq_truncate(self, slot, keep):
+        self._guard(slot)
+        super().seq_truncate(slot, keep)
+
+    def prefill_batch(self, slots, *a):
+        for s in slots:
+            self._guard(s)
+        if self.in_flight is not None:
+            self.log.append(("overlapped",))
+        super().prefill_batch(slots, *a)
+
+    def chain_begin(self, slot, params, stream):
+        assert self.in_flight is None
+        super().chain_begin(slot, params, stream)
+
+
+def test_overlapped_admission_gives_the_same_tokens_and_never_touches_a_chain_in_flight():
+    """overlap=True: a burst is begun, ONE prefill pass of the admission round runs beside it, the burst is collected, the
+    pass's chains join the next burst.  Same tokens as the sequential loop; follow-ups keep their slot and cached prompt."""
+    def run(overlap):
+        model = make_model(max_seqs=3, max_prefill_rows=12)
+        if overlap:
+            e = OverlapEngine(max_seqs=3, max_prefill_rows=12)
+            model.engine = e
+        sched = ChainScheduler(model, Proc(), burst=3, overlap=overlap)
+        out = {}
+
+        def first(i):
+            def cb(req, toks, text):
+                out[(i, 1)] = toks
+                return Request(prompt=req.prompt + " " + text + " <img>", images=list(req.images) + [f"crop{i}"], max_new_tokens=4,
+                               on_done=lambda r, t, x: out.__setitem__((i, 2), t))
+            return cb
+
+        for i in range(7):
+            sched.submit(Request(prompt=f"{41 + 2 * i} <img> 60 61", images=[f"view{i % 2}"], max_new_tokens=5 + i % 3, on_done=first(i)))
+        sched.run()
+        return out, model.engine.log, sched.stats
+
+    seq, _, st0 = run(False)
+    ovl, log, st1 = run(True)
+    assert seq == ovl and len(ovl) == 14
+    assert st1["overlapped_passes"] > 0 and any(x[0] == "overlapped" for x in log)
+    assert st1["admitted"] == st0["admitted"] == 14 and st1["chain_steps"] == st0["chain_steps"]
+
+
 def test_a_failing_vit_call_or_prefill_pass_orphans_nobody():
     """a ViT error (or any failure after the round's requests left `waiting`) must fail every request
     of that round that is not live yet -- on_error called, slot back in `free` and reset -- instead of escaping step() with

@@ -103,6 +103,8 @@ _SIGS = {
     "ze_chain_begin": (C.c_int, [_P, C.c_int, C.POINTER(ZeGenParams), C.c_int, _P]),
     "ze_decode_burst": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(ZeGenParams),
                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
+    "ze_decode_burst_begin": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(ZeGenParams), _P]),
+    "ze_decode_burst_end": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
     "ze_chain_tokens": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int), _P]),
     "ze_seq_mark_seen": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.c_int, _P]),
     "ze_op_sample_greedy": (C.c_int, [_P, C.c_int, _P, C.c_float, C.POINTER(C.c_int32), _P]),

@@ -456,6 +456,22 @@ __global__ void __launch_bounds__(256) k_embed_tokens_batch(const ze_seq_dev* __
     *reinterpret_cast<uint4*>(out + (size_t)b * hidden + v * 8) =
         *reinterpret_cast<const uint4*>(embed + (size_t)tok * hidden + v * 8);
 }
+struct ze_int_pack {
+    int v[128];
+};
+__global__ void k_set_ints(int* __restrict__ dst, ze_int_pack p, int n) {
+    const int i = threadIdx.x;
+    if (i < n) dst[i] = p.v[i];
+}
+void ze_launch_set_ints(int* dst, const int* host_vals, int n, hipStream_t s) {
+    for (int o = 0; o < n; o += 128) {
+        ze_int_pack p;
+        const int m = n - o < 128 ? n - o : 128;
+        for (int i = 0; i < 128; ++i) p.v[i] = i < m ? host_vals[o + i] : 0;
+        hipLaunchKernelGGL(k_set_ints, dim3(1), dim3(128), 0, s, dst + o, p, m);
+    }
+}
+
 void ze_launch_embed_tokens_batch(const ze_seq_dev* st, const int* seq_ids, int n, const bf16_t* embed, bf16_t* out,
                                   int hidden, hipStream_t s) {
     const size_t tot = (size_t)n * (hidden / 8);

@@ -151,7 +151,9 @@ struct ze_engine {
     int gticket_cap = 0;
     ze_gemm_ws gemm_ws() const { return ze_gemm_ws{gslab, gslab_floats, gtickets, gticket_cap}; }
     unsigned* gtickets = nullptr;
-    // batched decode
+    // batched decode: activations of its own (rows = chains), so that a decode burst on one HIP stream and a prefill / ViT
+    // round on another never share a buffer (the scheduler overlaps them: zoomearth_amd/scheduler.py)
+    bf16_t *bh = nullptr, *by = nullptr, *bqkv = nullptr, *bo = nullptr, *ba = nullptr;
     int* bseq = nullptr;
     float *blogits = nullptr, *bpartial = nullptr, *bsample = nullptr;
     ze_seq_dev* bstate_host = nullptr;  // pinned

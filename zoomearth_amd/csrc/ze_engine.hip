@@ -362,6 +362,14 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
         e->gslab_floats = slab_floats;
         e->gticket_cap = 4096;
     }
+    {
+        const size_t br = (size_t)(std::max(c.max_seqs, 64) + 63) / 64 * 64;  // rows of the batched step (whole 64-row tiles)
+        chk(dev_alloc(e, &e->bh, br * c.hidden));
+        chk(dev_alloc(e, &e->by, br * c.hidden));
+        chk(dev_alloc(e, &e->bqkv, br * nqkv));
+        chk(dev_alloc(e, &e->bo, br * c.heads * e->head_dim));
+        chk(dev_alloc(e, &e->ba, br * e->text_ipad));
+    }
     chk(dev_alloc(e, &e->bseq, c.max_seqs));
     chk(dev_alloc(e, &e->blogits, (size_t)c.max_seqs * c.vocab));
     chk(dev_alloc(e, &e->bpartial, (size_t)c.max_seqs * std::max(e->max_splits, 8) * c.heads * 132));  // >= 8 parts per chain (ze_attn_batch.hip)
@@ -408,7 +416,7 @@ extern "C" int ze_engine_destroy(ze_engine* e) {
                    e->st_dev, e->seen, e->out_tokens, e->fe_tmp, e->fe_img, e->fe_coef, e->vx, e->vh, e->vy, e->vqkv,
                    e->vo, e->va, e->vz, e->vz2, e->vcos, e->vsin, e->vperm, e->vinv, e->vtiles_win, e->vtiles_full,
                    e->th, e->ty, e->tqkv, e->to, e->ta, e->tsrc, e->tpos, e->ttiles, e->ttile_aux, e->trow_aux, e->dh, e->dq, e->dattn, e->dact,
-                   e->dlogits, e->dpartial, e->dsample, e->gbar, e->atickets, e->gslab, e->gtickets, e->bseq, e->blogits, e->bpartial, e->bsample, e->arena8, e->arena_f, e->arena_f8,
+                   e->dlogits, e->dpartial, e->dsample, e->gbar, e->atickets, e->gslab, e->gtickets, e->bh, e->by, e->bqkv, e->bo, e->ba, e->bseq, e->blogits, e->bpartial, e->bsample, e->arena8, e->arena_f, e->arena_f8,
                    e->ty8, e->ty8_scale, e->damax, e->ty8p, e->ty8p_scale};
     for (void* p : dev)
         if (p) hipFree(p);

@@ -312,9 +312,8 @@ static int push_state(ze_engine* e, int seq, hipStream_t s, int token, int n_gen
     st.finished = finished;
     st.n_gen = n_gen;
     st.max_gen = e->cfg.max_ctx;
-    ZE_HIP(hipStreamSynchronize(s));
-    memcpy(e->d_host_ints, &st, sizeof(st));
-    ZE_HIP(hipMemcpyAsync(e->st_dev + seq, e->d_host_ints, sizeof(st), hipMemcpyHostToDevice, s));
+    static_assert(sizeof(ze_seq_dev) == 8 * sizeof(int), "chain state is eight ints");
+    ze_launch_set_ints(reinterpret_cast<int*>(e->st_dev + seq), reinterpret_cast<const int*>(&st), 8, s);
     return ZE_OK;
 }
 
@@ -838,11 +837,7 @@ extern "C" int ze_decode_step(ze_engine* e, int seq, int token, float* out_logit
     if (token >= c.vocab) return ze_fail(e, ZE_ERR_INVALID, "token id out of range");
     hipStream_t s = (hipStream_t)stream;
     hipSetDevice(e->device);
-    if (token >= 0) {
-        ZE_HIP(hipStreamSynchronize(s));
-        e->d_host_ints[16] = token;
-        ZE_HIP(hipMemcpyAsync(&(e->st_dev + seq)->token, e->d_host_ints + 16, sizeof(int), hipMemcpyHostToDevice, s));
-    }
+    if (token >= 0) ze_launch_set_ints(&(e->st_dev + seq)->token, &token, 1, s);
     const int th = ze_timer_begin(e, 3, s);
     ZE_TRY(ze_enqueue_decode_step(e, seq, 1.0f, 1, false, ze_sample_opts{}, s));
     ze_timer_end(e, th, s);
@@ -863,10 +858,7 @@ static int op_sample(ze_engine* e, int seq, const float* logits, float repetitio
     hipSetDevice(e->device);
     // n_gen is set so the sampled token lands in out_tokens[index] of this chain's slot
     ZE_TRY(push_state(e, seq, s, 0, 0, 0));
-    if (index) {
-        e->d_host_ints[17] = index;
-        ZE_HIP(hipMemcpyAsync(&(e->st_dev + seq)->n_gen, e->d_host_ints + 17, sizeof(int), hipMemcpyHostToDevice, s));
-    }
+    if (index) ze_launch_set_ints(&(e->st_dev + seq)->n_gen, &index, 1, s);
     ze_launch_sample(logits, c.vocab, e->seen + (size_t)seq * c.vocab, repetition_penalty, e->st_dev + seq, e->eos_dev,
                      c.n_eos, c.pad_token_id, 1, 0, e->out_tokens + (size_t)seq * c.max_ctx, e->dsample, so, s);
     ZE_KCHECK();
@@ -1077,9 +1069,7 @@ static int upload_batch(ze_engine* e, const int32_t* seqs, int n, hipStream_t s)
             if (seqs[j] == seqs[i]) return ze_fail(e, ZE_ERR_INVALID, "duplicate sequence id in a batch");
         if (e->ctx_host[seqs[i]] + 1 > e->cfg.max_ctx) return ze_fail(e, ZE_ERR_NOMEM, "sequence exceeds max_ctx");
     }
-    ZE_HIP(hipStreamSynchronize(s));
-    memcpy(e->d_host_ints + 64, seqs, (size_t)n * sizeof(int));
-    ZE_HIP(hipMemcpyAsync(e->bseq, e->d_host_ints + 64, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+    ze_launch_set_ints(e->bseq, seqs, n, s);
     return ZE_OK;
 }
 
@@ -1092,7 +1082,7 @@ static void launch_batch_attention(ze_engine* e, int li, int n, bool frag_out, h
     const size_t seq_stride = (size_t)c.kv_heads * c.max_ctx * hd;
     const float scale = 1.0f / sqrtf((float)hd);
     if (ze_gemv_knobs[8] == 1)
-        ze_launch_attn_decode(e->tqkv, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, e->to, frag_out ? -(nq / 32) : nq, e->st_dev,
+        ze_launch_attn_decode(e->bqkv, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, e->bo, frag_out ? -(nq / 32) : nq, e->st_dev,
                               e->bseq, n, c.heads, c.kv_heads, hd, c.max_ctx, scale, e->bpartial, e->max_splits, e->atickets, s);
     else {
         // tokens per part (a multiple of 32; knob 11 for measurements): a function of nothing but the build, so a chain's
@@ -1104,7 +1094,7 @@ static void launch_batch_attention(ze_engine* e, int li, int n, bool frag_out, h
                               hd == 128 && c.heads / c.kv_heads <= 16;  // (128-wide heads, the q heads of a kv head as MFMA columns)
         const int chunk = ze_gemv_knobs[11] >= 64 ? ze_gemv_knobs[11] / 32 * 32 : 0;  // 0: a sixth of the chain's context
         const int max_parts = chunk ? (c.max_ctx + chunk - 1) / chunk : 8;           // (at most 8 parts: 128-token floor)
-        ze_launch_attn_decode_stream(e->tqkv, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, e->to, frag_out ? -(nq / 32) : nq,
+        ze_launch_attn_decode_stream(e->bqkv, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, e->bo, frag_out ? -(nq / 32) : nq,
                                      e->st_dev, e->bseq, n, c.heads, c.kv_heads, c.max_ctx, scale, e->bpartial, max_parts,
                                      e->atickets, s, chunk, per_wave ? 1 : 0);
     }
@@ -1116,7 +1106,7 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
     const int H = c.hidden, hd = e->head_dim, nq = c.heads * hd, nkv = c.kv_heads * hd, nqkv = nq + 2 * nkv;
     const size_t seq_stride = (size_t)c.kv_heads * c.max_ctx * hd;
     const float scale = 1.0f / sqrtf((float)hd);
-    ze_launch_embed_tokens_batch(e->st_dev, e->bseq, n, e->embed, e->th, H, s);
+    ze_launch_embed_tokens_batch(e->st_dev, e->bseq, n, e->embed, e->bh, H, s);
     for (int li = 0; li < c.layers; ++li) {
         const ze_text_layer& L = e->tl[li];
         // every projection on fragment-major operands when the copy exists (ensure_fragments) and n <= 64: the norms, the
@@ -1132,64 +1122,64 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
         // fp8 MFMA); any other path takes the same values as bf16
         const bool a8q = e->fp8_act && fr && L.qkv.wf8 && ze_gemv_knobs[10] != 1;
         const bool a8g = e->fp8_act && fr && L.gate_up.wf8 && ze_gemv_knobs[10] != 1;
-        ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, n, H, c.rms_eps, s, fr ? 1 : 2, a8q ? 2 : (e->fp8_act ? 1 : 0), e->ty8,
+        ze_launch_rmsnorm(e->bh, H, L.in_norm, e->by, H, n, H, c.rms_eps, s, fr ? 1 : 2, a8q ? 2 : (e->fp8_act ? 1 : 0), e->ty8,
                           e->ty8_scale);
         if (fr) {  // projection + M-RoPE + KV append in one launch (the fragment copy of qkv is packed for it)
             const bool w8 = L.qkv.wf8 && ze_gemv_knobs[10] != 1;  // FP8 fragment stream (quantised engine)
-            ze_launch_qkv_rope_oneshot(a8q ? (const bf16_t*)e->ty8 : e->ty, w8 ? (const bf16_t*)L.qkv.wf8 : L.qkv.wf, L.qkv.bias,
-                                       e->tqkv, nqkv, n, H, c.heads, c.kv_heads, e->cosT, e->sinT, e->st_dev, e->bseq,
+            ze_launch_qkv_rope_oneshot(a8q ? (const bf16_t*)e->ty8 : e->by, w8 ? (const bf16_t*)L.qkv.wf8 : L.qkv.wf, L.qkv.bias,
+                                       e->bqkv, nqkv, n, H, c.heads, c.kv_heads, e->cosT, e->sinT, e->st_dev, e->bseq,
                                        e->kc(li, 0), e->vc(li, 0), seq_stride, c.max_ctx, s, w8 ? L.qkv.scale8 : nullptr,
                                        a8q ? e->ty8_scale : nullptr);
         } else {
-            if (tiled) ze_launch_gemm_wide(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, ws, s);
-            else ze_launch_gemm_stream(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, ws, s);
-            ze_launch_rope_kv_batch(e->tqkv, n, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(li, 0),
+            if (tiled) ze_launch_gemm_wide(ZE_EPI_NONE, e->by, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->bqkv, nqkv, n, nqkv, H, ws, s);
+            else ze_launch_gemm_stream(ZE_EPI_NONE, e->by, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->bqkv, nqkv, n, nqkv, H, ws, s);
+            ze_launch_rope_kv_batch(e->bqkv, n, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(li, 0),
                                     e->vc(li, 0), seq_stride, c.max_ctx, s);
         }
         launch_batch_attention(e, li, n, fr, s);
         if (fr && ze_gemv_knobs[9] != 1) {
             const bool w8 = L.o.wf8 && ze_gemv_knobs[10] != 1;
-            ze_launch_gemm_oneshot(ZE_EPI_RESIDUAL, e->to, w8 ? (const bf16_t*)L.o.wf8 : L.o.wf, nullptr, e->th, H, e->th, H, n, H,
+            ze_launch_gemm_oneshot(ZE_EPI_RESIDUAL, e->bo, w8 ? (const bf16_t*)L.o.wf8 : L.o.wf, nullptr, e->bh, H, e->bh, H, n, H,
                                    nq, s, w8 ? L.o.scale8 : nullptr);
         } else if (fr)
-            ze_launch_gemm_frag(ZE_EPI_RESIDUAL, e->to, L.o.wf, nullptr, e->th, H, e->th, H, n, H, nq, s);
+            ze_launch_gemm_frag(ZE_EPI_RESIDUAL, e->bo, L.o.wf, nullptr, e->bh, H, e->bh, H, n, H, nq, s);
         else if (tiled)
-            ze_launch_gemm_wide(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, n, H, nq, ws, s);
+            ze_launch_gemm_wide(ZE_EPI_RESIDUAL, e->bo, nq, L.o.w, L.o.ld, nullptr, e->bh, H, e->bh, H, n, H, nq, ws, s);
         else
-            ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, n, H, nq, ws, s);
-        ze_launch_rmsnorm(e->th, H, L.post_norm, e->ty, H, n, H, c.rms_eps, s, fr ? 1 : 2, a8g ? 2 : (e->fp8_act ? 1 : 0), e->ty8,
+            ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->bo, nq, L.o.w, L.o.ld, nullptr, e->bh, H, e->bh, H, n, H, nq, ws, s);
+        ze_launch_rmsnorm(e->bh, H, L.post_norm, e->by, H, n, H, c.rms_eps, s, fr ? 1 : 2, a8g ? 2 : (e->fp8_act ? 1 : 0), e->ty8,
                           e->ty8_scale);
         if (fr) {
             const bool w8 = L.gate_up.wf8 && ze_gemv_knobs[10] != 1;
-            ze_launch_gemm_frag(ZE_EPI_SWIGLU, a8g ? (const bf16_t*)e->ty8 : e->ty, w8 ? (const bf16_t*)L.gate_up.wf8 : L.gate_up.wf,
-                                nullptr, nullptr, 0, e->ta, e->text_ipad, n, 2 * e->text_ipad, H, s,
+            ze_launch_gemm_frag(ZE_EPI_SWIGLU, a8g ? (const bf16_t*)e->ty8 : e->by, w8 ? (const bf16_t*)L.gate_up.wf8 : L.gate_up.wf,
+                                nullptr, nullptr, 0, e->ba, e->text_ipad, n, 2 * e->text_ipad, H, s,
                                 w8 ? L.gate_up.scale8 : nullptr, a8g ? e->ty8_scale : nullptr);
         } else if (tiled)
-            ze_launch_gemm_wide(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad, n,
+            ze_launch_gemm_wide(ZE_EPI_SWIGLU, e->by, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ba, e->text_ipad, n,
                                 2 * e->text_ipad, H, ws, s);
         else
-            ze_launch_gemm_stream(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad, n,
+            ze_launch_gemm_stream(ZE_EPI_SWIGLU, e->by, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ba, e->text_ipad, n,
                                   2 * e->text_ipad, H, ws, s);
         // the down projection (K = 11008) stays on the split-K ring: the fragment kernel with K split over 8 x 32
         // workgroups measured 22.6-25.3 us against 17.9 (slab reduction included in both)
         if (tiled)
-            ze_launch_gemm_wide(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, n, H,
+            ze_launch_gemm_wide(ZE_EPI_RESIDUAL, e->ba, e->text_ipad, L.down.w, L.down.ld, nullptr, e->bh, H, e->bh, H, n, H,
                                 e->text_ipad, ws, s);
         else
-            ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, n, H,
+            ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->ba, e->text_ipad, L.down.w, L.down.ld, nullptr, e->bh, H, e->bh, H, n, H,
                                   e->text_ipad, ws, s);
     }
     const bool fl = e->lm_head_f && !e->wide_regime() && ze_gemv_knobs[5] != 1;
-    ze_launch_rmsnorm(e->th, H, e->final_norm, e->ty, H, n, H, c.rms_eps, s, fl ? 1 : 2);
+    ze_launch_rmsnorm(e->bh, H, e->final_norm, e->by, H, n, H, c.rms_eps, s, fl ? 1 : 2);
     if (fl) {
         const bool w8 = e->lm_head8.wf8 && ze_gemv_knobs[10] != 1;
-        ze_launch_gemm_frag(ZE_EPI_F32, e->ty, w8 ? (const bf16_t*)e->lm_head8.wf8 : e->lm_head_f, nullptr, nullptr, 0,
+        ze_launch_gemm_frag(ZE_EPI_F32, e->by, w8 ? (const bf16_t*)e->lm_head8.wf8 : e->lm_head_f, nullptr, nullptr, 0,
                             (bf16_t*)e->blogits, c.vocab, n, c.vocab, H, s, w8 ? e->lm_head8.scale8 : nullptr);
     } else if (e->wide_regime() && ze_gemv_knobs[13] != 1)  // (one pass over K whatever the row count: batch invariance)
-        ze_launch_gemm_wide(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab, H,
+        ze_launch_gemm_wide(ZE_EPI_F32, e->by, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab, H,
                             e->gemm_ws(), s);
     else
-        ze_launch_gemm_stream(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n,
+        ze_launch_gemm_stream(ZE_EPI_F32, e->by, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n,
                               c.vocab, H, e->gemm_ws(), s);
     ze_launch_sample_batch(e->blogits, c.vocab, e->seen, penalty, e->st_dev, e->bseq, n, e->eos_dev, c.n_eos,
                            c.pad_token_id, ignore_eos, 1, sample, e->out_tokens, c.max_ctx, e->bsample,
@@ -1209,12 +1199,7 @@ extern "C" int ze_decode_batch(ze_engine* e, const int32_t* seqs, int n, const i
     if (tokens) {
         for (int i = 0; i < n; ++i) {
             if (tokens[i] >= c.vocab) return ze_fail(e, ZE_ERR_INVALID, "token id out of range");
-            if (tokens[i] >= 0) {
-                e->d_host_ints[16] = tokens[i];
-                ZE_HIP(hipMemcpyAsync(&(e->st_dev + seqs[i])->token, e->d_host_ints + 16, sizeof(int),
-                                      hipMemcpyHostToDevice, s));
-                ZE_HIP(hipStreamSynchronize(s));
-            }
+            if (tokens[i] >= 0) ze_launch_set_ints(&(e->st_dev + seqs[i])->token, &tokens[i], 1, s);
         }
     }
     const int th = ze_timer_begin(e, 3, s);
@@ -1279,11 +1264,7 @@ static int run_burst(ze_engine* e, const std::vector<int>& active, int steps, co
 static int begin_chain(ze_engine* e, int q, const ze_gen_params* p, float pen, int ign, int sample_stream, hipStream_t s) {
     const ze_config& c = e->cfg;
     ze_sample_opts so = sample_opts_of(p, q);
-    if (so.temperature > 0.f) {
-        ZE_HIP(hipStreamSynchronize(s));
-        e->d_host_ints[40] = sample_stream;
-        ZE_HIP(hipMemcpyAsync(&(e->st_dev + q)->stream, e->d_host_ints + 40, sizeof(int), hipMemcpyHostToDevice, s));
-    }
+    if (so.temperature > 0.f) ze_launch_set_ints(&(e->st_dev + q)->stream, &sample_stream, 1, s);
     ze_launch_sample(e->dlogits + (size_t)q * c.vocab, c.vocab, e->seen + (size_t)q * c.vocab, pen, e->st_dev + q, e->eos_dev,
                      c.n_eos, c.pad_token_id, ign, 0, e->out_tokens + (size_t)q * c.max_ctx, e->dsample, so, s);
     ZE_KCHECK();
@@ -1346,7 +1327,9 @@ extern "C" int ze_generate_batch(ze_engine* e, const int32_t* seqs, int n, const
     for (int i = 0; i < n; ++i) {
         const int q = seqs[i];
         int32_t* dst = out_tokens + (size_t)i * max_new;
-        ZE_HIP(hipMemcpy(dst, e->out_tokens + (size_t)q * c.max_ctx, (size_t)produced[q] * sizeof(int), hipMemcpyDeviceToHost));
+        // (on the caller's stream: a legacy-stream copy would synchronise with every other engine's stream of the process)
+        ZE_HIP(hipMemcpyAsync(dst, e->out_tokens + (size_t)q * c.max_ctx, (size_t)produced[q] * sizeof(int), hipMemcpyDeviceToHost, s));
+        ZE_HIP(hipStreamSynchronize(s));
         int cnt = produced[q];
         if (!ign) {
             for (int t = 0; t < produced[q]; ++t) {
@@ -1377,8 +1360,11 @@ extern "C" int ze_chain_begin(ze_engine* e, int seq, const ze_gen_params* p, int
     return r;
 }
 
-extern "C" int ze_decode_burst(ze_engine* e, const int32_t* seqs, int n, int steps, const ze_gen_params* p,
-                               int32_t* n_generated, int32_t* finished, void* stream) {
+// A burst in two halves, so that the host can enqueue other work (the prefill / ViT round of the next newcomers, on ANOTHER
+// stream) while the burst runs: _begin enqueues `steps` captured decode steps for the live chains and returns at once (the
+// number of steps actually enqueued: every chain must have room for all of them); _end waits for the burst and reports
+// each chain's token count and EOS flag.  ze_decode_burst = _begin + _end.
+extern "C" int ze_decode_burst_begin(ze_engine* e, const int32_t* seqs, int n, int steps, const ze_gen_params* p, void* stream) {
     if (!e || !seqs || !p || n <= 0 || steps < 0) return ze_fail(e, ZE_ERR_INVALID, "bad burst arguments");
     const ze_config& c = e->cfg;
     hipSetDevice(e->device);
@@ -1395,13 +1381,30 @@ extern "C" int ze_decode_burst(ze_engine* e, const int32_t* seqs, int n, int ste
     const int td = ze_timer_begin(e, 3, s);
     if (steps > 0) ZE_TRY(run_burst(e, active, steps, p, pen, ign, sample_opts_of(p, 0), s));
     ze_timer_end(e, td, s);
+    return steps;
+}
+
+extern "C" int ze_decode_burst_end(ze_engine* e, const int32_t* seqs, int n, int32_t* n_generated, int32_t* finished, void* stream) {
+    if (!e || !seqs || n <= 0) return ze_fail(e, ZE_ERR_INVALID, "bad burst arguments");
+    const ze_config& c = e->cfg;
+    hipSetDevice(e->device);
+    hipStream_t s = (hipStream_t)stream;
     ZE_HIP(hipMemcpyAsync(e->bstate_host, e->st_dev, sizeof(ze_seq_dev) * c.max_seqs, hipMemcpyDeviceToHost, s));
     ZE_HIP(hipStreamSynchronize(s));
     for (int i = 0; i < n; ++i) {
+        if (seqs[i] < 0 || seqs[i] >= c.max_seqs) return ze_fail(e, ZE_ERR_NOTFOUND, "sequence id out of range");
         if (n_generated) n_generated[i] = e->bstate_host[seqs[i]].n_gen;
         if (finished) finished[i] = e->bstate_host[seqs[i]].finished;
     }
-    return steps;
+    return ZE_OK;
+}
+
+extern "C" int ze_decode_burst(ze_engine* e, const int32_t* seqs, int n, int steps, const ze_gen_params* p,
+                               int32_t* n_generated, int32_t* finished, void* stream) {
+    const int ran = ze_decode_burst_begin(e, seqs, n, steps, p, stream);
+    if (ran < 0) return ran;
+    ZE_TRY(ze_decode_burst_end(e, seqs, n, n_generated, finished, stream));
+    return ran;
 }
 
 extern "C" int ze_chain_tokens(ze_engine* e, int seq, int32_t* out, int cap, int* n_out, void* stream) {
@@ -1414,7 +1417,10 @@ extern "C" int ze_chain_tokens(ze_engine* e, int seq, int32_t* out, int cap, int
     ZE_HIP(hipMemcpyAsync(&st, e->st_dev + seq, sizeof(st), hipMemcpyDeviceToHost, s));
     ZE_HIP(hipStreamSynchronize(s));
     int n = std::min(std::min(st.n_gen, cap), c.max_ctx);
-    if (n > 0) ZE_HIP(hipMemcpy(out, e->out_tokens + (size_t)seq * c.max_ctx, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    if (n > 0) {  // (on the caller's stream: a legacy-stream copy would synchronise with every other engine's stream of the process)
+        ZE_HIP(hipMemcpyAsync(out, e->out_tokens + (size_t)seq * c.max_ctx, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+        ZE_HIP(hipStreamSynchronize(s));
+    }
     // trim at the first EOS (tokens after it are pad, as HF emits for finished rows)
     for (int i = 0; i < n; ++i) {
         bool is_eos = false;
@@ -1730,9 +1736,7 @@ extern "C" int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters
         seqs[i] = i;
         kv_bytes += (double)(std::min(e->ctx_host[i] + 1, c.max_ctx)) * nkv * 2 * 2;
     }
-    ZE_HIP(hipStreamSynchronize(s));
-    memcpy(e->d_host_ints + 64, seqs.data(), (size_t)n * sizeof(int));
-    ZE_HIP(hipMemcpyAsync(e->bseq, e->d_host_ints + 64, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+    ze_launch_set_ints(e->bseq, seqs.data(), n, s);
     double bytes = 0;
     auto launch = [&](int it) {
         const int li = it % c.layers;
@@ -1742,34 +1746,34 @@ extern "C" int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters
         const ze_gemm_ws ws = e->gemm_ws();
         switch (which) {
             case 0:
-                if (fr) ze_launch_qkv_rope_oneshot(e->ty, L.qkv.wf, L.qkv.bias, e->tqkv, nqkv, n, H, c.heads, c.kv_heads, e->cosT, e->sinT,
+                if (fr) ze_launch_qkv_rope_oneshot(e->by, L.qkv.wf, L.qkv.bias, e->bqkv, nqkv, n, H, c.heads, c.kv_heads, e->cosT, e->sinT,
                                                    e->st_dev, e->bseq, e->kc(li, 0), e->vc(li, 0), seq_stride, c.max_ctx, s);
-                else if (tiled) ze_launch_gemm_wide(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, ws, s);
-                else ze_launch_gemm_stream(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, n, nqkv, H, ws, s);
+                else if (tiled) ze_launch_gemm_wide(ZE_EPI_NONE, e->by, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->bqkv, nqkv, n, nqkv, H, ws, s);
+                else ze_launch_gemm_stream(ZE_EPI_NONE, e->by, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->bqkv, nqkv, n, nqkv, H, ws, s);
                 bytes = (double)nqkv * H * 2;
                 break;
             case 1:
-                if (fr && ze_gemv_knobs[9] != 1) ze_launch_gemm_oneshot(ZE_EPI_RESIDUAL, e->to, L.o.wf, nullptr, e->th, H, e->th, H, n, H, nq, s);
-                else if (fr) ze_launch_gemm_frag(ZE_EPI_RESIDUAL, e->to, L.o.wf, nullptr, e->th, H, e->th, H, n, H, nq, s);
-                else if (tiled) ze_launch_gemm_wide(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, n, H, nq, ws, s);
-                else ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, n, H, nq, ws, s);
+                if (fr && ze_gemv_knobs[9] != 1) ze_launch_gemm_oneshot(ZE_EPI_RESIDUAL, e->bo, L.o.wf, nullptr, e->bh, H, e->bh, H, n, H, nq, s);
+                else if (fr) ze_launch_gemm_frag(ZE_EPI_RESIDUAL, e->bo, L.o.wf, nullptr, e->bh, H, e->bh, H, n, H, nq, s);
+                else if (tiled) ze_launch_gemm_wide(ZE_EPI_RESIDUAL, e->bo, nq, L.o.w, L.o.ld, nullptr, e->bh, H, e->bh, H, n, H, nq, ws, s);
+                else ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->bo, nq, L.o.w, L.o.ld, nullptr, e->bh, H, e->bh, H, n, H, nq, ws, s);
                 bytes = (double)H * nq * 2;
                 break;
             case 2:
-                if (fr) ze_launch_gemm_frag(ZE_EPI_SWIGLU, e->ty, L.gate_up.wf, nullptr, nullptr, 0, e->ta, e->text_ipad, n, 2 * e->text_ipad, H, s);
-                else if (tiled) ze_launch_gemm_wide(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad, n, 2 * e->text_ipad, H, ws, s);
-                else ze_launch_gemm_stream(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, e->text_ipad, n, 2 * e->text_ipad, H, ws, s);
+                if (fr) ze_launch_gemm_frag(ZE_EPI_SWIGLU, e->by, L.gate_up.wf, nullptr, nullptr, 0, e->ba, e->text_ipad, n, 2 * e->text_ipad, H, s);
+                else if (tiled) ze_launch_gemm_wide(ZE_EPI_SWIGLU, e->by, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ba, e->text_ipad, n, 2 * e->text_ipad, H, ws, s);
+                else ze_launch_gemm_stream(ZE_EPI_SWIGLU, e->by, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ba, e->text_ipad, n, 2 * e->text_ipad, H, ws, s);
                 bytes = 2.0 * c.intermediate * H * 2;
                 break;
             case 3:
-                if (tiled) ze_launch_gemm_wide(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, n, H, e->text_ipad, ws, s);
-                else ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, n, H, e->text_ipad, ws, s);
+                if (tiled) ze_launch_gemm_wide(ZE_EPI_RESIDUAL, e->ba, e->text_ipad, L.down.w, L.down.ld, nullptr, e->bh, H, e->bh, H, n, H, e->text_ipad, ws, s);
+                else ze_launch_gemm_stream(ZE_EPI_RESIDUAL, e->ba, e->text_ipad, L.down.w, L.down.ld, nullptr, e->bh, H, e->bh, H, n, H, e->text_ipad, ws, s);
                 bytes = (double)H * c.intermediate * 2;
                 break;
             case 4:
-                if (e->lm_head_f && fr) ze_launch_gemm_frag(ZE_EPI_F32, e->ty, e->lm_head_f, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab, H, s);
-                else if (tiled) ze_launch_gemm_wide(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab, H, ws, s);
-                else ze_launch_gemm_stream(ZE_EPI_F32, e->ty, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab, H, ws, s);
+                if (e->lm_head_f && fr) ze_launch_gemm_frag(ZE_EPI_F32, e->by, e->lm_head_f, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab, H, s);
+                else if (tiled) ze_launch_gemm_wide(ZE_EPI_F32, e->by, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab, H, ws, s);
+                else ze_launch_gemm_stream(ZE_EPI_F32, e->by, H, e->lm_head, H, nullptr, nullptr, 0, (bf16_t*)e->blogits, c.vocab, n, c.vocab, H, ws, s);
                 bytes = (double)c.vocab * H * 2;
                 break;
             case 5:
@@ -1777,11 +1781,11 @@ extern "C" int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters
                 bytes = kv_bytes;
                 break;
             case 6:
-                ze_launch_rmsnorm(e->th, H, L.in_norm, e->ty, H, n, H, c.rms_eps, s, fr ? 1 : 2);
+                ze_launch_rmsnorm(e->bh, H, L.in_norm, e->by, H, n, H, c.rms_eps, s, fr ? 1 : 2);
                 bytes = (double)n * H * 2 * 2;
                 break;
             default:
-                ze_launch_rope_kv_batch(e->tqkv, n, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(li, 0),
+                ze_launch_rope_kv_batch(e->bqkv, n, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(li, 0),
                                         e->vc(li, 0), seq_stride, c.max_ctx, s);
                 bytes = (double)n * nqkv * 2 * 2;
                 break;

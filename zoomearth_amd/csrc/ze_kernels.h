@@ -231,6 +231,9 @@ void ze_launch_sample_folded(const float* amax_ws, int vocab, uint8_t* seen, ze_
 void ze_launch_amax_init(float* amax_ws, hipStream_t s);  // 2048 (value, index) slots
 void ze_launch_advance_ctx(ze_seq_dev* st, hipStream_t s);
 // batched decode helpers (one token for each of n chains)
+// dst[0..n) = vals[0..n): the values travel as kernel arguments (no host staging buffer to keep alive, no stream
+// synchronisation before it can be reused): chain-state pushes and the chain-id list of a batched step
+void ze_launch_set_ints(int* dst, const int* host_vals, int n, hipStream_t s);
 void ze_launch_embed_tokens_batch(const ze_seq_dev* st, const int* seq_ids, int n, const bf16_t* embed, bf16_t* out,
                                   int hidden, hipStream_t s);
 void ze_launch_rope_kv_batch(bf16_t* qkv, int n, int heads, int kv_heads, int D, const bf16_t* cosT, const bf16_t* sinT,

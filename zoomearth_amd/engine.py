@@ -340,6 +340,20 @@ class Engine:
                                                    self._stream()))
         return ran, list(ng), [bool(f) for f in fin]
 
+    def decode_burst_begin(self, seqs, steps: int, params):
+        """First half of decode_burst: enqueues the steps on the current stream and returns at once (steps enqueued).  The
+        caller may now enqueue a ViT / prefill round for OTHER chains on another stream; decode_burst_end collects."""
+        sq, sp = _i32(seqs)
+        return self._check(self.lib.ze_decode_burst_begin(self.h, sp, len(sq), int(steps), C.byref(params), self._stream()))
+
+    def decode_burst_end(self, seqs):
+        """Waits for the burst begun on the current stream; returns (n_generated[], finished[])."""
+        sq, sp = _i32(seqs)
+        ng = (C.c_int32 * len(sq))()
+        fin = (C.c_int32 * len(sq))()
+        self._check(self.lib.ze_decode_burst_end(self.h, sp, len(sq), ng, fin, self._stream()))
+        return list(ng), [bool(f) for f in fin]
+
     def chain_tokens(self, seq: int, capacity: int = 0):
         cap = int(capacity) if capacity else self.max_ctx
         out = (C.c_int32 * max(cap, 1))()

@@ -18,6 +18,8 @@ for every engine of one regime; engines of different regimes agree within bf16 r
 """
 from __future__ import annotations
 
+import contextlib
+import os
 from collections import OrderedDict, deque
 from dataclasses import dataclass, field
 from typing import Any, Callable, List, Optional
@@ -53,7 +55,7 @@ class ChainScheduler:
     def __init__(self, model, processor, do_sample: bool = False, temperature=None, repetition_penalty=None, seed: int = 0,
                  burst: int = 8, max_batch: Optional[int] = None, ignore_eos: bool = False, use_graph: bool = True,
                  feature_cache: int = 64, min_admit: int = 1, max_wait_bursts: int = 2, share_prefix: bool = True,
-                 min_shared: int = 64, reuse_generated: bool = True):
+                 min_shared: int = 64, reuse_generated: bool = True, overlap: Optional[bool] = None):
         self.model, self.processor, self.engine = model, processor, model.engine
         gc = model.generation_config
         pen = repetition_penalty if repetition_penalty is not None else (getattr(gc, "repetition_penalty", 1.0) or 1.0)
@@ -92,15 +94,35 @@ class ChainScheduler:
         self._features = OrderedDict()     # image key -> ViT features (LRU)
         self._feature_cap = feature_cache
         self.stats = dict(bursts=0, steps=0, chain_steps=0, prefill_rows=0, admitted=0, vit_calls=0, shared_rows=0,
-                          reused_generated_rows=0)
+                          reused_generated_rows=0, overlapped_passes=0)
+        # Overlap of the two kinds of work on one GPU: while a burst of decode steps runs on the caller's stream
+        # (ze_decode_burst_begin: enqueued, not awaited), ONE prefill pass of the admission round -- its ViT call included --
+        # is enqueued on a side stream; the burst is collected afterwards (ze_decode_burst_end) and the chains whose pass
+        # has completed join the next burst.  The batched decode step has activation buffers of its own and the chains of
+        # a pass are not in the burst, so the two streams share no state; the matrix-bound pass fills what the bandwidth-
+        # and latency-bound decode steps leave idle, and the host work of admission (tokeniser, index builders, callbacks)
+        # hides behind the burst.  Results are unchanged: the same kernels on the same operands.
+        if overlap is None:
+            overlap = hasattr(self.engine, "decode_burst_begin") and os.environ.get("ZE_OVERLAP", "1") != "0"
+        self.overlap = bool(overlap)
+        self._side = torch.cuda.Stream(device=self.engine.device) if (self.overlap and torch.cuda.is_available()) else None
+        self._groups = deque()             # prefill passes of the admission round in progress, one per step
+        self._round = None                 # (todo, needed) of that round: images still to encode / features to keep
+        self._ready = []                   # prefilled requests waiting to join the live set
         model._chains.clear()              # the scheduler owns every chain slot while it runs
 
     # ------------------------------------------------------------------ queue
     def submit(self, req: Request) -> None:
         self.waiting.append(req)
 
+    def pending_requests(self):
+        """Every request the scheduler holds, whatever its state (a caller that gives up on the engine fails them all)."""
+        reqs = [l.req for l in self.live.values()] + list(self.waiting) + [r for r, _, _ in self._ready]
+        reqs += [it["req"] for g in self._groups for it in g if it.get("final", True)]
+        return reqs
+
     def busy(self) -> bool:
-        return bool(self.waiting or self.live)
+        return bool(self.waiting or self.live or self._groups or self._ready)
 
     def run(self) -> None:
         while self.busy():
@@ -108,9 +130,23 @@ class ChainScheduler:
 
     # ------------------------------------------------------------------ one scheduling round
     def step(self) -> None:
-        self._admit()
-        if self.live:
+        handle = self._burst_begin() if (self.live and self.overlap) else None
+        with self._side_stream():
+            if not self._groups:
+                self._admit()
+            if self._groups:
+                self._run_group(self._groups.popleft())
+                if handle is not None:
+                    self.stats["overlapped_passes"] += 1
+        if handle is not None:
+            self._burst_end(handle)
+        self._join_ready()
+        if handle is None and self.live:
             self._burst()
+
+    def _side_stream(self):
+        """Admission work (front-end, ViT, prefill, the callbacks' crops) runs on the side stream when overlapping."""
+        return torch.cuda.stream(self._side) if self._side is not None else contextlib.nullcontext()
 
     # -- admission: waiting requests take free slots (a follow-up keeps the slot its predecessor parked)
     def _admit(self) -> None:
@@ -160,24 +196,48 @@ class ChainScheduler:
                                      upto=len(ids), final=True))
             except Exception as ex:  # a malformed request must not take the batch down
                 self._fail(req, ex)
-        # From here on a failure (the ViT call, a prefill pass) must not orphan a request that already left `waiting`:
-        # whatever escapes fails every request of the round that is not live yet -- slots freed, on_error called.
+        # The round's prefill passes: rows of several chains share every GEMM, up to max_prefill_rows per pass; pass A (the
+        # prefixes that other newcomers of this round will copy) goes first.  One pass runs per step (beside the decode burst
+        # when overlapping); each encodes the images it needs that are not cached yet -- ONE multi-resolution ViT call.
         try:
-            self._encode(todo, needed)
             anchors = self._plan_sharing(prepared) if self.share_prefix else []
-            # prefill: rows of several chains share every GEMM, up to max_prefill_rows per pass; pass A (the prefixes
-            # that other newcomers of this round will copy) goes first
-            for items in (anchors, prepared):
-                group, rows = [], 0
-                for item in items + [None]:
-                    if group and (item is None or rows + item["upto"] - item["reuse"] > e.max_prefill_rows):
-                        self._prefill(group)
-                        group, rows = [], 0
-                    if item is not None:
-                        group.append(item)
-                        rows += item["upto"] - item["reuse"]
         except Exception as ex:
-            self._fail_all([p["req"] for p in prepared if p["req"].slot >= 0 and p["req"].slot not in self.live], ex)
+            self._fail_all([p["req"] for p in prepared if p["req"].slot >= 0], ex)
+            return
+        self._round = (todo, needed)
+        for items in (anchors, prepared):
+            group, rows = [], 0
+            for item in items + [None]:
+                if group and (item is None or rows + item["upto"] - item["reuse"] > e.max_prefill_rows):
+                    self._groups.append(group)
+                    group, rows = [], 0
+                if item is not None:
+                    group.append(item)
+                    rows += item["upto"] - item["reuse"]
+        if not self.overlap:  # everything at once: one ViT call per round, then the passes back to back
+            while self._groups:
+                self._run_group(self._groups.popleft())
+
+    def _run_group(self, group) -> None:
+        """One prefill pass of the round, behind the ViT call for its uncached images.  A failure (the ViT call, the pass)
+        must not orphan a request that already left `waiting`: whatever escapes fails every request of the pass -- slots
+        freed, on_error called."""
+        todo, needed = self._round
+        try:
+            if self.overlap:
+                want = OrderedDict()
+                for it in group:
+                    for k in it["keys"]:
+                        if k in todo and k not in want:
+                            want[k] = todo.pop(k)
+                self._encode(want, needed)
+            elif todo:
+                self._encode(OrderedDict(todo), needed)
+                todo.clear()
+            self._prefill(group)
+        except Exception as ex:
+            self._fail_all([it["req"] for it in group if it["req"].slot >= 0 and it["req"].slot not in self.live
+                            and not any(r is it["req"] for r, _, _ in self._ready)], ex)
 
     # -- shared prompt prefixes
     def _prefix_len(self, a, b) -> int:
@@ -339,10 +399,20 @@ class ChainScheduler:
             req, ids, keys = it["req"], it["ids"], it["keys"]
             if self.penalty != 1.0:
                 e.mark_seen(req.slot, ids)
-            e.chain_begin(req.slot, self.params, req.stream_id)
             req.n_prompt = len(ids)
-            self.live[req.slot] = _Live(req, tuple(ids), tuple(keys))
+            self._ready.append((req, tuple(ids), tuple(keys)))
+
+    def _join_ready(self) -> None:
+        """The prefilled newcomers draw their first token (from the logits their pass left) and join the live set."""
+        if not self._ready:
+            return
+        if self._side is not None:
+            self._side.synchronize()   # their pass ran on the side stream; chain_begin runs on the caller's
+        for req, ids, keys in self._ready:
+            self.engine.chain_begin(req.slot, self.params, req.stream_id)
+            self.live[req.slot] = _Live(req, ids, keys)
             self.stats["admitted"] += 1
+        self._ready = []
 
     # -- one burst of decode steps for every live chain, then retire the finished ones
     def _burst(self) -> None:
@@ -359,6 +429,28 @@ class ChainScheduler:
             l.produced = ng
             if f or ng >= min(l.req.max_new_tokens, e.max_ctx - l.req.n_prompt + 1):
                 self._retire(slot)
+
+    def _burst_begin(self):
+        e = self.engine
+        slots = list(self.live.keys())
+        budget = min(min(l.req.max_new_tokens, e.max_ctx - l.req.n_prompt + 1) - l.produced for l in self.live.values())
+        steps = max(0, min(self.burst, budget))
+        ran = e.decode_burst_begin(slots, steps, self.params)
+        return slots, ran
+
+    def _burst_end(self, handle) -> None:
+        e = self.engine
+        slots, ran = handle
+        n_gen, fin = e.decode_burst_end(slots)
+        self.stats["bursts"] += 1
+        self.stats["steps"] += ran
+        self.stats["chain_steps"] += ran * len(slots)
+        with self._side_stream():   # (the callbacks of finished chains crop / resize on the front-end's stream)
+            for slot, ng, f in zip(slots, n_gen, fin):
+                l = self.live[slot]
+                l.produced = ng
+                if f or ng >= min(l.req.max_new_tokens, e.max_ctx - l.req.n_prompt + 1):
+                    self._retire(slot)
 
     def _retire(self, slot: int) -> None:
         l = self.live.pop(slot)

@@ -239,7 +239,7 @@ class ChatServer:
                     try:
                         sched.step()
                     except Exception as ex:  # an engine failure: every request of the running batch gets the error
-                        for r in [l.req for l in sched.live.values()] + list(sched.waiting):
+                        for r in sched.pending_requests():
                             if r.on_error:
                                 r.on_error(r, ex)
                         sched = None
