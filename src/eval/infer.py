@@ -48,8 +48,22 @@ def prepare_dataloader(ds_path, collate_fn):
     return DataLoader(load_from_disk(ds_path), batch_size=1, collate_fn=collate_fn, shuffle=False, num_workers=0)
 
 
+def done_question_ids(path):
+    """question_ids already recorded in a rank file (a run that was interrupted): complete JSON lines only."""
+    import json
+    ids = set()
+    if os.path.exists(path):
+        with open(path, encoding="utf-8") as f:
+            for line in f:
+                try:
+                    ids.add(json.loads(line)["question_id"])
+                except Exception:
+                    pass  # a torn last line: that question runs again
+    return ids
+
+
 def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir="./image/", max_new_tokens=1024,
-                    batch_size=BATCH_SIZE, max_ctx=4096, do_sample=True):
+                    batch_size=BATCH_SIZE, max_ctx=4096, do_sample=True, resume=False, decode_workers=2, decode_ahead=3):
     # capacity: the stage-2 prompt holds the stage-1 prompt, its output and a second image (<= ~3200 tokens at the
     # default budgets); prefill passes of up to 16 prompts share their GEMMs
     # one rank per GPU (torchrun / accelerate launch): rank 0 reads the checkpoint, the others receive the packed weight
@@ -74,14 +88,29 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
 
     os.makedirs("results", exist_ok=True)
     out_path = f"results/{exp_name}{accelerator.process_index}.jsonl"
-    fout = open(out_path, "w", encoding="utf-8")
+    # --resume: keep what an interrupted run of this rank wrote and skip those question_ids (the reference opens the file
+    # with "w" and starts over, :167)
+    skip = done_question_ids(out_path) if resume else set()
+    if resume and skip:  # drop a torn last line before appending
+        with open(out_path, encoding="utf-8") as f:
+            good = [ln for ln in f if ln.endswith("\n")]
+        with open(out_path, "w", encoding="utf-8") as f:
+            f.writelines(ln for ln in good if _is_json(ln))
+    fout = open(out_path, "a" if resume else "w", encoding="utf-8")
     model, dl = accelerator.prepare(model, prepare_dataloader(ds_path, collate_fn))
 
     def tile_path(name):
         return os.path.join(image_dir, name.split("/")[-1])
 
     # the rank's questions arrive grouped by tile: decode the next tile while the current one is being questioned
-    tiles = TilePrefetcher([tile_path(n) for n in dl.image_names()], model.engine)
+    todo_names = dl.image_names()
+    if skip:  # tiles whose questions are all recorded are never decoded
+        try:
+            qids = dl.dl.dataset["question_id"]
+            todo_names = [n for n, j in zip(todo_names, dl._indices()) if qids[j] not in skip]
+        except Exception:
+            pass
+    tiles = TilePrefetcher([tile_path(n) for n in todo_names], model.engine, depth=decode_ahead, workers=decode_workers)
     sched = ChainScheduler(model, processor, do_sample=do_sample, temperature=0.01 if do_sample else None, burst=8,
                            min_admit=max(1, batch_size // 2), max_wait_bursts=12)
     done, next_out = {}, [0]
@@ -90,7 +119,8 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
     def flush():  # records leave in the rank's dataset order, whatever order the chains finish in
         while next_out[0] in done:
             sample, r = done.pop(next_out[0])
-            H.record(fout, sample["question"], sample, sample, r["output1"], r["output2"], r["error"])
+            if r is not None:  # (None: recorded by an earlier run, --resume)
+                H.record(fout, sample["question"], sample, sample, r["output1"], r["output2"], r["error"])
             next_out[0] += 1
             bar.update(1)
 
@@ -103,6 +133,9 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
                 flush()
             idx = i
             i += 1
+            if sample.get("question_id") in skip:
+                done[idx] = (sample, None)
+                continue
             try:
                 path = tile_path(sample["image_name"])
                 tile = tiles.get(path)
@@ -125,7 +158,18 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
-    return sched.stats
+    stats = dict(sched.stats)
+    stats.update(tile_decodes=tiles.decodes, tile_decode_s=round(tiles.decode_s, 3), tile_wait_s=round(tiles.wait_s, 3))
+    return stats
+
+
+def _is_json(line):
+    import json
+    try:
+        json.loads(line)
+        return True
+    except Exception:
+        return False
 
 
 if __name__ == "__main__":
@@ -139,6 +183,11 @@ if __name__ == "__main__":
                                                                            "batch; 256 gives about 1.5x the questions/s, DESIGN.md 7b)")
     parser.add_argument("--max_ctx", type=int, default=4096, help="tokens per chain (KV capacity)")
     parser.add_argument("--greedy", action="store_true", help="arg-max instead of the reference's T=0.01 sampling")
+    parser.add_argument("--resume", action="store_true", help="keep the records results/{exp_name}{rank}.jsonl already holds and "
+                                                              "run only the questions that are missing")
+    parser.add_argument("--decode_workers", type=int, default=2, help="tile decode threads per rank")
+    parser.add_argument("--decode_ahead", type=int, default=3, help="tiles decoded ahead of the one in use (75 MB pinned each)")
     args = parser.parse_args()
     eval_model_lora(args.model_name, args.exp_name, args.dataset, args.image_dir, args.max_new_tokens, args.batch_size,
-                    args.max_ctx, do_sample=not args.greedy)
+                    args.max_ctx, do_sample=not args.greedy, resume=args.resume, decode_workers=args.decode_workers,
+                    decode_ahead=args.decode_ahead)

@@ -142,6 +142,25 @@ def test_infer_entry_point_batched_equals_sequential_then_eval(workdir):
     assert "Total Samples: 11" in out and "Overall Accuracy (OA, stage 2)" in out
 
 
+def test_resume_runs_only_the_missing_questions(workdir):
+    """--resume (resume of a partial run; the reference opens its file with "w" and starts over,
+    /root/reference/src/eval/infer.py:167): the records an interrupted run left -- a torn last line dropped -- are kept, only
+    the missing questions run, and the file ends up equal to an uninterrupted run's."""
+    d, rows = workdir
+    base = [sys.executable, "src/infer.py", "--model_name", "ckpt", "--max_new_tokens", "14", "--max_ctx", "2048", "--batch_size", "4",
+            "--greedy"]
+    run(base + ["--exp_name", "full_"], d)
+    full = open(d / "results" / "full_0.jsonl", encoding="utf-8").read().splitlines(keepends=True)
+    with open(d / "results" / "part_0.jsonl", "w", encoding="utf-8") as f:   # five whole records and half of the sixth
+        f.writelines(full[:5])
+        f.write(full[5][: len(full[5]) // 2])
+    out = run(base + ["--exp_name", "part_", "--resume"], d)
+    assert load(d / "results" / "part_0.jsonl") == load(d / "results" / "full_0.jsonl")
+    assert "Done!" in out
+    run(base + ["--exp_name", "part_", "--resume"], d)                       # nothing left to do: the file is unchanged
+    assert load(d / "results" / "part_0.jsonl") == load(d / "results" / "full_0.jsonl")
+
+
 def test_infer_sh_defaults(workdir):
     """`bash run_scripts/infer.sh <ckpt> <exp>` exactly as shipped (64 chains, 1024 new tokens per stage)."""
     d, rows = workdir

@@ -236,6 +236,12 @@ def test_tile_prefetcher_decodes_each_tile_once_and_ahead(tmp_path):
             pf2.get(bad)
         assert pf2.get(paths[1]).size == (50, 41)
         assert pf2.get(paths[2]).size == (50, 42)  # never announced: decoded on demand
+        # several decode threads, several tiles ahead (a 50 questions/s stream needs ~5 tiles/s): same tiles, one decode each
+        log.clear()
+        pf3 = TilePrefetcher(stream, Eng(), decode=decode, pin=False, depth=3, workers=2)
+        assert [pf3.get(p).size for p in stream] == [(50, 40)] * 3 + [(50, 41)] * 2 + [(50, 42)] + [(50, 40)]
+        assert sorted(p for p, _ in log) == sorted([paths[0], paths[1], paths[2], paths[0]]) and pf3.decodes == 4
+        assert pf3.decode_s > 0
     finally:
         I.DeviceImage.__init__ = orig
 

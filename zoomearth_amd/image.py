@@ -112,12 +112,15 @@ class TilePrefetcher:
         for q in questions: tile = pf.get(q.path)
     """
 
-    def __init__(self, paths, engine, decode=decode_rgb, pin: bool = True):
+    def __init__(self, paths, engine, decode=decode_rgb, pin: bool = True, depth: int = 1, workers: int = 1):
+        """depth: decoded tiles held ahead of the one in use (75 MB of pinned memory each at 5000 px); workers: decode
+        threads (a stream that answers 50 questions/s needs ~5 tiles/s: more than one core's worth of TIFF / PNG decode)."""
         import threading
 
         self._engine = engine
         self._decode = decode
         self._pin = pin
+        self._depth, self._workers = max(1, int(depth)), max(1, int(workers))
         order = []
         for p in paths:  # distinct tiles in first-use order
             if not order or order[-1] != p:
@@ -125,26 +128,28 @@ class TilePrefetcher:
         self._order = order
         self._next = 0            # index in _order of the next tile to decode ahead
         self._ready = {}          # path -> decoded host array / exception
+        self._busy = 0            # decodes in progress
         self._current = (None, None)
         self._cv = threading.Condition()
-        self._thread = None
         self.decodes = 0
+        self.decode_s = 0.0       # seconds spent inside the decoder (all threads)
+        self.wait_s = 0.0         # seconds get() waited for a tile that was not ready
         self._kick()
 
     def _kick(self):
         import threading
 
         with self._cv:
-            if self._thread is not None and self._thread.is_alive():
-                return
-            if self._next >= len(self._order) or len(self._ready) >= 1:
-                return
-            path = self._order[self._next]
-            self._next += 1
-            self._thread = threading.Thread(target=self._work, args=(path,), daemon=True)
-            self._thread.start()
+            while (self._next < len(self._order) and self._busy < self._workers
+                   and len(self._ready) + self._busy < self._depth):
+                path = self._order[self._next]
+                self._next += 1
+                self._busy += 1
+                threading.Thread(target=self._work, args=(path,), daemon=True).start()
 
     def _work(self, path):
+        import time
+        t0 = time.perf_counter()
         try:
             arr = self._decode(path)
             if self._pin and torch.cuda.is_available():
@@ -153,21 +158,28 @@ class TilePrefetcher:
             arr = ex
         with self._cv:
             self._ready[path] = arr
+            self._busy -= 1
             self.decodes += 1
+            self.decode_s += time.perf_counter() - t0
             self._cv.notify_all()
+        self._kick()
 
     def get(self, path: str) -> DeviceImage:
         if self._current[0] == path:
             return self._current[1]
+        import time
+        t0 = time.perf_counter()
         with self._cv:
             while path not in self._ready:
-                if self._thread is None or not self._thread.is_alive():
+                queued = path in self._order[:self._next]     # requested from a worker: in progress or done
+                if not queued or (self._busy == 0 and path not in self._ready):
                     break
                 self._cv.wait(timeout=0.05)
             arr = self._ready.pop(path, None)
         if arr is None:  # out-of-order request: decode here
             arr = self._decode(path)
             self.decodes += 1
+        self.wait_s += time.perf_counter() - t0
         if isinstance(arr, Exception):
             self._kick()
             raise arr
