@@ -63,7 +63,7 @@ def done_question_ids(path):
 
 
 def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir="./image/", max_new_tokens=1024,
-                    batch_size=BATCH_SIZE, max_ctx=4096, do_sample=True, resume=False, decode_workers=2, decode_ahead=3):
+                    batch_size=BATCH_SIZE, max_ctx=4096, do_sample=True, resume=False, decode_workers=3, decode_ahead=6):
     # capacity: the stage-2 prompt holds the stage-1 prompt, its output and a second image (<= ~3200 tokens at the
     # default budgets); prefill passes of up to 16 prompts share their GEMMs
     # one rank per GPU (torchrun / accelerate launch): rank 0 reads the checkpoint, the others receive the packed weight
@@ -128,16 +128,18 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
     i = 0
     for examples in dl:
         for sample in examples:
-            while len(sched.waiting) >= batch_size:  # keep the queue short: tiles stay resident only while needed
-                sched.step()
-                flush()
             idx = i
             i += 1
             if sample.get("question_id") in skip:
                 done[idx] = (sample, None)
                 continue
+            path = tile_path(sample["image_name"])
+            # keep the queue short (tiles stay resident only while needed) -- and while the next tile is still being
+            # decoded, advance the chains that are already in: the GPU never idles behind a decode
+            while len(sched.waiting) >= batch_size or (sched.busy() and not tiles.ready(path)):
+                sched.step()
+                flush()
             try:
-                path = tile_path(sample["image_name"])
                 tile = tiles.get(path)
                 if view_of[0] != path:
                     view_of = (path,) + tuple(H.resize_image(tile))
@@ -185,8 +187,8 @@ if __name__ == "__main__":
     parser.add_argument("--greedy", action="store_true", help="arg-max instead of the reference's T=0.01 sampling")
     parser.add_argument("--resume", action="store_true", help="keep the records results/{exp_name}{rank}.jsonl already holds and "
                                                               "run only the questions that are missing")
-    parser.add_argument("--decode_workers", type=int, default=2, help="tile decode threads per rank")
-    parser.add_argument("--decode_ahead", type=int, default=3, help="tiles decoded ahead of the one in use (75 MB pinned each)")
+    parser.add_argument("--decode_workers", type=int, default=3, help="tile decode threads per rank")
+    parser.add_argument("--decode_ahead", type=int, default=6, help="tiles decoded ahead of the one in use (75 MB pinned each)")
     args = parser.parse_args()
     eval_model_lora(args.model_name, args.exp_name, args.dataset, args.image_dir, args.max_new_tokens, args.batch_size,
                     args.max_ctx, do_sample=not args.greedy, resume=args.resume, decode_workers=args.decode_workers,

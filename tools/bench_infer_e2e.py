@@ -25,9 +25,10 @@ import numpy as np  # noqa: E402
 
 
 def word(i: int) -> str:
-    if i % 40 == 7:
-        x, y = (i * 37) % 380, (i * 91) % 380
-        return f'"bbox_2d":[{x},{y},{x + 20 + i % 90},{y + 20 + (i // 7) % 90}]'
+    if i % 40 == 7:  # (distinct numbers per id: a word-level vocabulary needs distinct words)
+        k = i // 40
+        x, y = k % 380, (k // 380) * 37 % 380
+        return f'"bbox_2d":[{x},{y},{x + 20 + k % 90},{y + 20 + (k // 90) % 90}]'
     return f"w{i}"
 
 
@@ -89,8 +90,8 @@ def main():
     ap.add_argument("--batch_size", type=int, default=256)
     ap.add_argument("--max_new_tokens", type=int, default=192)
     ap.add_argument("--tile", type=int, default=5000)
-    ap.add_argument("--decode_workers", type=int, default=2)
-    ap.add_argument("--decode_ahead", type=int, default=3)
+    ap.add_argument("--decode_workers", type=int, default=3)
+    ap.add_argument("--decode_ahead", type=int, default=6)
     ap.add_argument("--workdir", default=None)
     args = ap.parse_args()
     d = args.workdir or tempfile.mkdtemp(prefix="ze_e2e_")
@@ -129,12 +130,15 @@ def main():
         def __init__(self, *a, **kw):
             marks["loaded"] = time.perf_counter()
             super().__init__(*a, **kw)
+            marks["engine"] = self.engine
+            self.engine.phase_timers(enable=True, reset=True)
 
     infer.ChainScheduler = Timed
     stats = infer.eval_model_lora("ckpt", "e2e_", "./LRS_GRO/test", "./image/", args.max_new_tokens, args.batch_size, 2048,
                                   do_sample=False, decode_workers=args.decode_workers, decode_ahead=args.decode_ahead)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    phases = marks["engine"].phase_timers(enable=False)
     recs = [json.loads(l) for l in open("results/e2e_0.jsonl")]
     out.update({
         "entry_point": "src/eval/infer.py eval_model_lora, --batch_size %d --max_new_tokens %d --greedy" % (args.batch_size, args.max_new_tokens),
@@ -144,6 +148,8 @@ def main():
         "questions_per_s_incl_load": round(len(recs) / (t1 - t0), 2),
         "records": len(recs), "stage2_ran": sum(1 for r in recs if not r["error"]),
         "mean_words_stage1": float(np.mean([len(r["stage1"].split()) for r in recs])),
+        "gpu_phase_s": {k: round(v / 1000.0, 2) for k, v in phases.items()},
+        "host_gap_s": round((t1 - marks["loaded"]) - sum(phases.values()) / 1000.0, 2),
         "scheduler": stats,
     })
     print(json.dumps(out), flush=True)

@@ -131,6 +131,9 @@ class TilePrefetcher:
         self._busy = 0            # decodes in progress
         self._current = (None, None)
         self._cv = threading.Condition()
+        self._in_copy = []        # (event, pinned buffer) of uploads that may still be running
+        self._pinned = []         # free pinned staging buffers, reused tile after tile (hipHostMalloc of 75 MB per tile costs
+        #                           more than the decode itself and serialises with the GPU's work)
         self.decodes = 0
         self.decode_s = 0.0       # seconds spent inside the decoder (all threads)
         self.wait_s = 0.0         # seconds get() waited for a tile that was not ready
@@ -147,13 +150,29 @@ class TilePrefetcher:
                 self._busy += 1
                 threading.Thread(target=self._work, args=(path,), daemon=True).start()
 
+    def _to_pinned(self, arr):
+        """The decoded tile in a pinned buffer of the pool (allocated on first use, recycled by get() once uploaded)."""
+        n = int(arr.size)
+        buf = None
+        with self._cv:
+            for i, b in enumerate(self._pinned):
+                if b.numel() >= n:
+                    buf = self._pinned.pop(i)
+                    break
+        if buf is None:
+            buf = torch.empty(n, dtype=torch.uint8).pin_memory()
+        view = buf[:n].view(arr.shape)
+        view.numpy()[...] = arr
+        view._ze_pool_buffer = buf
+        return view
+
     def _work(self, path):
         import time
         t0 = time.perf_counter()
         try:
             arr = self._decode(path)
             if self._pin and torch.cuda.is_available():
-                arr = torch.from_numpy(arr).pin_memory()
+                arr = self._to_pinned(arr)
         except Exception as ex:  # surfaced by get()
             arr = ex
         with self._cv:
@@ -163,6 +182,13 @@ class TilePrefetcher:
             self.decode_s += time.perf_counter() - t0
             self._cv.notify_all()
         self._kick()
+
+    def ready(self, path: str) -> bool:
+        """True when get(path) would not wait for a decode in progress (the caller has better things to do meanwhile)."""
+        if self._current[0] == path:
+            return True
+        with self._cv:
+            return path in self._ready or path not in self._order[:self._next]
 
     def get(self, path: str) -> DeviceImage:
         if self._current[0] == path:
@@ -184,7 +210,21 @@ class TilePrefetcher:
             self._kick()
             raise arr
         t = arr if isinstance(arr, torch.Tensor) else torch.from_numpy(arr)
-        img = DeviceImage(t.to(self._engine.device, non_blocking=True), self._engine)
+        dev = t.to(self._engine.device, non_blocking=True)
+        buf = getattr(t, "_ze_pool_buffer", None)
+        if buf is not None:  # the staging buffer goes back to the pool once the copy has run (checked at later calls)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self._engine.device))
+            self._in_copy.append((ev, buf))
+        still = []
+        for ev, b in self._in_copy:
+            if ev.query():
+                with self._cv:
+                    self._pinned.append(b)
+            else:
+                still.append((ev, b))
+        self._in_copy = still
+        img = DeviceImage(dev, self._engine)
         self._current = (path, img)  # the previous tile's HBM is released with its last reference
         self._kick()
         return img
