@@ -222,6 +222,9 @@ int ze_decode_batch(ze_engine* e, const int32_t* seqs, int n, const int32_t* tok
  * property of the engine, never of how many chains are live, so a chain's tokens do not depend on the batch it shares
  * (within a family bit for bit; the two families agree within bf16 rounding).  Returns the family in force (0 / 1). */
 int ze_set_decode_regime(ze_engine* e, int regime);
+/* 1 when the library was built with the experimental one-launch-per-layer decode kernels (`make MEGA=1`; ze_tune knobs
+ * 3 / 4), 0 in the default build (they lost to the stand-alone kernels and are kept for A/B measurements only). */
+int ze_mega_available(void);
 int ze_generate_batch(ze_engine* e, const int32_t* seqs, int n, const ze_gen_params* p, int32_t* out_tokens,
                       int32_t* n_out, void* stream);
 /* Continuous batching (replaces: the request stream the reference keeps in flight against its serving back-end,

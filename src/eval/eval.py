@@ -63,8 +63,9 @@ def are_synonyms(a: str, b: str) -> bool:
         return False
     if not HAVE_WORDNET:
         index, _ = _lite()
-        s1 = index.get(_lemmatize_lite(a.lower().replace(" ", "_")), set())
-        s2 = index.get(_lemmatize_lite(b.lower().replace(" ", "_")), set())
+        # (no space -> underscore mapping: nltk's wordnet.synsets() has none, so "parking lot" finds nothing there either)
+        s1 = index.get(_lemmatize_lite(a.lower()), set())
+        s2 = index.get(_lemmatize_lite(b.lower()), set())
         return bool(s1 & s2)
     try:
         lem = _Lem()

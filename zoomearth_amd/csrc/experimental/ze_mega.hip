@@ -24,7 +24,7 @@
 // order, same reductions); the test-suite compares the two paths token for token and logit for logit.
 #include <algorithm>
 
-#include "ze_attn_decode.h"
+#include "../ze_attn_decode.h"
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
@@ -638,3 +638,5 @@ int ze_layer_mlp_blocks(int hidden, int nq, int ipad) {
 void ze_launch_layer_mlp(const ze_layer_mlp_args& a, int blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_layer_mlp<4>, dim3(blocks), dim3(320), kLayerMlpLds, s, a);
 }
+
+extern "C" int ze_mega_available() { return 1; }
