@@ -302,6 +302,13 @@ def test_openai_server_batches_concurrent_requests(stack):
     for i, o in enumerate(out):
         got = o.json()["choices"][0]["message"]["content"]
         assert got in (want_batched[i], want_single[i]), (i, got, want_batched[i], want_single[i])
+    # sampled requests that share temperature and seed run as ONE batch too, and a request draws
+    # what it draws alone: the same text as `complete` (one request through model.generate), request by request
+    sreqs = [dict(r, temperature=0.9, seed=11) for r in reqs]
+    alone = [srv.complete(r)["choices"][0]["message"]["content"] for r in sreqs]
+    futs = [srv.submit(r) for r in sreqs] + [srv.submit(dict(reqs[0], temperature=0.9, seed=12))]
+    got = [f.result(timeout=120)["choices"][0]["message"]["content"] for f in futs]
+    assert got[:3] == alone and got[3] != alone[0]
     srv.close()
 
 

@@ -443,7 +443,7 @@ def test_submit_zoom_chain_on_the_scheduler():
 def test_serve_dispatcher_admits_into_the_running_batch():
     """The OpenAI shim's dispatcher (src/eval/infer_vllm.py:244-271 keeps up to 100 requests in flight): greedy
     requests join the running batch, each future resolves when its own chain ends, per-request max_tokens / EOS
-    trimming, sampled requests alone through model.generate, malformed requests rejected at submit, an engine failure
+    trimming, sampled requests batched per sampling configuration, malformed requests rejected at submit, an engine failure
     reaches every request of the running batch and the server recovers."""
     from zoomearth_amd import serve
 
@@ -477,7 +477,7 @@ def test_serve_dispatcher_admits_into_the_running_batch():
             srv.submit(req("cccc", max_tokens=6, temperature=0.7, seed=9)), srv.submit(req("dd", max_tokens=4)),
             srv.submit(req("eeee")), srv.submit(req("ffff", max_tokens=2))]
     res = [f.result(timeout=10) for f in futs]
-    assert model.calls == [(1, 6, True, 9)]                  # only the sampled request went through generate, alone
+    assert model.calls == []                                 # the sampled request ran on a scheduler too (a batch of its own kind)
     firsts = [ord(c) % 50 + 10 for c in "abcdef"]
     budgets = [5, 3, 6, 4, 1024, 2]
     for i, r in enumerate(res):

@@ -188,8 +188,9 @@ class ChatServer:
         """Running-batch admission (the concurrency model of /root/reference/src/eval/infer_vllm.py:244-271, where the
         client keeps up to 100 requests in flight): greedy requests go to a `ChainScheduler` -- a request that arrives
         while others are decoding is prefilled and joins their next burst, one that finishes frees its KV slot at once --
-        and each future resolves as soon as ITS chain ends.  A sampled request (its temperature / seed are baked into
-        the captured decode step) waits for the running chains to drain and runs alone."""
+        and each future resolves as soon as ITS chain ends.  Sampled requests (temperature / seed are baked into the captured
+        decode step) wait for the running chains to drain; those that share a temperature and a seed then run together
+        as a batch of their own."""
         from .image import DeviceImage
         from .scheduler import ChainScheduler, Request
 
@@ -244,15 +245,42 @@ class ChatServer:
                                 r.on_error(r, ex)
                         sched = None
                     continue
-            if sampled:  # the running batch has drained
-                p = sampled.pop(0)
-                try:
-                    p.future.set_result(self._run([p])[0])
-                except Exception as ex:
-                    if not p.future.done():
-                        p.future.set_exception(ex)
+            if sampled:
+                # The running (greedy) batch has drained.  Temperature and seed are baked into the captured decode step, so
+                # the sampled requests that share both run TOGETHER on a scheduler of their own (continuous batching, a
+                # request's random stream = stream 0 of its seed: what it would draw running alone, so a request's tokens
+                # do not depend on its company); other sampling configurations follow in turn.
+                key = (sampled[0].temperature, sampled[0].seed)
+                group = [p for p in sampled if (p.temperature, p.seed) == key]
+                sampled = [p for p in sampled if (p.temperature, p.seed) != key]
                 with self._lock:
-                    sched = None  # _run went through model.generate, which re-registers chain slots
+                    ss = ChainScheduler(self.model, self.processor, do_sample=True, temperature=key[0], seed=key[1],
+                                        max_batch=self.max_batch, burst=8)
+                    for p in group:
+                        def done(req, tokens, text, p=p):
+                            p.future.set_result(self._response(p, tokens, req.n_prompt))
+                            return None
+
+                        def failed(req, ex, p=p):
+                            if not p.future.done():
+                                p.future.set_exception(ex)
+
+                        try:
+                            imgs = [DeviceImage.from_pil(im, self.model.engine) for im in p.pil_images]
+                            ss.submit(Request(prompt=p.prompt, images=imgs, max_new_tokens=max(1, min(p.max_tokens, self.model.engine.max_ctx)),
+                                              stream_id=0, on_done=done, on_error=failed))
+                        except Exception as ex:
+                            failed(None, ex)
+                    try:
+                        ss.run()
+                    except Exception as ex:
+                        for r in ss.pending_requests():
+                            if r.on_error:
+                                r.on_error(r, ex)
+                    for p in group:  # (belt and braces: nobody is left waiting)
+                        if not p.future.done():
+                            p.future.set_exception(RuntimeError("request was dropped by the sampled batch"))
+                    sched = None  # the sampled scheduler used the chain slots: the greedy one starts afresh
 
 
 def create_app(server: ChatServer):
