@@ -303,9 +303,9 @@ def test_openai_server_batches_concurrent_requests(stack):
         got = o.json()["choices"][0]["message"]["content"]
         assert got in (want_batched[i], want_single[i]), (i, got, want_batched[i], want_single[i])
     # sampled requests that share temperature and seed run as ONE batch too, and a request draws
-    # what it draws alone: the same text as `complete` (one request through model.generate), request by request
+    # what it draws alone: the same text as when it is the dispatcher's only request (a batch of one chain)
     sreqs = [dict(r, temperature=0.9, seed=11) for r in reqs]
-    alone = [srv.complete(r)["choices"][0]["message"]["content"] for r in sreqs]
+    alone = [srv.submit(r).result(timeout=120)["choices"][0]["message"]["content"] for r in sreqs]
     futs = [srv.submit(r) for r in sreqs] + [srv.submit(dict(reqs[0], temperature=0.9, seed=12))]
     got = [f.result(timeout=120)["choices"][0]["message"]["content"] for f in futs]
     assert got[:3] == alone and got[3] != alone[0]
