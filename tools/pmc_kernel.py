@@ -1,0 +1,45 @@
+"""The kernels whose roofline bench.py reports, launched exactly as bench.py's live measurement launches them
+(ze_profile_batch_kernel / ze_profile_decode_kernel: the layers' real weights and KV caches in rotation), for a rocprofv3
+--pmc pass around this script: every dispatch of a kernel name is then ONE configuration, so the mean FETCH_SIZE /
+WRITE_SIZE per dispatch is the HBM traffic of the launch whose duration bench.py divides the algorithmic bytes by.
+usage: rocprofv3 --pmc FETCH_SIZE --kernel-trace ... -- python3 tools/pmc_kernel.py wide|batch64|configs1
+prints one JSON line: {kernel key: {"us": ..., "bytes_per_launch": ...}} (HIP-event time under the profiler, for reference)"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from zoomearth_amd.config import ModelConfig  # noqa: E402
+from zoomearth_amd.engine import Engine  # noqa: E402
+from zoomearth_amd.synth import uniform_ints  # noqa: E402
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "wide"
+slots = {"wide": 256, "batch64": 64, "configs1": 1}[mode]
+n = {"wide": 220, "batch64": 64, "configs1": 1}[mode]
+e = Engine(ModelConfig.zoomearth_3b(), max_seqs=slots, max_ctx=2048, max_patches=2048, max_tile_side=1024, max_prefill_rows=16 * 1024)
+e.fill_synthetic(0)
+out = {"mode": mode, "chains": n}
+if mode == "configs1":
+    ids = uniform_ints(100, 1200, 1000, 150000).tolist()
+    pos, delta = e.rope_index(ids, [])
+    e.seq_reset(0)
+    e.prefill(0, ids, None, pos, delta, want_logits=False)
+    for which, name in ((2, "gate_up"), (3, "down"), (0, "qkv"), (1, "o_proj"), (4, "lm_head")):
+        us, by = e.profile_decode_kernel(which, iters=72)
+        out[name] = {"us": round(us, 2), "bytes_per_launch": by}
+else:
+    lens = [800 + int(v) for v in uniform_ints(5, slots, 0, 640)]  # ragged: 800 .. 1440 tokens (mean ~1120), as the stream holds
+    for g0 in range(0, slots, 8):
+        gs = list(range(g0, min(slots, g0 + 8)))
+        ids = [uniform_ints(100 + s, lens[s], 1000, 150000).tolist() for s in gs]
+        pl = [e.rope_index(i, []) for i in ids]
+        for s in gs:
+            e.seq_reset(s)
+        e.prefill_batch(gs, ids, [None] * len(gs), [p[0] for p in pl], [p[1] for p in pl])
+    e.set_decode_regime(1 if mode == "wide" else 0)
+    for which, name in ((5, "attention"), (2, "gate_up"), (3, "down"), (0, "qkv"), (1, "o_proj")):
+        us, by = e.profile_batch_kernel(which, n, iters=72)
+        out[name] = {"us": round(us, 2), "bytes_per_launch": by}
+print(json.dumps(out), flush=True)
+e.close()

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Digest of the rocprofv3 summaries in profiles/: writes profiles/traffic_latest.json (HBM bytes per launch of the
-dominant decode kernel, PMC-corrected as MI355X_MICROARCH.md prescribes) and prints the per-kernel duration and
-MFMA-utilisation tables quoted in profiles/README.md.
+"""Digest of the round's rocprofv3 summaries in profiles/: writes profiles/traffic_latest.json -- HBM bytes per launch of
+the kernels whose roofline bench.py reports, from the PMC passes of tools/pmc_kernel.py (FETCH_SIZE and WRITE_SIZE collected
+in separate runs; FETCH_SIZE x 1024 x 2 because gfx950 tallies 128-B read requests at 64 B, WRITE_SIZE x 1024:
+MI355X_MICROARCH.md, HBM) -- and prints the per-kernel duration and MFMA-utilisation tables quoted in profiles/README.md.
 
 usage: tools/profile_digest.py [profiles_dir] [round]
 """
@@ -11,44 +12,73 @@ import os
 import sys
 
 D = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
-ROUND = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+ROUND = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 P = f"r{ROUND:02d}"
-DOMINANT = "void k_gemv<2, 1, 1, 4, 16>(ze_gemv_args)"
-ALG_BYTES = 90177536  # gate/up of one 3B layer: 2 x 11008 x 2048 bf16 weights + x + the activation row
-
-
-def rows(name, source):
-    with open(os.path.join(D, f"{P}_{name}")) as fh:
-        return [r for r in csv.DictReader(fh) if r["source"] == source]
-
-
-stats = {r["kernel"]: r for r in rows("bench_kernel_stats.csv", "kernel_stats")}
-fetch = {r["kernel"]: float(r["mean"]) for r in rows("pmc_fetch_size.csv", "pmc") if r["quantity"] == "FETCH_SIZE"}
-write = {r["kernel"]: float(r["mean"]) for r in rows("pmc_write_size.csv", "pmc") if r["quantity"] == "WRITE_SIZE"}
-hbm = fetch[DOMINANT] * 1024 * 2 + write[DOMINANT] * 1024
-out = {
-    "round": ROUND, "kernel": DOMINANT, "fetch_size_kb_mean": fetch[DOMINANT], "write_size_kb_mean": write[DOMINANT],
-    "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": ALG_BYTES,
-    "correction": "FETCH_SIZE x 1024 x 2 (gfx950 counts 128-B read requests at 64 B) + WRITE_SIZE x 1024; separate --pmc passes",
-    "avg_duration_us_rocprof_kernel_trace": float(stats[DOMINANT]["mean"]) / 1e3,
-    "source": [f"profiles/{P}_pmc_fetch_size.csv", f"profiles/{P}_pmc_write_size.csv", f"profiles/{P}_bench_kernel_stats.csv"],
+# bench.py's kernel keys -> substring of the kernel's name, per measured configuration (tools/pmc_kernel.py modes)
+KEYS = {
+    "configs1": {"gate_up": "k_gemv<2, 1, 1, 4, 16>", "down": "k_gemv<1, 1, 4, 4, 16>", "lm_head": "k_gemv<3, 2, 1, 4, 16>"},
+    "wide": {"attention": "k_attn_decode_wave<8>", "gate_up": "k_gemm_wstream<256, 96", "down": "k_gemm_ring<64, 64, 4, 2, 4, 2, false>"},
+    "batch64": {"attention": "k_attn_decode_wave<8>", "gate_up": "k_gemm_skinny<6, 3", "down": "k_gemm_ring<64, 64, 4, 2, 4, 2, false>"},
 }
+SECTION = {"configs1": "configs1", "wide": "stream", "batch64": "batch64"}
+
+
+def rows(name, source=None):
+    with open(os.path.join(D, f"{P}_{name}")) as fh:
+        return [r for r in csv.DictReader(fh) if source is None or r["source"] == source]
+
+
+def find(table, sub):
+    hits = [(k, v) for k, v in table.items() if sub in k]
+    return max(hits, key=lambda kv: kv[1][1]) if hits else (None, None)  # the most-dispatched match
+
+
+out = {"round": ROUND, "correction": "FETCH_SIZE x 1024 x 2 (gfx950 counts 128-B read requests at 64 B) + WRITE_SIZE x 1024; "
+       "separate --pmc passes around tools/pmc_kernel.py (the launches bench.py times)"}
+for mode, keys in KEYS.items():
+    try:
+        fetch = {r["kernel"]: (float(r["mean"]), int(r["dispatches"])) for r in rows(f"pmc_{mode}_fetch_size.csv", "pmc") if r["quantity"] == "FETCH_SIZE"}
+        write = {r["kernel"]: (float(r["mean"]), int(r["dispatches"])) for r in rows(f"pmc_{mode}_write_size.csv", "pmc") if r["quantity"] == "WRITE_SIZE"}
+        with open(os.path.join(D, f"{P}_pmc_{mode}_launches.json")) as fh:
+            launches = json.loads(fh.read().strip().splitlines()[-1])
+    except FileNotFoundError:
+        continue
+    sec = out.setdefault(SECTION[mode], {})
+    for key, sub in keys.items():
+        name, f = find(fetch, sub)
+        _, w = find(write, sub)
+        if name is None or w is None or key not in launches:
+            continue
+        hbm = f[0] * 1024 * 2 + w[0] * 1024
+        alg = launches[key]["bytes_per_launch"]
+        sec[key] = {"kernel": name.split("(")[0], "fetch_size_kb_mean": f[0], "write_size_kb_mean": w[0], "dispatches": f[1],
+                    "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "ratio": hbm / alg,
+                    "chains": launches.get("chains")}
+        print(f"{SECTION[mode]:9s} {key:10s} {name.split('(')[0][:60]:60s} fetch {2 * f[0] * 1024 / 1e6:8.2f} MB + write {w[0] * 1024 / 1e6:7.2f} MB"
+              f" = {hbm / 1e6:8.2f} MB per launch = {hbm / alg:.3f} x algorithmic ({alg / 1e6:.2f} MB)")
+out["source"] = [f"profiles/{P}_pmc_{m}_{c}.csv" for m in KEYS for c in ("fetch_size", "write_size")]
 with open(os.path.join(D, "traffic_latest.json"), "w") as fh:
     json.dump(out, fh, indent=1)
-print(f"dominant kernel: {out['avg_duration_us_rocprof_kernel_trace']:.2f} us, HBM {hbm / 1e6:.2f} MB per launch = "
-      f"{hbm / ALG_BYTES:.4f} x algorithmic, {ALG_BYTES / out['avg_duration_us_rocprof_kernel_trace'] / 1e3:.0f} GB/s")
 
-tot = sum(float(r["mean"]) * int(r["dispatches"]) for r in stats.values())
-print("\nkernel | calls | mean us | % of GPU time")
-for k, r in sorted(stats.items(), key=lambda kv: -float(kv[1]["mean"]) * int(kv[1]["dispatches"]))[:16]:
-    print(f"{k[:70]:70s} | {r['dispatches']:>6s} | {float(r['mean']) / 1e3:8.2f} | {100 * float(r['mean']) * int(r['dispatches']) / tot:5.2f}")
+for name in ("stream", "configs1", "batch64"):
+    try:
+        stats = {r["kernel"]: r for r in rows(f"{name}_kernel_stats.csv", "kernel_stats")}
+    except FileNotFoundError:
+        continue
+    tot = sum(float(r["mean"]) * int(r["dispatches"]) for r in stats.values())
+    print(f"\n[{name}] kernel | calls | mean us | % of GPU time")
+    for k, r in sorted(stats.items(), key=lambda kv: -float(kv[1]["mean"]) * int(kv[1]["dispatches"]))[:18]:
+        print(f"{k.split('(')[0][:78]:78s} | {r['dispatches']:>7s} | {float(r['mean']) / 1e3:8.2f} | {100 * float(r['mean']) * int(r['dispatches']) / tot:5.2f}")
 
-busy, gui, dur = {}, {}, {}
-for r in rows("pmc_mfma_busy.csv", "pmc"):
-    (busy if r["quantity"] == "SQ_VALU_MFMA_BUSY_CYCLES" else gui)[r["kernel"]] = float(r["mean"])
-for r in rows("pmc_mfma_busy.csv", "kernel_trace"):
-    dur[r["kernel"]] = float(r["mean"]) / 1e3
-print("\nkernel | mean us (eager 1-question run) | MFMA utilisation = busy / (1024 SIMDs x GUI_ACTIVE / 8)")
-for k in sorted(busy, key=lambda k: -busy[k]):
-    if busy[k] > 0 and gui.get(k, 0) > 0:
-        print(f"{k[:70]:70s} | {dur.get(k, float('nan')):8.1f} | {busy[k] / (1024 * gui[k] / 8):.3f}")
+try:
+    busy, gui, dur = {}, {}, {}
+    for r in rows("stream_pmc_mfma_busy.csv", "pmc"):
+        (busy if r["quantity"] == "SQ_VALU_MFMA_BUSY_CYCLES" else gui)[r["kernel"]] = float(r["mean"])
+    for r in rows("stream_pmc_mfma_busy.csv", "kernel_trace"):
+        dur[r["kernel"]] = (float(r["mean"]) / 1e3, int(r["dispatches"]))
+    print("\n[stream, eager] kernel | calls | mean us | MFMA utilisation = busy / (1024 SIMDs x GUI_ACTIVE / 8)")
+    for k in sorted(busy, key=lambda k: -busy[k] * dur.get(k, (0, 0))[1])[:16]:
+        if busy[k] > 0 and gui.get(k, 0) > 0:
+            print(f"{k.split('(')[0][:78]:78s} | {dur.get(k, (0, 0))[1]:6d} | {dur.get(k, (float('nan'), 0))[0]:8.1f} | {busy[k] / (1024 * gui[k] / 8):.3f}")
+except FileNotFoundError:
+    pass
