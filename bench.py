@@ -45,9 +45,9 @@ BATCH_KERNELS = {0: "qkv", 1: "o_proj", 2: "gate_up", 3: "down", 4: "lm_head", 5
 BATCH_KERNEL_NAMES_WIDE = {
     0: "k_gemm_ring (row-streaming decode qkv projection, rows = chains)",
     1: "k_gemm_ring (row-streaming decode o projection + residual)",
-    2: "k_gemm_ring<SWIGLU> (row-streaming decode gate/up projection, all chains' rows per workgroup, weights streamed once)",
-    3: "k_gemm_ring<RESIDUAL> split-K x 8 (row-streaming decode down projection)",
-    4: "k_gemm_ring<F32> (row-streaming decode lm_head)",
+    2: "k_gemm_wstream<256,96,SWIGLU> (row-streaming decode gate/up projection: all chains' rows per workgroup, weights prefetched eight K-steps deep in registers)",
+    3: "k_gemm_ring<64,64,4,RESIDUAL> split-K x 8 (row-streaming decode down projection)",
+    4: "k_gemm_wstream / k_gemm_ring<256,256,F32> (row-streaming decode lm_head)",
     5: "k_attn_decode_wave<8> (batched decode attention: every wave streams 16 keys of each 64-key round, K rows straight into MFMA registers, V rows through its own LDS stages)",
     7: "k_rope_kv_batch (M-RoPE + KV append of the row-streaming family)",
 }
@@ -784,24 +784,30 @@ def main():
         r = rows[BATCH_KERNELS[dom]]
         ach = r["bytes"] / (r["us"] * 1e-6) / 1e9
         layer_us = sum(per_step.values())
-        traffic, traffic_src = committed_traffic("stream" if wide else "batch64", BATCH_KERNELS[dom])
+        traffic, traffic_src = committed_traffic("stream" if wide else "batch64", BATCH_KERNELS[dom], r["bytes"])
         e.set_decode_regime(-1)
         return {"bound": "hbm", "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "avg_us": r["us"],
                 "bytes_per_launch": r["bytes"], "chains": n, "layer_us": round(layer_us, 1),
                 "step_kernels": {k: {"us": v["us"], "GBps": v["GBps"]} for k, v in rows.items()}}
 
-    def committed_traffic(section, kernel):
+    def committed_traffic(section, kernel, alg_bytes=None):
         """HBM bytes per launch from the PMC passes of the latest committed profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-        cannot run inside this process): profiles/traffic_latest.json, written by tools/profile_round.sh"""
+        cannot run inside this process): profiles/traffic_latest.json, written by tools/profile_digest.py from the passes
+        of tools/profile_round3.sh around tools/pmc_kernel.py (the same launcher this process times).  Where the live
+        launch's algorithmic bytes differ from the profiled launch's (the attention kernel: other contexts), the profiled
+        traffic / algorithmic RATIO is applied to the live launch's bytes, and the source string says so."""
         tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
         try:
             with open(tp) as f:
                 tj = json.load(f)
-            ent = tj[section][kernel] if section in tj else None
-            if ent is None and section == "configs1":
-                ent = tj
-            return ent["hbm_bytes_per_launch"], f"profiles/traffic_latest.json (rocprofv3 --pmc, round {tj.get('round')})"
+            ent = tj[section][kernel]
+            src = (f"profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024 in separate passes, round "
+                   f"{tj.get('round')}: {ent['hbm_bytes_per_launch'] / 1e6:.2f} MB per launch = {ent['ratio']:.3f} x algorithmic at "
+                   f"{ent.get('chains')} chains)")
+            if alg_bytes and abs(alg_bytes / ent["algorithmic_bytes_per_launch"] - 1.0) > 0.01:
+                return ent["ratio"] * alg_bytes, src + "; that ratio applied to this launch's algorithmic bytes"
+            return ent["hbm_bytes_per_launch"], src
         except Exception:
             return None, None
 
