@@ -18,7 +18,7 @@ import pytest
 from gpu_util import CHAIN_W
 from oracle import frontend, prng
 from oracle import qwen25vl as Q
-from test_gpu_infer_e2e import ROOT, build_workdir
+from test_gpu_infer_e2e import ROOT, build_workdir, write_tokenizer
 
 pytestmark = pytest.mark.gpu
 QUESTION = "Are there any building on the top-right island?"  # the question of /root/reference/src/demo.py:150
@@ -28,6 +28,9 @@ QUESTION = "Are there any building on the top-right island?"  # the question of 
 def demo_dir(tmp_path_factory):
     from PIL import Image
     d, _ = build_workdir(tmp_path_factory.mktemp("demo"), 1)
+    # every box word of this vocabulary has four numbers: the reference's demo (like this one) unpacks the first box it
+    # finds and dies on a malformed one (/root/reference/src/demo.py:31 `x1, y1, x2, y2 = map(int, bbox)`)
+    write_tokenizer(str(d / "ckpt"), three_number=False)
     os.makedirs(d / "images")
     Image.fromarray(prng.synthetic_tile(77, 448, 448)).save(d / "images" / "demo3.png")
     return d

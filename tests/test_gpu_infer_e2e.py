@@ -31,22 +31,22 @@ KEYS = ["question_id", "ground_truth", "answer1", "answer2", "bbox_ref", "bbox",
         "type", "image", "error", "model_id"]  # /root/reference/src/eval/infer.py:126-143
 
 
-def word(i: int) -> str:
+def word(i: int, three_number: bool = True) -> str:
     if i % 3 == 0:
         return f"w{i}"
     x, y = (i * 37) % 400, (i * 91) % 300
-    if i % 11 == 1:
+    if i % 11 == 1 and three_number:
         return f'"bbox_2d":[{x},{y},{x + 40}]'          # three numbers: cut_image cannot unpack it
     return f'"bbox_2d":[{x},{y},{x + 30 + i % 200},{y + 20 + i % 150}]'
 
 
-def write_tokenizer(path):
+def write_tokenizer(path, three_number: bool = True):
     from tokenizers import AddedToken, Tokenizer
     from tokenizers.models import WordLevel
     from tokenizers.pre_tokenizers import WhitespaceSplit
     specials = {"<|endoftext|>": 2043, "<|im_end|>": 2045, "<|im_start|>": 2044, "<|vision_start|>": 2002,
                 "<|vision_end|>": 2003, "<|image_pad|>": 2005, "<unk>": 2047}
-    vocab = {word(i): i for i in range(2000)}
+    vocab = {word(i, three_number): i for i in range(2000)}
     vocab.update(specials)
     tok = Tokenizer(WordLevel(vocab, unk_token="<unk>"))
     tok.pre_tokenizer = WhitespaceSplit()
