@@ -5,7 +5,7 @@
 (1 included): a synthetic question table (tiles of 5000 x 5000 px with 3..18 questions each, 10.7 on average as LRS-GRO's
 9734 questions about 908 images) is assigned to the N ranks tile by tile (`accel.shard_by_tile`: a tile never splits,
 longest-processing-time packing), and every rank drives its share through the continuous-batching scheduler
-(`zoomearth_amd/scheduler.py`, the code path of `src/eval/infer.py`) with 256 chain slots.  One "step" = 64 questions per
+(`zoomearth_amd/scheduler.py`, the code path of `src/eval/infer.py`) with 512 chain slots.  One "step" = 64 questions per
 GPU entering the stream; the K timed steps are ONE stream of K x 64 questions per GPU (filled at the start, drained at the
 end, both inside the timed region), bracketed by barrier + device synchronisation; `value` = all questions of all ranks
 over the slowest rank's time.  A question = one full two-stage zoom chain:
@@ -211,7 +211,8 @@ class Model64:
 
 
 Q_STEP = 64          # questions per step per GPU of the stream workload
-STREAM_SLOTS = 256   # chain slots per GPU of the stream workload (the engine's choice in configs[3])
+STREAM_SLOTS = 512   # chain slots per GPU of the stream workload (the engine's choice in configs[3]: 256 slots answer 53.0, 384
+                     # 54.0, 512 56.3 questions/s on the 1280-question stream of --steps 20; 39 GB of KV cache at max_ctx 2048)
 
 
 def question_table(n_questions: int, seed: int = 0):

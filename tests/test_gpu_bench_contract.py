@@ -41,7 +41,7 @@ def test_bench_line_contract():
     assert "configs[3]" in d["config"]["workload"] and d["config"]["questions_per_step_per_gpu"] == 64
     assert abs(d["value"] - 64 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]     # 64 questions per step per GPU
     assert d["per_rank"]["questions"] == [128] and d["scheduler"]["admitted"] == 256  # two stages per question
-    assert 64 < d["mean_chains_per_step"] <= 256 or d["steps"] < 4
+    assert 32 < d["mean_chains_per_step"] <= 512
     assert d["value"] > 10.0
     check_roofline(d["roofline"])
     assert d["roofline"]["chains"] >= 1 and "decode" in d["roofline"]["kernel"]

@@ -9,6 +9,7 @@
 //    the staging write (8 lanes = 8 chunks of one row, ds_write_b128) covers all 32 banks (conflict-free).
 // Staging is register based and split (issue global loads for tile t+1 before the MFMAs of tile t, write LDS after),
 // two LDS buffers, one barrier per K-tile.
+#include <algorithm>
 #include <type_traits>
 
 #include "ze_kernels.h"
@@ -1522,14 +1523,24 @@ void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int
     // 217 / 256 rows: gate/up 26.6 / 28.1 / 37.9 / 38.0 against 24.3 / 29.7 / 39.9 / 41.3 on the ring tiles, lm_head 168 /
     // 181 / 240 / 245 against 192 / 215 / 226 / 228); knob 15 = 9: ring tiles only, 1: k_gemm_wstream wherever it applies.
     // (the wide-store epilogue of k_gemm_wstream moves whole 16-byte row pieces: aligned rows, N a multiple of 32)
-    const bool ok = K % GEMM_BK == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && M <= 256 && (size_t)N * ldw * sizeof(bf16_t) < ((size_t)1 << 31) &&
+    const bool ok = K % GEMM_BK == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && (size_t)N * ldw * sizeof(bf16_t) < ((size_t)1 << 31) &&
                     N % 32 == 0 && (ldc % 8) == 0 && ((size_t)A % 16) == 0 && ((size_t)C % 16) == 0;
     const int v = ze_gemv_knobs[15];
     const bool want = v == 1 || (v != 9 && ((epi == ZE_EPI_SWIGLU && M > 96) || (epi == ZE_EPI_F32 && M <= 160)));
     bool done = false;
     if (ok && want && N >= 8192) {
-        if (M > 128) done = launch_wstream<256, 96, 3, 8>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s);
-        else done = launch_wstream<128, 96, 3, 8>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s);
+        // more than 256 rows (engines with up to 512 chain slots): blocks of 256 rows, one launch each -- the second pass over
+        // the weights is served by the Infinity Cache (90 MB of gate/up against 256 MB), rows stay independent of each other
+        const size_t crow = (epi == ZE_EPI_F32) ? 2 * (size_t)ldc : (size_t)ldc;  // (fp32 output rows are twice as long in bf16 units)
+        done = true;
+        for (int r0 = 0; r0 < M && done; r0 += 256) {
+            const int mb = std::min(256, M - r0);
+            const bf16_t* Ab = A + (size_t)r0 * lda;
+            bf16_t* Cb = C + (size_t)r0 * crow;
+            if (mb > 128) done = launch_wstream<256, 96, 3, 8>(epi, Ab, lda, W, ldw, bias, R, ldr, Cb, ldc, mb, N, K, ws, s);
+            else done = launch_wstream<128, 96, 3, 8>(epi, Ab, lda, W, ldw, bias, R, ldr, Cb, ldc, mb, N, K, ws, s);
+            if (!done && r0 > 0) done = true, ze_launch_gemm(epi, Ab, lda, W, ldw, bias, R, ldr, Cb, ldc, nullptr, mb, N, K, s);
+        }
     }
     if (!done) ze_launch_gemm(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s);
 }
