@@ -239,9 +239,9 @@ def run_stream(engine, table, q0: int, slots: int, stats=None, use_graph=True):
 
     model = Model64(engine)
     proc = SynthProcessor(engine.config, engine)
-    sched = ChainScheduler(model, proc, do_sample=False, repetition_penalty=PENALTY, ignore_eos=True, burst=16,
-                           use_graph=use_graph, min_admit=int(os.environ.get("ZE_MIN_ADMIT", str(max(1, slots // 2)))),
-                           max_wait_bursts=int(os.environ.get("ZE_MAX_WAIT", "6")), max_batch=slots)
+    sched = ChainScheduler(model, proc, do_sample=False, repetition_penalty=PENALTY, ignore_eos=True, burst=int(os.environ.get("ZE_BURST", "16")),
+                           use_graph=use_graph, min_admit=int(os.environ.get("ZE_MIN_ADMIT", str(max(1, 3 * slots // 4 if slots > 64 else slots // 2)))),
+                           max_wait_bursts=int(os.environ.get("ZE_MAX_WAIT", "8" if slots > 64 else "6")), max_batch=slots)
     done = {}
     views = {}
     for b, tile, vkey in table:
@@ -651,7 +651,8 @@ def main():
     cfg = ModelConfig.zoomearth_3b() if args.model == "3b" else ModelConfig.qwen25vl_7b()
     chains = SLOTS if stream else B
     e = Engine(cfg, device=local, max_seqs=chains, max_ctx=2048, max_patches=max(4096, 1400 * min(max(chains, 64 if want64 else 1), 40)),
-               max_prefill_rows=(int(os.environ.get("ZE_PREFILL_ROWS", str(16 * 832))) if chains > 1 else 0), max_tile_side=max(args.tile, 1024))
+               max_prefill_rows=(int(os.environ.get("ZE_PREFILL_ROWS", str(32 * 832 if chains > 64 else 16 * 832))) if chains > 1 else 0),
+               max_tile_side=max(args.tile, 1024))
     if rank == 0 or os.environ.get("ZE_BENCH_EVERY_RANK_FILLS") == "1":
         e.fill_synthetic(seed=0, std=0.02)
     for kv in os.environ.get("ZE_TUNE", "").split(","):  # measurement-only A/B knobs, e.g. ZE_TUNE=2:64
