@@ -161,6 +161,20 @@ def test_resume_runs_only_the_missing_questions(workdir):
     assert load(d / "results" / "part_0.jsonl") == load(d / "results" / "full_0.jsonl")
 
 
+def test_two_lanes_write_the_same_records(workdir):
+    """--lanes 2: the rank's tiles are dealt to two engines on its GPU (weights copied device to device, each lane its own
+    scheduler thread, HIP stream and tile prefetcher; the prefill rounds of one overlap the decode bursts of the other).
+    A chain's tokens do not depend on the lane: the file equals the --lanes 1 run, record for record, in dataset order --
+    sampled (the random stream is keyed by the question id) and greedy."""
+    d, rows = workdir
+    base = [sys.executable, "src/infer.py", "--model_name", "ckpt", "--max_new_tokens", "14", "--max_ctx", "2048", "--batch_size", "4"]
+    for extra, tag in (([], "s"), (["--greedy"], "g")):
+        run(base + extra + ["--exp_name", f"l1{tag}_", "--lanes", "1"], d)
+        run(base + extra + ["--exp_name", f"l2{tag}_", "--lanes", "2"], d)
+        one, two = load(d / "results" / f"l1{tag}_0.jsonl"), load(d / "results" / f"l2{tag}_0.jsonl")
+        assert len(one) == len(rows) and one == two
+
+
 def test_infer_sh_defaults(workdir):
     """`bash run_scripts/infer.sh <ckpt> <exp>` exactly as shipped (64 chains, 1024 new tokens per stage)."""
     d, rows = workdir

@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--tile", type=int, default=5000)
     ap.add_argument("--decode_workers", type=int, default=3)
     ap.add_argument("--decode_ahead", type=int, default=6)
+    ap.add_argument("--lanes", type=int, default=1)
     ap.add_argument("--workdir", default=None)
     args = ap.parse_args()
     d = args.workdir or tempfile.mkdtemp(prefix="ze_e2e_")
@@ -128,20 +129,24 @@ def main():
 
     class Timed(real):  # the clock starts when the model is loaded and the scheduler exists
         def __init__(self, *a, **kw):
-            marks["loaded"] = time.perf_counter()
+            marks.setdefault("loaded", time.perf_counter())
             super().__init__(*a, **kw)
-            marks["engine"] = self.engine
+            marks.setdefault("engines", []).append(self.engine)
             self.engine.phase_timers(enable=True, reset=True)
 
     infer.ChainScheduler = Timed
     stats = infer.eval_model_lora("ckpt", "e2e_", "./LRS_GRO/test", "./image/", args.max_new_tokens, args.batch_size, 2048,
-                                  do_sample=False, decode_workers=args.decode_workers, decode_ahead=args.decode_ahead)
+                                  do_sample=False, decode_workers=args.decode_workers, decode_ahead=args.decode_ahead, lanes=args.lanes)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    phases = marks["engine"].phase_timers(enable=False)
+    phases = {}
+    for en in marks["engines"]:
+        if en.h:
+            for k, v in en.phase_timers(enable=False).items():
+                phases[k] = phases.get(k, 0.0) + v
     recs = [json.loads(l) for l in open("results/e2e_0.jsonl")]
     out.update({
-        "entry_point": "src/eval/infer.py eval_model_lora, --batch_size %d --max_new_tokens %d --greedy" % (args.batch_size, args.max_new_tokens),
+        "entry_point": "src/eval/infer.py eval_model_lora, --batch_size %d --max_new_tokens %d --greedy --lanes %d" % (args.batch_size, args.max_new_tokens, args.lanes),
         "model_load_s": round(marks["loaded"] - t0, 2),
         "stream_s": round(t1 - marks["loaded"], 2),
         "questions_per_s": round(len(recs) / (t1 - marks["loaded"]), 2),

@@ -97,6 +97,30 @@ class ZoomEarthForConditionalGeneration:
     def eval(self):
         return self
 
+    def clone_lane(self, **engine_kw):
+        """A second engine on the same GPU with a copy of this model's weights (device-to-device), for a further LANE of
+        question chains: its own KV cache, workspaces, scheduler thread and HIP stream, so that the prefill / ViT rounds of
+        one lane overlap the decode bursts of the other (src/eval/infer.py --lanes; bench.py --lanes)."""
+        e = self.engine
+        kw = dict(device=e.device.index or 0, max_seqs=e.max_seqs, max_ctx=e.max_ctx, max_patches=e.max_patches,
+                  max_tile_side=int(e.zcfg.max_tile_side), max_prefill_rows=int(e.zcfg.max_prefill_rows))
+        kw.update(engine_kw)
+        e2 = Engine(self.config, **kw)
+        try:
+            e2.weights_arena().copy_(e.weights_arena())
+            torch.cuda.synchronize(e.device)
+            e2.weights_invalidate()
+            e2.assert_ready()
+        except Exception:
+            e2.close()
+            raise
+        gen = SimpleNamespace(**vars(self.generation_config))
+        lane = ZoomEarthForConditionalGeneration.__new__(ZoomEarthForConditionalGeneration)
+        lane.config, lane.engine, lane.generation_config = self.config, e2, gen
+        lane._vit_cache, lane._chains, lane._next_slot, lane.reuse_prefix = OrderedDict(), OrderedDict(), 0, True
+        lane.weight_broadcast_s = 0.0
+        return lane
+
     @property
     def device(self):
         return self.engine.device
