@@ -79,3 +79,29 @@ def test_front_end_errors(tiny_engine):
         tiny_engine.patchify(dev(prng.synthetic_tile(1, 30, 56)))
     with pytest.raises(ZoomEarthError):
         tiny_engine.preprocess_image(dev(prng.synthetic_tile(1, 4, 900)))
+
+
+def test_front_end_from_two_streams(tiny_engine, big_tile):
+    """The front-end workspace (coefficient tables, pinned staging, intermediate images) is ONE per engine, and the
+    scheduler calls it on its side stream while the loop that feeds it resizes the next tile's view on its own stream
+    (zoomearth_amd/scheduler.py step(); src/eval/infer.py run_lane).  Calls alternating between two streams, with nothing
+    but the engine's own ordering between them, give the results of the same calls made one after the other."""
+    t = dev(big_tile)
+    small = dev(prng.synthetic_tile(5, 300, 280))
+    jobs = [(t, (0, 0, 5000, 5000), (512, 512)), (small, (10, 20, 250, 260), (140, 84)), (t, (1000, 1200, 3500, 3300), (512, 430)),
+            (small, (0, 0, 280, 300), (308, 336)), (t, (40, 4000, 900, 4990), (448, 476)), (small, (100, 100, 180, 190), (28, 56))]
+    want = [tiny_engine.crop_resize(*j).cpu() for j in jobs]
+    want_pv = tiny_engine.preprocess_image(small)[0].cpu()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    for rep in range(12):
+        got = []
+        for i, j in enumerate(jobs):
+            with torch.cuda.stream(a if (i + rep) % 2 else b):
+                got.append(tiny_engine.crop_resize(*j))
+        with torch.cuda.stream(a if rep % 2 else b):
+            pv = tiny_engine.preprocess_image(small)[0]
+        torch.cuda.synchronize()
+        for g, w in zip(got, want):
+            assert torch.equal(g.cpu(), w), rep
+        assert torch.equal(pv.cpu(), want_pv), rep

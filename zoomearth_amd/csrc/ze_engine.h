@@ -109,6 +109,8 @@ struct ze_engine {
     int *fe_coef = nullptr;  // device coefficient tables
     size_t fe_tmp_bytes = 0, fe_img_bytes = 0, fe_coef_ints = 0;
     int* fe_coef_host = nullptr;  // pinned
+    hipEvent_t fe_done = nullptr;  // recorded behind the last kernel that reads the front-end workspace (any stream)
+    bool fe_in_flight = false;
 
     // ViT workspace
     bf16_t *vx = nullptr, *vh = nullptr, *vy = nullptr, *vqkv = nullptr, *vo = nullptr, *va = nullptr, *vz = nullptr,

@@ -420,6 +420,7 @@ extern "C" int ze_engine_destroy(ze_engine* e) {
                    e->ty8, e->ty8_scale, e->damax, e->ty8p, e->ty8p_scale};
     for (void* p : dev)
         if (p) hipFree(p);
+    if (e->fe_done) hipEventDestroy(e->fe_done);
     void* host[] = {e->fe_coef_host, e->v_host_ints, e->v_host_f32, e->t_host_ints, e->d_host_ints, e->bstate_host};
     for (void* p : host)
         if (p) hipHostFree(p);

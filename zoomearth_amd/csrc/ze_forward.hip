@@ -17,6 +17,20 @@ extern int ze_gemv_knobs[16];
 
 // ================================================================== front-end
 // dst = crop(src, box).resize((dst_w, dst_h), BICUBIC), Pillow-exact (two passes, u8 intermediate).
+static int frontend_acquire(ze_engine* e) {
+    if (e->fe_in_flight) {
+        ZE_HIP(hipEventSynchronize(e->fe_done));
+        e->fe_in_flight = false;
+    }
+    return ZE_OK;
+}
+// called behind the last kernel that reads the workspace
+static int frontend_release(ze_engine* e, hipStream_t s) {
+    if (!e->fe_done) ZE_HIP(hipEventCreateWithFlags(&e->fe_done, hipEventDisableTiming));
+    ZE_HIP(hipEventRecord(e->fe_done, s));
+    e->fe_in_flight = true;
+    return ZE_OK;
+}
 static int crop_resize(ze_engine* e, const uint8_t* src, int src_h, int src_w, const int32_t box[4], uint8_t* dst,
                        int dst_h, int dst_w, hipStream_t s) {
     const int bx0 = box[0], by0 = box[1];
@@ -41,8 +55,10 @@ static int crop_resize(ze_engine* e, const uint8_t* src, int src_h, int src_w, c
     if (ints > e->fe_coef_ints) return ze_fail(e, ZE_ERR_NOMEM, "bicubic coefficient table exceeds workspace");
     if (need_h && need_v && (size_t)bh * dst_w * 3 > e->fe_tmp_bytes)
         return ze_fail(e, ZE_ERR_NOMEM, "resize intermediate exceeds workspace (max_tile_side)");
-    // the pinned staging buffer is reused by every call: wait until the previous upload was consumed
-    ZE_HIP(hipStreamSynchronize(s));
+    // ONE workspace per engine (coefficient tables, their pinned staging buffer, the horizontal-pass image, the resized
+    // image) and callers on several streams (the scheduler crops on its side stream while the loop that feeds it resizes
+    // the next tile's view on its own): wait for the previous front-end op, whatever stream it ran on
+    ZE_TRY(frontend_acquire(e));
     int* hp = e->fe_coef_host;
     int* dp = e->fe_coef;
     size_t o = 0;
@@ -100,7 +116,8 @@ extern "C" int ze_op_crop_resize(ze_engine* e, const uint8_t* src, int src_h, in
     hipSetDevice(e->device);
     hipStream_t s = (hipStream_t)stream;
     const int h = ze_timer_begin(e, 0, s);
-    const int r = crop_resize(e, src, src_h, src_w, box, dst, dst_h, dst_w, s);
+    int r = crop_resize(e, src, src_h, src_w, box, dst, dst_h, dst_w, s);
+    if (r == ZE_OK) r = frontend_release(e, s);
     ze_timer_end(e, h, s);
     return r;
 }
@@ -147,6 +164,7 @@ extern "C" int ze_preprocess_image(ze_engine* e, const uint8_t* img, int h, int 
     }
     ze_launch_patchify(cur, rh, rw, e->lut, out, c.patch_size, c.spatial_merge_size, c.temporal_patch_size,
                        c.in_channels, s);
+    if (cur == e->fe_img) ZE_TRY(frontend_release(e, s));
     ze_timer_end(e, th, s);
     ZE_KCHECK();
     grid_thw[0] = 1;

@@ -6,6 +6,7 @@ every computation goes through the C ABI of libzoomearth_hip.so.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Iterable, Sequence
 
 import numpy as np
@@ -285,6 +286,8 @@ class Engine:
     def _gen_params(max_new_tokens, repetition_penalty, ignore_eos, use_graph, sync_every, do_sample, temperature, seed):
         if do_sample and not (temperature and temperature > 0):
             raise ValueError("`temperature` has to be a strictly positive float when sampling")  # as HF raises
+        if os.environ.get("ZE_NO_GRAPH") == "1":  # debugging aid: every decode step launched eagerly
+            use_graph = False
         return _lib.ZeGenParams(max_new_tokens, repetition_penalty, int(ignore_eos), int(use_graph), sync_every,
                                 int(bool(do_sample)), float(temperature or 0.0), int(seed) & (2 ** 64 - 1))
 

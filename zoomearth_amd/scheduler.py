@@ -130,6 +130,10 @@ class ChainScheduler:
 
     # ------------------------------------------------------------------ one scheduling round
     def step(self) -> None:
+        if self._side is not None:
+            # what the caller put on ITS stream before submitting (the tile upload, the view's resize) is read by the
+            # admission work on the side stream: order the two here, while the caller's stream holds nothing else
+            self._side.wait_stream(torch.cuda.current_stream(self.engine.device))
         handle = self._burst_begin() if (self.live and self.overlap) else None
         with self._side_stream():
             if not self._groups:
