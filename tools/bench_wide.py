@@ -31,7 +31,7 @@ for tune in tunes:
     for kv in tune.split(","):
         if ":" in kv:
             e.lib.ze_tune(int(kv.split(":")[0]), int(kv.split(":")[1]))
-    for n in sorted({min(32, B), min(64, B), min(128, B), min(217, B), min(256, B), min(344, B), B}):
+    for n in sorted({min(64, B), min(128, B), min(217, B), min(256, B), min(261, B), min(344, B), min(384, B), min(440, B), B}):
         row = []
         for w in (0, 1, 2, 3, 4, 5):
             us, by = e.profile_batch_kernel(w, n, 72)

@@ -1533,11 +1533,16 @@ void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int
         // the weights is served by the Infinity Cache (90 MB of gate/up against 256 MB), rows stay independent of each other
         const size_t crow = (epi == ZE_EPI_F32) ? 2 * (size_t)ldc : (size_t)ldc;  // (fp32 output rows are twice as long in bf16 units)
         done = true;
-        for (int r0 = 0; r0 < M && done; r0 += 256) {
-            const int mb = std::min(256, M - r0);
+        // (gate/up: blocks of up to 512 rows on the 384- and 512-row instances -- a pass costs ~18 us whatever its rows and
+        //  ~10 us per 128 rows on top, so 261 chains in one pass instead of a 256- and a 5-row pass; knob 15 = 5: 256 at most)
+        const int blk = (epi == ZE_EPI_SWIGLU && K / GEMM_BK == 32 && v != 5) ? 512 : 256;
+        for (int r0 = 0; r0 < M && done; r0 += blk) {
+            const int mb = std::min(blk, M - r0);
             const bf16_t* Ab = A + (size_t)r0 * lda;
             bf16_t* Cb = C + (size_t)r0 * crow;
-            if (mb > 128) done = launch_wstream<256, 96, 3, 8>(epi, Ab, lda, W, ldw, bias, R, ldr, Cb, ldc, mb, N, K, ws, s);
+            if (mb > 384) launch_wstream_one<512, 96, 2, 6, 32, ZE_EPI_SWIGLU>(Ab, lda, W, ldw, bias, R, ldr, Cb, ldc, mb, N, K, 1, ws, s);
+            else if (mb > 256) launch_wstream_one<384, 96, 2, 8, 32, ZE_EPI_SWIGLU>(Ab, lda, W, ldw, bias, R, ldr, Cb, ldc, mb, N, K, 1, ws, s);
+            else if (mb > 128) done = launch_wstream<256, 96, 3, 8>(epi, Ab, lda, W, ldw, bias, R, ldr, Cb, ldc, mb, N, K, ws, s);
             else done = launch_wstream<128, 96, 3, 8>(epi, Ab, lda, W, ldw, bias, R, ldr, Cb, ldc, mb, N, K, ws, s);
             if (!done && r0 > 0) done = true, ze_launch_gemm(epi, Ab, lda, W, ldw, bias, R, ldr, Cb, ldc, nullptr, mb, N, K, s);
         }
