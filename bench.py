@@ -5,7 +5,7 @@
 (1 included): a synthetic question table (tiles of 5000 x 5000 px with 3..18 questions each, 10.7 on average as LRS-GRO's
 9734 questions about 908 images) is assigned to the N ranks tile by tile (`accel.shard_by_tile`: a tile never splits,
 longest-processing-time packing), and every rank drives its share through the continuous-batching scheduler
-(`zoomearth_amd/scheduler.py`, the code path of `src/eval/infer.py`) with 512 chain slots.  One "step" = 64 questions per
+(`zoomearth_amd/scheduler.py`, the code path of `src/eval/infer.py`) with two lanes of 768 chain slots.  One "step" = 64 questions per
 GPU entering the stream; the K timed steps are ONE stream of K x 64 questions per GPU (filled at the start, drained at the
 end, both inside the timed region), bracketed by barrier + device synchronisation; `value` = all questions of all ranks
 over the slowest rank's time.  A question = one full two-stage zoom chain:
@@ -211,8 +211,9 @@ class Model64:
 
 
 Q_STEP = 64          # questions per step per GPU of the stream workload
-STREAM_SLOTS = 512   # chain slots per GPU of the stream workload (the engine's choice in configs[3]: 256 slots answer 53.0, 384
-                     # 54.0, 512 56.3 questions/s on the 1280-question stream of --steps 20; 39 GB of KV cache at max_ctx 2048)
+STREAM_SLOTS = 768   # chain slots per LANE of the stream workload (the engine's choice in configs[3]; on the 1280-question stream
+                     # of --steps 20, one lane: 256 slots answer 53.0, 384 54.0, 512 56.3, 1024 60.3 questions/s; two lanes: 2 x 256
+                     # 62.9, 2 x 512 66.2, 2 x 768 67.6, 2 x 1024 67.7; 58 GB of KV cache per lane at max_ctx 2048)
 
 
 def question_table(n_questions: int, seed: int = 0):
@@ -606,7 +607,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("ZE_LANES", "2")),
                     help="engines per GPU of the stream workload, each with its own scheduler thread and HIP stream (prefill of one "
                          "overlaps decode of the other; `src/eval/infer.py --lanes`); --slots chain slots EACH.  Measured on the "
-                         "1280-question stream: 1 x 512 slots 57.7, 2 x 256 62.9, 2 x 512 65.0, 3 x 256 61.8 questions/s")
+                         "1280-question stream: 1 x 512 slots 57.7, 1 x 1024 60.3, 2 x 256 62.9, 2 x 512 66.2, 2 x 768 67.6, 3 x 512 65.4 questions/s")
     ap.add_argument("--no-batch64", action="store_true", help="skip the batch64 object of the default N = 1 line")
     ap.add_argument("--no-configs1", action="store_true", help="skip the configs1 object of the default N = 1 line")
     ap.add_argument("--spawn-check", action="store_true", help=argparse.SUPPRESS)

@@ -63,6 +63,7 @@ __device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / (16 * WM)][BN / (1
                     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, base + (unsigned)(i * TN + j) * NT * 16, 0, 16 /* sc1 */);
                 }
         }
+        if (tickets == nullptr) return;  // slab-only launch: k_splitk_reduce adds the slices (ze_launch_gemm_wide, long K)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the ticket
         __syncthreads();
         unsigned* flag = reinterpret_cast<unsigned*>(smem);  // the staging buffers are dead now
@@ -1488,6 +1489,87 @@ static void launch_skinny(int epi, const bf16_t* A, int lda, const bf16_t* W, in
     else launch_skinny_mt<TN, 4>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ksplit, s);
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Second launch of the two-launch split-K form (the down projection of a batched decode step with more than 256 chains):
+// k_gemm_ring<BM, BN, ...> ran with a null ticket array and left every slice's fp32 accumulators in the slabs, laid out
+// [slice][tile][MFMA tile t][thread] exactly as gemm_finish parks them.  One thread here = one thread of the producing
+// workgroup for one MFMA tile: it adds the slices IN SLICE ORDER starting from zero and applies the epilogue -- the
+// arithmetic of gemm_finish's last-arriver reduction, value for value, so the result is bit-identical to the one-launch
+// form on any tile size (a row's bits do not depend on which form served the step).  The whole chip reduces (16.8 MB of
+// slabs at 256 rows) instead of one workgroup per tile reading 1 MB.
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ void __launch_bounds__(64 * WM * WN) k_splitk_reduce(const float* __restrict__ slab, int ksplit,
+                                                                 const bf16_t* __restrict__ bias, const bf16_t* __restrict__ R,
+                                                                 int ldr, bf16_t* __restrict__ C, int ldc, int M, int N) {
+    constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN), NT = 64 * WM * WN;
+    const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM, nwg = nbx * nby;
+    const int bid = blockIdx.x / (TM * TN), t = blockIdx.x % (TM * TN);
+    const int i = t / TN, j = t % TN;
+    const bool col_major = N > M;  // (k_gemm_ring's walk of the tile grid)
+    const int bm0 = (col_major ? bid % nby : bid / nbx) * BM, bn0 = (col_major ? bid / nby : bid % nbx) * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm0 = (wid / WN) * (BM / WM), wn0 = (wid % WN) * (BN / WN);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int col = bn0 + wn0 + j * 16 + fr;
+    const int row0 = bm0 + wm0 + i * 16 + fq * 4;
+    if (row0 >= M) return;  // (whole waves of a ragged last row tile leave before they load anything)
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float4* sl = reinterpret_cast<const float4*>(slab);
+    float4 v[8];
+    for (int q0 = 0; q0 < ksplit; q0 += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            v[q] = sl[((size_t)(min(q0 + q, ksplit - 1) * nwg + bid) * (TM * TN) + t) * NT + tid];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q0 + q < ksplit) {
+                acc[0] += v[q].x;
+                acc[1] += v[q].y;
+                acc[2] += v[q].z;
+                acc[3] += v[q].w;
+            }
+    }
+    if (col >= N) return;
+    const float b = bias ? bf16_to_f32(bias[col]) : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = row0 + r;
+        if (row >= M) continue;
+        float o = bf16_round(acc[r] + b);
+        if (EPI == ZE_EPI_RESIDUAL) o = bf16_to_f32(R[(size_t)row * ldr + col]) + o;
+        C[(size_t)row * ldc + col] = f32_to_bf16(o);
+    }
+}
+
+// the slice count of the weight-streaming split (launch_cfg, stream mode, 64-column tiles): a function of (N, K) alone
+static int stream_ksplit(int N, int K) {
+    int ksplit = 1;
+    const int nk = ze_cdiv(K, GEMM_BK), tiles_n = ze_cdiv(N, 64);
+    while (tiles_n * ksplit < 200 && ksplit < 8 && nk / (ksplit * 2) >= 4) ksplit *= 2;
+    return ksplit;
+}
+
+// long-K projection, more than 256 rows: 128 x 256 tiles (64 x 64 per wave: half the LDS fragment reads per MFMA of the
+// 64 x 64 tile's 16 x 32) on the slices of the one-launch form, then the chip-wide reduction; false = does not apply
+static bool launch_splitk_two(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
+                              int ldr, bf16_t* C, int ldc, int M, int N, int K, const ze_gemm_ws& ws, hipStream_t s) {
+    constexpr int BM = 128, BN = 256;
+    if (epi != ZE_EPI_RESIDUAL && epi != ZE_EPI_NONE) return false;
+    const int ksplit = stream_ksplit(N, K);
+    const int nwg = ze_cdiv(M, BM) * ze_cdiv(N, BN);
+    if (ksplit < 2 || K % GEMM_BK != 0 || K / GEMM_BK / ksplit < 4 || !ws.slab || (size_t)ksplit * nwg * BM * BN > ws.slab_floats)
+        return false;
+    ze_gemm_ws slabs_only = ws;
+    slabs_only.tickets = nullptr;
+    launch_ring_variant<BM, BN, 3, 2, 4, true>(ZE_EPI_NONE, A, lda, W, ldw, nullptr, nullptr, 0, C, ldc, nullptr, M, N, K, s, ksplit, slabs_only);
+    const int grid = nwg * (BM / 32) * (BN / 64);
+    if (epi == ZE_EPI_RESIDUAL)
+        hipLaunchKernelGGL((k_splitk_reduce<BM, BN, 2, 4, ZE_EPI_RESIDUAL>), dim3(grid), dim3(512), 0, s, ws.slab, ksplit, bias, R, ldr, C, ldc, M, N);
+    else
+        hipLaunchKernelGGL((k_splitk_reduce<BM, BN, 2, 4, ZE_EPI_NONE>), dim3(grid), dim3(512), 0, s, ws.slab, ksplit, bias, R, ldr, C, ldc, M, N);
+    return true;
+}
+
 void ze_launch_gemm_stream(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,
                            const bf16_t* R, int ldr, bf16_t* C, int ldc, int M, int N, int K, const ze_gemm_ws& ws,
                            hipStream_t s) {
@@ -1515,6 +1597,12 @@ void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int
     // split K loses to it at every row count: 36.7 against 34.1 us at 256 rows, 23.4 against 17.4 at 64 -- its K loop alone
     // takes 19 us there, but 256-row tiles make the slab reduction eight times the bytes per reducer)
     if (K > 4096) {
+        // more than 256 rows: two launches -- 128 x 256 tiles leave the slices in the slabs, the whole chip adds them (3B down
+        // projection, us at 217 / 256 / 261 / 344 / 384 / 440 / 512 rows: 32.9 / 34.4 / 31.6 / 35.7 / 37.1 / 37.6 / 40.5 against
+        // 31.7 / 34.1 / 37.2 / 43.2 / 45.3 / 50.4 / 57.0 in one launch; both bounded by the bytes a CU keeps in flight towards its
+        // LDS -- 2 x 48 KB on these tiles -- so up to 256 rows, 128 workgroups, the one-launch form on 64 x 64 tiles stays);
+        // knob 15 = 6: off
+        if (M > 256 && ze_gemv_knobs[15] != 6 && launch_splitk_two(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
         ze_launch_gemm_stream(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s);
         return;
     }
