@@ -559,6 +559,192 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
 
 
 // ----------------------------------------------------------------------------------------------------------------
+// 256 x 256 tiles, eight phases per two K-tiles (the many-round grids of the batched prefill and of the ViT).  Same tile,
+// same eight waves (2 x 4, 128 x 64 outputs each) and the same two 64-KB K-tile buffers as k_gemm_ring<256, 256, 2>, but the
+// K-tile is staged and consumed in four HALF-TILES of 16 KB -- A rows {wr*128 + mh*64 + 0..63} for both wave rows (mh = 0, 1),
+// W rows {wc*64 + nh*32 + 0..31} for the four wave columns (nh = 0, 1) -- and a K-tile's 64 MFMAs per wave run as four
+// quadrants (mh, nh) of 16, one per phase:
+//   phase 1: read A-half 0 + W-half 0 (12 ds_read_b128), stage A-half 1 of tile t+1;   MFMA quadrant (0, 0)
+//   phase 2: read W-half 1 (4),                          stage A-half 0 of tile t+2;   MFMA quadrant (0, 1)
+//   phase 3: read A-half 1 (8),                          stage W-half 0 of tile t+2;   MFMA quadrant (1, 1)
+//   phase 4: no read,                                    stage W-half 1 of tile t+2;   MFMA quadrant (1, 0)
+// each phase = reads + 2 LDS-DMA instructions per wave, s_barrier, the 16 MFMAs at raised priority, s_barrier.  A half-tile
+// is restaged as soon as its last fragment read is over (two phases later; A-half 0 one phase later, behind an lgkmcnt that
+// retires its reads before the barrier), so three half-tiles (48 KB per workgroup) are in flight at the ONE counted wait of a
+// K-tile -- s_waitcnt vmcnt(6) in phase 4, never 0 inside the loop -- against one K-tile issued behind the barrier and
+// drained at the next in the two-stage ring.  The two wave rows run one barrier apart (wave w and w + 4 share a SIMD): while
+// one row's waves issue MFMAs the other's read fragments and issue DMAs (cdna_hip_programming.md, the 256^2 8-phase
+// template).  A staged half-tile is read one phase after the wait + barrier that retire it.  Per output element the MFMAs and
+// their K order are k_gemm_ring's: identical bits.
+template <int EPI>
+__global__ void __launch_bounds__(512) k_gemm_p8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
+                                                 const bf16_t* __restrict__ bias, const bf16_t* __restrict__ R, int ldr,
+                                                 bf16_t* __restrict__ C, int ldc, const int* __restrict__ c_rows, int M, int N,
+                                                 int K) {
+    constexpr int BM = 256, BN = 256, HALF = 128 * 128, BUF = 4 * HALF;  // buffer = [A-half 0][A-half 1][W-half 0][W-half 1]
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
+    const int nwg = nbx * nby;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const bool col_major = N > M;  // (see k_gemm_ring)
+    const int bm0 = (col_major ? bid % nby : bid / nbx) * BM, bn0 = (col_major ? bid / nby : bid % nbx) * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = K / GEMM_BK;
+
+    const unsigned smem_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem);
+    // DMA sources: this wave moves pieces 2 wid and 2 wid + 1 (8 half-tile rows x 128 B each) of every half-tile; byte offsets
+    // from the operand's base (32 bits: the operands of this path are far below 4 GB), the K offset rides in the scalar base
+    unsigned offA[2][2], offB[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int hr = (wid * 2 + q) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((hr >> 1) & 7);
+            const int ra = min(bm0 + (hr >> 6) * 128 + h * 64 + (hr & 63), M - 1);
+            const int rb = min(bn0 + (hr >> 5) * 64 + h * 32 + (hr & 31), N - 1);
+            offA[h][q] = (unsigned)(((size_t)ra * lda + c * 8) * sizeof(bf16_t));
+            offB[h][q] = (unsigned)(((size_t)rb * ldw + c * 8) * sizeof(bf16_t));
+        }
+    // slot 0..3 = A-half 0, A-half 1, W-half 0, W-half 1
+    auto stage = [&](int slot, int t) {
+        const unsigned dst = smem_lds + (t & 1) * BUF + slot * HALF + wid * 2048;
+        const bf16_t* base = (slot < 2 ? A : W) + (size_t)t * GEMM_BK;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const unsigned off = slot == 0 ? offA[0][q] : slot == 1 ? offA[1][q] : slot == 2 ? offB[0][q] : offB[1][q];
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(off), "s"(dst + q * 1024), "s"(base)
+                         : "memory");
+        }
+    };
+    // fragment addresses: half-tile row = (wr * 64 | wc * 32) + 16 i + fr; the swizzle term (row >> 1) & 7 = fr >> 1 for all i
+    const int sw = (fr >> 1) & 7;
+    const unsigned aoff0 = (wr * 64 + fr) * 128 + (((0 + fq) ^ sw) << 4), aoff1 = (wr * 64 + fr) * 128 + (((4 + fq) ^ sw) << 4);
+    const unsigned boff0 = (wc * 32 + fr) * 128 + (((0 + fq) ^ sw) << 4), boff1 = (wc * 32 + fr) * 128 + (((4 + fq) ^ sw) << 4);
+    bf16x8 fa[2][4], fb0[2][2], fb1[2][2];
+    auto read_a = [&](int b, int mh) {
+        const uint8_t* p = smem + b * BUF + mh * HALF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[0][i] = *reinterpret_cast<const bf16x8*>(p + aoff0 + i * 2048);
+            fa[1][i] = *reinterpret_cast<const bf16x8*>(p + aoff1 + i * 2048);
+        }
+    };
+    auto read_b = [&](bf16x8 (&f)[2][2], int b, int nh) {
+        const uint8_t* p = smem + b * BUF + (2 + nh) * HALF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f[0][j] = *reinterpret_cast<const bf16x8*>(p + boff0 + j * 2048);
+            f[1][j] = *reinterpret_cast<const bf16x8*>(p + boff1 + j * 2048);
+        }
+    };
+    auto quadrant = [&](int mh, int nh, const bf16x8 (&f)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][i], f[kk][j], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // prologue, in the loop's order of issue: tile 0 whole, then the three half-tiles of tile 1 that phases 2-4 of a tile stage
+    stage(0, 0);
+    stage(2, 0);
+    stage(3, 0);
+    stage(1, 0);
+    if (nk > 1) {
+        stage(0, 1);
+        stage(2, 1);
+        stage(3, 1);
+        ring_wait<6>();
+    } else {
+        ring_wait<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs one barrier behind the first
+
+    for (int t = 0; t < nk; ++t) {
+        const int b = t & 1;
+        // ---- phase 1
+        read_a(b, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(fb0, b, 0);
+        if (t + 1 < nk) stage(1, t + 1);
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // the A-half 0 reads are over: phase 2 restages it
+        __builtin_amdgcn_s_barrier();
+        quadrant(0, 0, fb0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2
+        read_b(fb1, b, 1);
+        if (t + 2 < nk) stage(0, t + 2);
+        __builtin_amdgcn_s_barrier();
+        quadrant(0, 1, fb1);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 3
+        read_a(b, 1);
+        if (t + 2 < nk) stage(2, t + 2);
+        __builtin_amdgcn_s_barrier();
+        quadrant(1, 1, fb1);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 4: everything older than the three half-tiles just issued has landed (= all of tile t + 1)
+        if (t + 2 < nk) {
+            stage(3, t + 2);
+            ring_wait<6>();
+        } else {
+            ring_wait<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        quadrant(1, 0, fb0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    __syncthreads();  // the tail reuses the staging LDS
+    gemm_finish<BM, BN, EPI, 2, 4>(acc, smem, bias, R, ldr, C, ldc, c_rows, M, N, 1, 0, bid, nwg, bm0, bn0, nullptr, nullptr);
+}
+
+static void launch_p8(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R, int ldr,
+                      bf16_t* C, int ldc, const int* c_rows, int M, int N, int K, hipStream_t s) {
+    const int grid = ze_cdiv(M, 256) * ze_cdiv(N, 256);
+    const size_t lds = 128 * 1024;
+#define ZE_P8_LAUNCH(E)                                                                                                        \
+    do {                                                                                                                       \
+        static bool attr_set = false;                                                                                          \
+        if (!attr_set) {                                                                                                       \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_p8<E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr_set = true;                                                                                                   \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((k_gemm_p8<E>), dim3(grid), dim3(512), lds, s, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K); \
+    } while (0)
+    switch (epi) {
+        case ZE_EPI_NONE: ZE_P8_LAUNCH(ZE_EPI_NONE); break;
+        case ZE_EPI_GELU: ZE_P8_LAUNCH(ZE_EPI_GELU); break;
+        case ZE_EPI_RESIDUAL: ZE_P8_LAUNCH(ZE_EPI_RESIDUAL); break;
+        case ZE_EPI_SWIGLU: ZE_P8_LAUNCH(ZE_EPI_SWIGLU); break;
+        case ZE_EPI_F32: ZE_P8_LAUNCH(ZE_EPI_F32); break;
+    }
+#undef ZE_P8_LAUNCH
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // Weight-streaming GEMM of the batched decode step in the row-streaming regime (65..256 chains; ze_launch_gemm_wide).
 // Rows = chains: a workgroup takes ALL rows (BM = 128 or 256, rows past M re-read the last one) and BN weight columns, so
 // the weights cross the chip once; the activations (M x K, L2-resident) are what every workgroup re-reads.  What bounds the
@@ -1270,7 +1456,16 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
         }
         const int grid4 = ze_cdiv(M, 256) * ze_cdiv(N, 256);
         const bool big = (2 * grid4 >= 3 * cus8) || (grid4 <= cus8 && 10 * grid4 >= 9 * cus8);
-        if (ze_gemv_knobs[7] == 4 || (ze_gemv_knobs[7] != 6 && big))
+        // (the 256 x 256 tile runs on the eight-phase kernel; knob 7 = 4: on the two-stage ring, 8: eight-phase at every grid)
+        const bool p8_ok = (lda % 8) == 0 && (ldw % 8) == 0 && (size_t)M * lda < ((size_t)1 << 31) && (size_t)N * ldw < ((size_t)1 << 31);
+        // its grid against the 128 x 256 ring's, in rounds of workgroups: a 128 x 256 tile takes ~0.6 of a 256 x 256 one
+        // (measured on the 3B prefill / ViT shapes at 1-13 K rows, tools/bench_prefill_shapes.py: e.g. 192 tiles of 256 x 256 =
+        // 0.75 round beat 384 of 128 x 256 = 2 rounds, 215 against 291 us for down at 6144 rows; 128 tiles lose, 210 against 160)
+        const int r8 = ze_cdiv(grid4, cus8), ra = ze_cdiv(2 * grid4, cus8);
+        const bool p8_wins = 10 * r8 <= 6 * ra;
+        if (p8_ok && (ze_gemv_knobs[7] == 8 || (ze_gemv_knobs[7] == 0 && p8_wins)))
+            launch_p8(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s);
+        else if (ze_gemv_knobs[7] == 4 || (ze_gemv_knobs[7] != 6 && big))
             launch_ring_variant<256, 256, 2, 2, 4, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s);
         else
             launch_ring_variant<128, 256, 3, 2, 4, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s);
