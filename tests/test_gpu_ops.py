@@ -234,26 +234,26 @@ def test_attention_every_instantiation(tiny_engine, d, heads, kvh, t, causal):
 
 @pytest.mark.parametrize("m,n,k,bias,act", [
     (200, 256, 64, True, 0), (300, 520, 128, False, 0), (777, 1000, 640, True, 0), (600, 1024, 192, False, 4),
-    (1000, 2560, 2048, True, 0), (2304, 4096, 2048, False, 4), (513, 257 * 8, 320, True, 1), (4096, 2048, 2752, False, 0),
+    (1000, 2560, 2048, True, 0), (2304, 4096, 2048, False, 4), (513, 257 * 8, 320, True, 0), (4096, 2048, 2752, False, 0),
+    (5, 16, 256, True, 0),
 ])
 def test_gemm_eight_phase_kernel(tiny_engine, m, n, k, bias, act):
     """k_gemm_p8 (256 x 256 tiles, half-tiles restaged three deep behind counted waits; the many-round GEMMs of the batched
-    prefill and of the ViT) against float64 and, bit for bit, against the two-stage ring on the same tile (ze_tune 7: 8 = the
-    eight-phase kernel at every grid, 4 = the ring): one K-tile, two, an odd count, ragged edges in both dimensions, every
-    epilogue of the path; repeats bit-identical (the race screen of a hand-placed wait)."""
+    prefill and of the ViT), launched directly (op_linear act 8 / 9), against float64 and, bit for bit, against the policy's
+    choice for the shape (the ring / register-staged kernels: same MFMA, same K order): one K-tile, two, three, an odd count,
+    ragged edges in both dimensions, a single partial tile; repeats bit-identical (the race screen of a hand-placed wait)."""
     a, w = rnd(41, (m, k)), rnd(42, (n, k), 0.05)
     b = rnd(43, (n,), 0.5) if bias else None
     da, dw, db = to_dev_bf16(a), to_dev_bf16(w), to_dev_bf16(b) if bias else None
     try:
-        tiny_engine.lib.ze_tune(7, 4)
-        ring = tiny_engine.op_linear(da, dw, db, act)
-        tiny_engine.lib.ze_tune(7, 8)
-        got_t = tiny_engine.op_linear(da, dw, db, act)
-        assert torch.equal(got_t, ring)
-        for _ in range(8):
-            assert torch.equal(tiny_engine.op_linear(da, dw, db, act), got_t)
+        tiny_engine.lib.ze_tune(7, 4)  # (never the eight-phase kernel)
+        ref = tiny_engine.op_linear(da, dw, db, act)
     finally:
         tiny_engine.lib.ze_tune(7, 0)
+    got_t = tiny_engine.op_linear(da, dw, db, 9 if act == 4 else 8)
+    assert torch.equal(got_t, ref)
+    for _ in range(8):
+        assert torch.equal(tiny_engine.op_linear(da, dw, db, 9 if act == 4 else 8), got_t)
     if act == 0:
         want = a.astype(np.float64) @ w.astype(np.float64).T + (b.astype(np.float64) if bias else 0.0)
         close_bf16(got_t.float().cpu().numpy(), want, scale=0.05 * np.sqrt(k) * 0.05)

@@ -1495,6 +1495,11 @@ extern "C" int ze_op_linear(ze_engine* e, const void* a, const void* w, const vo
         if (act == 7 && N % 32) return ze_fail(e, ZE_ERR_INVALID, "SwiGLU: N = 2 * width with width % 16 == 0");
         ze_launch_gemm_wide(act == 7 ? ZE_EPI_SWIGLU : ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias,
                             nullptr, 0, (bf16_t*)cmat, act == 7 ? N / 2 : N, M, N, K, e->gemm_ws(), s);
+    } else if (act == 8 || act == 9) {  // the eight-phase 256 x 256 kernel whatever the grid (9: SwiGLU), for its tests
+        if (act == 9 && N % 32) return ze_fail(e, ZE_ERR_INVALID, "SwiGLU: N = 2 * width with width % 16 == 0");
+        if (K % 64 || K < 64) return ze_fail(e, ZE_ERR_INVALID, "eight-phase kernel: K a multiple of 64");
+        ze_launch_gemm_p8(act == 9 ? ZE_EPI_SWIGLU : ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias, nullptr, 0,
+                          (bf16_t*)cmat, act == 9 ? N / 2 : N, nullptr, M, N, K, s);
     } else if (act == 2) {  // weight-streaming mode of the batched decode step (rows = chains), for measurements
         ze_launch_gemm_stream(ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias, nullptr, 0,
                               (bf16_t*)cmat, N, M, N, K, e->gemm_ws(), s);

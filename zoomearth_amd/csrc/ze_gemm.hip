@@ -585,40 +585,41 @@ __global__ void __launch_bounds__(512) k_gemm_p8(const bf16_t* __restrict__ A, i
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
     const int nwg = nbx * nby;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
     const bool col_major = N > M;  // (see k_gemm_ring)
-    const int bm0 = (col_major ? bid % nby : bid / nbx) * BM, bn0 = (col_major ? bid / nby : bid % nbx) * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
     const int fr = lane & 15, fq = lane >> 4;
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nk = K / GEMM_BK;
-
     const unsigned smem_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem);
+
+    // PERSISTENT: workgroup g takes tiles g, g + gridDim.x, ... of the launch order (the XCD-aware remap of k_gemm_ring applied to
+    // that order: gridDim.x is a multiple of 8, so a workgroup's tiles keep its XCD label), and the first seven half-tiles of
+    // its NEXT tile are requested before the epilogue of the current one -- the ~2 us a tile's prologue waits for its first
+    // K-tile pass behind the stores (K = 2048: 32 K-tiles of ~1.9 us per tile; K = 1280, the ViT: 20).
+    int bm0 = 0, bn0 = 0, bid = 0;
+    auto place = [&](int tile) {
+        const int q = nwg / 8, r = nwg % 8, xcd = tile % 8, idx = tile / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        bm0 = (col_major ? bid % nby : bid / nbx) * BM;
+        bn0 = (col_major ? bid / nby : bid % nbx) * BN;
+    };
     // DMA sources: this wave moves pieces 2 wid and 2 wid + 1 (8 half-tile rows x 128 B each) of every half-tile; byte offsets
     // from the operand's base (32 bits: the operands of this path are far below 4 GB), the K offset rides in the scalar base
     unsigned offA[2][2], offB[2][2];
+    auto sources = [&]() {
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int hr = (wid * 2 + q) * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((hr >> 1) & 7);
-            const int ra = min(bm0 + (hr >> 6) * 128 + h * 64 + (hr & 63), M - 1);
-            const int rb = min(bn0 + (hr >> 5) * 64 + h * 32 + (hr & 31), N - 1);
-            offA[h][q] = (unsigned)(((size_t)ra * lda + c * 8) * sizeof(bf16_t));
-            offB[h][q] = (unsigned)(((size_t)rb * ldw + c * 8) * sizeof(bf16_t));
-        }
+            for (int q = 0; q < 2; ++q) {
+                const int hr = (wid * 2 + q) * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ ((hr >> 1) & 7);
+                const int ra = min(bm0 + (hr >> 6) * 128 + h * 64 + (hr & 63), M - 1);
+                const int rb = min(bn0 + (hr >> 5) * 64 + h * 32 + (hr & 31), N - 1);
+                offA[h][q] = (unsigned)(((size_t)ra * lda + c * 8) * sizeof(bf16_t));
+                offB[h][q] = (unsigned)(((size_t)rb * ldw + c * 8) * sizeof(bf16_t));
+            }
+    };
     // slot 0..3 = A-half 0, A-half 1, W-half 0, W-half 1
     auto stage = [&](int slot, int t) {
         const unsigned dst = smem_lds + (t & 1) * BUF + slot * HALF + wid * 2048;
@@ -633,11 +634,24 @@ __global__ void __launch_bounds__(512) k_gemm_p8(const bf16_t* __restrict__ A, i
                          : "memory");
         }
     };
+    // a tile's prologue, in the loop's order of issue: tile 0 whole, then the three half-tiles of tile 1 that phases 2-4 stage
+    auto prologue = [&]() {
+        stage(0, 0);
+        stage(2, 0);
+        stage(3, 0);
+        stage(1, 0);
+        if (nk > 1) {
+            stage(0, 1);
+            stage(2, 1);
+            stage(3, 1);
+        }
+    };
     // fragment addresses: half-tile row = (wr * 64 | wc * 32) + 16 i + fr; the swizzle term (row >> 1) & 7 = fr >> 1 for all i
     const int sw = (fr >> 1) & 7;
     const unsigned aoff0 = (wr * 64 + fr) * 128 + (((0 + fq) ^ sw) << 4), aoff1 = (wr * 64 + fr) * 128 + (((4 + fq) ^ sw) << 4);
     const unsigned boff0 = (wc * 32 + fr) * 128 + (((0 + fq) ^ sw) << 4), boff1 = (wc * 32 + fr) * 128 + (((4 + fq) ^ sw) << 4);
     bf16x8 fa[2][4], fb0[2][2], fb1[2][2];
+    f32x4 acc[8][4];
     auto read_a = [&](int b, int mh) {
         const uint8_t* p = smem + b * BUF + mh * HALF;
 #pragma unroll
@@ -666,64 +680,83 @@ __global__ void __launch_bounds__(512) k_gemm_p8(const bf16_t* __restrict__ A, i
         __builtin_amdgcn_s_setprio(0);
     };
 
-    // prologue, in the loop's order of issue: tile 0 whole, then the three half-tiles of tile 1 that phases 2-4 of a tile stage
-    stage(0, 0);
-    stage(2, 0);
-    stage(3, 0);
-    stage(1, 0);
-    if (nk > 1) {
-        stage(0, 1);
-        stage(2, 1);
-        stage(3, 1);
-        ring_wait<6>();
-    } else {
-        ring_wait<0>();
-    }
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs one barrier behind the first
+    int tile = blockIdx.x;
+    if (tile >= nwg) return;
+    place(tile);
+    sources();
+    prologue();
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (a first tile: the seven half-tiles just issued; a later one: they were issued before the previous tile's epilogue,
+        //  whose stores share the counter -- everything has to be back)
+        if (tile == (int)blockIdx.x && nk > 1) ring_wait<6>();
+        else ring_wait<0>();
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave row runs one barrier behind the first
 
-    for (int t = 0; t < nk; ++t) {
-        const int b = t & 1;
-        // ---- phase 1
-        read_a(b, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        read_b(fb0, b, 0);
-        if (t + 1 < nk) stage(1, t + 1);
-        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // the A-half 0 reads are over: phase 2 restages it
-        __builtin_amdgcn_s_barrier();
-        quadrant(0, 0, fb0);
-        __builtin_amdgcn_s_barrier();
-        // ---- phase 2
-        read_b(fb1, b, 1);
-        if (t + 2 < nk) stage(0, t + 2);
-        __builtin_amdgcn_s_barrier();
-        quadrant(0, 1, fb1);
-        __builtin_amdgcn_s_barrier();
-        // ---- phase 3
-        read_a(b, 1);
-        if (t + 2 < nk) stage(2, t + 2);
-        __builtin_amdgcn_s_barrier();
-        quadrant(1, 1, fb1);
-        __builtin_amdgcn_s_barrier();
-        // ---- phase 4: everything older than the three half-tiles just issued has landed (= all of tile t + 1)
-        if (t + 2 < nk) {
-            stage(3, t + 2);
-            ring_wait<6>();
-        } else {
-            ring_wait<0>();
+        for (int t = 0; t < nk; ++t) {
+            const int b = t & 1;
+            // ---- phase 1
+            read_a(b, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_b(fb0, b, 0);
+            if (t + 1 < nk) stage(1, t + 1);
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // the A-half 0 reads are over: phase 2 restages it
+            __builtin_amdgcn_s_barrier();
+            quadrant(0, 0, fb0);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 2
+            read_b(fb1, b, 1);
+            if (t + 2 < nk) stage(0, t + 2);
+            __builtin_amdgcn_s_barrier();
+            quadrant(0, 1, fb1);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 3
+            read_a(b, 1);
+            if (t + 2 < nk) stage(2, t + 2);
+            __builtin_amdgcn_s_barrier();
+            quadrant(1, 1, fb1);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 4: everything older than the three half-tiles just issued has landed (= all of tile t + 1)
+            if (t + 2 < nk) {
+                stage(3, t + 2);
+                ring_wait<6>();
+            } else {
+                ring_wait<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            quadrant(1, 0, fb0);
+            __builtin_amdgcn_s_barrier();
         }
-        __builtin_amdgcn_s_barrier();
-        quadrant(1, 0, fb0);
-        __builtin_amdgcn_s_barrier();
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+        // every wave is past its last fragment read (wave row 0: of phase 3, two barriers back; row 1: likewise behind the
+        // barrier it just shared): the LDS is free for the next tile's first half-tiles
+        const int done_bid = bid, done_bm0 = bm0, done_bn0 = bn0;
+        tile += gridDim.x;
+        const bool more = tile < nwg;
+        if (more) {
+            place(tile);
+            sources();
+            prologue();
+        }
+        gemm_finish<BM, BN, EPI, 2, 4>(acc, smem, bias, R, ldr, C, ldc, c_rows, M, N, 1, 0, done_bid, nwg, done_bm0, done_bn0, nullptr, nullptr);
+        if (!more) break;
     }
-    if (wr == 0) __builtin_amdgcn_s_barrier();
-    __syncthreads();  // the tail reuses the staging LDS
-    gemm_finish<BM, BN, EPI, 2, 4>(acc, smem, bias, R, ldr, C, ldc, c_rows, M, N, 1, 0, bid, nwg, bm0, bn0, nullptr, nullptr);
 }
 
 static void launch_p8(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R, int ldr,
                       bf16_t* C, int ldc, const int* c_rows, int M, int N, int K, hipStream_t s) {
-    const int grid = ze_cdiv(M, 256) * ze_cdiv(N, 256);
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cus = std::max(8, cus / 8 * 8);  // (a multiple of 8: a persistent workgroup's tiles keep its XCD label)
+    }
+    const int grid = std::min(ze_cdiv(M, 256) * ze_cdiv(N, 256), cus);
     const size_t lds = 128 * 1024;
 #define ZE_P8_LAUNCH(E)                                                                                                        \
     do {                                                                                                                       \
@@ -1763,6 +1796,12 @@ static bool launch_splitk_two(int epi, const bf16_t* A, int lda, const bf16_t* W
     else
         hipLaunchKernelGGL((k_splitk_reduce<BM, BN, 2, 4, ZE_EPI_NONE>), dim3(grid), dim3(512), 0, s, ws.slab, ksplit, bias, R, ldr, C, ldc, M, N);
     return true;
+}
+
+void ze_launch_gemm_p8(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R, int ldr,
+                       bf16_t* C, int ldc, const int* c_rows, int M, int N, int K, hipStream_t s) {
+    if (M <= 0 || N <= 0) return;
+    launch_p8(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s);
 }
 
 void ze_launch_gemm_stream(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,

@@ -102,6 +102,10 @@ void ze_launch_gemm_stream(int epi, const bf16_t* A, int lda, const bf16_t* W, i
 void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
                          int ldr, bf16_t* C, int ldc, int M, int N, int K, const ze_gemm_ws& ws, hipStream_t s);
 
+// the eight-phase 256 x 256 kernel directly (ze_launch_gemm picks it for many-round grids); K % 64 == 0, lda / ldw % 8 == 0
+void ze_launch_gemm_p8(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R, int ldr,
+                       bf16_t* C, int ldc, const int* c_rows, int M, int N, int K, hipStream_t s);
+
 // ---- decode GEMV family (batch-1 weight streaming)
 struct ze_gemv_args {
     const bf16_t* W;      // [N, ldw] packed weight

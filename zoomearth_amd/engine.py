@@ -418,7 +418,7 @@ class Engine:
     def op_linear(self, a, w, bias=None, act: int = 0):
         m, k = a.shape
         n = w.shape[0]
-        out = torch.empty((m, n // 2 if act in (4, 7) else n), dtype=torch.bfloat16, device=self.device)
+        out = torch.empty((m, n // 2 if act in (4, 7, 9) else n), dtype=torch.bfloat16, device=self.device)
         self._check(self.lib.ze_op_linear(self.h, _ptr(a), _ptr(w), _ptr(bias), _ptr(out), m, n, k, act, self._stream()))
         return out
 
