@@ -156,6 +156,14 @@ int ze_vit_forward(ze_engine* e, const float* pixel_values, const int32_t* grid_
  * also clears the repetition-penalty set (the caller re-marks the new prompt with ze_seq_mark_seen). */
 int ze_seq_reset(ze_engine* e, int seq, void* stream);
 int ze_seq_truncate(ze_engine* e, int seq, int keep_len, void* stream);
+/* The chain in `seq` is over and the slot may go to another chain.  Chains that copied their prompt prefix from it
+ * (ze_seq_copy_prefix) read those rows from ITS cache during decode (one copy per tile crosses the memory interface): this
+ * call moves them to another holder of the same rows, in stream order.  ze_seq_reset does the same; a scheduler that
+ * prefills on a second stream calls ze_seq_retire on the DECODE stream when it frees the slot, before the next decode step
+ * (reference: no counterpart -- HF generate() holds every chain's cache for the whole call). */
+int ze_seq_retire(ze_engine* e, int seq, void* stream);
+/* (source chain << 16) | rows: whose cache the decode attention reads the first rows of `seq` from; 0 = its own. */
+int ze_seq_prefix_hint(ze_engine* e, int seq);
 int ze_seq_len(ze_engine* e, int seq);
 /* Shared prompt prefixes (the questions about one tile start with the same system turn and the same view's image tokens --
  * 347 of the 802 tokens of a stage-1 prompt, src/eval/infer.py:180-214): chain `dst_seq` becomes the first `n_tokens`

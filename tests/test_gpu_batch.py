@@ -364,3 +364,66 @@ def test_per_wave_attention_kernel_is_batch_invariant_and_agrees_with_the_ring_k
     finally:
         e.lib.ze_tune(8, 0)
         e.close()
+
+
+@pytest.fixture()
+def eng4():
+    from gpu_util import oracle_cfg_to_model_cfg
+    from zoomearth_amd.engine import Engine
+    e = Engine(oracle_cfg_to_model_cfg(), device=0, max_seqs=4, max_ctx=512, max_patches=1024, max_tile_side=1024)
+    e.fill_synthetic(**CHAIN_W)
+    yield e
+    e.close()
+
+
+def test_decode_reads_a_shared_prefix_from_one_holder_and_survives_its_retirement(eng4):
+    """The questions of a tile copy their common prefix (ze_seq_copy_prefix); during decode the attention reads those rows
+    from the SOURCE chain's cache (ze_seq_dev::prefix: one copy per tile crosses the memory interface).  Checked: the hints
+    follow the copies; the steps equal, bit for bit, those of chains prefilled in full (no hint); when the source retires
+    or is reset and its slot is overwritten by another prompt, the readers move to the holder of the longest copy and the
+    steps still equal the reference."""
+    e = eng4
+    head = [int(t) for t in prng.uniform_ints(401, 120, 10, 1990)]
+    prompts = [head + [int(t) for t in prng.uniform_ints(402 + s, 20 + 9 * s, 10, 1990)] for s in range(4)]
+    keep = {1: 120, 2: 64, 3: 97}
+    forced = [[int(t) for t in prng.uniform_ints(450 + i, 4, 10, 1990)] for i in range(6)]
+
+    def steps(slots, lo, hi):
+        return [e.decode_batch(slots, [forced[i][s] for s in slots]).cpu().numpy() for i in range(lo, hi)]
+
+    # reference: every prompt prefilled in full, no hint anywhere
+    for s in range(4):
+        prefill_text(e, s, prompts[s])
+        assert e.seq_prefix_hint(s) == (s, 0)
+    want = steps([1, 2, 3], 0, 6)
+    # chain 0 holds the head; 1..3 copy 120 / 64 / 97 rows of it and prefill the rest of their prompts
+    prefill_text(e, 0, prompts[0])
+    for s, n in keep.items():
+        e.seq_reset(s)
+        e.seq_copy_prefix(s, 0, n)
+        pos, delta = e.rope_index(prompts[s], [])
+        e.prefill(s, prompts[s][n:], None, pos[:, n:], delta, want_logits=False)
+        assert e.seq_prefix_hint(s) == (0, n)
+    got = steps([1, 2, 3], 0, 2)
+    # the source's slot goes to another prompt: the readers move to chain 1 (the holder of the longest copy)
+    e.seq_retire(0)
+    assert e.seq_prefix_hint(1) == (1, 0) and e.seq_prefix_hint(2) == (1, 64) and e.seq_prefix_hint(3) == (1, 97)
+    prefill_text(e, 0, [int(t) for t in prng.uniform_ints(499, 150, 10, 1990)])
+    got += steps([1, 2, 3], 2, 4)
+    # ... and chain 1's too (a reset): 3 takes over, 2 follows it
+    e.seq_reset(1)
+    assert e.seq_prefix_hint(3) == (3, 0) and e.seq_prefix_hint(2) == (3, 64)
+    prefill_text(e, 1, [int(t) for t in prng.uniform_ints(498, 140, 10, 1990)])
+    got += steps([2, 3], 4, 6)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert np.array_equal(a, b if i < 4 else b[1:]), i
+    # a chain that copies from a reader is pointed at the reader's source when that one covers the rows
+    e.seq_reset(0)
+    e.seq_copy_prefix(0, 2, 50)
+    assert e.seq_prefix_hint(0) == (3, 50)
+    e.seq_reset(0)
+    e.seq_copy_prefix(0, 2, 70)   # (beyond the 64 rows chain 2 shares with chain 3: chain 2's own rows)
+    assert e.seq_prefix_hint(0) == (2, 70)
+    for s in range(4):
+        e.seq_reset(s)
+        assert e.seq_prefix_hint(s) == (s, 0)

@@ -283,6 +283,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AW_VST
     const int fr = lane & 15, fq = lane >> 4;
     const bf16_t* kb = kcache + (size_t)seq * cache_seq_stride + (size_t)kvh * max_ctx * D;
     const bf16_t* vb = vcache + (size_t)seq * cache_seq_stride + (size_t)kvh * max_ctx * D;
+    // rows below P: the same bits live in the source chain's cache (ze_seq_dev::prefix) -- read THAT copy, the one every
+    // question of the tile reads, so that the image prefix crosses the HBM interface once per step and not once per chain
+    const int hint = st_base[seq].prefix;
+    const int pfx_rows = hint & 0xffff;
+    const long long pfx_delta = ((long long)(hint >> 16) - (long long)seq) * (long long)cache_seq_stride;  // in elements
     const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem) +
                               (unsigned)wid * (AW_VSTAGES * AW_VSTAGE);
     const uint8_t* ring = smem + wid * (AW_VSTAGES * AW_VSTAGE);
@@ -306,7 +311,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AW_VST
         for (int pp = 0; pp < 4; ++pp) {  // piece pp = rows 4pp .. 4pp + 3; the ad_off swizzle on the source chunk (ab_issue)
             const int row = 4 * pp + r4;
             const int ch = pos ^ ((r4 << 2) | (pp & 3));
-            const bf16_t* src = vb + (size_t)min(tok0 + row, t1 - 1) * D + ch * 8;
+            const int tok = min(tok0 + row, t1 - 1);
+            const bf16_t* src = vb + (tok < pfx_rows ? pfx_delta : 0ll) + (size_t)tok * D + ch * 8;
             unsigned keep;
             asm volatile(
                 "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -318,7 +324,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AW_VST
 #pragma unroll
     for (int u = 0; u < AW_ROUNDS; ++u) {
         const int tok0 = t0 + u * AW_TOK + wid * 16;  // rows past t1 re-read row t1 - 1 (finite; masked below)
-        const bf16_t* ksrc = kb + (size_t)min(tok0 + fr, t1 - 1) * D + fq * 8;
+        const int ktok = min(tok0 + fr, t1 - 1);
+        const bf16_t* ksrc = kb + (ktok < pfx_rows ? pfx_delta : 0ll) + (size_t)ktok * D + fq * 8;
         asm volatile(
             "global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:64\n\t"
             "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:192"

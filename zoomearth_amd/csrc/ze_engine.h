@@ -100,6 +100,8 @@ struct ze_engine {
     uint8_t* seen = nullptr;
     int32_t* out_tokens = nullptr;
     std::vector<int> ctx_host, delta_host;
+    std::vector<int> pfx_host;     // ze_seq_dev::prefix per chain
+    bool prefix_hints = true;      // ZE_PREFIX_HINT=0: every chain reads its own rows
     std::vector<hipGraphExec_t> graphs;
     std::vector<float> graph_penalty;
     std::vector<int> graph_ignore_eos;

@@ -281,6 +281,11 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     chk(dev_alloc(e, &e->seen, (size_t)c.max_seqs * c.vocab));
     chk(dev_alloc(e, &e->out_tokens, (size_t)c.max_seqs * c.max_ctx));
     e->ctx_host.assign(c.max_seqs, 0);
+    e->pfx_host.assign(c.max_seqs, 0);
+    {
+        const char* ph = getenv("ZE_PREFIX_HINT");
+        e->prefix_hints = !(ph && ph[0] == '0') && c.max_seqs < 32768 && c.max_ctx < 65536;
+    }
     e->delta_host.assign(c.max_seqs, 0);
     e->graphs.assign(c.max_seqs, nullptr);
     e->graph_penalty.assign(c.max_seqs, 0.f);

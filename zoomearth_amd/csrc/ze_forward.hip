@@ -321,9 +321,33 @@ static int check_seq(ze_engine* e, int seq) {
     return ZE_OK;
 }
 
+// ---- shared-prefix hints (ze_seq_dev::prefix)
+static void set_prefix_hint(ze_engine* e, int seq, int value, hipStream_t s) {
+    if (e->pfx_host[seq] == value) return;
+    e->pfx_host[seq] = value;
+    ze_launch_set_ints(&(e->st_dev + seq)->prefix, &value, 1, s);
+}
+// rows below `keep` of chain `seq` are about to change (or the chain is over): chains that read their prefix from it move to
+// the one among them with the longest prefix (its own copy holds the same bits), which goes back to reading its own rows
+static void prefix_source_gone(ze_engine* e, int seq, int keep, hipStream_t s) {
+    int leader = -1, lead_p = 0;
+    const int n = (int)e->pfx_host.size();
+    for (int d = 0; d < n; ++d) {
+        const int h = e->pfx_host[d];
+        if (h != 0 && (h >> 16) == seq && (h & 0xffff) > keep && (h & 0xffff) > lead_p) leader = d, lead_p = h & 0xffff;
+    }
+    if (leader < 0) return;
+    for (int d = 0; d < n; ++d) {
+        const int h = e->pfx_host[d];
+        if (h == 0 || (h >> 16) != seq || (h & 0xffff) <= keep) continue;
+        set_prefix_hint(e, d, d == leader ? 0 : ((leader << 16) | (h & 0xffff)), s);
+    }
+}
+
 static int push_state(ze_engine* e, int seq, hipStream_t s, int token, int n_gen, int finished) {
     ze_seq_dev st;
     memset(&st, 0, sizeof(st));
+    st.prefix = e->pfx_host[seq];
     st.ctx = e->ctx_host[seq];
     st.rope_delta = e->delta_host[seq];
     st.token = token;
@@ -341,8 +365,27 @@ extern "C" int ze_seq_reset(ze_engine* e, int seq, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     e->ctx_host[seq] = 0;
     e->delta_host[seq] = 0;
+    prefix_source_gone(e, seq, 0, s);
+    e->pfx_host[seq] = 0;
     ZE_HIP(hipMemsetAsync(e->seen + (size_t)seq * e->cfg.vocab, 0, e->cfg.vocab, s));
     return push_state(e, seq, s, 0, 0, 0);
+}
+
+// The chain in `seq` is over and its slot may be given to another chain: nobody reads a prefix from it after this call (in
+// stream order).  A scheduler that prefills on a second stream calls this on the DECODE stream when it releases a slot, before
+// the next decode step is enqueued -- ze_seq_reset, which does the same, may run there on the other stream.
+extern "C" int ze_seq_retire(ze_engine* e, int seq, void* stream) {
+    ZE_TRY(check_seq(e, seq));
+    hipSetDevice(e->device);
+    prefix_source_gone(e, seq, 0, (hipStream_t)stream);
+    set_prefix_hint(e, seq, 0, (hipStream_t)stream);
+    return ZE_OK;
+}
+
+// (source chain << 16) | rows: where the decode attention reads the first rows of `seq` from; 0 = its own cache
+extern "C" int ze_seq_prefix_hint(ze_engine* e, int seq) {
+    if (check_seq(e, seq) != 0) return ZE_ERR_NOTFOUND;
+    return e->pfx_host[seq];
 }
 
 extern "C" int ze_seq_truncate(ze_engine* e, int seq, int keep_len, void* stream) {
@@ -350,6 +393,8 @@ extern "C" int ze_seq_truncate(ze_engine* e, int seq, int keep_len, void* stream
     if (keep_len < 0 || keep_len > e->ctx_host[seq]) return ze_fail(e, ZE_ERR_INVALID, "keep_len out of range");
     hipSetDevice(e->device);
     e->ctx_host[seq] = keep_len;
+    prefix_source_gone(e, seq, keep_len, (hipStream_t)stream);   // rows from keep_len on will be rewritten
+    if ((e->pfx_host[seq] & 0xffff) > keep_len) e->pfx_host[seq] = 0;
     // the seen-set belongs to the dropped continuation: the caller re-marks the (new) prompt
     ZE_HIP(hipMemsetAsync(e->seen + (size_t)seq * e->cfg.vocab, 0, e->cfg.vocab, (hipStream_t)stream));
     return push_state(e, seq, (hipStream_t)stream, 0, 0, 0);
@@ -369,6 +414,15 @@ extern "C" int ze_seq_copy_prefix(ze_engine* e, int dst_seq, int src_seq, int n_
     ZE_KCHECK();
     e->ctx_host[dst_seq] = n_tokens;
     e->delta_host[dst_seq] = 0;
+    prefix_source_gone(e, dst_seq, 0, s);
+    // the copy stays (the prefill attention of a later pass reads the chain's own rows); the decode attention reads the
+    // source's -- or the source's own source, when that one covers these rows
+    {
+        int src = src_seq;
+        const int hs = e->pfx_host[src_seq];
+        if (hs != 0 && (hs & 0xffff) >= n_tokens) src = hs >> 16;
+        e->pfx_host[dst_seq] = (e->prefix_hints && n_tokens < 65536 && src != dst_seq) ? ((src << 16) | n_tokens) : 0;
+    }
     ZE_HIP(hipMemsetAsync(e->seen + (size_t)dst_seq * c.vocab, 0, c.vocab, s));
     return push_state(e, dst_seq, s, 0, 0, 0);
 }

@@ -756,7 +756,8 @@ static void launch_p8(int epi, const bf16_t* A, int lda, const bf16_t* W, int ld
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         cus = std::max(8, cus / 8 * 8);  // (a multiple of 8: a persistent workgroup's tiles keep its XCD label)
     }
-    const int grid = std::min(ze_cdiv(M, 256) * ze_cdiv(N, 256), cus);
+    const int tiles = ze_cdiv(M, 256) * ze_cdiv(N, 256);
+    const int grid = ze_gemv_knobs[7] == 9 ? tiles : std::min(tiles, cus);  // (knob 7 = 9: one tile per workgroup, for A/B runs)
     const size_t lds = 128 * 1024;
 #define ZE_P8_LAUNCH(E)                                                                                                        \
     do {                                                                                                                       \
@@ -1496,7 +1497,7 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
         // 0.75 round beat 384 of 128 x 256 = 2 rounds, 215 against 291 us for down at 6144 rows; 128 tiles lose, 210 against 160)
         const int r8 = ze_cdiv(grid4, cus8), ra = ze_cdiv(2 * grid4, cus8);
         const bool p8_wins = 10 * r8 <= 6 * ra;
-        if (p8_ok && (ze_gemv_knobs[7] == 8 || (ze_gemv_knobs[7] == 0 && p8_wins)))
+        if (p8_ok && (ze_gemv_knobs[7] == 8 || ((ze_gemv_knobs[7] == 0 || ze_gemv_knobs[7] == 9) && p8_wins)))
             launch_p8(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s);
         else if (ze_gemv_knobs[7] == 4 || (ze_gemv_knobs[7] != 6 && big))
             launch_ring_variant<256, 256, 2, 2, 4, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s);

@@ -17,7 +17,9 @@ struct ze_seq_dev {
     int32_t n_gen;      // tokens written to out_tokens so far
     int32_t max_gen;    // capacity of out_tokens
     int32_t stream;     // sampling stream of this chain: its row in the generate call (0 for single-chain calls)
-    int32_t pad1;
+    int32_t prefix;     // (source chain << 16) | P: rows 0 .. P-1 of the source chain's KV cache hold the same bits as this
+                        // chain's own (ze_seq_copy_prefix); 0 = none.  The decode attention reads those rows from the SOURCE,
+                        // so the questions of one tile stream one copy of the image prefix (Infinity Cache hits)
 };
 
 // ---- front-end

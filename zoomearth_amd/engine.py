@@ -208,6 +208,20 @@ class Engine:
     def seq_reset(self, seq: int):
         self._check(self.lib.ze_seq_reset(self.h, seq, self._stream()))
 
+    def seq_retire(self, seq: int, stream=None):
+        """The chain in `seq` is over: chains that read their prompt prefix from its cache move to another holder of the same
+        rows.  `stream`: the stream the decode steps run on (default: the current one)."""
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
+        self._check(self.lib.ze_seq_retire(self.h, seq, st))
+
+    def seq_prefix_hint(self, seq: int):
+        """(source chain, rows): the decode attention reads the first `rows` cached tokens of `seq` from the source's cache
+        (the same bits; one copy per tile in flight); (seq, 0) when it reads its own."""
+        h = int(self.lib.ze_seq_prefix_hint(self.h, seq))
+        if h < 0:
+            self._check(h)
+        return (h >> 16, h & 0xffff) if h else (seq, 0)
+
     def seq_truncate(self, seq: int, keep: int):
         self._check(self.lib.ze_seq_truncate(self.h, seq, keep, self._stream()))
 

@@ -445,6 +445,7 @@ class ChainScheduler:
     def _burst_end(self, handle) -> None:
         e = self.engine
         slots, ran = handle
+        self._decode_stream = torch.cuda.current_stream(e.device) if self._side is not None else None
         n_gen, fin = e.decode_burst_end(slots)
         self.stats["bursts"] += 1
         self.stats["steps"] += ran
@@ -476,12 +477,22 @@ class ChainScheduler:
             self.parked[slot] = (l.ids, l.keys, tuple(req.tokens[:max(0, cached)]))
             self.waiting.appendleft(follow)
         else:
+            self._retire_slot(slot)
             self.free.append(slot)
+
+    def _retire_slot(self, slot: int) -> None:
+        """The slot's rows may be overwritten from now on: the chains that read their prompt prefix from it (the decode
+        attention streams ONE copy of a tile's image prefix) are moved to another holder -- on the stream the decode steps run
+        on, i.e. before the next burst, whatever stream the admission work uses."""
+        retire = getattr(self.engine, "seq_retire", None)
+        if retire is not None:
+            retire(slot, stream=getattr(self, "_decode_stream", None))
 
     def _release(self, req: Request) -> None:
         if req.slot >= 0:
             self.parked.pop(req.slot, None)
             try:
+                self._retire_slot(req.slot)
                 self.engine.seq_reset(req.slot)   # nothing may copy a prefix from what the slot held before
             except Exception:
                 pass
