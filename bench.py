@@ -884,8 +884,8 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[3] (LRS-GRO question stream, sharded by tile across the GPUs; ZoomEarth-3B shape): "
                                     f"{n_questions} questions about {len(set(tile_of))} tiles of {args.tile}x{args.tile} px ({Q_STEP} questions per GPU "
-                                    f"per step), full two-stage zoom chain per question, greedy, {SLOTS} chain slots per GPU on the "
-                                    f"continuous-batching scheduler (the path of src/eval/infer.py)") if stream else
+                                    f"per step), full two-stage zoom chain per question, greedy, {len(engines)} lane(s) x {SLOTS} chain slots per GPU on the "
+                                    f"continuous-batching scheduler (the path of src/eval/infer.py --lanes)") if stream else
                                    ("BASELINE configs[1]: ZoomEarth-3B shape, one 5000x5000 tile per GPU, full two-stage "
                                     "zoom chain per question, greedy, batch 1") if B == 1 else
                                    (f"BASELINE configs[2]: ZoomEarth-3B shape, {B} question chains about {len(dev_tiles)} tiles advanced "
@@ -897,7 +897,8 @@ def main():
                        "repetition_penalty": PENALTY, "hip_graph": use_graph,
                        "reuse": ("stage-1 prompt KV and view features reused in stage 2 (bit-identical); the KV rows of the "
                                  "generated tokens that stage 2 re-inserts id for id are kept as the decode steps wrote them; "
-                                 "prompt prefixes shared between the questions of a tile (bit-identical)"),
+                                 "prompt prefixes shared between the questions of a tile (bit-identical) and read from ONE holder's cache "
+                                 "by the decode attention"),
                        "parallelism": f"dp{world}", "sharding": "accel.shard_by_tile (tile-level LPT, no data-path collective)",
                        "weight_broadcast_s": round(bcast_s, 4)},
             "weight_broadcast_s": round(bcast_s, 4),

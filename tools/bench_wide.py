@@ -17,13 +17,25 @@ NAMES = ["qkv", "o_proj", "gate_up", "down", "lm_head", "attention", "rmsnorm", 
 e = Engine(ModelConfig.zoomearth_3b(), max_seqs=B, max_ctx=2048, max_patches=2048, max_tile_side=1024, max_prefill_rows=16 * 1024)
 e.fill_synthetic(0)
 lens = [800 + int(v) for v in uniform_ints(5, B, 0, 640)]  # ragged: 800 .. 1440 tokens (mean ~1120)
+GROUP = int(os.environ.get("ZE_GROUP", "1"))      # chains per tile: the first ZE_SHARED prompt tokens are the tile's (one prefill,
+SHARED = int(os.environ.get("ZE_SHARED", "347"))  # copied to the others: ze_seq_copy_prefix, as the scheduler does)
 for g0 in range(0, B, 8):
     gs = list(range(g0, min(B, g0 + 8)))
     ids = [uniform_ints(100 + s, lens[s], 1000, 150000).tolist() for s in gs]
+    if GROUP > 1:
+        ids = [uniform_ints(7000 + s // GROUP, SHARED, 1000, 150000).tolist() + i[SHARED:] for s, i in zip(gs, ids)]
     pl = [e.rope_index(i, []) for i in ids]
     for s in gs:
         e.seq_reset(s)
-    e.prefill_batch(gs, ids, [None] * len(gs), [p[0] for p in pl], [p[1] for p in pl])
+    lead = [s for s in gs if GROUP == 1 or s % GROUP == 0]
+    if lead:
+        e.prefill_batch(lead, [ids[s - g0] for s in lead], [None] * len(lead), [pl[s - g0][0] for s in lead], [pl[s - g0][1] for s in lead])
+    rest = [s for s in gs if s not in lead]
+    for s in rest:
+        e.seq_copy_prefix(s, s - s % GROUP, SHARED)
+    if rest:
+        e.prefill_batch(rest, [ids[s - g0][SHARED:] for s in rest], [None] * len(rest), [pl[s - g0][0][:, SHARED:] for s in rest],
+                        [pl[s - g0][1] for s in rest])
 print(f"{B} chain slots, contexts {min(lens)}..{max(lens)} (mean {sum(lens) / B:.0f}); family {e.set_decode_regime(-1)}", flush=True)
 for tune in tunes:
     for k in range(16):

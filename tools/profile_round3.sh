@@ -31,6 +31,6 @@ for mode in wide batch64 configs1; do
 done
 # MFMA utilisation of the stream's kernels (eager launches: counters are per dispatch)
 rm -rf /tmp/p_mfma
-( cd "$root" && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/p_mfma -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-batch64 --no-configs1 --no-graph > /dev/null 2> "$out/${tag}_mfma.log" )
+( cd "$root" && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/p_mfma -- python3 bench.py --steps 2 --warmup 0 --lanes 1 --no-cpu-baseline --no-batch64 --no-configs1 --no-graph > /dev/null 2> "$out/${tag}_mfma.log" )
 python3 "$root/tools/summarize_prof.py" /tmp/p_mfma "$out/${tag}_stream_pmc_mfma_busy.csv" --delete-raw
 ls -la "$out" | grep "${tag}_" | tail -30

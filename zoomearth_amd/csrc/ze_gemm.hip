@@ -1780,9 +1780,9 @@ static int stream_ksplit(int N, int K) {
 
 // long-K projection, more than 256 rows: 128 x 256 tiles (64 x 64 per wave: half the LDS fragment reads per MFMA of the
 // 64 x 64 tile's 16 x 32) on the slices of the one-launch form, then the chip-wide reduction; false = does not apply
+template <int BM, int BN, int ST, bool SPR>
 static bool launch_splitk_two(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
                               int ldr, bf16_t* C, int ldc, int M, int N, int K, const ze_gemm_ws& ws, hipStream_t s) {
-    constexpr int BM = 128, BN = 256;
     if (epi != ZE_EPI_RESIDUAL && epi != ZE_EPI_NONE) return false;
     const int ksplit = stream_ksplit(N, K);
     const int nwg = ze_cdiv(M, BM) * ze_cdiv(N, BN);
@@ -1790,7 +1790,7 @@ static bool launch_splitk_two(int epi, const bf16_t* A, int lda, const bf16_t* W
         return false;
     ze_gemm_ws slabs_only = ws;
     slabs_only.tickets = nullptr;
-    launch_ring_variant<BM, BN, 3, 2, 4, true>(ZE_EPI_NONE, A, lda, W, ldw, nullptr, nullptr, 0, C, ldc, nullptr, M, N, K, s, ksplit, slabs_only);
+    launch_ring_variant<BM, BN, ST, 2, 4, SPR>(ZE_EPI_NONE, A, lda, W, ldw, nullptr, nullptr, 0, C, ldc, nullptr, M, N, K, s, ksplit, slabs_only);
     const int grid = nwg * (BM / 32) * (BN / 64);
     if (epi == ZE_EPI_RESIDUAL)
         hipLaunchKernelGGL((k_splitk_reduce<BM, BN, 2, 4, ZE_EPI_RESIDUAL>), dim3(grid), dim3(512), 0, s, ws.slab, ksplit, bias, R, ldr, C, ldc, M, N);
@@ -1837,7 +1837,11 @@ void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int
         // 31.7 / 34.1 / 37.2 / 43.2 / 45.3 / 50.4 / 57.0 in one launch; both bounded by the bytes a CU keeps in flight towards its
         // LDS -- 2 x 48 KB on these tiles -- so up to 256 rows, 128 workgroups, the one-launch form on 64 x 64 tiles stays);
         // knob 15 = 6: off
-        if (M > 256 && ze_gemv_knobs[15] != 6 && launch_splitk_two(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
+        if (M > 256 && ze_gemv_knobs[15] != 6 && launch_splitk_two<128, 256, 3, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
+        // (knob 15 = 7, an experiment: the two-launch form from 65 rows on, tiles sized for one round of workgroups --
+        //  64 x 128 up to 128 rows, 128 x 128 up to 256)
+        if (ze_gemv_knobs[15] == 7 && M > 128 && launch_splitk_two<128, 128, 4, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
+        if (ze_gemv_knobs[15] == 7 && M > 64 && launch_splitk_two<64, 128, 4, false>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
         ze_launch_gemm_stream(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s);
         return;
     }
