@@ -799,7 +799,7 @@ __global__ void __launch_bounds__(512) k_gemm_wstream(const bf16_t* __restrict__
                                                       int ldw, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ R,
                                                       int ldr, bf16_t* __restrict__ C, int ldc, int M, int N, int K, int ksplit,
                                                       float* __restrict__ slab, unsigned* __restrict__ tickets) {
-    constexpr int WM = 8, WN = 1, NT = 512;
+    constexpr int WM = 8, WN = 1;
     constexpr int TM = BM / (16 * WM), TN = BN / 16;
     constexpr int A_STAGE = BM * 128, W_STAGE = BN * 128;
     constexpr int LA = BM / 8 / 4;   // activation pieces (8 rows x 128 B) per loader wave per K-step
@@ -1719,7 +1719,7 @@ static void launch_skinny(int epi, const bf16_t* A, int lda, const bf16_t* W, in
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// Second launch of the two-launch split-K form (the down projection of a batched decode step with more than 256 chains):
+// Second launch of the two-launch split-K form (the down projection of a batched decode step with more than 64 chains):
 // k_gemm_ring<BM, BN, ...> ran with a null ticket array and left every slice's fp32 accumulators in the slabs, laid out
 // [slice][tile][MFMA tile t][thread] exactly as gemm_finish parks them.  One thread here = one thread of the producing
 // workgroup for one MFMA tile: it adds the slices IN SLICE ORDER starting from zero and applies the epilogue -- the
@@ -1778,8 +1778,8 @@ static int stream_ksplit(int N, int K) {
     return ksplit;
 }
 
-// long-K projection, more than 256 rows: 128 x 256 tiles (64 x 64 per wave: half the LDS fragment reads per MFMA of the
-// 64 x 64 tile's 16 x 32) on the slices of the one-launch form, then the chip-wide reduction; false = does not apply
+// long-K projection, more than 64 rows: big tiles on the slices of the one-launch form, then the chip-wide reduction;
+// false = does not apply
 template <int BM, int BN, int ST, bool SPR>
 static bool launch_splitk_two(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
                               int ldr, bf16_t* C, int ldc, int M, int N, int K, const ze_gemm_ws& ws, hipStream_t s) {
@@ -1832,16 +1832,18 @@ void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int
     // split K loses to it at every row count: 36.7 against 34.1 us at 256 rows, 23.4 against 17.4 at 64 -- its K loop alone
     // takes 19 us there, but 256-row tiles make the slab reduction eight times the bytes per reducer)
     if (K > 4096) {
-        // more than 256 rows: two launches -- 128 x 256 tiles leave the slices in the slabs, the whole chip adds them (3B down
-        // projection, us at 217 / 256 / 261 / 344 / 384 / 440 / 512 rows: 32.9 / 34.4 / 31.6 / 35.7 / 37.1 / 37.6 / 40.5 against
-        // 31.7 / 34.1 / 37.2 / 43.2 / 45.3 / 50.4 / 57.0 in one launch; both bounded by the bytes a CU keeps in flight towards its
-        // LDS -- 2 x 48 KB on these tiles -- so up to 256 rows, 128 workgroups, the one-launch form on 64 x 64 tiles stays);
-        // knob 15 = 6: off
-        if (M > 256 && ze_gemv_knobs[15] != 6 && launch_splitk_two<128, 256, 3, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
-        // (knob 15 = 7, an experiment: the two-launch form from 65 rows on, tiles sized for one round of workgroups --
-        //  64 x 128 up to 128 rows, 128 x 128 up to 256)
-        if (ze_gemv_knobs[15] == 7 && M > 128 && launch_splitk_two<128, 128, 4, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
-        if (ze_gemv_knobs[15] == 7 && M > 64 && launch_splitk_two<64, 128, 4, false>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
+        // more than 64 rows: TWO launches -- tiles sized for about one round of workgroups (64 x 128 up to 128 rows, 128 x 128
+        // up to 256, 128 x 256 beyond: 64 x 64 outputs per wave = half the LDS fragment reads per MFMA of the 64 x 64 tile's
+        // 16 x 32) leave the K slices in the slabs, k_splitk_reduce adds them on the whole chip (the one-launch form has ONE
+        // workgroup per tile read all its slabs).  3B down projection, us at 128 / 217 / 256 / 261 / 344 / 384 / 440 / 512 rows:
+        // 20.9 / 25.7 / 27.0 / 31.2 / 35.4 / 36.9 / 37.4 / 40.4 against 22.5 / 31.2 / 33.8 / 37.2 / 43.2 / 45.3 / 50.4 / 57.0 in one
+        // launch on 64 x 64 tiles (with 128 x 256 tiles at 217 / 256 rows: 32.9 / 34.4 -- 128 workgroups, half the chip).  Same
+        // slices, same order of additions: the same bits whatever the form.  knob 15 = 6: one launch at every row count
+        if (ze_gemv_knobs[15] != 6) {
+            if (M > 256 && launch_splitk_two<128, 256, 3, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
+            if (M > 128 && M <= 256 && launch_splitk_two<128, 128, 4, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
+            if (M > 64 && M <= 128 && launch_splitk_two<64, 128, 4, false>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
+        }
         ze_launch_gemm_stream(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s);
         return;
     }
