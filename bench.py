@@ -772,9 +772,14 @@ def main():
         dist.all_reduce(g, op=dist.ReduceOp.SUM)
         per_rank = g.cpu().tolist()
 
-    def batch_roofline(n):
+    def batch_roofline(n, shared=None):
         """dominant kernel of the batched decode step at n chains (largest device time per step among its launches),
-        measured live with HIP events on the launch stream; the chains hold the contexts the run left behind"""
+        measured live with HIP events on the launch stream; the chains hold the contexts the run left behind.
+        shared = (chains per tile, rows): the attention is timed TWICE -- with independent chains and with the sharing the
+        question stream has (the chains of a tile read their common prompt prefix from one holder's cache:
+        ze_seq_dev::prefix; declared here with ze_seq_set_prefix_hint, the launch's results are discarded) -- and the
+        second is the object's `achieved`: same algorithmic bytes (every chain attends over all its rows), fewer of them
+        from HBM (`traffic`)."""
         wide = e.set_decode_regime(1 if n > 64 else 0) == 1
         names = BATCH_KERNEL_NAMES_WIDE if wide else BATCH_KERNEL_NAMES
         rows = {}
@@ -789,11 +794,35 @@ def main():
         ach = r["bytes"] / (r["us"] * 1e-6) / 1e9
         layer_us = sum(per_step.values())
         traffic, traffic_src = committed_traffic("stream" if wide else "batch64", BATCH_KERNELS[dom], r["bytes"])
+        obj = {"bound": "hbm", "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "avg_us": r["us"],
+               "bytes_per_launch": r["bytes"], "chains": n, "layer_us": round(layer_us, 1),
+               "step_kernels": {k: {"us": v["us"], "GBps": v["GBps"]} for k, v in rows.items()}}
+        if shared and BATCH_KERNELS[dom] == "attention" and hasattr(e, "seq_set_prefix_hint"):
+            group, prows = shared
+            hinted = 0
+            for s_ in range(n):
+                lead = s_ - s_ % group
+                if s_ != lead and min(e.seq_len(s_), e.seq_len(lead)) >= prows:
+                    e.seq_set_prefix_hint(s_, lead, prows)
+                    hinted += 1
+            u2, by2 = e.profile_batch_kernel(5, n, iters=72)
+            for s_ in range(n):
+                e.seq_set_prefix_hint(s_, s_, 0)
+            if hinted:
+                ach2 = by2 / (u2 * 1e-6) / 1e9
+                t2, t2_src = committed_traffic("stream_shared", "attention", by2)
+                obj["independent_chains"] = {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "avg_us": r["us"], "traffic": traffic,
+                                             "traffic_source": traffic_src}
+                obj.update(achieved=ach2, frac=ach2 / HBM_PEAK_GBS, avg_us=round(u2, 2), traffic=t2, traffic_source=t2_src,
+                           layer_us=round(layer_us - r["us"] + u2, 1),
+                           sharing=(f"{hinted} of the {n} chains read their first {prows} rows (system turn + the view's image tokens) from the "
+                                    f"cache of the first chain of their tile ({group} chains per tile, as the stream's 10.5), "
+                                    "ze_seq_dev::prefix: the algorithmic bytes are those of independent chains, the prefix "
+                                    "crosses the HBM interface once per tile and step"))
+                obj["step_kernels"]["attention"] = {"us": round(u2, 2), "GBps": round(ach2, 1)}
         e.set_decode_regime(-1)
-        return {"bound": "hbm", "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "avg_us": r["us"],
-                "bytes_per_launch": r["bytes"], "chains": n, "layer_us": round(layer_us, 1),
-                "step_kernels": {k: {"us": v["us"], "GBps": v["GBps"]} for k, v in rows.items()}}
+        return obj
 
     def committed_traffic(section, kernel, alg_bytes=None):
         """HBM bytes per launch from the PMC passes of the latest committed profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
@@ -918,7 +947,7 @@ def main():
             line["scheduler"] = st
             if args.model == "3b" and not args.fp8:
                 live = int(min(SLOTS, max(1, round(line["mean_chains_per_step"]))))
-                line["roofline"] = batch_roofline(live)
+                line["roofline"] = batch_roofline(live, shared=(10, 347))
         if args.model == "3b" and not args.fp8 and not stream:
             if B == 1:
                 pm = line["phase_ms_per_question"]

@@ -162,6 +162,10 @@ int ze_seq_truncate(ze_engine* e, int seq, int keep_len, void* stream);
  * prefills on a second stream calls ze_seq_retire on the DECODE stream when it frees the slot, before the next decode step
  * (reference: no counterpart -- HF generate() holds every chain's cache for the whole call). */
 int ze_seq_retire(ze_engine* e, int seq, void* stream);
+/* Declares that the first `rows` cached tokens of `seq` equal the source chain's, bit for bit (ze_seq_copy_prefix records
+ * this itself; a caller that wrote the same prefix into both may say so; rows = 0 clears).  Also how bench.py times the
+ * decode attention with the sharing its question stream has. */
+int ze_seq_set_prefix_hint(ze_engine* e, int seq, int src_seq, int rows, void* stream);
 /* (source chain << 16) | rows: whose cache the decode attention reads the first rows of `seq` from; 0 = its own. */
 int ze_seq_prefix_hint(ze_engine* e, int seq);
 int ze_seq_len(ze_engine* e, int seq);

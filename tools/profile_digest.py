@@ -17,10 +17,13 @@ P = f"r{ROUND:02d}"
 # bench.py's kernel keys -> substring of the kernel's name, per measured configuration (tools/pmc_kernel.py modes)
 KEYS = {
     "configs1": {"gate_up": "k_gemv<2, 1, 1, 4, 16>", "down": "k_gemv<1, 1, 4, 4, 16>", "lm_head": "k_gemv<3, 2, 1, 4, 16>"},
-    "wide": {"attention": "k_attn_decode_wave<8>", "gate_up": "k_gemm_wstream<256, 96", "down": "k_gemm_ring<64, 64, 4, 2, 4, 2, false>"},
+    # (down at 220 chains = two launches: 128 x 128 tiles park the K slices, k_splitk_reduce adds them -- summed)
+    "wide": {"attention": "k_attn_decode_wave<8>", "gate_up": "k_gemm_wstream<256, 96",
+             "down": ("k_gemm_ring<128, 128, 4, 0, 2, 4, true>", "k_splitk_reduce<128, 128")},
+    "wide_shared": {"attention": "k_attn_decode_wave<8>"},
     "batch64": {"attention": "k_attn_decode_wave<8>", "gate_up": "k_gemm_skinny<6, 3", "down": "k_gemm_ring<64, 64, 4, 2, 4, 2, false>"},
 }
-SECTION = {"configs1": "configs1", "wide": "stream", "batch64": "batch64"}
+SECTION = {"configs1": "configs1", "wide": "stream", "wide_shared": "stream_shared", "batch64": "batch64"}
 
 
 def rows(name, source=None):
@@ -45,10 +48,13 @@ for mode, keys in KEYS.items():
         continue
     sec = out.setdefault(SECTION[mode], {})
     for key, sub in keys.items():
-        name, f = find(fetch, sub)
-        _, w = find(write, sub)
-        if name is None or w is None or key not in launches:
+        subs = sub if isinstance(sub, tuple) else (sub,)
+        parts = [(find(fetch, x), find(write, x)) for x in subs]
+        if any(pf[0] is None or pw[1] is None for pf, pw in parts) or key not in launches:
             continue
+        name = " + ".join(pf[0].split("(")[0] for pf, _ in parts)
+        f = (sum(pf[1][0] for pf, _ in parts), parts[0][0][1][1])
+        w = (sum(pw[1][0] for _, pw in parts), parts[0][1][1][1])
         hbm = f[0] * 1024 * 2 + w[0] * 1024
         alg = launches[key]["bytes_per_launch"]
         sec[key] = {"kernel": name.split("(")[0], "fetch_size_kb_mean": f[0], "write_size_kb_mean": w[0], "dispatches": f[1],

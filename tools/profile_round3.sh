@@ -25,7 +25,7 @@ pmc() {  # counter list, file tag, mode
 stats stream --steps 8 --warmup 2 --no-cpu-baseline --no-batch64 --no-configs1
 stats configs1 --batch 1 --steps 3 --warmup 1 --no-cpu-baseline
 stats batch64 --batch 64 --steps 1 --warmup 1 --no-cpu-baseline
-for mode in wide batch64 configs1; do
+for mode in wide wide_shared batch64 configs1; do
   pmc FETCH_SIZE fetch_size $mode
   pmc WRITE_SIZE write_size $mode
 done

@@ -88,6 +88,7 @@ _SIGS = {
     "ze_seq_reset": (C.c_int, [_P, C.c_int, _P]),
     "ze_seq_retire": (C.c_int, [_P, C.c_int, _P]),
     "ze_seq_prefix_hint": (C.c_int, [_P, C.c_int]),
+    "ze_seq_set_prefix_hint": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "ze_seq_truncate": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "ze_seq_len": (C.c_int, [_P, C.c_int]),
     "ze_seq_copy_prefix": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),

@@ -382,6 +382,23 @@ extern "C" int ze_seq_retire(ze_engine* e, int seq, void* stream) {
     return ZE_OK;
 }
 
+// Declares that the first `rows` cached tokens of `seq` hold the same bits as the source chain's (the caller's knowledge: a
+// prefix it wrote to both; ze_seq_copy_prefix records this by itself).  rows = 0 clears.  Also the measurement hook of
+// bench.py / tools/pmc_kernel.py: the decode attention timed with the sharing the question stream has.
+extern "C" int ze_seq_set_prefix_hint(ze_engine* e, int seq, int src_seq, int rows, void* stream) {
+    ZE_TRY(check_seq(e, seq));
+    hipSetDevice(e->device);
+    if (rows <= 0 || src_seq == seq) {
+        set_prefix_hint(e, seq, 0, (hipStream_t)stream);
+        return ZE_OK;
+    }
+    ZE_TRY(check_seq(e, src_seq));
+    if (rows > e->ctx_host[seq] || rows > e->ctx_host[src_seq] || rows >= 65536 || !e->prefix_hints)
+        return ze_fail(e, ZE_ERR_INVALID, "prefix hint: rows exceed a chain's context (or hints are switched off)");
+    set_prefix_hint(e, seq, (src_seq << 16) | rows, (hipStream_t)stream);
+    return ZE_OK;
+}
+
 // (source chain << 16) | rows: where the decode attention reads the first rows of `seq` from; 0 = its own cache
 extern "C" int ze_seq_prefix_hint(ze_engine* e, int seq) {
     if (check_seq(e, seq) != 0) return ZE_ERR_NOTFOUND;

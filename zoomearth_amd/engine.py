@@ -214,6 +214,10 @@ class Engine:
         st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
         self._check(self.lib.ze_seq_retire(self.h, seq, st))
 
+    def seq_set_prefix_hint(self, seq: int, src: int, rows: int):
+        """Declares that the first `rows` cached tokens of `seq` equal those of chain `src` (rows = 0 clears)."""
+        self._check(self.lib.ze_seq_set_prefix_hint(self.h, seq, src, rows, self._stream()))
+
     def seq_prefix_hint(self, seq: int):
         """(source chain, rows): the decode attention reads the first `rows` cached tokens of `seq` from the source's cache
         (the same bits; one copy per tile in flight); (seq, 0) when it reads its own."""
