@@ -1524,6 +1524,9 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
         if (BM == 64 && BN == 64 && ze_gemv_knobs[7] != 3) {
             // (round 3, the split-K stream of the down projection, us at 64 / 256 rows: this tile 17.4 / 35.2; eight or six
             //  stages 17.8 / 44.1 and 17.7 / 42.9; 128 x 64 tiles 21.3 / 36.7; 256 x 64 tiles, three stages 32.8 / 39.1)
+            // (qkv / o of a decode step -- 128-240 tiles of 32 K-steps, at most one workgroup per CU -- with EIGHT stages, 112 KB in
+            //  flight per CU instead of 48: 13.8 against 12.9 us; these launches are bound by the per-step chain wait -> barrier ->
+            //  fragment reads -> 4 MFMAs, not by bytes in flight)
             launch_ring_variant<64, 64, 4, 4, 2, false>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, ksplit, ws);
             return;
         }
