@@ -14,7 +14,7 @@ from zoomearth_amd.synth import uniform_ints  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 tunes = sys.argv[2:] or [""]
 NAMES = ["qkv", "o_proj", "gate_up", "down", "lm_head", "attention", "rmsnorm", "rope_kv"]
-e = Engine(ModelConfig.zoomearth_3b(), max_seqs=B, max_ctx=2048, max_patches=2048, max_tile_side=1024, max_prefill_rows=16 * 1024)
+e = Engine(ModelConfig.zoomearth_3b(), max_seqs=B, max_ctx=int(os.environ.get("ZE_MAX_CTX", "2048")), max_patches=2048, max_tile_side=1024, max_prefill_rows=16 * 1024)
 e.fill_synthetic(0)
 lens = [800 + int(v) for v in uniform_ints(5, B, 0, 640)]  # ragged: 800 .. 1440 tokens (mean ~1120)
 GROUP = int(os.environ.get("ZE_GROUP", "1"))      # chains per tile: the first ZE_SHARED prompt tokens are the tile's (one prefill,
