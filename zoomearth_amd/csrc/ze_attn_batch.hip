@@ -266,12 +266,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AW_VST
     const bf16_t* __restrict__ q, int q_row_stride, const bf16_t* __restrict__ kcache, const bf16_t* __restrict__ vcache,
     size_t cache_seq_stride, const ze_seq_dev* __restrict__ st_base, const int* __restrict__ seq_ids, int heads, int kv_heads,
     int max_ctx, float scale_log2e, float* __restrict__ ws, int max_parts, unsigned* __restrict__ tickets,
-    bf16_t* __restrict__ out, int out_row_stride) {
+    bf16_t* __restrict__ out, int out_row_stride, int x_rot) {
     constexpr int D = 128;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 4 waves x AW_VSTAGES V stages of 4 KB
     __shared__ float s_ml[4][32];                                   // the waves' (m, l) per head column
     const int bz = blockIdx.y;
-    const int kvh = blockIdx.x % kv_heads, part = blockIdx.x / kv_heads;
+    // Workgroups go to the eight XCDs round robin by their linear id, blockIdx.y * gridDim.x + blockIdx.x.  A chain's work is
+    // a PREFIX of its x range (the parts it has), so with gridDim.x a multiple of 8 every chain would put the same part on the
+    // same XCD and the XCDs of the high part numbers would idle (measured: 16 or 32 workgroups per chain 3.97 / 2.49 TB/s
+    // against 4.58 with 22).  The x range is therefore rotated, by 3 per group of FOUR consecutive chains (x_rot = 3 | 2 << 4: a
+    // bijection per chain, whatever the grid; four chains of a tile in a row keep the same part on the same XCD, whose L2 then
+    // serves the prefix rows they share -- rotating per chain cost the shared case 2 %, per 8 or 16 chains the balance).
+    const int xr = (int)((blockIdx.x + (unsigned)(x_rot & 15) * ((unsigned)bz >> (x_rot >> 4))) % gridDim.x);
+    const int kvh = xr % kv_heads, part = xr / kv_heads;
     const int seq = seq_ids[bz];
     const int ctx = st_base[seq].ctx + 1;
     const int nparts = (ctx + AW_PART - 1) / AW_PART;
@@ -461,6 +468,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AW_VST
                              out + (size_t)bz * out_row_stride, 0, 0, nparts);
 }
 
+extern int ze_gemv_knobs[16];
+
 void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_t* kcache, const bf16_t* vcache,
                                   size_t cache_seq_stride, bf16_t* out, int out_row_stride, const ze_seq_dev* st,
                                   const int* seq_ids, int n, int heads, int kv_heads, int max_ctx, float scale,
@@ -474,9 +483,15 @@ void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_
     }
     if (per_wave) {  // 192-key parts whatever the context: max_parts here = ceil(max_ctx / 192)
         const int wparts = (max_ctx + AW_PART - 1) / AW_PART;
-        k_attn_decode_wave<8><<<dim3(kv_heads * wparts, n), 256, 4 * AW_VSTAGES * AW_VSTAGE, s>>>(
+        // per_wave = the parts the LONGEST chain of this batch can have (the caller's host-side context lengths): workgroups
+        // for parts no chain has would only look their chain up and leave -- 22 parts instead of 11 per chain and kv head
+        // (max_ctx 4096 against 2048, contexts of ~1100) cost the launch 9 %
+        // (knob 8 = 3, for A/B runs: every part of max_ctx in the grid, no rotation)
+        const bool plain = ze_gemv_knobs[8] == 3;
+        const int gparts = plain ? wparts : std::min(wparts, std::max(1, per_wave));
+        k_attn_decode_wave<8><<<dim3(kv_heads * gparts, n), 256, 4 * AW_VSTAGES * AW_VSTAGE, s>>>(
             q, q_row_stride, kcache, vcache, cache_seq_stride, st, seq_ids, heads, kv_heads, max_ctx, sl, ws_partial, wparts, tickets,
-            out, out_row_stride);
+            out, out_row_stride, plain ? 0 : (3 | (2 << 4)));
     }
     else
         k_attn_decode_stream<8><<<dim3(kv_heads * max_parts, n), 256, lds, s>>>(q, q_row_stride, kcache, vcache, cache_seq_stride, st,

@@ -161,7 +161,8 @@ struct ze_engine {
     int* bseq = nullptr;
     float *blogits = nullptr, *bpartial = nullptr, *bsample = nullptr;
     ze_seq_dev* bstate_host = nullptr;  // pinned
-    std::map<std::tuple<int, float, int, float, unsigned long long>, hipGraphExec_t> bgraphs;  // captured batched decode step per batch size
+    std::map<std::tuple<int, float, int, float, unsigned long long, int>, hipGraphExec_t> bgraphs;  // captured batched decode step per batch size (and attention grid)
+    int live_parts = 0;  // 192-key parts the longest chain of the current batch needs (the attention grid's extent); 0 = all
 
     // timers
     bool timers_on = false;

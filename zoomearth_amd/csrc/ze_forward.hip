@@ -1148,6 +1148,13 @@ static int ensure_fragments(ze_engine* e, hipStream_t s) {
     return ZE_OK;
 }
 
+// the attention grid's extent for the next `steps` decode steps of these chains: the parts of the longest context
+static void set_live_parts(ze_engine* e, const int32_t* seqs, int n, int steps) {
+    int mx = 0;
+    for (int i = 0; i < n; ++i) mx = std::max(mx, e->ctx_host[seqs[i]]);
+    e->live_parts = (mx + std::max(1, steps) + 1 + 191) / 192;
+}
+
 static int upload_batch(ze_engine* e, const int32_t* seqs, int n, hipStream_t s) {
     if (n <= 0 || n > e->cfg.max_seqs) return ze_fail(e, ZE_ERR_INVALID, "batch size out of range");
     if (n > 64 && !e->wide_regime())
@@ -1185,7 +1192,7 @@ static void launch_batch_attention(ze_engine* e, int li, int n, bool frag_out, h
         const int max_parts = chunk ? (c.max_ctx + chunk - 1) / chunk : 8;           // (at most 8 parts: 128-token floor)
         ze_launch_attn_decode_stream(e->bqkv, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, e->bo, frag_out ? -(nq / 32) : nq,
                                      e->st_dev, e->bseq, n, c.heads, c.kv_heads, c.max_ctx, scale, e->bpartial, max_parts,
-                                     e->atickets, s, chunk, per_wave ? 1 : 0);
+                                     e->atickets, s, chunk, per_wave ? (e->live_parts > 0 ? e->live_parts : wparts) : 0);
     }
 }
 
@@ -1285,6 +1292,7 @@ extern "C" int ze_decode_batch(ze_engine* e, const int32_t* seqs, int n, const i
     hipSetDevice(e->device);
     ZE_TRY(ensure_fragments(e, s));
     ZE_TRY(upload_batch(e, seqs, n, s));
+    set_live_parts(e, seqs, n, 1);
     if (tokens) {
         for (int i = 0; i < n; ++i) {
             if (tokens[i] >= c.vocab) return ze_fail(e, ZE_ERR_INVALID, "token id out of range");
@@ -1303,7 +1311,7 @@ extern "C" int ze_decode_batch(ze_engine* e, const int32_t* seqs, int n, const i
 // The captured batched decode step for `na` chains (chain ids / positions live in device memory, so one graph per
 // batch size and sampling setting serves every composition); nullptr in *out = run eagerly.
 static int batch_step_graph(ze_engine* e, int na, float pen, int ign, const ze_sample_opts& bso, hipGraphExec_t* out) {
-    auto key = std::make_tuple(na, pen, ign, bso.temperature, bso.seed);
+    auto key = std::make_tuple(na, pen, ign, bso.temperature, bso.seed, e->live_parts);
     if (e->bgraph_epoch != ze_tune_epoch) {
         for (auto& kv : e->bgraphs) hipGraphExecDestroy(kv.second);
         e->bgraphs.clear();
@@ -1337,6 +1345,7 @@ static int run_burst(ze_engine* e, const std::vector<int>& active, int steps, co
                      const ze_sample_opts& bso, hipStream_t s) {
     const int na = (int)active.size();
     ZE_TRY(upload_batch(e, active.data(), na, s));
+    set_live_parts(e, active.data(), na, steps);
     hipGraphExec_t gx = nullptr;
     if (p->use_graph) ZE_TRY(batch_step_graph(e, na, pen, ign, bso, &gx));
     for (int i = 0; i < steps; ++i) {
@@ -1831,6 +1840,7 @@ extern "C" int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters
         kv_bytes += (double)(std::min(e->ctx_host[i] + 1, c.max_ctx)) * nkv * 2 * 2;
     }
     ze_launch_set_ints(e->bseq, seqs.data(), n, s);
+    set_live_parts(e, seqs.data(), n, 1);  // (the grid a decode step of these chains would launch)
     double bytes = 0;
     auto launch = [&](int it) {
         const int li = it % c.layers;
