@@ -230,7 +230,7 @@ def question_table(n_questions: int, seed: int = 0):
     return [t for t, c in enumerate(counts) for _ in range(c)]
 
 
-def run_stream(engine, table, q0: int, slots: int, stats=None, use_graph=True):
+def run_stream(engine, table, q0: int, slots: int, stats=None, use_graph=None):
     """The questions `table` = [(question number offset, tile DeviceImage, view key)] through the continuous-batching
     scheduler and the host code of src/eval/infer.py (hostloop: views, crops, prompts); the "parsed" box is scripted,
     lengths are ragged and EOS is ignored (random weights emit neither).  Every question of a (tile, view key) looks at
@@ -268,7 +268,7 @@ def run_stream(engine, table, q0: int, slots: int, stats=None, use_graph=True):
     return done
 
 
-def run_stream_lanes(engines, table, q0: int, slots: int, stats=None, use_graph=True):
+def run_stream_lanes(engines, table, q0: int, slots: int, stats=None, use_graph=None):
     """The same stream on several LANES of one GPU: every lane is an engine of its own (weights, KV cache, workspaces) with
     its own scheduler, host thread and HIP stream; tiles are dealt to the lanes whole (a tile's questions share its view and
     its prompt prefix).  While one lane is in a prefill / ViT round (matrix-bound) the other one decodes (bandwidth- and
@@ -319,7 +319,7 @@ def run_stream_lanes(engines, table, q0: int, slots: int, stats=None, use_graph=
     return done
 
 
-def batch_step(engine, tiles, q0: int, B: int, stats=None, use_graph=True, slots=None):
+def batch_step(engine, tiles, q0: int, B: int, stats=None, use_graph=None, slots=None):
     """B questions about len(tiles) tiles (6 : 64 as LRS-GRO's 908 : 9734), passes of 64 questions over the tiles."""
     table = []
     for b in range(B):
@@ -704,6 +704,7 @@ def main():
     line = {}
     bstats = {}
     use_graph = not args.no_graph
+    sched_graph = False if args.no_graph else None  # (None: the scheduler's own choice -- graphs up to 64 chain slots only)
     if stream:
         # global question table of the timed region: world x steps x 64 questions, tiles assigned to ranks whole
         n_total = world * args.steps * Q_STEP
@@ -716,12 +717,12 @@ def main():
         table = [(i, dev[tile_of[i]], tile_of[i]) for i in mine]
         warm_table = [(i, warm_dev[t], ("w", t)) for i, t in enumerate(warm_tile_of)]
         if warm_table:
-            run_stream_lanes(engines, warm_table, 9_000_000 + rank * 100_000, SLOTS, use_graph=use_graph)
+            run_stream_lanes(engines, warm_table, 9_000_000 + rank * 100_000, SLOTS, use_graph=sched_graph)
         for en in engines:
             en.phase_timers(enable=True, reset=True)
         barrier()
         t0 = time.perf_counter()
-        run_stream_lanes(engines, table, 1_000_000, SLOTS, bstats, use_graph=use_graph)
+        run_stream_lanes(engines, table, 1_000_000, SLOTS, bstats, use_graph=sched_graph)
         torch.cuda.synchronize()
         my_dt = time.perf_counter() - t0
         barrier()
@@ -739,7 +740,7 @@ def main():
         def run_step(q):
             if B == 1:
                 return chain.question(q)
-            d = batch_step(e, tiles64, q * B, B, bstats, use_graph=use_graph)
+            d = batch_step(e, tiles64, q * B, B, bstats, use_graph=sched_graph)
             l = d[q * B]
             return [0] * l[1], [0] * l[3], l[0], l[2]
 
@@ -923,7 +924,7 @@ def main():
                        "questions_per_step_per_gpu": Q_STEP if stream else B, "chain_slots_per_gpu": chains * len(engines),
                        "lanes_per_gpu": len(engines),
                        "tile": [args.tile, args.tile], "L1": lens[0], "L2": lens[1], "N1": lens[2], "N2": lens[3],
-                       "repetition_penalty": PENALTY, "hip_graph": use_graph,
+                       "repetition_penalty": PENALTY, "hip_graph": (use_graph and SLOTS <= 64) if stream else (use_graph if B == 1 else (use_graph and B <= 64)),
                        "reuse": ("stage-1 prompt KV and view features reused in stage 2 (bit-identical); the KV rows of the "
                                  "generated tokens that stage 2 re-inserts id for id are kept as the decode steps wrote them; "
                                  "prompt prefixes shared between the questions of a tile (bit-identical) and read from ONE holder's cache "
