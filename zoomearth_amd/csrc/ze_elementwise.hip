@@ -343,6 +343,39 @@ void ze_launch_vision_rope(bf16_t* qkv, const float* cosT, const float* sinT, in
     k_vision_rope<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(qkv, cosT, sinT, n, heads, D);
 }
 
+int ze_mrope_vec_ok = 1;  // (process-wide, conservative: any engine with odd M-RoPE sections switches the 16-byte form off)
+#define mrope_vec_ok (ze_mrope_vec_ok != 0)
+
+// eight rotate_half pairs at once: (x1[k], x2[k]) = elements (j + k, j + half + k), cos / sin of the same eight j.  The
+// arithmetic per element is the scalar kernels': bf16(bf16(x1 c) + bf16(-x2 s)), bf16(bf16(x2 c) + bf16(x1 s)).
+__device__ __forceinline__ void rope8(const uint4& a, const uint4& b, const uint4& c4, const uint4& s4, uint4& o1, uint4& o2) {
+    const uint32_t* pa = reinterpret_cast<const uint32_t*>(&a);
+    const uint32_t* pb = reinterpret_cast<const uint32_t*>(&b);
+    const uint32_t* pc = reinterpret_cast<const uint32_t*>(&c4);
+    const uint32_t* ps = reinterpret_cast<const uint32_t*>(&s4);
+    uint32_t r1[4], r2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t lo1, hi1, lo2, hi2;
+        {
+            const float x1 = __uint_as_float(pa[q] << 16), x2 = __uint_as_float(pb[q] << 16);
+            const float c = __uint_as_float(pc[q] << 16), sn = __uint_as_float(ps[q] << 16);
+            lo1 = f32_to_bf16(bf16_round(x1 * c) + bf16_round(-x2 * sn));
+            lo2 = f32_to_bf16(bf16_round(x2 * c) + bf16_round(x1 * sn));
+        }
+        {
+            const float x1 = __uint_as_float(pa[q] & 0xffff0000u), x2 = __uint_as_float(pb[q] & 0xffff0000u);
+            const float c = __uint_as_float(pc[q] & 0xffff0000u), sn = __uint_as_float(ps[q] & 0xffff0000u);
+            hi1 = f32_to_bf16(bf16_round(x1 * c) + bf16_round(-x2 * sn));
+            hi2 = f32_to_bf16(bf16_round(x2 * c) + bf16_round(x1 * sn));
+        }
+        r1[q] = lo1 | (hi1 << 16);
+        r2[q] = lo2 | (hi2 << 16);
+    }
+    o1 = make_uint4(r1[0], r1[1], r1[2], r1[3]);
+    o2 = make_uint4(r2[0], r2[1], r2[2], r2[3]);
+}
+
 // ------------------------------------------------------------------ text M-RoPE + KV append (prefill)
 // qkv: [T, (heads + 2*kv_heads) * D] bf16 (q | k | v).  cos/sin tables: bf16 [max_pos, D/2] (already rounded to the
 // model dtype like HF's cos.to(x.dtype)).  pos3: int32 [3, T].  axis_of[j] in {0,1,2} for j < D/2 picks t/h/w.
@@ -394,11 +427,55 @@ __global__ void __launch_bounds__(256) k_mrope_kv(bf16_t* __restrict__ qkv, int 
         d[j + half] = o2;
     }
 }
+// The same, eight pairs per thread with 16-byte accesses (D % 16 == 0, the three M-RoPE sections multiples of 8 pairs --
+// Qwen2.5-VL: 16 / 24 / 24 -- so the eight pairs of a thread share their position axis; rows 16-byte aligned).
+__global__ void __launch_bounds__(256) k_mrope_kv_vec(bf16_t* __restrict__ qkv, int T, int heads, int kv_heads, int D,
+                                                      const bf16_t* __restrict__ cosT, const bf16_t* __restrict__ sinT,
+                                                      const int* __restrict__ pos3, const int* __restrict__ axis_of,
+                                                      bf16_t* __restrict__ kcache, bf16_t* __restrict__ vcache,
+                                                      int max_ctx, int past, const int* __restrict__ row_aux,
+                                                      size_t cache_seq_stride) {
+    const int half = D >> 1, hv = half >> 3;
+    const int nh = heads + 2 * kv_heads;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)T * nh * hv) return;
+    const int j = (int)(i % hv) * 8;
+    const int hh = (int)((i / hv) % nh);
+    const int t = (int)(i / ((size_t)hv * nh));
+    int cpos = past + t;
+    if (row_aux) {
+        kcache += (size_t)row_aux[2 * t] * cache_seq_stride;
+        vcache += (size_t)row_aux[2 * t] * cache_seq_stride;
+        cpos = row_aux[2 * t + 1];
+    }
+    bf16_t* p = qkv + (size_t)t * nh * D + (size_t)hh * D;
+    const uint4 a = *reinterpret_cast<const uint4*>(p + j), b = *reinterpret_cast<const uint4*>(p + j + half);
+    if (hh >= heads + kv_heads) {  // v: plain copy into the cache
+        bf16_t* d = vcache + ((size_t)(hh - heads - kv_heads) * max_ctx + cpos) * D;
+        *reinterpret_cast<uint4*>(d + j) = a;
+        *reinterpret_cast<uint4*>(d + j + half) = b;
+        return;
+    }
+    const int pos = pos3[axis_of[j] * T + t];
+    const uint4 c4 = *reinterpret_cast<const uint4*>(cosT + (size_t)pos * half + j);
+    const uint4 s4 = *reinterpret_cast<const uint4*>(sinT + (size_t)pos * half + j);
+    uint4 o1, o2;
+    rope8(a, b, c4, s4, o1, o2);
+    bf16_t* d = hh < heads ? p : kcache + ((size_t)(hh - heads) * max_ctx + cpos) * D;
+    *reinterpret_cast<uint4*>(d + j) = o1;
+    *reinterpret_cast<uint4*>(d + j + half) = o2;
+}
 void ze_launch_mrope_kv(bf16_t* qkv, int T, int heads, int kv_heads, int D, const bf16_t* cosT, const bf16_t* sinT,
                         const int* pos3, const int* axis_of, bf16_t* kcache, bf16_t* vcache, int max_ctx, int past,
                         const int* row_aux, size_t cache_seq_stride, hipStream_t s) {
     const size_t total = (size_t)T * (heads + 2 * kv_heads) * (D / 2);
     if (total == 0) return;
+    if (D % 16 == 0 && mrope_vec_ok) {
+        const size_t tv = total / 8;
+        k_mrope_kv_vec<<<(unsigned)((tv + 255) / 256), 256, 0, s>>>(qkv, T, heads, kv_heads, D, cosT, sinT, pos3, axis_of, kcache,
+                                                                  vcache, max_ctx, past, row_aux, cache_seq_stride);
+        return;
+    }
     k_mrope_kv<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(qkv, T, heads, kv_heads, D, cosT, sinT, pos3,
                                                                axis_of, kcache, vcache, max_ctx, past, row_aux,
                                                                cache_seq_stride);
@@ -517,11 +594,47 @@ __global__ void __launch_bounds__(256) k_rope_kv_batch(bf16_t* __restrict__ qkv,
         d[j + half] = o2;
     }
 }
+__global__ void __launch_bounds__(256) k_rope_kv_batch_vec(bf16_t* __restrict__ qkv, int n, int heads, int kv_heads, int D,
+                                                           const bf16_t* __restrict__ cosT, const bf16_t* __restrict__ sinT,
+                                                           const ze_seq_dev* __restrict__ st, const int* __restrict__ seq_ids,
+                                                           bf16_t* __restrict__ kcache, bf16_t* __restrict__ vcache,
+                                                           size_t cache_seq_stride, int max_ctx) {
+    const int half = D >> 1, hv = half >> 3;
+    const int nh = heads + 2 * kv_heads;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)n * nh * hv) return;
+    const int j = (int)(i % hv) * 8;
+    const int hh = (int)((i / hv) % nh);
+    const int b_ = (int)(i / ((size_t)hv * nh));
+    const int seq = seq_ids[b_];
+    const int ctx = st[seq].ctx, pos = ctx + st[seq].rope_delta;
+    bf16_t* p = qkv + (size_t)b_ * nh * D + (size_t)hh * D;
+    const uint4 a = *reinterpret_cast<const uint4*>(p + j), b = *reinterpret_cast<const uint4*>(p + j + half);
+    if (hh >= heads + kv_heads) {
+        bf16_t* d = vcache + seq * cache_seq_stride + ((size_t)(hh - heads - kv_heads) * max_ctx + ctx) * D;
+        *reinterpret_cast<uint4*>(d + j) = a;
+        *reinterpret_cast<uint4*>(d + j + half) = b;
+        return;
+    }
+    const uint4 c4 = *reinterpret_cast<const uint4*>(cosT + (size_t)pos * half + j);
+    const uint4 s4 = *reinterpret_cast<const uint4*>(sinT + (size_t)pos * half + j);
+    uint4 o1, o2;
+    rope8(a, b, c4, s4, o1, o2);
+    bf16_t* d = hh < heads ? p : kcache + seq * cache_seq_stride + ((size_t)(hh - heads) * max_ctx + ctx) * D;
+    *reinterpret_cast<uint4*>(d + j) = o1;
+    *reinterpret_cast<uint4*>(d + j + half) = o2;
+}
 void ze_launch_rope_kv_batch(bf16_t* qkv, int n, int heads, int kv_heads, int D, const bf16_t* cosT, const bf16_t* sinT,
                              const ze_seq_dev* st, const int* seq_ids, bf16_t* kcache, bf16_t* vcache,
                              size_t cache_seq_stride, int max_ctx, hipStream_t s) {
     const size_t tot = (size_t)n * (heads + 2 * kv_heads) * (D / 2);
     if (tot == 0) return;
+    if (D % 16 == 0) {  // (eight pairs per thread, 16-byte accesses; the arithmetic of the scalar kernel)
+        const size_t tv = tot / 8;
+        k_rope_kv_batch_vec<<<(unsigned)((tv + 255) / 256), 256, 0, s>>>(qkv, n, heads, kv_heads, D, cosT, sinT, st, seq_ids, kcache,
+                                                                       vcache, cache_seq_stride, max_ctx);
+        return;
+    }
     k_rope_kv_batch<<<(unsigned)((tot + 255) / 256), 256, 0, s>>>(qkv, n, heads, kv_heads, D, cosT, sinT, st, seq_ids,
                                                                   kcache, vcache, cache_seq_stride, max_ctx);
 }

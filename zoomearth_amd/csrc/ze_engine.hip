@@ -6,6 +6,7 @@
 #include "ze_prng.h"
 
 thread_local std::string ze_global_error;
+extern int ze_mrope_vec_ok;  // ze_elementwise.hip: cleared by an engine whose M-RoPE sections are not multiples of eight pairs
 unsigned ze_tune_epoch = 0;  // bumped whenever captured decode graphs go stale (launch policy or weight streams changed)
 static int ze_bound_device = -1;  // the launch-policy caches (hipFuncSetAttribute, CU count) are per process: one GPU per process
 
@@ -201,6 +202,11 @@ static int init_tables(ze_engine* e) {
         for (int s = 0; s < 3; ++s)
             for (int k = 0; k < c.mrope_section[s] && o < half; ++k) axis[o++] = s;
         for (; o < half; ++o) axis[o] = 0;
+        // (the 16-byte form of k_mrope_kv gives a thread eight consecutive pairs: they have to share their axis)
+        for (int g = 0; g + 8 <= half; g += 8)
+            for (int k = 1; k < 8; ++k)
+                if (axis[g + k] != axis[g]) ze_mrope_vec_ok = 0;
+        if (half % 8) ze_mrope_vec_ok = 0;
     }
     ZE_TRY(dev_alloc(e, &e->axis_of, half, false));
     ZE_HIP(hipMemcpy(e->axis_of, axis.data(), half * sizeof(int), hipMemcpyHostToDevice));
