@@ -427,3 +427,36 @@ def test_decode_reads_a_shared_prefix_from_one_holder_and_survives_its_retiremen
     for s in range(4):
         e.seq_reset(s)
         assert e.seq_prefix_hint(s) == (s, 0)
+
+
+@pytest.mark.parametrize("max_ctx", [768, 1536])
+def test_attention_grid_rotation_and_extent_do_not_change_a_bit(max_ctx):
+    """The decode attention's launch grid is rotated per group of four chains (XCD balance whenever kv heads x parts of
+    max_ctx is a multiple of 8: here 8 and 16 workgroups per chain) and covers only the parts the batch's longest chain has
+    (ze_engine::live_parts).  Which workgroup computes which part must not matter: ragged chains, several steps, against the
+    plain full grid (ze_tune knob 8 = 3), bit for bit -- also right after the longest chain crosses into a new part."""
+    from gpu_util import oracle_cfg_to_model_cfg
+    from zoomearth_amd.engine import Engine
+    e = Engine(oracle_cfg_to_model_cfg(), device=0, max_seqs=12, max_ctx=max_ctx, max_patches=1024, max_tile_side=1024)
+    try:
+        e.fill_synthetic(**CHAIN_W)
+        lens = [3, 190, 191, 192, 193, 383, 384, 40, 500, 575, 576 if max_ctx > 768 else 300, 250]
+        prompts = [text_ids(700 + s, n) for s, n in enumerate(lens)]
+
+        def run(knob):
+            e.lib.ze_tune(8, knob)
+            for s, ids in enumerate(prompts):
+                prefill_text(e, s, ids)
+            out = []
+            for i in range(4):
+                out.append(e.decode_batch(list(range(12)), [20 + i + s for s in range(12)]).cpu().numpy())
+            out.append(e.decode_batch([5, 2, 9], [31, 32, 33]).cpu().numpy())   # a sub-batch, another order
+            return out
+        try:
+            plain, rotated = run(3), run(0)
+        finally:
+            e.lib.ze_tune(8, 0)
+        for a, b in zip(plain, rotated):
+            assert np.array_equal(a, b)
+    finally:
+        e.close()
