@@ -135,8 +135,20 @@ def main():
             self.engine.phase_timers(enable=True, reset=True)
 
     infer.ChainScheduler = Timed
+    prof = None
+    if os.environ.get("ZE_E2E_PROFILE") == "1":  # host-side profile of the calling thread (meaningful with --lanes 1)
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     stats = infer.eval_model_lora("ckpt", "e2e_", "./LRS_GRO/test", "./image/", args.max_new_tokens, args.batch_size, 2048,
                                   do_sample=False, decode_workers=args.decode_workers, decode_ahead=args.decode_ahead, lanes=args.lanes)
+    if prof is not None:
+        import io
+        import pstats
+        prof.disable()
+        buf = io.StringIO()
+        pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(28)
+        sys.stderr.write(buf.getvalue())
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     phases = {}
