@@ -291,3 +291,25 @@ def test_bench_gpus_flag_spawns_the_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--spawn-check"], capture_output=True,
                        text=True, timeout=120, env=dict(env, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2"))
     assert r.returncode == 0 and r.stdout.strip() == ""  # a torchrun rank 1: no spawn, no line
+
+
+def test_decode_rgb_reads_uncompressed_tiff_strips_directly(tmp_path):
+    """zoomearth_amd/image.py decode_rgb: an uncompressed 8-bit RGB TIFF is read strip by strip straight into the array (no
+    interpreter lock held: the decode threads of the tile prefetcher must not starve the threads that drive the GPU); every
+    other format goes through PIL.  Same pixels either way, writable and contiguous."""
+    from PIL import Image
+
+    from zoomearth_amd.image import _raw_rgb_strips, decode_rgb
+    rng = np.random.default_rng(7)
+    a = rng.integers(0, 255, (257, 131, 3), dtype=np.uint8)
+    for name, kw, direct in (("u.tif", {}, True), ("l.tif", {"compression": "tiff_lzw"}, False), ("p.png", {}, False)):
+        fp = str(tmp_path / name)
+        Image.fromarray(a).save(fp, **kw)
+        with Image.open(fp) as im:
+            assert (_raw_rgb_strips(im) is not None) == direct, name
+        got = decode_rgb(fp)
+        assert np.array_equal(got, a) and got.flags.writeable and got.flags.c_contiguous, name
+    g = rng.integers(0, 255, (40, 30), dtype=np.uint8)
+    fp = str(tmp_path / "g.tif")
+    Image.fromarray(g).save(fp)
+    assert np.array_equal(decode_rgb(fp), np.repeat(g[:, :, None], 3, axis=2))   # not RGB on disk: PIL converts

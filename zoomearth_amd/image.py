@@ -95,7 +95,48 @@ def decode_rgb(path: str) -> np.ndarray:
 
     Image.MAX_IMAGE_PIXELS = None
     with Image.open(path) as im:
-        return np.array(im.convert("RGB"), dtype=np.uint8)  # a writable, contiguous copy
+        raw = _raw_rgb_strips(im)
+        if raw is None:
+            return np.array(im.convert("RGB"), dtype=np.uint8)  # a writable, contiguous copy
+        w, h = im.size
+    # Uncompressed 8-bit RGB (the usual way a 5000-px TIFF tile is stored): the file's strips ARE the pixels.  Reading them
+    # straight into the array keeps the interpreter lock free (readinto releases it) -- through PIL the same tile goes
+    # through load() + tobytes(), 64 KB at a time under the lock, and three decode threads then take 0.66 s per tile instead of
+    # 0.16 and starve the threads that drive the GPU (measured on the real entry point: tools/bench_infer_e2e.py)
+    arr = np.empty((h, w, 3), dtype=np.uint8)
+    with open(path, "rb", buffering=0) as f:
+        for y0, y1, off in raw:
+            f.seek(off)
+            mv = memoryview(arr[y0:y1]).cast("B")
+            got = 0
+            while got < len(mv):
+                n = f.readinto(mv[got:])
+                if not n:
+                    raise OSError(f"{path}: truncated image data")
+                got += n
+    return arr
+
+
+def _raw_rgb_strips(im):
+    """[(first row, end row, file offset)] when the opened image is uncompressed, tightly packed, top-down 8-bit RGB stored
+    in full-width strips (PIL's tile list says so); None otherwise."""
+    try:
+        if im.mode != "RGB" or not im.tile:
+            return None
+        w, h = im.size
+        out, y = [], 0
+        for t in im.tile:
+            name, (x0, y0, x1, y1), off, args = t[0], t[1], t[2], t[3]
+            rawmode = args if isinstance(args, str) else args[0]
+            stride = 0 if isinstance(args, str) or len(args) < 2 else args[1]
+            orient = 1 if isinstance(args, str) or len(args) < 3 else args[2]
+            if name != "raw" or rawmode != "RGB" or stride not in (0, 3 * w) or orient != 1 or x0 != 0 or x1 != w or y0 != y:
+                return None
+            out.append((y0, y1, int(off)))
+            y = y1
+        return out if y == h else None
+    except Exception:
+        return None
 
 
 class TilePrefetcher:
