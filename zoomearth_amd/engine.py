@@ -375,11 +375,15 @@ class Engine:
         self._check(self.lib.ze_decode_burst_end(self.h, sp, len(sq), ng, fin, self._stream()))
         return list(ng), [bool(f) for f in fin]
 
-    def chain_tokens(self, seq: int, capacity: int = 0):
+    def chain_tokens(self, seq: int, capacity: int = 0, stream=None):
+        """The tokens chain `seq` has generated.  `stream`: the stream its decode steps ran on (default: the current one) --
+        the call copies on it and waits for it, so a scheduler inside its admission stream's context names the decode stream
+        (waiting for the admission stream would serialise the next burst behind the prefill pass in flight)."""
         cap = int(capacity) if capacity else self.max_ctx
         out = (C.c_int32 * max(cap, 1))()
         n = C.c_int()
-        self._check(self.lib.ze_chain_tokens(self.h, seq, out, cap, C.byref(n), self._stream()))
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
+        self._check(self.lib.ze_chain_tokens(self.h, seq, out, cap, C.byref(n), st))
         return [int(out[i]) for i in range(n.value)]
 
     def tile_upload(self, host_rgb) -> torch.Tensor:

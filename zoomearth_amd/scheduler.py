@@ -467,7 +467,9 @@ class ChainScheduler:
     def _retire(self, slot: int) -> None:
         l = self.live.pop(slot)
         req = l.req
-        req.tokens = self.engine.chain_tokens(slot, req.max_new_tokens)
+        ds = getattr(self, "_decode_stream", None)
+        req.tokens = (self.engine.chain_tokens(slot, req.max_new_tokens, stream=ds) if ds is not None
+                      else self.engine.chain_tokens(slot, req.max_new_tokens))
         req.text = self.processor.tokenizer.decode(req.tokens, skip_special_tokens=True).strip()
         follow = None
         try:
