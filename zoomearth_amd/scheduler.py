@@ -116,6 +116,7 @@ class ChainScheduler:
         self._groups = deque()             # prefill passes of the admission round in progress, one per step
         self._round = None                 # (todo, needed) of that round: images still to encode / features to keep
         self._ready = []                   # prefilled requests waiting to join the live set
+        self._pass_done = []               # (overlap) per entry of _ready: the event behind its prefill pass
         model._chains.clear()              # the scheduler owns every chain slot while it runs
 
     # ------------------------------------------------------------------ queue
@@ -245,7 +246,14 @@ class ChainScheduler:
             elif todo:
                 self._encode(OrderedDict(todo), needed)
                 todo.clear()
+            n0 = len(self._ready)
             self._prefill(group)
+            if self._side is not None and len(self._ready) > n0:
+                # the pass's own event: its chains may join the live set as soon as THIS pass is over, whatever else the
+                # admission stream has been given since
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+                self._pass_done.extend([ev] * (len(self._ready) - n0))
         except Exception as ex:
             self._fail_all([it["req"] for it in group if it["req"].slot >= 0 and it["req"].slot not in self.live
                             and not any(r is it["req"] for r, _, _ in self._ready)], ex)
@@ -414,16 +422,31 @@ class ChainScheduler:
             self._ready.append((req, tuple(ids), tuple(keys)))
 
     def _join_ready(self) -> None:
-        """The prefilled newcomers draw their first token (from the logits their pass left) and join the live set."""
+        """The prefilled newcomers draw their first token (from the logits their pass left) and join the live set.  When
+        overlapping, a pass that is still running does not hold the live chains up: they go into their next burst, the
+        newcomers join behind a later one (with nothing live, the call waits for the oldest pass)."""
         if not self._ready:
             return
+        keep_from = len(self._ready)
         if self._side is not None:
-            self._side.synchronize()   # their pass ran on the side stream; chain_begin runs on the caller's
-        for req, ids, keys in self._ready:
+            if len(self._pass_done) != len(self._ready):   # (entries without an event: wait for everything, as before)
+                self._side.synchronize()
+                self._pass_done = [None] * len(self._ready)
+            for i, ev in enumerate(self._pass_done):
+                if ev is not None and not ev.query():
+                    if i == 0 and not self.live:
+                        ev.synchronize()                    # nothing to decode meanwhile
+                        continue
+                    keep_from = i
+                    break
+        for req, ids, keys in self._ready[:keep_from]:
             self.engine.chain_begin(req.slot, self.params, req.stream_id)
             self.live[req.slot] = _Live(req, ids, keys)
             self.stats["admitted"] += 1
-        self._ready = []
+        if keep_from < len(self._ready):
+            self.stats["deferred_joins"] = self.stats.get("deferred_joins", 0) + 1
+        self._ready = self._ready[keep_from:]
+        self._pass_done = self._pass_done[keep_from:]
 
     # -- one burst of decode steps for every live chain, then retire the finished ones
     def _burst(self) -> None:
