@@ -111,6 +111,7 @@ struct ze_engine {
     int *fe_coef = nullptr;  // device coefficient tables
     size_t fe_tmp_bytes = 0, fe_img_bytes = 0, fe_coef_ints = 0;
     int* fe_coef_host = nullptr;  // pinned
+    hipEvent_t v_staged = nullptr, t_staged = nullptr;  // behind the last H2D copy out of v_host_* / t_host_ints (stage_acquire)
     hipEvent_t fe_done = nullptr;  // recorded behind the last kernel that reads the front-end workspace (any stream)
     bool fe_in_flight = false;
 

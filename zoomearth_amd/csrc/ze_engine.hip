@@ -432,6 +432,8 @@ extern "C" int ze_engine_destroy(ze_engine* e) {
     for (void* p : dev)
         if (p) hipFree(p);
     if (e->fe_done) hipEventDestroy(e->fe_done);
+    if (e->v_staged) hipEventDestroy(e->v_staged);
+    if (e->t_staged) hipEventDestroy(e->t_staged);
     void* host[] = {e->fe_coef_host, e->v_host_ints, e->v_host_f32, e->t_host_ints, e->d_host_ints, e->bstate_host};
     for (void* p : host)
         if (p) hipHostFree(p);

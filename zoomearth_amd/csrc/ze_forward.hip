@@ -31,6 +31,18 @@ static int frontend_release(ze_engine* e, hipStream_t s) {
     e->fe_in_flight = true;
     return ZE_OK;
 }
+// A pinned staging buffer is rewritten by the next call: wait until the copies that read it have run -- an event right behind
+// them, not the whole stream (which holds the ViT / prefill kernels enqueued since: the scheduler's thread used to sit 20-40 ms
+// in every vit_forward / prefill_batch call, and with bursts shorter than that -- 64 chain slots -- the decode stream idled)
+static int stage_acquire(ze_engine* e, hipEvent_t& ev) {
+    if (ev) ZE_HIP(hipEventSynchronize(ev));
+    return ZE_OK;
+}
+static int stage_release(ze_engine* e, hipEvent_t& ev, hipStream_t s) {
+    if (!ev) ZE_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    ZE_HIP(hipEventRecord(ev, s));
+    return ZE_OK;
+}
 static int crop_resize(ze_engine* e, const uint8_t* src, int src_h, int src_w, const int32_t box[4], uint8_t* dst,
                        int dst_h, int dst_w, hipStream_t s) {
     const int bx0 = box[0], by0 = box[1];
@@ -242,7 +254,7 @@ extern "C" int ze_vit_forward(ze_engine* e, const float* pixel_values, const int
         for (int t = 0; t < grid_thw[3 * i]; ++t)
             cu_full.push_back(cu_full.back() + grid_thw[3 * i + 1] * grid_thw[3 * i + 2]);
     ze_vision_pos_ids_impl(grid_thw, n_images, c.spatial_merge_size, hw);
-    ZE_HIP(hipStreamSynchronize(s));  // pinned staging reuse
+    ZE_TRY(stage_acquire(e, e->v_staged));  // pinned staging reuse
     int* hi = e->v_host_ints;
     int* perm = hi;              // [n]   new row r <- old row perm[r]
     int* inv = hi + n;           // [n/mu] merged row j (window order) -> HF order row
@@ -277,6 +289,7 @@ extern "C" int ze_vit_forward(ze_engine* e, const float* pixel_values, const int
     ZE_HIP(hipMemcpyAsync(e->vtiles_full, tf, (size_t)ntf * 16, hipMemcpyHostToDevice, s));
     ZE_HIP(hipMemcpyAsync(e->vcos, hc, (size_t)n * half * sizeof(float), hipMemcpyHostToDevice, s));
     ZE_HIP(hipMemcpyAsync(e->vsin, hs, (size_t)n * half * sizeof(float), hipMemcpyHostToDevice, s));
+    ZE_TRY(stage_release(e, e->v_staged, s));
 
     const int th = ze_timer_begin(e, 1, s);
     // ---- patch embed on window-ordered rows (pixel_values.type(bf16), conv3d == GEMM, no bias)
@@ -494,7 +507,7 @@ static int prefill_impl(ze_engine* e, int seq, const int32_t* input_ids, int len
     hipSetDevice(e->device);
     const int H = c.hidden, hd = e->head_dim, nq = c.heads * hd, nkv = c.kv_heads * hd, nqkv = nq + 2 * nkv;
 
-    ZE_HIP(hipStreamSynchronize(s));  // pinned staging reuse
+    ZE_TRY(stage_acquire(e, e->t_staged));  // pinned staging reuse
     int* src = e->t_host_ints;
     int* pos = src + len;
     int* tiles = pos + 3 * len;
@@ -522,6 +535,7 @@ static int prefill_impl(ze_engine* e, int seq, const int32_t* input_ids, int len
     ZE_HIP(hipMemcpyAsync(e->tsrc, src, (size_t)len * sizeof(int), hipMemcpyHostToDevice, s));
     ZE_HIP(hipMemcpyAsync(e->tpos, pos, (size_t)3 * len * sizeof(int), hipMemcpyHostToDevice, s));
     ZE_HIP(hipMemcpyAsync(e->ttiles, tiles, (size_t)nt * 16, hipMemcpyHostToDevice, s));
+    ZE_TRY(stage_release(e, e->t_staged, s));
 
     const int th = ze_timer_begin(e, 2, s);
     ze_launch_embed_rows(e->tsrc, e->embed, (const bf16_t*)image_embeds, e->th, len, H, s);
@@ -614,7 +628,7 @@ extern "C" int ze_prefill_batch(ze_engine* e, const int32_t* seqs, int n, const 
     }
     if (total > e->prefill_rows) return ze_fail(e, ZE_ERR_NOMEM, "batched prefill exceeds max_prefill_rows");
 
-    ZE_HIP(hipStreamSynchronize(s));  // pinned staging reuse
+    ZE_TRY(stage_acquire(e, e->t_staged));  // pinned staging reuse
     int* src = e->t_host_ints;
     int* pos = src + total;
     int* row_aux = pos + 3 * total;
@@ -664,6 +678,7 @@ extern "C" int ze_prefill_batch(ze_engine* e, const int32_t* seqs, int n, const 
     ZE_HIP(hipMemcpyAsync(e->trow_aux, row_aux, (size_t)2 * total * sizeof(int), hipMemcpyHostToDevice, s));
     ZE_HIP(hipMemcpyAsync(e->ttiles, tiles, (size_t)nt * 16, hipMemcpyHostToDevice, s));
     ZE_HIP(hipMemcpyAsync(e->ttile_aux, taux, (size_t)nt * 2 * sizeof(int), hipMemcpyHostToDevice, s));
+    ZE_TRY(stage_release(e, e->t_staged, s));
 
     const int th = ze_timer_begin(e, 2, s);
     ze_launch_embed_rows(e->tsrc, e->embed, (const bf16_t*)image_embeds, e->th, total, H, s);
