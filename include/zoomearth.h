@@ -158,8 +158,13 @@ int ze_seq_reset(ze_engine* e, int seq, void* stream);
 int ze_seq_truncate(ze_engine* e, int seq, int keep_len, void* stream);
 /* The chain in `seq` is over and the slot may go to another chain.  Chains that copied their prompt prefix from it
  * (ze_seq_copy_prefix) read those rows from ITS cache during decode (one copy per tile crosses the memory interface): this
- * call moves them to another holder of the same rows, in stream order.  ze_seq_reset does the same; a scheduler that
- * prefills on a second stream calls ze_seq_retire on the DECODE stream when it frees the slot, before the next decode step
+ * call moves them to another holder of the same rows -- the reader with the longest copy THAT HAS LANDED (an event behind
+ * every copy), or each to its own rows.  Hints are host state; the device words the decode attention reads are written by
+ * the batched decode call itself, on ITS stream, for ITS chains, before it enqueues the step -- so a chain state pushed from a
+ * prefill stream can never bring a stale hint back (round 4).  Contract: call this after the decode steps that may
+ * still read the slot have been enqueued and before anything that overwrites the slot's rows is (a scheduler: between two
+ * bursts); every step enqueued afterwards reads the new holders.  ze_seq_reset / ze_seq_truncate / a copy into the slot move
+ * the readers likewise.  `stream` is unused (kept for the ABI).
  * (reference: no counterpart -- HF generate() holds every chain's cache for the whole call). */
 int ze_seq_retire(ze_engine* e, int seq, void* stream);
 /* Declares that the first `rows` cached tokens of `seq` equal the source chain's, bit for bit (ze_seq_copy_prefix records
@@ -234,9 +239,6 @@ int ze_decode_batch(ze_engine* e, const int32_t* seqs, int n, const int32_t* tok
  * property of the engine, never of how many chains are live, so a chain's tokens do not depend on the batch it shares
  * (within a family bit for bit; the two families agree within bf16 rounding).  Returns the family in force (0 / 1). */
 int ze_set_decode_regime(ze_engine* e, int regime);
-/* 1 when the library was built with the experimental one-launch-per-layer decode kernels (`make MEGA=1`; ze_tune knobs
- * 3 / 4), 0 in the default build (they lost to the stand-alone kernels and are kept for A/B measurements only). */
-int ze_mega_available(void);
 int ze_generate_batch(ze_engine* e, const int32_t* seqs, int n, const ze_gen_params* p, int32_t* out_tokens,
                       int32_t* n_out, void* stream);
 /* Continuous batching (replaces: the request stream the reference keeps in flight against its serving back-end,
@@ -348,7 +350,7 @@ int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters, float* av
 /* Measurement-only kernel-configuration override (A/B of kernels and launch shapes inside one process; value 0 is always
  * the shipped default, every alternative computes the same function -- bit for bit unless noted).  Knobs (0..15):
  *   0, 1  variants of the single-chain down / gate-up GEMVs          2   grid cap of the GEMV family
- *   3, 4  the experimental fused per-layer launches (ze_mega.hip)    5   1: no fragment / skinny kernels in the batched step
+ *   3, 4  unused (the one-launch-per-layer kernels left in round 4)  5   1: no fragment / skinny kernels in the batched step
  *   6, 7  GEMM policy (register-staged vs LDS-DMA ring; forced tile) 8   batched decode attention: 2 = ring kernel,
  *                                                                        1 = 64-key slice kernel (agree within rounding)
  *   9     1: skinny instead of one-shot o projection                 10  1: bf16 fragments on a quantised engine

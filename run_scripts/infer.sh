@@ -4,12 +4,19 @@
 model_name="${model_name:-${1:-}}"
 exp_name="${exp_name:-${2:-zoomearth}}"
 NGPU="${NGPU:-1}"
+# ZE_THROUGHPUT=1: the setting of the benchmark's headline (bench.py: two engines per GPU with 768 chain slots of 2048 tokens
+# each, ~2 x 58 GB of KV cache).  The default (64 chains, one engine) keeps a chain's output independent of the batch size for
+# every --batch_size up to 64; above 64 the decode step runs on the row-streaming kernel family (same records for every size
+# above 64, equal to the first family within bf16 rounding: DESIGN.md section 5).  EXTRA_ARGS are passed through.
+if [ "${ZE_THROUGHPUT:-0}" = "1" ]; then
+  EXTRA_ARGS="--batch_size 768 --lanes 2 --max_ctx 2048 ${EXTRA_ARGS:-}"
+fi
 echo "Infering model: $model_name on LRS-GRO!"
 echo "Experiment name: $exp_name!"
 if [ "$NGPU" -gt 1 ]; then
   python -m torch.distributed.run --nnodes=1 --nproc-per-node "$NGPU" --master-addr 127.0.0.1 --master-port "${MASTER_PORT:-29511}" \
-    src/infer.py --model_name "$model_name" --exp_name "$exp_name"
+    src/infer.py --model_name "$model_name" --exp_name "$exp_name" ${EXTRA_ARGS:-}
   python -c "from zoomearth_amd.accel import merge_results; print(merge_results('results/$exp_name', $NGPU, 'results/$exp_name.jsonl'), 'records merged')"
 else
-  python src/infer.py --model_name "$model_name" --exp_name "$exp_name"
+  python src/infer.py --model_name "$model_name" --exp_name "$exp_name" ${EXTRA_ARGS:-}
 fi

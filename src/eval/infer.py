@@ -93,7 +93,7 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
     # --resume: keep what an interrupted run of this rank wrote and skip those question_ids (the reference opens the file
     # with "w" and starts over, :167)
     skip = done_question_ids(out_path) if resume else set()
-    if resume and skip:  # drop a torn last line before appending
+    if resume and os.path.exists(out_path):  # drop a torn last line before appending -- also when it is the ONLY line
         with open(out_path, encoding="utf-8") as f:
             good = [ln for ln in f if ln.endswith("\n")]
         with open(out_path, "w", encoding="utf-8") as f:

@@ -429,6 +429,60 @@ def test_decode_reads_a_shared_prefix_from_one_holder_and_survives_its_retiremen
         assert e.seq_prefix_hint(s) == (s, 0)
 
 
+def test_prefix_source_retires_while_a_copying_pass_is_in_flight_on_another_stream(eng4):
+    """ADVICE r3 (high).  A scheduler prefills on a side stream and decodes on another.  Chain B's pass (copy of the holder H's
+    prefix + its own tail) is still queued on the side stream when H finishes, H's slot is retired between two bursts and
+    given to a new prompt.  Required: (1) the live reader R is never pointed at B, whose copy has not landed -- although B's
+    copy is the longest; (2) nothing B's pass pushes afterwards brings the hint to H back: B decodes its own rows once H's
+    slot holds another prompt.  Bit for bit against chains prefilled in full."""
+    e = eng4
+    head = [int(t) for t in prng.uniform_ints(601, 120, 10, 1990)]
+    prompts = [head + [int(t) for t in prng.uniform_ints(602 + s, 25 + 7 * s, 10, 1990)] for s in range(3)]
+    forced = [[int(t) for t in prng.uniform_ints(650 + i, 3, 10, 1990)] for i in range(4)]
+    other = [int(t) for t in prng.uniform_ints(699, 150, 10, 1990)]
+
+    def step(slots, i):
+        return e.decode_batch(slots, [forced[i][s] for s in slots]).cpu().numpy()
+
+    for s in range(3):                                   # reference: no sharing anywhere
+        prefill_text(e, s, prompts[s])
+    want_r = [step([1], 0), step([1], 1)]
+    want_b = [step([2], 2), step([2], 3)]
+
+    prefill_text(e, 0, prompts[0])                       # H
+    e.seq_reset(1)                                       # R: 64 rows of H, joined (its pass is over)
+    e.seq_copy_prefix(1, 0, 64)
+    pos, delta = e.rope_index(prompts[1], [])
+    e.prefill(1, prompts[1][64:], None, pos[:, 64:], delta, want_logits=False)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=e.device)
+    side.wait_stream(torch.cuda.current_stream(e.device))
+    with torch.cuda.stream(side):                        # B: 100 rows of H, its pass held back behind a long wait
+        torch.cuda._sleep(int(3e8))
+        e.seq_reset(2)
+        e.seq_copy_prefix(2, 0, 100)
+        pos, delta = e.rope_index(prompts[2], [])
+        e.prefill(2, prompts[2][100:], None, pos[:, 100:], delta, want_logits=False)
+    assert not side.query(), "the side stream drained before the retirement: the test would prove nothing"
+    assert e.seq_prefix_hint(1) == (0, 64) and e.seq_prefix_hint(2) == (0, 100)
+    e.seq_retire(0)                                      # between two bursts, on the decode stream
+    assert e.seq_prefix_hint(1) == (1, 0), "the reader must go back to its own rows, not to a copy still in flight"
+    assert e.seq_prefix_hint(2) == (2, 0)
+    got_r = [step([1], 0)]                               # R decodes while B's pass is still queued
+    with torch.cuda.stream(side):                        # H's slot goes to the next newcomer, behind B's pass
+        pos, delta = e.rope_index(other, [])
+        e.seq_reset(0)
+        e.prefill(0, other, None, pos, delta, want_logits=False)
+    got_r.append(step([1], 1))
+    side.synchronize()                                   # B's pass is over: it joins
+    got_b = [step([2], 2), step([2], 3)]
+    assert e.seq_prefix_hint(2) == (2, 0)
+    for a, b in zip(got_r + got_b, want_r + want_b):
+        assert np.array_equal(a, b)
+    for s in range(3):
+        e.seq_reset(s)
+
+
 @pytest.mark.parametrize("max_ctx", [768, 1536])
 def test_attention_grid_rotation_and_extent_do_not_change_a_bit(max_ctx):
     """The decode attention's launch grid is rotated per group of four chains (XCD balance whenever kv heads x parts of

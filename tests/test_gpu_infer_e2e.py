@@ -159,6 +159,10 @@ def test_resume_runs_only_the_missing_questions(workdir):
     assert "Done!" in out
     run(base + ["--exp_name", "part_", "--resume"], d)                       # nothing left to do: the file is unchanged
     assert load(d / "results" / "part_0.jsonl") == load(d / "results" / "full_0.jsonl")
+    with open(d / "results" / "torn_0.jsonl", "w", encoding="utf-8") as f:   # interrupted inside its FIRST record
+        f.write(full[0][: len(full[0]) // 2])
+    run(base + ["--exp_name", "torn_", "--resume"], d)
+    assert load(d / "results" / "torn_0.jsonl") == load(d / "results" / "full_0.jsonl")
 
 
 def test_two_lanes_write_the_same_records(workdir):

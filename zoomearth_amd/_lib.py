@@ -71,7 +71,6 @@ _SIGS = {
     "ze_weights_arena": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "ze_weights_invalidate": (C.c_int, [_P]),
     "ze_set_decode_regime": (C.c_int, [_P, C.c_int]),
-    "ze_mega_available": (C.c_int, []),
     "ze_weights_broadcast": (C.c_int, [_P, _P, C.c_int, _P]),
     "ze_tile_upload": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "ze_op_crop_resize": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(C.c_int32), _P, C.c_int, C.c_int, _P]),

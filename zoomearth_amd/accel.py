@@ -74,12 +74,22 @@ class Accelerator:
         every rank.  mode "scatter_allgather" (SURVEY.md section 5 / 8e): xGMI is a point-to-point mesh (7 links per GPU),
         so rank `src` first sends a DIFFERENT 1/N of the arena to every peer -- all of its links busy at once -- and
         the ranks then all-gather the pieces, every link of every GPU carrying 1/N of the bytes, instead of pushing
-        the whole 7.5 GB down one ring; "broadcast" (default: the form verified on hardware) is the plain collective."""
+        the whole 7.5 GB down one ring; "broadcast" (default: the form verified on hardware) is the plain collective.
+        Prefer `broadcast_engine(engine)`.  Kept for callers that hold the arena view: an arena that came from
+        `Engine.weights_arena()` knows its engine, and the engine's derived copies (fragment / FP8 copies, captured decode
+        graphs) are invalidated here after the bytes changed -- `weights_arena()` itself has no side effect since round 3, so
+        without this the receiving ranks would keep decoding on stale copies.  A plain tensor is just broadcast."""
         if self.num_processes <= 1:
             return
         import torch.distributed as dist
         self.init_process_group("nccl" if arena.is_cuda else "gloo")
         scatter_allgather_broadcast(arena, src, dist) if mode == "scatter_allgather" else dist.broadcast(arena, src=src)
+        engine = getattr(arena, "_ze_keepalive", None)
+        if engine is not None and hasattr(engine, "weights_invalidate"):
+            if arena.is_cuda:
+                import torch
+                torch.cuda.synchronize(arena.device)
+            engine.weights_invalidate()
 
     def broadcast_engine(self, engine, src: int = 0, mode=None, backend=None) -> float:
         """The whole packed weight arena of `engine` from rank `src` to every rank (in place) and the bookkeeping that goes

@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AW_VST
     const bf16_t* __restrict__ q, int q_row_stride, const bf16_t* __restrict__ kcache, const bf16_t* __restrict__ vcache,
     size_t cache_seq_stride, const ze_seq_dev* __restrict__ st_base, const int* __restrict__ seq_ids, int heads, int kv_heads,
     int max_ctx, float scale_log2e, float* __restrict__ ws, int max_parts, unsigned* __restrict__ tickets,
-    bf16_t* __restrict__ out, int out_row_stride, int x_rot) {
+    bf16_t* __restrict__ out, int out_row_stride, int x_rot, const int* __restrict__ prefix) {
     constexpr int D = 128;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 4 waves x AW_VSTAGES V stages of 4 KB
     __shared__ float s_ml[4][32];                                   // the waves' (m, l) per head column
@@ -290,9 +290,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AW_VST
     const int fr = lane & 15, fq = lane >> 4;
     const bf16_t* kb = kcache + (size_t)seq * cache_seq_stride + (size_t)kvh * max_ctx * D;
     const bf16_t* vb = vcache + (size_t)seq * cache_seq_stride + (size_t)kvh * max_ctx * D;
-    // rows below P: the same bits live in the source chain's cache (ze_seq_dev::prefix) -- read THAT copy, the one every
-    // question of the tile reads, so that the image prefix crosses the HBM interface once per step and not once per chain
-    const int hint = st_base[seq].prefix;
+    // rows below P: the same bits live in the source chain's cache (prefix[seq], ze_engine::pfx_dev) -- read THAT copy, the one
+    // every question of the tile reads, so that the image prefix crosses the HBM interface once per step and not once per chain
+    const int hint = prefix ? prefix[seq] : 0;
     const int pfx_rows = hint & 0xffff;
     const long long pfx_delta = ((long long)(hint >> 16) - (long long)seq) * (long long)cache_seq_stride;  // in elements
     const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem) +
@@ -473,7 +473,8 @@ extern int ze_gemv_knobs[16];
 void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_t* kcache, const bf16_t* vcache,
                                   size_t cache_seq_stride, bf16_t* out, int out_row_stride, const ze_seq_dev* st,
                                   const int* seq_ids, int n, int heads, int kv_heads, int max_ctx, float scale,
-                                  float* ws_partial, int max_parts, unsigned* tickets, hipStream_t s, int chunk, int per_wave) {
+                                  float* ws_partial, int max_parts, unsigned* tickets, hipStream_t s, int chunk, int per_wave,
+                                  const int* prefix) {
     const float sl = scale * 1.4426950408889634f;
     const size_t lds = AB_STAGES * AB_STAGE;
     static bool attr_set = false;
@@ -491,7 +492,7 @@ void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_
         const int gparts = plain ? wparts : std::min(wparts, std::max(1, per_wave));
         k_attn_decode_wave<8><<<dim3(kv_heads * gparts, n), 256, 4 * AW_VSTAGES * AW_VSTAGE, s>>>(
             q, q_row_stride, kcache, vcache, cache_seq_stride, st, seq_ids, heads, kv_heads, max_ctx, sl, ws_partial, wparts, tickets,
-            out, out_row_stride, plain ? 0 : (3 | (2 << 4)));
+            out, out_row_stride, plain ? 0 : (3 | (2 << 4)), prefix);
     }
     else
         k_attn_decode_stream<8><<<dim3(kv_heads * max_parts, n), 256, lds, s>>>(q, q_row_stride, kcache, vcache, cache_seq_stride, st,

@@ -1,6 +1,6 @@
-// Device bodies of the one-token (decode) attention, shared by the stand-alone kernel (ze_attn_decode.hip) and the
-// fused per-layer kernel (ze_mega.hip).  Same arithmetic in both; the FRESH form moves cross-workgroup data with
-// sc1 (write-through / L1-bypassing) accesses so it can be handed over inside a running launch.
+// Device bodies of the one-token (decode) attention (ze_attn_decode.hip; until round 3 also the fused per-layer kernel).  The
+// FRESH form moves cross-workgroup data with sc1 (write-through / L1-bypassing) accesses so it can be handed over inside a
+// running launch (the in-launch merge of the slices).
 #pragma once
 #include "ze_kernels.h"
 

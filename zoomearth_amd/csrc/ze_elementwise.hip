@@ -549,6 +549,22 @@ void ze_launch_set_ints(int* dst, const int* host_vals, int n, hipStream_t s) {
     }
 }
 
+__global__ void k_scatter_ints(int* __restrict__ dst, ze_int_pack p, int n) {
+    const int i = threadIdx.x;
+    if (i < n) dst[p.v[i]] = p.v[64 + i];
+}
+void ze_launch_scatter_ints(int* dst, const int* host_idx, const int* host_vals, int n, hipStream_t s) {
+    for (int o = 0; o < n; o += 64) {
+        ze_int_pack p;
+        const int m = n - o < 64 ? n - o : 64;
+        for (int i = 0; i < 64; ++i) {
+            p.v[i] = i < m ? host_idx[o + i] : 0;
+            p.v[64 + i] = i < m ? host_vals[o + i] : 0;
+        }
+        hipLaunchKernelGGL(k_scatter_ints, dim3(1), dim3(64), 0, s, dst, p, m);
+    }
+}
+
 void ze_launch_embed_tokens_batch(const ze_seq_dev* st, const int* seq_ids, int n, const bf16_t* embed, bf16_t* out,
                                   int hidden, hipStream_t s) {
     const size_t tot = (size_t)n * (hidden / 8);

@@ -100,7 +100,15 @@ struct ze_engine {
     uint8_t* seen = nullptr;
     int32_t* out_tokens = nullptr;
     std::vector<int> ctx_host, delta_host;
-    std::vector<int> pfx_host;     // ze_seq_dev::prefix per chain
+    // Shared-prefix hints, (source chain << 16) | P per chain slot.  pfx_host is the truth, kept by whatever call changes it
+    // (ze_seq_copy_prefix on the admission stream, ze_seq_retire, ...); the device copy pfx_dev -- what the decode attention
+    // reads -- is written by ONE stream only: the stream of the batched decode step, which pushes the words that differ from
+    // pfx_pushed for ITS chains before it enqueues the step (sync_prefix, ze_forward.hip).  A chain state pushed from another
+    // stream can therefore never bring a stale hint back.  pfx_copy_ev[seq]: recorded behind the chain's last
+    // ze_seq_copy_prefix (null = none): only a chain whose copy has COMPLETED may become the holder other chains read from.
+    std::vector<int> pfx_host, pfx_pushed;
+    int* pfx_dev = nullptr;
+    std::vector<hipEvent_t> pfx_copy_ev;
     bool prefix_hints = true;      // ZE_PREFIX_HINT=0: every chain reads its own rows
     std::vector<hipGraphExec_t> graphs;
     std::vector<float> graph_penalty;
@@ -141,11 +149,7 @@ struct ze_engine {
     float *dlogits = nullptr, *dpartial = nullptr, *dsample = nullptr;
     int max_splits = 64;
     int* d_host_ints = nullptr;  // pinned, small
-    // fused decode attention block (ze_mega.hip)
     unsigned* atickets = nullptr;  // decode attention: one arrival ticket per (chain, kv head)
-    ze_grid_barrier* gbar = nullptr;
-    int attn_blocks = 0;  // 0: shape unsupported, the four stand-alone kernels run instead
-    int mlp_blocks = 0;   // fused O-proj + MLP launch (ze_mega.hip); 0: shape unsupported
     std::vector<int> graph_variant;  // ze_tune epoch the chain's graph was captured under
     unsigned bgraph_epoch = 0;
     std::vector<float> graph_temperature;

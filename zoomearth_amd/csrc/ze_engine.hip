@@ -288,6 +288,9 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     chk(dev_alloc(e, &e->out_tokens, (size_t)c.max_seqs * c.max_ctx));
     e->ctx_host.assign(c.max_seqs, 0);
     e->pfx_host.assign(c.max_seqs, 0);
+    e->pfx_pushed.assign(c.max_seqs, 0);
+    e->pfx_copy_ev.assign(c.max_seqs, nullptr);
+    chk(dev_alloc(e, &e->pfx_dev, c.max_seqs));
     {
         const char* ph = getenv("ZE_PREFIX_HINT");
         e->prefix_hints = !(ph && ph[0] == '0') && c.max_seqs < 32768 && c.max_ctx < 65536;
@@ -367,11 +370,18 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     chk(dev_alloc(e, &e->dact, e->text_ipad));
     chk(dev_alloc(e, &e->dlogits, (size_t)c.max_seqs * c.vocab));
     {
-        const size_t slab_floats = (size_t)16 << 20;  // 64 MB of fp32 split-K slabs
+        // fp32 split-K slabs of the weight-streaming GEMMs, sized for EVERY row count this engine can see: the slice count is a
+        // function of (N, K) alone (launch_cfg: ksplit * ceil(N / 64) < 400 whenever it splits), rows <= max_seqs padded to the
+        // largest row tile -- so the split, and with it the order of a chain's sums, never follows the row count (ADVICE r3:
+        // with a fixed 64 MB the 3B shape sat exactly at the limit at 1024 rows and larger shapes would have dropped to one
+        // slice above some batch size).  64 MB at least (the unit-op entry points call with shapes of their own).
+        const size_t rows_pad = ((size_t)std::max(c.max_seqs, 64) + 255) / 256 * 256;
+        const size_t slab_floats = std::max((size_t)16 << 20, (size_t)400 * 64 * rows_pad);
+        const int ticket_cap = std::max(4096, (int)(200 * (rows_pad / 64)) + 64);
         chk(dev_alloc(e, &e->gslab, slab_floats, false));
-        chk(dev_alloc(e, &e->gtickets, 4096, true));
+        chk(dev_alloc(e, &e->gtickets, (size_t)ticket_cap, true));
         e->gslab_floats = slab_floats;
-        e->gticket_cap = 4096;
+        e->gticket_cap = ticket_cap;
     }
     {
         const size_t br = (size_t)(std::max(c.max_seqs, 64) + 63) / 64 * 64;  // rows of the batched step (whole 64-row tiles)
@@ -389,10 +399,7 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
         r = ze_fail(e, ZE_ERR_HIP, "hipHostMalloc failed");
     chk(dev_alloc(e, &e->dpartial, (size_t)e->max_splits * c.heads * 132));
     chk(dev_alloc(e, &e->dsample, 2 * 128 + 64 + 128 + 8));  // arg-max partials, spare, chunk sums
-    chk(dev_alloc(e, &e->gbar, 1));
     chk(dev_alloc(e, &e->atickets, (size_t)c.max_seqs * c.kv_heads));
-    if (r == 0) e->attn_blocks = ze_layer_attn_blocks(c.hidden, c.heads, c.kv_heads, e->head_dim);
-    if (r == 0) e->mlp_blocks = ze_layer_mlp_blocks(c.hidden, c.heads * e->head_dim, e->text_ipad);
     if (r == 0 && hipHostMalloc((void**)&e->d_host_ints, (64 + c.max_seqs) * sizeof(int)) != hipSuccess)
         r = ze_fail(e, ZE_ERR_HIP, "hipHostMalloc failed");
     e->staging_bytes = (size_t)64 << 20;
@@ -427,10 +434,13 @@ extern "C" int ze_engine_destroy(ze_engine* e) {
                    e->st_dev, e->seen, e->out_tokens, e->fe_tmp, e->fe_img, e->fe_coef, e->vx, e->vh, e->vy, e->vqkv,
                    e->vo, e->va, e->vz, e->vz2, e->vcos, e->vsin, e->vperm, e->vinv, e->vtiles_win, e->vtiles_full,
                    e->th, e->ty, e->tqkv, e->to, e->ta, e->tsrc, e->tpos, e->ttiles, e->ttile_aux, e->trow_aux, e->dh, e->dq, e->dattn, e->dact,
-                   e->dlogits, e->dpartial, e->dsample, e->gbar, e->atickets, e->gslab, e->gtickets, e->bh, e->by, e->bqkv, e->bo, e->ba, e->bseq, e->blogits, e->bpartial, e->bsample, e->arena8, e->arena_f, e->arena_f8,
+                   e->dlogits, e->dpartial, e->dsample, e->atickets, e->gslab, e->gtickets, e->bh, e->by, e->bqkv, e->bo, e->ba, e->bseq, e->blogits, e->bpartial, e->bsample, e->arena8, e->arena_f, e->arena_f8,
                    e->ty8, e->ty8_scale, e->damax, e->ty8p, e->ty8p_scale};
     for (void* p : dev)
         if (p) hipFree(p);
+    if (e->pfx_dev) hipFree(e->pfx_dev);
+    for (hipEvent_t ev : e->pfx_copy_ev)
+        if (ev) hipEventDestroy(ev);
     if (e->fe_done) hipEventDestroy(e->fe_done);
     if (e->v_staged) hipEventDestroy(e->v_staged);
     if (e->t_staged) hipEventDestroy(e->t_staged);

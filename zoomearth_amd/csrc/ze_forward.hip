@@ -334,33 +334,50 @@ static int check_seq(ze_engine* e, int seq) {
     return ZE_OK;
 }
 
-// ---- shared-prefix hints (ze_seq_dev::prefix)
-static void set_prefix_hint(ze_engine* e, int seq, int value, hipStream_t s) {
-    if (e->pfx_host[seq] == value) return;
-    e->pfx_host[seq] = value;
-    ze_launch_set_ints(&(e->st_dev + seq)->prefix, &value, 1, s);
+// ---- shared-prefix hints (ze_engine::pfx_host / pfx_dev; the ownership rule is stated in ze_engine.h)
+static void set_prefix_hint(ze_engine* e, int seq, int value) { e->pfx_host[seq] = value; }
+// the K/V rows chain `d` copied (ze_seq_copy_prefix) have landed: nothing recorded, or the event behind the copy is over
+static bool prefix_copy_done(ze_engine* e, int d) {
+    hipEvent_t ev = e->pfx_copy_ev[d];
+    return !ev || hipEventQuery(ev) == hipSuccess;
 }
 // rows below `keep` of chain `seq` are about to change (or the chain is over): chains that read their prefix from it move to
-// the one among them with the longest prefix (its own copy holds the same bits), which goes back to reading its own rows
-static void prefix_source_gone(ze_engine* e, int seq, int keep, hipStream_t s) {
+// the one among them with the longest prefix WHOSE COPY HAS LANDED (its own rows hold the same bits), which goes back to reading
+// its own rows; readers it does not cover -- and all of them when no copy has landed yet -- go back to their own rows as well
+// (a chain joins a decode step only behind its own prefill pass, so its own rows are always good by then)
+static void prefix_source_gone(ze_engine* e, int seq, int keep) {
     int leader = -1, lead_p = 0;
     const int n = (int)e->pfx_host.size();
     for (int d = 0; d < n; ++d) {
         const int h = e->pfx_host[d];
-        if (h != 0 && (h >> 16) == seq && (h & 0xffff) > keep && (h & 0xffff) > lead_p) leader = d, lead_p = h & 0xffff;
+        if (h != 0 && (h >> 16) == seq && (h & 0xffff) > keep && (h & 0xffff) > lead_p && prefix_copy_done(e, d))
+            leader = d, lead_p = h & 0xffff;
     }
-    if (leader < 0) return;
     for (int d = 0; d < n; ++d) {
         const int h = e->pfx_host[d];
         if (h == 0 || (h >> 16) != seq || (h & 0xffff) <= keep) continue;
-        set_prefix_hint(e, d, d == leader ? 0 : ((leader << 16) | (h & 0xffff)), s);
+        const int p = h & 0xffff;
+        set_prefix_hint(e, d, (leader < 0 || d == leader || p > lead_p) ? 0 : ((leader << 16) | p));
     }
+}
+// Before a batched decode step is enqueued on `s`: the device words of ITS chains follow the host's (the one place pfx_dev is
+// written, on the one stream that reads it)
+static void sync_prefix(ze_engine* e, const int32_t* seqs, int n, hipStream_t s) {
+    int idx[64], val[64], m = 0;
+    for (int i = 0; i < n; ++i) {
+        const int q = seqs[i];
+        const int want = e->prefix_hints ? e->pfx_host[q] : 0;
+        if (e->pfx_pushed[q] == want) continue;
+        e->pfx_pushed[q] = want;
+        idx[m] = q, val[m] = want;
+        if (++m == 64) ze_launch_scatter_ints(e->pfx_dev, idx, val, m, s), m = 0;
+    }
+    if (m) ze_launch_scatter_ints(e->pfx_dev, idx, val, m, s);
 }
 
 static int push_state(ze_engine* e, int seq, hipStream_t s, int token, int n_gen, int finished) {
     ze_seq_dev st;
     memset(&st, 0, sizeof(st));
-    st.prefix = e->pfx_host[seq];
     st.ctx = e->ctx_host[seq];
     st.rope_delta = e->delta_host[seq];
     st.token = token;
@@ -378,20 +395,21 @@ extern "C" int ze_seq_reset(ze_engine* e, int seq, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     e->ctx_host[seq] = 0;
     e->delta_host[seq] = 0;
-    prefix_source_gone(e, seq, 0, s);
+    prefix_source_gone(e, seq, 0);
     e->pfx_host[seq] = 0;
     ZE_HIP(hipMemsetAsync(e->seen + (size_t)seq * e->cfg.vocab, 0, e->cfg.vocab, s));
     return push_state(e, seq, s, 0, 0, 0);
 }
 
-// The chain in `seq` is over and its slot may be given to another chain: nobody reads a prefix from it after this call (in
-// stream order).  A scheduler that prefills on a second stream calls this on the DECODE stream when it releases a slot, before
-// the next decode step is enqueued -- ze_seq_reset, which does the same, may run there on the other stream.
+// The chain in `seq` is over and its slot may be given to another chain: no decode step ENQUEUED after this call reads a prefix
+// from it (the step pushes the changed hints on its own stream first: sync_prefix).  The caller orders the call behind the
+// steps already in flight that may still read the slot's rows -- a scheduler calls it between bursts -- before it lets anything
+// overwrite them.  `stream` is unused since round 4 (kept for the ABI): hints are host state until a decode step picks them up.
 extern "C" int ze_seq_retire(ze_engine* e, int seq, void* stream) {
+    (void)stream;
     ZE_TRY(check_seq(e, seq));
-    hipSetDevice(e->device);
-    prefix_source_gone(e, seq, 0, (hipStream_t)stream);
-    set_prefix_hint(e, seq, 0, (hipStream_t)stream);
+    prefix_source_gone(e, seq, 0);
+    set_prefix_hint(e, seq, 0);
     return ZE_OK;
 }
 
@@ -399,16 +417,16 @@ extern "C" int ze_seq_retire(ze_engine* e, int seq, void* stream) {
 // prefix it wrote to both; ze_seq_copy_prefix records this by itself).  rows = 0 clears.  Also the measurement hook of
 // bench.py / tools/pmc_kernel.py: the decode attention timed with the sharing the question stream has.
 extern "C" int ze_seq_set_prefix_hint(ze_engine* e, int seq, int src_seq, int rows, void* stream) {
+    (void)stream;
     ZE_TRY(check_seq(e, seq));
-    hipSetDevice(e->device);
     if (rows <= 0 || src_seq == seq) {
-        set_prefix_hint(e, seq, 0, (hipStream_t)stream);
+        set_prefix_hint(e, seq, 0);
         return ZE_OK;
     }
     ZE_TRY(check_seq(e, src_seq));
     if (rows > e->ctx_host[seq] || rows > e->ctx_host[src_seq] || rows >= 65536 || !e->prefix_hints)
         return ze_fail(e, ZE_ERR_INVALID, "prefix hint: rows exceed a chain's context (or hints are switched off)");
-    set_prefix_hint(e, seq, (src_seq << 16) | rows, (hipStream_t)stream);
+    set_prefix_hint(e, seq, (src_seq << 16) | rows);
     return ZE_OK;
 }
 
@@ -423,7 +441,7 @@ extern "C" int ze_seq_truncate(ze_engine* e, int seq, int keep_len, void* stream
     if (keep_len < 0 || keep_len > e->ctx_host[seq]) return ze_fail(e, ZE_ERR_INVALID, "keep_len out of range");
     hipSetDevice(e->device);
     e->ctx_host[seq] = keep_len;
-    prefix_source_gone(e, seq, keep_len, (hipStream_t)stream);   // rows from keep_len on will be rewritten
+    prefix_source_gone(e, seq, keep_len);   // rows from keep_len on will be rewritten
     if ((e->pfx_host[seq] & 0xffff) > keep_len) e->pfx_host[seq] = 0;
     // the seen-set belongs to the dropped continuation: the caller re-marks the (new) prompt
     ZE_HIP(hipMemsetAsync(e->seen + (size_t)seq * e->cfg.vocab, 0, e->cfg.vocab, (hipStream_t)stream));
@@ -444,7 +462,9 @@ extern "C" int ze_seq_copy_prefix(ze_engine* e, int dst_seq, int src_seq, int n_
     ZE_KCHECK();
     e->ctx_host[dst_seq] = n_tokens;
     e->delta_host[dst_seq] = 0;
-    prefix_source_gone(e, dst_seq, 0, s);
+    prefix_source_gone(e, dst_seq, 0);
+    if (!e->pfx_copy_ev[dst_seq]) ZE_HIP(hipEventCreateWithFlags(&e->pfx_copy_ev[dst_seq], hipEventDisableTiming));
+    ZE_HIP(hipEventRecord(e->pfx_copy_ev[dst_seq], s));  // (a holder other chains may be pointed at only once this is over)
     // the copy stays (the prefill attention of a later pass reads the chain's own rows); the decode attention reads the
     // source's -- or the source's own source, when that one covers these rows
     {
@@ -729,70 +749,15 @@ extern "C" int ze_prefill_batch(ze_engine* e, const int32_t* seqs, int n, const 
 // ================================================================== decode
 // One token for chain `seq`: everything is read from the device-side chain state, so the same launch
 // sequence can be captured once into a hipGraph and replayed.
-// 1: the fused attention block (ze_mega.hip) replaces QKV GEMV + slices + merge + O-proj; 0: the stand-alone kernels
-static int ze_decode_variant(const ze_engine* e) {
-    if (e->fp8_ready) return 0;  // the experimental fused launches stream bf16 rows
-    return ((ze_gemv_knobs[3] > 0 && e->attn_blocks > 0) ? 1 : 0) | ((ze_gemv_knobs[4] > 0 && e->mlp_blocks > 0) ? 2 : 0);
-}
-// the fused kernel's bounded spins gave up somewhere in the work enqueued so far (stream must be idle)
-static int ze_check_grid_timeout(ze_engine* e, hipStream_t s) {
-    unsigned flag = 0;
-    ZE_HIP(hipMemcpyAsync(&flag, e->gbar->timeout, sizeof(flag), hipMemcpyDeviceToHost, s));
-    ZE_HIP(hipStreamSynchronize(s));
-#ifdef ZE_MLP_STAMPS
-    {  // diagnostic build (make EXTRA=-DZE_MLP_STAMPS): phase stamps of the last k_layer_mlp launch (100 MHz)
-        unsigned long long st[10];
-        hipMemcpy(st, e->gbar->timeout + 8, sizeof(st), hipMemcpyDeviceToHost);
-        fprintf(stderr, "mlp stamps (us from start):");
-        for (int i = 1; i < 10; ++i) fprintf(stderr, " %d:%.2f", i, (double)(st[i] - st[0]) / 100.0);
-        fprintf(stderr, "\n");
-    }
-#endif
-    if (!flag) return ZE_OK;
-    ZE_HIP(hipMemsetAsync(e->gbar, 0, sizeof(ze_grid_barrier), s));  // counters may have been left mid-barrier
-    ZE_HIP(hipStreamSynchronize(s));
-    return ze_fail(e, ZE_ERR_HIP, "grid barrier timed out in the fused decode kernel (workgroups not co-resident?)");
-}
-
 int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos, bool sample, const ze_sample_opts& so,
                            hipStream_t s) {
     const ze_config& c = e->cfg;
     const int H = c.hidden, hd = e->head_dim, nq = c.heads * hd, nqkv = nq + 2 * c.kv_heads * hd;
     const ze_seq_dev* st = e->st_dev + seq;
     const float scale = 1.0f / sqrtf((float)hd);
-    const int fused = ze_decode_variant(e);
     for (int li = 0; li < c.layers; ++li) {
         const ze_text_layer& L = e->tl[li];
-        if (fused & 1) {
-            ze_layer_attn_args f;
-            memset(&f, 0, sizeof(f));
-            f.wqkv = L.qkv.w;
-            f.ldqkv = L.qkv.ld;
-            f.bqkv = L.qkv.bias;
-            f.wo = L.o.w;
-            f.ldo = L.o.ld;
-            f.bo = L.o.bias;
-            f.in_norm = L.in_norm;
-            f.eps = c.rms_eps;
-            f.h = e->dh;
-            f.embed = li == 0 ? e->embed : nullptr;
-            f.st = st;
-            f.cosT = e->cosT;
-            f.sinT = e->sinT;
-            f.kcache = e->kc(li, seq);
-            f.vcache = e->vc(li, seq);
-            f.q = e->dq;
-            f.attn = e->dattn;
-            f.partial = e->dpartial;
-            f.max_splits = e->max_splits;
-            f.hidden = H;
-            f.heads = c.heads;
-            f.kv_heads = c.kv_heads;
-            f.max_ctx = c.max_ctx;
-            f.scale_log2e = scale * 1.4426950408889634f;
-            f.bar = e->gbar;
-            ze_launch_layer_attn(f, e->attn_blocks, s);
-        } else {
+        {
         ze_gemv_args a;
         memset(&a, 0, sizeof(a));
         a.W = L.qkv.w;
@@ -826,28 +791,6 @@ int ze_enqueue_decode_step(ze_engine* e, int seq, float penalty, int ignore_eos,
         ze_launch_gemv(ZE_GV_QKV_ROPE, a, s);
         ze_launch_attn_decode(e->dq, 0, e->kc(li, seq), e->vc(li, seq), 0, e->dattn, 0, st, nullptr, 1, c.heads,
                               c.kv_heads, hd, c.max_ctx, scale, e->dpartial, e->max_splits, e->atickets, s);
-        if (ze_gemv_knobs[4] > 0 && e->mlp_blocks > 0 && !e->fp8_ready) {  // O-proj + MLP of the layer in one launch
-            ze_layer_mlp_args m;
-            memset(&m, 0, sizeof(m));
-            m.wo = L.o.w;
-            m.ldo = L.o.ld;
-            m.bo = L.o.bias;
-            m.wgu = L.gate_up.w;
-            m.ldgu = L.gate_up.ld;
-            m.wdown = L.down.w;
-            m.lddown = L.down.ld;
-            m.post_norm = L.post_norm;
-            m.eps = c.rms_eps;
-            m.attn = e->dattn;
-            m.h = e->dh;
-            m.act = e->dact;
-            m.hidden = H;
-            m.nq = nq;
-            m.ipad = e->text_ipad;
-            m.bar = e->gbar;
-            ze_launch_layer_mlp(m, e->mlp_blocks, s);
-            continue;
-        }
         ze_gemv_args o;
         memset(&o, 0, sizeof(o));
         o.W = L.o.w;
@@ -1081,7 +1024,6 @@ extern "C" int ze_generate(ze_engine* e, int seq, const ze_gen_params* p, int32_
     ze_timer_end(e, t_d, s);
     ZE_HIP(hipMemcpyAsync(out_tokens, dev_out, (size_t)produced * sizeof(int), hipMemcpyDeviceToHost, s));
     ZE_HIP(hipStreamSynchronize(s));
-    if (ze_decode_variant(e)) ZE_TRY(ze_check_grid_timeout(e, s));  // any launch with in-launch grid barriers
     // trim at the first EOS (tokens after it are pad, as HF emits for finished rows)
     int n = produced;
     if (!ign) {
@@ -1182,6 +1124,7 @@ static int upload_batch(ze_engine* e, const int32_t* seqs, int n, hipStream_t s)
         if (e->ctx_host[seqs[i]] + 1 > e->cfg.max_ctx) return ze_fail(e, ZE_ERR_NOMEM, "sequence exceeds max_ctx");
     }
     ze_launch_set_ints(e->bseq, seqs, n, s);
+    sync_prefix(e, seqs, n, s);
     return ZE_OK;
 }
 
@@ -1208,7 +1151,7 @@ static void launch_batch_attention(ze_engine* e, int li, int n, bool frag_out, h
         const int max_parts = chunk ? (c.max_ctx + chunk - 1) / chunk : 8;           // (at most 8 parts: 128-token floor)
         ze_launch_attn_decode_stream(e->bqkv, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, e->bo, frag_out ? -(nq / 32) : nq,
                                      e->st_dev, e->bseq, n, c.heads, c.kv_heads, c.max_ctx, scale, e->bpartial, max_parts,
-                                     e->atickets, s, chunk, per_wave ? (e->live_parts > 0 ? e->live_parts : wparts) : 0);
+                                     e->atickets, s, chunk, per_wave ? (e->live_parts > 0 ? e->live_parts : wparts) : 0, e->pfx_dev);
     }
 }
 
@@ -1217,7 +1160,6 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
     const ze_config& c = e->cfg;
     const int H = c.hidden, hd = e->head_dim, nq = c.heads * hd, nkv = c.kv_heads * hd, nqkv = nq + 2 * nkv;
     const size_t seq_stride = (size_t)c.kv_heads * c.max_ctx * hd;
-    const float scale = 1.0f / sqrtf((float)hd);
     ze_launch_embed_tokens_batch(e->st_dev, e->bseq, n, e->embed, e->bh, H, s);
     for (int li = 0; li < c.layers; ++li) {
         const ze_text_layer& L = e->tl[li];
@@ -1848,7 +1790,6 @@ extern "C" int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters
     ZE_TRY(ensure_fragments(e, s));
     const int H = c.hidden, hd = e->head_dim, nq = c.heads * hd, nkv = c.kv_heads * hd, nqkv = nq + 2 * nkv;
     const size_t seq_stride = (size_t)c.kv_heads * c.max_ctx * hd;
-    const float scale = 1.0f / sqrtf((float)hd);
     std::vector<int> seqs(n);
     double kv_bytes = 0;
     for (int i = 0; i < n; ++i) {
@@ -1856,6 +1797,7 @@ extern "C" int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters
         kv_bytes += (double)(std::min(e->ctx_host[i] + 1, c.max_ctx)) * nkv * 2 * 2;
     }
     ze_launch_set_ints(e->bseq, seqs.data(), n, s);
+    sync_prefix(e, seqs.data(), n, s);
     set_live_parts(e, seqs.data(), n, 1);  // (the grid a decode step of these chains would launch)
     double bytes = 0;
     auto launch = [&](int it) {

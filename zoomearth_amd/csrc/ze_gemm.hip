@@ -1449,7 +1449,17 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
         const int tiles_n = ze_cdiv(N, BN);
         while (tiles_n * ksplit < 200 && ksplit < 8 && nk / (ksplit * 2) >= 4) ksplit *= 2;
     }
-    if (ksplit > 1 && (!g_slab || (size_t)ksplit * nwg * BM * BN > g_slab_floats || nwg > g_ticket_cap)) ksplit = 1;
+    if (ksplit > 1 && (!g_slab || (size_t)ksplit * nwg * BM * BN > g_slab_floats || nwg > g_ticket_cap)) {
+        // never silently: one slice instead of `ksplit` changes the order of every sum of this projection, i.e. a chain's bits
+        // would follow the row count.  An engine sizes its slabs for its max_seqs (ze_engine_create), so this is a caller
+        // without a workspace (unit ops) or a bug.
+        static bool told = false;
+        if (g_slab && !told) {
+            told = true;
+            fprintf(stderr, "zoomearth: split-K workspace too small for M=%d N=%d K=%d (ksplit %d -> 1): results no longer batch-invariant\n", M, N, K, ksplit);
+        }
+        ksplit = 1;
+    }
     const int grid = nwg * ksplit;
     // The ring wins where a launch is at most one round of workgroups (few tiles, long K: o / down / merger / ViT
     // proj, 1.3-1.9x) and loses 15-25 % to the register-staged kernel on grids of many rounds, which hide latency

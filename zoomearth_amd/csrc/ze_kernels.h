@@ -17,9 +17,8 @@ struct ze_seq_dev {
     int32_t n_gen;      // tokens written to out_tokens so far
     int32_t max_gen;    // capacity of out_tokens
     int32_t stream;     // sampling stream of this chain: its row in the generate call (0 for single-chain calls)
-    int32_t prefix;     // (source chain << 16) | P: rows 0 .. P-1 of the source chain's KV cache hold the same bits as this
-                        // chain's own (ze_seq_copy_prefix); 0 = none.  The decode attention reads those rows from the SOURCE,
-                        // so the questions of one tile stream one copy of the image prefix (Infinity Cache hits)
+    int32_t reserved;   // (was the shared-prefix hint: that word now lives in an array of its own, ze_engine::pfx_dev, written
+                        // by the DECODE stream alone -- chain state is pushed from whatever stream prefills the chain)
 };
 
 // ---- front-end
@@ -150,47 +149,6 @@ bool ze_launch_gemv(int epi, const ze_gemv_args& a, hipStream_t s);
 // [rows, ld8], the scales, and REPLACES the bf16 values by the dequantised ones (exactly representable)
 void ze_launch_quantize_rows(bf16_t* w, int rows, int cols, int ld, uint8_t* q, int ld8, float* scale, hipStream_t s);
 
-// ---- fused decode attention block of one layer (ze_mega.hip): QKV GEMV -> slices -> merge -> O-proj in one launch
-struct ze_grid_barrier {  // zeroed once at engine creation; every word on its own 128-B line
-    unsigned cnt[8 * 32];  // arrivals per group (group = blockIdx % 8, up to 64 workgroups each); back to 0 per barrier
-    unsigned gen[8 * 32];  // barriers completed so far (monotonic, wraps), one copy per group
-    unsigned top[32];      // groups completed; back to 0 per barrier
-    unsigned timeout[32];  // set when a bounded spin gave up: the step's output is invalid and the host reports it
-};
-struct ze_layer_attn_args {
-    const bf16_t* wqkv; int ldqkv; const bf16_t* bqkv;  // [(heads + 2 kv_heads) * 128, hidden]
-    const bf16_t* wo; int ldo; const bf16_t* bo;        // [hidden, heads * 128]
-    const bf16_t* in_norm; float eps;
-    bf16_t* h;            // hidden stream [hidden], updated in place
-    const bf16_t* embed;  // non-null (layer 0): the stream starts as embed[st->token]
-    const ze_seq_dev* st;
-    const bf16_t* cosT; const bf16_t* sinT;
-    bf16_t* kcache; bf16_t* vcache;  // [kv_heads, max_ctx, 128] of this layer / chain
-    bf16_t* q; bf16_t* attn;         // scratch [heads * 128]
-    float* partial; int max_splits;
-    int hidden, heads, kv_heads, max_ctx;
-    float scale_log2e;
-    ze_grid_barrier* bar;
-};
-// second half of a decode layer in ONE launch: O-proj + residual -> RMSNorm + gate/up + SiLU*up -> down + residual
-struct ze_layer_mlp_args {
-    const bf16_t* wo; int ldo; const bf16_t* bo;     // [hidden, heads * 128]
-    const bf16_t* wgu; int ldgu;                     // [2 * ipad, hidden], gate / up rows interleaved in blocks of 16
-    const bf16_t* wdown; int lddown;                 // [hidden, ipad]
-    const bf16_t* post_norm; float eps;
-    const bf16_t* attn;  // [heads * 128] output of the attention launch
-    bf16_t* h;           // hidden stream [hidden], updated in place
-    bf16_t* act;         // scratch [ipad]
-    int hidden, nq, ipad;
-    ze_grid_barrier* bar;
-};
-int ze_layer_mlp_blocks(int hidden, int nq, int ipad);
-void ze_launch_layer_mlp(const ze_layer_mlp_args& a, int blocks, hipStream_t s);
-
-// workgroups the fused kernel may be launched with (all co-resident, multiple of 8), 0 when the shape is unsupported
-int ze_layer_attn_blocks(int hidden, int heads, int kv_heads, int head_dim);
-void ze_launch_layer_attn(const ze_layer_attn_args& a, int blocks, hipStream_t s);
-
 // ---- attention
 // Varlen flash attention (prefill / ViT). Tiles: host-built list of (q_start, q_end, kv_start, kv_end) int4 rows.
 void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_row_stride, int q_head_stride, const bf16_t* k,
@@ -216,7 +174,11 @@ void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_
                                   size_t cache_seq_stride, bf16_t* out, int out_row_stride, const ze_seq_dev* st,
                                   const int* seq_ids, int n, int heads, int kv_heads, int max_ctx, float scale,
                                   float* ws_partial, int max_parts, unsigned* tickets, hipStream_t s, int chunk = 0,
-                                  int per_wave = 0);  // per_wave: k_attn_decode_wave (every wave a stream of its own)
+                                  int per_wave = 0,   // per_wave: k_attn_decode_wave (every wave a stream of its own)
+                                  const int* prefix = nullptr);
+// prefix (per_wave only; per chain SLOT, null = none): (source chain << 16) | P -- rows 0 .. P-1 of the source chain's KV cache
+// hold the same bits as the chain's own (ze_seq_copy_prefix) and are read from the SOURCE, so the questions of one tile stream
+// one copy of their image prefix (Infinity Cache hits)
 
 // first n_tokens cached K/V rows of chain src -> chain dst (all layers / kv heads); strides in elements
 void ze_launch_kv_copy_prefix(bf16_t* kcache, bf16_t* vcache, size_t layer_stride, size_t seq_stride, size_t head_stride,
@@ -240,6 +202,8 @@ void ze_launch_advance_ctx(ze_seq_dev* st, hipStream_t s);
 // dst[0..n) = vals[0..n): the values travel as kernel arguments (no host staging buffer to keep alive, no stream
 // synchronisation before it can be reused): chain-state pushes and the chain-id list of a batched step
 void ze_launch_set_ints(int* dst, const int* host_vals, int n, hipStream_t s);
+// dst[idx[i]] = vals[i], i < n: the pairs travel as kernel arguments too
+void ze_launch_scatter_ints(int* dst, const int* host_idx, const int* host_vals, int n, hipStream_t s);
 void ze_launch_embed_tokens_batch(const ze_seq_dev* st, const int* seq_ids, int n, const bf16_t* embed, bf16_t* out,
                                   int hidden, hipStream_t s);
 void ze_launch_rope_kv_batch(bf16_t* qkv, int n, int heads, int kv_heads, int D, const bf16_t* cosT, const bf16_t* sinT,

@@ -75,6 +75,17 @@ class Engine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _use(self, *tensors):
+        """The kernels about to be enqueued on the CURRENT stream read these tensors.  A tensor allocated on another stream (a
+        tile uploaded or a view resized on the caller's stream, then cropped / encoded on the scheduler's admission stream)
+        goes back to ITS stream's pool when the last reference drops, and the caching allocator would hand the block out again
+        -- e.g. to the next tile's upload -- while this stream's reads are still queued: record_stream keeps the block until
+        they are over (a no-op for a tensor of this stream)."""
+        st = torch.cuda.current_stream(self.device)
+        for t in tensors:
+            if t is not None and t.is_cuda:
+                t.record_stream(st)
+
     def _check(self, code):
         return _lib.check(code, self.h)
 
@@ -121,7 +132,9 @@ class Engine:
             raise RuntimeError(self.lib.ze_last_error(self.h).decode())
 
     def weights_arena(self) -> torch.Tensor:
-        """uint8 view of the packed weight arena (no copy), e.g. for one torch.distributed.broadcast over RCCL."""
+        """uint8 view of the packed weight arena (no copy), e.g. for one torch.distributed.broadcast over RCCL.  Reading it
+        has no side effect; whoever WRITES through it calls weights_invalidate() afterwards (accel.broadcast_engine_weights
+        and Accelerator.broadcast_weights do): the fragment / FP8 copies and the captured decode graphs derive from it."""
         p, n = C.c_void_p(), C.c_size_t()
         self._check(self.lib.ze_weights_arena(self.h, C.byref(p), C.byref(n)))
 
@@ -145,6 +158,7 @@ class Engine:
         ow, oh = int(out_wh[0]), int(out_wh[1])
         out = torch.empty((oh, ow, 3), dtype=torch.uint8, device=self.device)
         b = (C.c_int32 * 4)(*[int(v) for v in box])
+        self._use(tile)
         self._check(self.lib.ze_op_crop_resize(self.h, _ptr(tile), h, w, b, _ptr(out), oh, ow, self._stream()))
         return out
 
@@ -158,6 +172,7 @@ class Engine:
         h, w = int(img.shape[0]), int(img.shape[1])
         p = self.config.vision.patch_size
         out = torch.empty(((h // p) * (w // p), self.patch_dim), dtype=torch.float32, device=self.device)
+        self._use(img)
         self._check(self.lib.ze_op_patchify(self.h, _ptr(img), h, w, _ptr(out), self._stream()))
         return out
 
@@ -170,6 +185,7 @@ class Engine:
         rows = (rh // p) * (rw // p)
         out = torch.empty((rows, self.patch_dim), dtype=torch.float32, device=self.device)
         grid = (C.c_int32 * 3)()
+        self._use(img)
         self._check(self.lib.ze_preprocess_image(self.h, _ptr(img), h, w, min_pixels, max_pixels, _ptr(out), rows,
                                                  grid, self._stream()))
         return out, (int(grid[0]), int(grid[1]), int(grid[2]))
@@ -202,6 +218,7 @@ class Engine:
         assert pixel_values.shape[0] == n, (pixel_values.shape, n)
         mu = self.config.vision.spatial_merge_size ** 2
         out = torch.empty((n // mu, self.config.vision.out_hidden_size), dtype=torch.bfloat16, device=self.device)
+        self._use(pixel_values)
         self._check(self.lib.ze_vit_forward(self.h, _ptr(pixel_values), gp, len(g), _ptr(out), self._stream()))
         return out
 
@@ -249,6 +266,7 @@ class Engine:
         if image_embeds is not None:
             assert image_embeds.dtype == torch.bfloat16 and image_embeds.is_contiguous()
         logits = torch.empty(self.config.text.vocab_size, dtype=torch.float32, device=self.device) if want_logits else None
+        self._use(image_embeds)
         self._check(self.lib.ze_prefill(self.h, seq, ip, len(ids), _ptr(image_embeds), n_img, pp, rope_delta,
                                         _ptr(logits), self._stream()))
         return logits
@@ -293,6 +311,7 @@ class Engine:
         if emb is not None:
             assert emb.dtype == torch.bfloat16
         dl, dp = _i32(deltas)
+        self._use(emb, *embs)
         self._check(self.lib.ze_prefill_batch(self.h, sp, len(sq), lp, ip, _ptr(emb), nrp, pp, dp, self._stream()))
 
     def decode_step(self, seq: int, token: int = -1, want_logits: bool = True):
