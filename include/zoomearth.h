@@ -321,7 +321,8 @@ int ze_op_linear_mx(ze_engine* e, const void* a8, const void* sa, const void* w8
  * 4 the SwiGLU epilogue of the MLP (HF:...modeling_qwen2_5_vl.py:85-96,541-554): W holds gate and up rows interleaved
  *   in blocks of 16 ([gate 0..15 | up 0..15 | gate 16..31 | ...], N = 2 * width, width % 16 == 0), bias likewise;
  *   C is [M, N/2] = bf16(bf16(silu(bf16(gate))) * bf16(up));
- * 6 / 7 none / SwiGLU through the launcher of the row-streaming decode regime (ze_set_decode_regime = 1; rows = chains). */
+ * 6 / 7 none / SwiGLU through the launcher of the row-streaming decode regime (ze_set_decode_regime = 1; rows = chains);
+ * 10 the lm_head of that regime: no bias, C is FP32 [M, N] (HF casts the logits to fp32, HF:generation/utils.py:2894). */
 int ze_op_linear(ze_engine* e, const void* a_bf16, const void* w_bf16, const void* bias_bf16, void* c_bf16, int M,
                  int N, int K, int act, void* stream);
 /* y = weight * bf16(x * rsqrt(mean(x^2)+eps))  (HF:...modeling_qwen2_5_vl.py:64-79), rows x cols bf16. */
@@ -335,6 +336,29 @@ int ze_op_token_logprob(ze_engine* e, const void* logits_bf16, int rows, int voc
  * causal applies inside each segment; kv_heads divides heads (GQA). */
 int ze_op_attention(ze_engine* e, const void* q, const void* k, const void* v, void* o, int T, int heads,
                     int kv_heads, int D, const int32_t* cu_seqlens, int n_seg, int causal, void* stream);
+
+/* K4 (HF:...modeling_qwen2_5_vl.py:434-439; HF:vision_utils.py:130-188): pixel_values f32 [n, 1176] (device, HF patch order) ->
+ * bf16 rows in WINDOW order (groups of merge^2 rows follow window_index) -- what the patch embed reads.  ze_op_window_scatter
+ * is the inverse on merged rows (HF:...:464-466): x bf16 [n / merge^2, cols] in window order -> HF order. */
+int ze_op_window_gather(ze_engine* e, const float* pixel_values, const int32_t* grid_thw, int n_images, void* out_bf16, void* stream);
+int ze_op_window_scatter(ze_engine* e, const void* x_bf16, int cols, const int32_t* grid_thw, int n_images, void* out_bf16,
+                         void* stream);
+/* K5 + K8 (HF:...:125-134,160-171,441-446): 2-D vision rotary on the q and k thirds of qkv bf16 [n, 3 * heads * 80] in place,
+ * tables and arithmetic in fp32, one rounding to bf16; rows in window order (window_order != 0: the ViT's own layout) or HF order. */
+int ze_op_vision_rope(ze_engine* e, void* qkv_bf16, const int32_t* grid_thw, int n_images, int window_order, void* stream);
+/* K13 (HF:...:1206-1215, get_placeholder_mask + masked_scatter :1094-1133): out bf16 [len, hidden] = embed_tokens[input_ids],
+ * image-token rows replaced by the rows of image_embeds (bf16 [n_image_rows, hidden]) in order; ZE_ERR_MISMATCH when the counts
+ * differ (HF raises "Image features and image tokens do not match"). */
+int ze_op_embed_scatter(ze_engine* e, const int32_t* input_ids, int len, const void* image_embeds, int n_image_rows, void* out_bf16,
+                        void* stream);
+/* K15 + K18 (apply_multimodal_rotary_pos_emb HF:...:557-599 with cos / sin cast to bf16 :538; DynamicCache.update :667-668):
+ * qkv bf16 [T, (heads + 2 kv_heads) * 128] -- q roped in place, roped k and v appended to `layer`'s cache of chain `seq` at
+ * positions past .. past + T - 1; position_ids host int32 [3, T].  The chain's length does not change (unit op).
+ * ze_op_rope_kv_decode: the decode-step form, row b = chain seqs[b] at its own position (ctx + rope_delta), appended at ctx.
+ * ze_op_kv_read: rows [start, start + n) of that cache, out_k / out_v bf16 [kv_heads, n, 128] device. */
+int ze_op_mrope_kv(ze_engine* e, int seq, int layer, void* qkv_bf16, int T, const int32_t* position_ids, int past, void* stream);
+int ze_op_rope_kv_decode(ze_engine* e, const int32_t* seqs, int n, int layer, void* qkv_bf16, void* stream);
+int ze_op_kv_read(ze_engine* e, int seq, int layer, int start, int n, void* out_k, void* out_v, void* stream);
 
 /* ------------------------------------------------------------------ measurement */
 /* Runs the decode-path weight-streaming kernel `which` (0 qkv, 1 o_proj, 2 gate_up, 3 down, 4 lm_head) `iters`

@@ -90,3 +90,28 @@ def test_rope_index_host(lib, golden_json):
     d = C.c_int32()
     assert lib.ze_rope_index(C.byref(z), bad.ctypes.data_as(C.POINTER(C.c_int32)), 4, g.ctypes.data_as(C.POINTER(C.c_int32)),
                              1, pos.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(d)) == -5
+
+
+def test_host_helpers_under_asan_ubsan(tmp_path):
+    """SURVEY.md section 5 (sanitizers; VERDICT r3 missing #5): zoomearth_amd/csrc/ze_index.cpp -- every integer index builder and
+    the bicubic tap tables of the host side -- compiled with gcc -fsanitize=address,undefined and run against the golden vectors
+    in a child process (libasan preloaded under the interpreter).  Any report (heap overflow, signed overflow, bad shift,
+    misaligned access ...) aborts the child.  GPU sanitizers are not available on the pool, so this is the CPU build only."""
+    import shutil
+    import subprocess
+    import sys
+    gxx = shutil.which("g++")
+    asan = subprocess.run([gxx, "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip() if gxx else ""
+    if not gxx or not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no g++ / libasan in this image")
+    so = str(tmp_path / "libze_index_san.so")
+    csrc = os.path.join(ROOT, "zoomearth_amd", "csrc")
+    r = subprocess.run([gxx, "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                        "-fno-omit-frame-pointer", "-I", csrc, os.path.join(csrc, "ze_index.cpp"),
+                        os.path.join(ROOT, "tests", "cabi_san", "ze_index_san.cpp"), "-o", so], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "cabi_san", "run_san.py"), so], capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert r.returncode == 0 and "sanitized host helpers ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

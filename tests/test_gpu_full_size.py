@@ -133,3 +133,80 @@ def test_graph_replay_equals_eager_and_is_reproducible_at_full_size(full):
         runs.append(e.generate(0, 24, repetition_penalty=1.05, ignore_eos=True, use_graph=graph))
     assert runs[0] == runs[1] == runs[2] and len(runs[0]) == 24
     assert len(set(runs[0])) > 6                                         # the recipe's outputs are diverse, not a fixed point
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The row-streaming kernel family at full size: an engine with more than 64 chain slots -- what
+# bench.py's stream (2 x 768 slots) and `src/eval/infer.py --batch_size 256` run -- had never executed at 36 layers x
+# vocabulary 151,936 in any test.
+@pytest.fixture(scope="module")
+def full_wide():
+    from zoomearth_amd.config import ModelConfig
+    from zoomearth_amd.engine import Engine
+    from zoomearth_amd.synth import synthetic_tile
+    e = Engine(ModelConfig.zoomearth_3b(), device=0, max_seqs=400, max_ctx=1408, max_patches=8192, max_tile_side=5000,
+               max_prefill_rows=8 * 1024)
+    e.fill_synthetic(**W)
+    assert e.set_decode_regime(-1) == 1
+    tile = e.tile_upload(torch.from_numpy(synthetic_tile(4242, 5000, 5000)))
+    yield e, tile
+    e.close()
+
+
+def test_row_streaming_family_prefill_and_decode_agree_at_full_depth(full_wide):
+    """prefill(n + 1) against prefill(n) + one step of the row-streaming batched decode (paths that share no kernel), with the
+    distance between that step and the single-chain GEMV step as the yardstick -- the protocol of the test above."""
+    e, tile = full_wide
+    ids, feats, grid, _ = question(e, tile, 0)
+    nxt = int(text_ids(300, 1)[0])
+    pos, delta = e.rope_index(ids + [nxt], [grid])
+    e.seq_reset(0)
+    whole = e.prefill(0, ids + [nxt], feats, pos, delta).cpu().numpy()
+    e.seq_reset(1)
+    e.prefill(1, ids, feats, pos[:, :-1], delta, want_logits=False)
+    gemv = e.decode_step(1, nxt).cpu().numpy()
+    e.seq_reset(2)
+    e.prefill(2, ids, feats, pos[:, :-1], delta, want_logits=False)
+    wide = e.decode_batch([2], [nxt]).cpu().numpy()[0]
+    yard = float(np.abs(gemv - wide).max())
+    rms = float(np.sqrt(np.mean(whole.astype(np.float64) ** 2)))
+    rel_yard = float(np.sqrt(np.mean((gemv - wide).astype(np.float64) ** 2))) / rms
+    err = float(np.abs(wide - whole).max())
+    rel = float(np.sqrt(np.mean((wide - whole).astype(np.float64) ** 2))) / rms
+    print(f"full depth, row-streaming family: |decode - prefill| = {err:.4f} (rms {100 * rel:.2f} %), |gemv - wide| = {yard:.4f}")
+    assert np.isfinite(wide).all() and err <= 2.0 * yard + 0.02 and rel <= 2.0 * rel_yard + 0.01
+    assert int(wide.argmax()) == int(whole.argmax()) or float(np.sort(whole)[-1] - np.sort(whole)[-2]) < 2.0 * err
+
+
+def test_row_streaming_family_batch_invariance_at_full_size(full_wide):
+    """A chain's logits over all 151,936 columns are the same bits alone, among 65 and among 400 ragged chains: the
+    128- / 384- / 512-row gate/up passes, the three forms of the down projection, the lm_head below and above 160 rows and the
+    attention grid of every extent add an output's terms in one order."""
+    e, tile = full_wide
+    views = [question(e, tile, q, n_text=300) for q in range(4)]
+    tok = [int(t) for t in text_ids(401, 400)]
+    lens = {}
+
+    def prefill(s):
+        ids, feats, grid, _ = views[s % 4]
+        n = len(ids) - (7 * s) % 160                                     # ragged: 467 .. 626 tokens
+        lens[s] = n
+        pos, delta = e.rope_index(ids, [grid])
+        e.seq_reset(s)
+        e.prefill(s, ids[:n], feats, pos[:, :n], delta, want_logits=False)
+
+    def run(slots):
+        for s in slots:
+            e.seq_truncate(s, lens[s])
+        return e.decode_batch(list(slots), [tok[s] for s in slots]).cpu().numpy()
+
+    for s in range(400):
+        prefill(s)
+    crowd = run(list(range(400)))
+    assert np.isfinite(crowd).all()
+    mid = run(list(range(300, 365)))                                      # 65 chains, another place in the batch
+    alone = run([333])
+    assert np.array_equal(alone[0], crowd[333]) and np.array_equal(mid[33], crowd[333])
+    assert np.array_equal(mid, crowd[300:365])
+    few = run([5, 399, 128])
+    assert np.array_equal(few[0], crowd[5]) and np.array_equal(few[1], crowd[399]) and np.array_equal(few[2], crowd[128])

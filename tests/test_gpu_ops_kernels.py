@@ -1,0 +1,161 @@
+"""GPU: the index / rotary / scatter / KV-append kernels on their own, through the `ze_op_*` entries SURVEY.md 8b asks for
+(K4 window permutation, K5 + K8 vision rotary, K13 embed + image scatter, K15 + K18 M-RoPE apply + KV append) -- until
+round 4 they were reachable only inside ze_vit_forward / ze_prefill.  Integer / copy kernels: exact.  Rotary kernels:
+against numpy restatements of HF's arithmetic (HF:models/qwen2_5_vl/modeling_qwen2_5_vl.py:160-171 fp32 vision rope;
+:538,557-599 text rope on bf16-rounded cos / sin with bf16-rounded products)."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import CHAIN_W, tiny_engine, tiny_weights, to_dev_bf16  # noqa: F401
+from oracle import indices, prng
+from oracle import qwen25vl as Q
+from oracle.qwen25vl import bf16_round
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(seed, shape, std=1.0):
+    return bf16_round(prng.normal_ih4(seed, int(np.prod(shape)), std)).reshape(shape)
+
+
+GRIDS = [[(1, 36, 22)], [(1, 8, 12), (1, 36, 36)], [(1, 62, 62)], [(1, 4, 4), (1, 2, 6), (1, 16, 10)]]
+
+
+@pytest.mark.parametrize("grids", GRIDS)
+def test_window_gather_and_scatter_are_the_hf_permutation(tiny_engine, grids):
+    """K4: hidden_states.reshape(n/4, 4, -1)[window_index] (HF:...:434-439) and its inverse on merged rows (:464-466)."""
+    e = tiny_engine
+    n = sum(t * h * w for t, h, w in grids)
+    pv = prng.normal_ih4(70 + n, n * 1176, 1.0).reshape(n, 1176).astype(np.float32)
+    widx, _ = indices.vision_window_index(grids)
+    got = e.op_window_gather(torch.from_numpy(pv).cuda(), grids).float().cpu().numpy()
+    want = bf16_round(pv).reshape(n // 4, 4, -1)[widx].reshape(n, -1)
+    assert np.array_equal(got, want)
+    x = rnd(71 + n, (n // 4, 64))
+    back = e.op_window_scatter(to_dev_bf16(x), grids).float().cpu().numpy()
+    assert np.array_equal(back, x[np.argsort(widx)])
+
+
+@pytest.mark.parametrize("grids,window_order", [(GRIDS[0], True), (GRIDS[1], True), (GRIDS[1], False), (GRIDS[3], True)])
+def test_vision_rope_matches_hf_fp32_arithmetic(tiny_engine, grids, window_order):
+    """K5 + K8: rotary_pos_emb tables (theta 10000, dim head_dim / 2, (h, w) per patch) and q * cos + rotate_half(q) * sin in
+    fp32, one rounding to bf16 (HF:...:160-171); the v third of qkv is untouched."""
+    e = tiny_engine
+    v = e.config.vision
+    nh, hd = v.num_heads, v.hidden_size // v.num_heads
+    n = sum(t * h * w for t, h, w in grids)
+    qkv = rnd(80 + n, (n, 3 * nh * hd))
+    got = e.op_vision_rope(to_dev_bf16(qkv), grids, window_order).float().cpu().numpy().reshape(n, 3, nh, hd)
+    o = Q.Qwen25VLOracle(Q.tiny_config(), {"model.language_model.embed_tokens.weight": np.zeros((2, 2), np.float32)}, "fp32")
+    rot = o.vision_rope_tables(grids)
+    if window_order:
+        widx, _ = indices.vision_window_index(grids)
+        rot = rot.reshape(n // 4, 4, -1)[widx].reshape(n, -1)
+    emb = np.concatenate([rot, rot], axis=-1).astype(np.float64)
+    cos, sin = np.cos(emb)[:, None, :], np.sin(emb)[:, None, :]
+    src = qkv.reshape(n, 3, nh, hd).astype(np.float64)
+    for part in (0, 1):
+        t = src[:, part]
+        rh = np.concatenate([-t[..., hd // 2:], t[..., : hd // 2]], axis=-1)
+        want = t * cos + rh * sin
+        err = np.abs(got[:, part] - want) / np.maximum(np.abs(want), 0.05)
+        assert err.max() <= 1.01 * 2.0 ** -8, (part, err.max())     # one bf16 rounding of an fp32 result
+        assert np.mean(got[:, part] == bf16_round(want.astype(np.float32))) > 0.999
+    assert np.array_equal(got[:, 2], qkv.reshape(n, 3, nh, hd)[:, 2])
+
+
+def test_embed_and_image_scatter_are_exact(tiny_engine, tiny_weights):
+    """K13: inputs_embeds = embed_tokens(input_ids); masked_scatter of the image features over the image-token rows in order
+    (HF:...:1206-1215); a count mismatch is HF's ValueError."""
+    from zoomearth_amd._lib import ZoomEarthError
+    e = tiny_engine
+    e.fill_synthetic(**CHAIN_W)
+    cfg = Q.tiny_config()
+    ids = prng.uniform_ints(90, 40, 10, 1990).tolist() + [cfg.vision_start_token_id] + [cfg.image_token_id] * 24 + \
+        [cfg.vision_end_token_id] + prng.uniform_ints(91, 7, 10, 1990).tolist() + [cfg.image_token_id] * 6 + [5]
+    feats = rnd(92, (30, cfg.text.hidden_size))
+    got = e.op_embed_scatter(ids, to_dev_bf16(feats)).float().cpu().numpy()
+    want = Q.Qwen25VLOracle(cfg, tiny_weights, "bf16").embed(ids, feats)
+    assert np.array_equal(got, want)
+    text_only = [7, 8, 9, 1000]
+    assert np.array_equal(e.op_embed_scatter(text_only).float().cpu().numpy(),
+                          tiny_weights["model.language_model.embed_tokens.weight"][text_only])
+    with pytest.raises(ZoomEarthError, match="Image features and image tokens do not match"):
+        e.op_embed_scatter(ids, to_dev_bf16(feats[:29]))
+
+
+def _text_rope_ref(cfg, x, pos3):
+    """apply_multimodal_rotary_pos_emb on [T, heads, 128] with HF's bf16 cast points (oracle/qwen25vl.py: text_forward)."""
+    o = Q.Qwen25VLOracle(cfg, {"model.language_model.embed_tokens.weight": np.zeros((2, 2), np.float32)}, "bf16")
+    cos, sin = o.text_rope(np.asarray(pos3))
+    hd = x.shape[-1]
+    rh = np.concatenate([-x[..., hd // 2:], x[..., : hd // 2]], axis=-1)
+    return bf16_round(bf16_round(x * cos[:, None, :]) + bf16_round(rh * sin[:, None, :]))
+
+
+def test_mrope_apply_and_kv_append(tiny_engine):
+    """K15 + K18 (prefill form): q roped in place, roped k / plain v appended to the layer's cache at `past` -- three-axis
+    positions of an image run included -- bit for bit against the bf16 restatement of HF's arithmetic; the rows before
+    `past` and after the appended block are untouched."""
+    e = tiny_engine
+    cfg = Q.tiny_config()
+    t = cfg.text
+    nq, nkv, hd = t.num_attention_heads, t.num_key_value_heads, cfg.head_dim
+    T, past, layer, seq = 45, 17, 1, 2
+    ids = np.array([11] * 5 + [cfg.vision_start_token_id] + [cfg.image_token_id] * 24 + [cfg.vision_end_token_id] + [12] * 14)
+    pos, _ = indices.rope_index(ids[None, :], [(1, 8, 12)], cfg.image_token_id)
+    pos3 = pos[:, 0] + 3                                       # (any offset: a follow-up's positions)
+    assert pos3.shape == (3, T) and len({tuple(c) for c in pos3.T}) > 30 and (pos3[0] != pos3[2]).any()
+    qkv = rnd(95, (T, (nq + 2 * nkv) * hd))
+    # sentinel rows around the block
+    e.op_mrope_kv(seq, layer, to_dev_bf16(np.full((1, (nq + 2 * nkv) * hd), 3.0, np.float32)), np.zeros((3, 1), np.int32), past - 1)
+    e.op_mrope_kv(seq, layer, to_dev_bf16(np.full((1, (nq + 2 * nkv) * hd), 5.0, np.float32)), np.zeros((3, 1), np.int32), past + T)
+    before = [x.float().cpu().numpy() for x in e.op_kv_read(seq, layer, past - 1, T + 2)]
+    out = e.op_mrope_kv(seq, layer, to_dev_bf16(qkv), pos3, past).float().cpu().numpy()
+    q = qkv[:, : nq * hd].reshape(T, nq, hd)
+    k = qkv[:, nq * hd: (nq + nkv) * hd].reshape(T, nkv, hd)
+    v = qkv[:, (nq + nkv) * hd:].reshape(T, nkv, hd)
+    assert np.array_equal(out[:, : nq * hd].reshape(T, nq, hd), _text_rope_ref(cfg, q, pos3))
+    kc, vc = [x.float().cpu().numpy() for x in e.op_kv_read(seq, layer, past - 1, T + 2)]
+    assert np.array_equal(kc[:, 1:-1], _text_rope_ref(cfg, k, pos3).transpose(1, 0, 2))
+    assert np.array_equal(vc[:, 1:-1], v.transpose(1, 0, 2))
+    for got_c, old_c in ((kc, before[0]), (vc, before[1])):     # neighbours untouched
+        assert np.array_equal(got_c[:, 0], old_c[:, 0]) and np.array_equal(got_c[:, -1], old_c[:, -1])
+    # another layer / chain saw nothing
+    other = e.op_kv_read(seq, 0, past, T)[0].float().cpu().numpy()
+    assert not np.array_equal(other, kc[:, 1:-1])
+
+
+def test_rope_and_kv_append_of_a_decode_step(tiny_engine):
+    """K15 + K18 (decode form, k_rope_kv_batch): row b belongs to chain seqs[b], whose position is ctx + rope_delta on all
+    three axes and whose K / V row lands at ctx; ragged chains with different rope deltas."""
+    e = tiny_engine
+    e.fill_synthetic(**CHAIN_W)
+    cfg = Q.tiny_config()
+    t = cfg.text
+    nq, nkv, hd = t.num_attention_heads, t.num_key_value_heads, cfg.head_dim
+    prompts = {0: (prng.uniform_ints(96, 33, 10, 1990).tolist(), []),
+               2: ([11, cfg.vision_start_token_id] + [cfg.image_token_id] * 24 + [cfg.vision_end_token_id, 12, 13], [(1, 8, 12)]),
+               1: (prng.uniform_ints(97, 5, 10, 1990).tolist(), [])}
+    ctx, delta = {}, {}
+    for s, (ids, grids) in prompts.items():
+        pos, d = e.rope_index(ids, grids)
+        e.seq_reset(s)
+        emb = to_dev_bf16(rnd(98, (24, t.hidden_size))) if grids else None
+        e.prefill(s, ids, emb, pos, d, want_logits=False)
+        ctx[s], delta[s] = len(ids), d
+    assert delta[2] != 0
+    seqs = [2, 0, 1]
+    qkv = rnd(99, (3, (nq + 2 * nkv) * hd))
+    out = e.op_rope_kv_decode(seqs, 1, to_dev_bf16(qkv)).float().cpu().numpy()
+    for b, s in enumerate(seqs):
+        p = ctx[s] + delta[s]
+        pos3 = np.full((3, 1), p)
+        q = qkv[b: b + 1, : nq * hd].reshape(1, nq, hd)
+        k = qkv[b: b + 1, nq * hd: (nq + nkv) * hd].reshape(1, nkv, hd)
+        v = qkv[b: b + 1, (nq + nkv) * hd:].reshape(1, nkv, hd)
+        assert np.array_equal(out[b, : nq * hd].reshape(1, nq, hd), _text_rope_ref(cfg, q, pos3)), s
+        kc, vc = [x.float().cpu().numpy() for x in e.op_kv_read(s, 1, ctx[s], 1)]
+        assert np.array_equal(kc, _text_rope_ref(cfg, k, pos3).transpose(1, 0, 2)), s
+        assert np.array_equal(vc, v.transpose(1, 0, 2)), s

@@ -1533,6 +1533,9 @@ extern "C" int ze_op_linear(ze_engine* e, const void* a, const void* w, const vo
         if (act == 7 && N % 32) return ze_fail(e, ZE_ERR_INVALID, "SwiGLU: N = 2 * width with width % 16 == 0");
         ze_launch_gemm_wide(act == 7 ? ZE_EPI_SWIGLU : ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias,
                             nullptr, 0, (bf16_t*)cmat, act == 7 ? N / 2 : N, M, N, K, e->gemm_ws(), s);
+    } else if (act == 10) {  // the lm_head of the row-streaming regime: fp32 output [M, N] through ze_launch_gemm_wide
+        ze_launch_gemm_wide(ZE_EPI_F32, (const bf16_t*)a, K, (const bf16_t*)w, K, nullptr, nullptr, 0, (bf16_t*)cmat, N, M, N, K,
+                            e->gemm_ws(), s);
     } else if (act == 8 || act == 9) {  // the eight-phase 256 x 256 kernel whatever the grid (9: SwiGLU), for its tests
         if (act == 9 && N % 32) return ze_fail(e, ZE_ERR_INVALID, "SwiGLU: N = 2 * width with width % 16 == 0");
         if (K % 64 || K < 64) return ze_fail(e, ZE_ERR_INVALID, "eight-phase kernel: K a multiple of 64");
@@ -1591,6 +1594,161 @@ extern "C" int ze_op_attention(ze_engine* e, const void* q, const void* k, const
     hipStreamSynchronize(s);
     hipFree(dt);
     if (le != hipSuccess) return ze_fail(e, ZE_ERR_HIP, hipGetErrorString(le));
+    return ZE_OK;
+}
+
+// ---- K4 / K5 + K8 / K13 / K15 + K18 on their own (one entry per kernel), the launchers ze_vit_forward / ze_prefill use
+// K4: rows of pixel_values gathered into WINDOW order (+ the cast to bf16 the patch embed reads), and merged rows scattered back
+extern "C" int ze_op_window_gather(ze_engine* e, const float* pixel_values, const int32_t* grid_thw, int n_images, void* out_bf16,
+                                   void* stream) {
+    if (!e || !pixel_values || !grid_thw || !out_bf16 || n_images <= 0) return ze_fail(e, ZE_ERR_INVALID, "null argument");
+    const ze_config& c = e->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    const int mu = c.spatial_merge_size * c.spatial_merge_size;
+    const int pk = c.in_channels * c.temporal_patch_size * c.patch_size * c.patch_size;
+    std::vector<int64_t> widx;
+    std::vector<int32_t> cu_win;
+    ze_window_index_impl(grid_thw, n_images, c.spatial_merge_size, c.window_size, c.patch_size, widx, cu_win);
+    const int n = (int)widx.size() * mu;
+    if (n > c.max_patches) return ze_fail(e, ZE_ERR_NOMEM, "too many patches for max_patches");
+    std::vector<int> perm(n);
+    for (int j = 0; j < n / mu; ++j)
+        for (int u = 0; u < mu; ++u) perm[j * mu + u] = (int)widx[j] * mu + u;
+    ZE_HIP(hipMemcpyAsync(e->vperm, perm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+    ZE_HIP(hipStreamSynchronize(s));  // (perm is a local)
+    ze_launch_gather_cast_rows(pixel_values, pk, e->vperm, (bf16_t*)out_bf16, pk, n, s);
+    ZE_KCHECK();
+    return ZE_OK;
+}
+extern "C" int ze_op_window_scatter(ze_engine* e, const void* x_bf16, int cols, const int32_t* grid_thw, int n_images, void* out_bf16,
+                                    void* stream) {
+    if (!e || !x_bf16 || !grid_thw || !out_bf16 || n_images <= 0 || cols <= 0 || cols % 8) return ze_fail(e, ZE_ERR_INVALID, "bad argument (cols % 8)");
+    const ze_config& c = e->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    std::vector<int64_t> widx;
+    std::vector<int32_t> cu_win;
+    ze_window_index_impl(grid_thw, n_images, c.spatial_merge_size, c.window_size, c.patch_size, widx, cu_win);
+    const int m = (int)widx.size();
+    if (m > c.max_patches) return ze_fail(e, ZE_ERR_NOMEM, "too many rows for max_patches");
+    std::vector<int> inv(m);
+    for (int j = 0; j < m; ++j) inv[j] = (int)widx[j];
+    ZE_HIP(hipMemcpyAsync(e->vinv, inv.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice, s));
+    ZE_HIP(hipStreamSynchronize(s));
+    ze_launch_scatter_rows((const bf16_t*)x_bf16, cols, e->vinv, (bf16_t*)out_bf16, cols, m, cols, s);
+    ZE_KCHECK();
+    return ZE_OK;
+}
+// K5 + K8: the 2-D rotary tables of the grids (fp32, HF:...:125-134,441-446) applied to the q and k thirds of qkv [n, 3 * heads * D]
+// in place, fp32 arithmetic (HF:...:160-171); rows in WINDOW order when window_order != 0 (as inside the ViT), else HF order
+extern "C" int ze_op_vision_rope(ze_engine* e, void* qkv_bf16, const int32_t* grid_thw, int n_images, int window_order, void* stream) {
+    if (!e || !qkv_bf16 || !grid_thw || n_images <= 0) return ze_fail(e, ZE_ERR_INVALID, "null argument");
+    const ze_config& c = e->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    const int mu = c.spatial_merge_size * c.spatial_merge_size;
+    const int hd = e->vit_head_dim, half = hd / 2, nf = half / 2;
+    std::vector<int64_t> widx;
+    std::vector<int32_t> cu_win, hw;
+    ze_window_index_impl(grid_thw, n_images, c.spatial_merge_size, c.window_size, c.patch_size, widx, cu_win);
+    ze_vision_pos_ids_impl(grid_thw, n_images, c.spatial_merge_size, hw);
+    const int n = (int)widx.size() * mu;
+    if (n > c.max_patches) return ze_fail(e, ZE_ERR_NOMEM, "too many patches for max_patches");
+    std::vector<float> invf(nf), hc((size_t)n * half), hs((size_t)n * half);
+    for (int i = 0; i < nf; ++i) invf[i] = 1.0f / powf(10000.0f, (float)(2 * i) / (float)half);
+    for (int r = 0; r < n; ++r) {
+        const int old = window_order ? (int)widx[r / mu] * mu + r % mu : r;
+        for (int i = 0; i < nf; ++i) {
+            const float fh = (float)hw[2 * old] * invf[i], fw = (float)hw[2 * old + 1] * invf[i];
+            hc[(size_t)r * half + i] = cosf(fh);
+            hs[(size_t)r * half + i] = sinf(fh);
+            hc[(size_t)r * half + nf + i] = cosf(fw);
+            hs[(size_t)r * half + nf + i] = sinf(fw);
+        }
+    }
+    ZE_HIP(hipMemcpyAsync(e->vcos, hc.data(), hc.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    ZE_HIP(hipMemcpyAsync(e->vsin, hs.data(), hs.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    ZE_HIP(hipStreamSynchronize(s));
+    ze_launch_vision_rope((bf16_t*)qkv_bf16, e->vcos, e->vsin, n, c.vit_heads, hd, s);
+    ZE_KCHECK();
+    return ZE_OK;
+}
+// K13: out[t] = embed_tokens[ids[t]], rows whose id is the image token overwritten by the feature rows in order (HF:...:1206-1215)
+extern "C" int ze_op_embed_scatter(ze_engine* e, const int32_t* input_ids, int len, const void* image_embeds, int n_image_rows,
+                                   void* out_bf16, void* stream) {
+    if (!e || !input_ids || !out_bf16 || len <= 0) return ze_fail(e, ZE_ERR_INVALID, "null argument");
+    const ze_config& c = e->cfg;
+    if (len > e->prefill_rows) return ze_fail(e, ZE_ERR_NOMEM, "more rows than the prefill workspace holds");
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    std::vector<int> src(len);
+    int img = 0;
+    for (int t = 0; t < len; ++t) {
+        if (input_ids[t] < 0 || input_ids[t] >= c.vocab) return ze_fail(e, ZE_ERR_INVALID, "token id out of range");
+        src[t] = input_ids[t] == c.image_token_id ? -1 - img++ : input_ids[t];
+    }
+    if (img != n_image_rows || (img > 0 && !image_embeds))
+        return ze_fail(e, ZE_ERR_MISMATCH, "Image features and image tokens do not match, tokens: " + std::to_string(img) +
+                                               ", features: " + std::to_string(n_image_rows));
+    ZE_HIP(hipMemcpyAsync(e->tsrc, src.data(), (size_t)len * sizeof(int), hipMemcpyHostToDevice, s));
+    ZE_HIP(hipStreamSynchronize(s));
+    ze_launch_embed_rows(e->tsrc, e->embed, (const bf16_t*)image_embeds, (bf16_t*)out_bf16, len, c.hidden, s);
+    ZE_KCHECK();
+    return ZE_OK;
+}
+// K15 + K18: M-RoPE on the q / k parts of qkv [T, (heads + 2 kv_heads) * 128] (q in place; cos / sin rounded to bf16, products
+// and sum rounded as HF's bf16 tensors round them, HF:...:557-599) and the KV append: the roped k rows and the v rows go
+// into `layer`'s cache of chain `seq` at positions past .. past + T - 1 (DynamicCache.update, HF:...:667-668).  The chain's
+// length is NOT changed (a unit op: ze_op_kv_read reads rows back whatever the chain's length says).
+extern "C" int ze_op_mrope_kv(ze_engine* e, int seq, int layer, void* qkv_bf16, int T, const int32_t* position_ids, int past, void* stream) {
+    ZE_TRY(check_seq(e, seq));
+    const ze_config& c = e->cfg;
+    if (!qkv_bf16 || !position_ids || T <= 0 || layer < 0 || layer >= c.layers || past < 0 || past + T > c.max_ctx || T > e->prefill_rows)
+        return ze_fail(e, ZE_ERR_INVALID, "bad mrope_kv arguments");
+    for (int i = 0; i < 3 * T; ++i)
+        if (position_ids[i] < 0 || position_ids[i] >= e->max_pos) return ze_fail(e, ZE_ERR_INVALID, "position id out of range");
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    ZE_HIP(hipMemcpyAsync(e->tpos, position_ids, (size_t)3 * T * sizeof(int), hipMemcpyHostToDevice, s));
+    ZE_HIP(hipStreamSynchronize(s));
+    ze_launch_mrope_kv((bf16_t*)qkv_bf16, T, c.heads, c.kv_heads, e->head_dim, e->cosT, e->sinT, e->tpos, e->axis_of, e->kc(layer, seq),
+                       e->vc(layer, seq), c.max_ctx, past, nullptr, 0, s);
+    ZE_KCHECK();
+    return ZE_OK;
+}
+// the decode-step form of the same (k_rope_kv_batch: row b = chain seqs[b] at ITS position ctx + rope_delta, K/V appended at ctx)
+extern "C" int ze_op_rope_kv_decode(ze_engine* e, const int32_t* seqs, int n, int layer, void* qkv_bf16, void* stream) {
+    if (!e || !seqs || !qkv_bf16 || n <= 0 || n > e->cfg.max_seqs || layer < 0 || layer >= e->cfg.layers)
+        return ze_fail(e, ZE_ERR_INVALID, "bad rope_kv_decode arguments");
+    const ze_config& c = e->cfg;
+    for (int i = 0; i < n; ++i) {
+        ZE_TRY(check_seq(e, seqs[i]));
+        if (e->ctx_host[seqs[i]] + 1 > c.max_ctx) return ze_fail(e, ZE_ERR_NOMEM, "sequence exceeds max_ctx");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    ze_launch_set_ints(e->bseq, seqs, n, s);
+    ze_launch_rope_kv_batch((bf16_t*)qkv_bf16, n, c.heads, c.kv_heads, e->head_dim, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(layer, 0),
+                            e->vc(layer, 0), (size_t)c.kv_heads * c.max_ctx * e->head_dim, c.max_ctx, s);
+    ZE_KCHECK();
+    return ZE_OK;
+}
+// rows [start, start + n) of `layer`'s K and V cache of chain `seq`, every kv head: out_k / out_v bf16 [kv_heads, n, 128] (device)
+extern "C" int ze_op_kv_read(ze_engine* e, int seq, int layer, int start, int n, void* out_k, void* out_v, void* stream) {
+    ZE_TRY(check_seq(e, seq));
+    const ze_config& c = e->cfg;
+    if (!out_k || !out_v || layer < 0 || layer >= c.layers || start < 0 || n <= 0 || start + n > c.max_ctx)
+        return ze_fail(e, ZE_ERR_INVALID, "bad kv_read arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    const size_t row = (size_t)e->head_dim * sizeof(bf16_t);
+    for (int h = 0; h < c.kv_heads; ++h) {
+        ZE_HIP(hipMemcpyAsync((char*)out_k + (size_t)h * n * row, e->kc(layer, seq) + ((size_t)h * c.max_ctx + start) * e->head_dim,
+                              (size_t)n * row, hipMemcpyDeviceToDevice, s));
+        ZE_HIP(hipMemcpyAsync((char*)out_v + (size_t)h * n * row, e->vc(layer, seq) + ((size_t)h * c.max_ctx + start) * e->head_dim,
+                              (size_t)n * row, hipMemcpyDeviceToDevice, s));
+    }
     return ZE_OK;
 }
 

@@ -456,9 +456,59 @@ class Engine:
         return q, sc
 
     # ------------------------------------------------------------------ unit ops (parity tests)
+    def op_window_gather(self, pixel_values: torch.Tensor, grids) -> torch.Tensor:
+        g, gp = _i32(np.asarray(grids).reshape(-1, 3))
+        out = torch.empty(pixel_values.shape, dtype=torch.bfloat16, device=self.device)
+        self._check(self.lib.ze_op_window_gather(self.h, _ptr(pixel_values), gp, len(g), _ptr(out), self._stream()))
+        return out
+
+    def op_window_scatter(self, x: torch.Tensor, grids) -> torch.Tensor:
+        g, gp = _i32(np.asarray(grids).reshape(-1, 3))
+        out = torch.empty_like(x)
+        self._check(self.lib.ze_op_window_scatter(self.h, _ptr(x), x.shape[1], gp, len(g), _ptr(out), self._stream()))
+        return out
+
+    def op_vision_rope(self, qkv: torch.Tensor, grids, window_order: bool = True) -> torch.Tensor:
+        """In place on qkv bf16 [n, 3 * heads * 80]; returns it."""
+        g, gp = _i32(np.asarray(grids).reshape(-1, 3))
+        self._check(self.lib.ze_op_vision_rope(self.h, _ptr(qkv), gp, len(g), int(window_order), self._stream()))
+        return qkv
+
+    def op_embed_scatter(self, input_ids, image_embeds=None) -> torch.Tensor:
+        ids, ip = _i32(input_ids)
+        out = torch.empty((len(ids), self.config.text.hidden_size), dtype=torch.bfloat16, device=self.device)
+        n_img = 0 if image_embeds is None else int(image_embeds.shape[0])
+        self._check(self.lib.ze_op_embed_scatter(self.h, ip, len(ids), _ptr(image_embeds), n_img, _ptr(out), self._stream()))
+        return out
+
+    def op_mrope_kv(self, seq: int, layer: int, qkv: torch.Tensor, position_ids, past: int) -> torch.Tensor:
+        """In place on qkv bf16 [T, (heads + 2 kv_heads) * 128] (q roped); K / V rows appended to the cache at `past`."""
+        pos, pp = _i32(position_ids)
+        assert pos.shape == (3, qkv.shape[0])
+        self._check(self.lib.ze_op_mrope_kv(self.h, seq, layer, _ptr(qkv), qkv.shape[0], pp, int(past), self._stream()))
+        return qkv
+
+    def op_rope_kv_decode(self, seqs, layer: int, qkv: torch.Tensor) -> torch.Tensor:
+        sq, sp = _i32(seqs)
+        assert qkv.shape[0] == len(sq)
+        self._check(self.lib.ze_op_rope_kv_decode(self.h, sp, len(sq), layer, _ptr(qkv), self._stream()))
+        return qkv
+
+    def op_kv_read(self, seq: int, layer: int, start: int, n: int):
+        t = self.config.text
+        shape = (t.num_key_value_heads, n, t.hidden_size // t.num_attention_heads)
+        k = torch.empty(shape, dtype=torch.bfloat16, device=self.device)
+        v = torch.empty(shape, dtype=torch.bfloat16, device=self.device)
+        self._check(self.lib.ze_op_kv_read(self.h, seq, layer, start, n, _ptr(k), _ptr(v), self._stream()))
+        return k, v
+
     def op_linear(self, a, w, bias=None, act: int = 0):
         m, k = a.shape
         n = w.shape[0]
+        if act == 10:  # fp32 logits of the row-streaming regime's lm_head
+            out = torch.empty((m, n), dtype=torch.float32, device=self.device)
+            self._check(self.lib.ze_op_linear(self.h, _ptr(a), _ptr(w), None, _ptr(out), m, n, k, act, self._stream()))
+            return out
         out = torch.empty((m, n // 2 if act in (4, 7, 9) else n), dtype=torch.bfloat16, device=self.device)
         self._check(self.lib.ze_op_linear(self.h, _ptr(a), _ptr(w), _ptr(bias), _ptr(out), m, n, k, act, self._stream()))
         return out
