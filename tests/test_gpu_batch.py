@@ -483,6 +483,43 @@ def test_prefix_source_retires_while_a_copying_pass_is_in_flight_on_another_stre
         e.seq_reset(s)
 
 
+def test_fused_qkv_rope_kv_append_equals_the_two_launches(eng4):
+    """Row-streaming regime: the qkv projection with M-RoPE + KV append as its epilogue (ZE_EPI_QKV_ROPE on head-permuted weight
+    rows) against the projection followed by k_rope_kv_batch (ze_tune knob 13 = 2): logits of three steps, and the K / V rows the
+    steps appended in every layer, bit for bit -- ragged chains, one with an image (rope_delta != 0), a sub-batch in another order."""
+    e = eng4
+    cfg = Q.tiny_config()
+    assert e.set_decode_regime(1) == 1
+    prompts = [(text_ids(801, 70), []), (text_ids(802, 9), []), (text_ids(803, 131), []),
+               ([11, cfg.vision_start_token_id] + [cfg.image_token_id] * 24 + [cfg.vision_end_token_id, 12, 13], [(1, 8, 12)])]
+    feats = torch.randn(24, cfg.text.hidden_size, device="cuda").to(torch.bfloat16)
+    forced = [[int(t) for t in text_ids(810 + i, 4)] for i in range(3)]
+
+    def run(knob):
+        e.lib.ze_tune(13, knob)
+        for s, (ids, grids) in enumerate(prompts):
+            pos, delta = e.rope_index(ids, grids)
+            e.seq_reset(s)
+            e.prefill(s, ids, feats if grids else None, pos, delta, want_logits=False)
+        out = [e.decode_batch([0, 1, 2, 3], forced[0]).cpu().numpy(), e.decode_batch([3, 1], [forced[1][3], forced[1][1]]).cpu().numpy(),
+               e.decode_batch([2, 0, 3, 1], [forced[2][c] for c in (2, 0, 3, 1)]).cpu().numpy()]
+        rows = []
+        for s, (ids, _) in enumerate(prompts):
+            for layer in range(cfg.text.num_hidden_layers):
+                k, v = e.op_kv_read(s, layer, len(ids), 3 if s in (1, 3) else 2)
+                rows.append((k.cpu(), v.cpu()))
+        return out, rows
+    try:
+        (a, ra), (b, rb) = run(2), run(0)
+    finally:
+        e.lib.ze_tune(13, 0)
+        e.set_decode_regime(-1)
+    for x, y in zip(a, b):
+        assert np.isfinite(x).all() and np.array_equal(x, y)
+    for (k1, v1), (k2, v2) in zip(ra, rb):
+        assert torch.equal(k1, k2) and torch.equal(v1, v2)
+
+
 @pytest.mark.parametrize("max_ctx", [768, 1536])
 def test_attention_grid_rotation_and_extent_do_not_change_a_bit(max_ctx):
     """The decode attention's launch grid is rotated per group of four chains (XCD balance whenever kv heads x parts of

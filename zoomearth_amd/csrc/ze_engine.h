@@ -31,6 +31,9 @@ struct ze_linear {
     int ld8 = 0;
     // MFMA-fragment-major copy for the batched decode step (ze_launch_pack_fragments), null = none
     bf16_t* wf = nullptr;
+    // qkv only, row-streaming regime: rows (and bias) permuted per head for the rope + KV-append epilogue (ze_launch_permute_qkv)
+    bf16_t* wp = nullptr;
+    bf16_t* bias_p = nullptr;
     // the same in FP8 (ze_launch_pack_fragments8 of w8), streamed with scale8 when the engine is quantised, null = none
     uint8_t* wf8 = nullptr;
 };
@@ -81,6 +84,8 @@ struct ze_engine {
     uint8_t* arena_f8 = nullptr;  // FP8 fragment copies (fp8_ready only)
     bf16_t* lm_head_f = nullptr;
     bool frag_ready = false;
+    bf16_t* arena_p = nullptr;        // permuted qkv rows + biases of every layer (row-streaming regime, head_dim 128)
+    ze_qkv_epi* qkv_epi_dev = nullptr;  // [layers] epilogue arguments of the fused qkv launch
     // Kernel family of the batched decode step (ze_set_decode_regime): 0 = fragment kernels (at most 64 chains per step),
     // 1 = row-streaming kernels (any count), -1 = by the engine's capacity (max_seqs > 64 -> 1).  Never a function of how
     // many chains are live: a chain's tokens do not depend on the batch it happens to share.

@@ -439,6 +439,8 @@ extern "C" int ze_engine_destroy(ze_engine* e) {
     for (void* p : dev)
         if (p) hipFree(p);
     if (e->pfx_dev) hipFree(e->pfx_dev);
+    if (e->arena_p) hipFree(e->arena_p);
+    if (e->qkv_epi_dev) hipFree(e->qkv_epi_dev);
     for (hipEvent_t ev : e->pfx_copy_ev)
         if (ev) hipEventDestroy(ev);
     if (e->fe_done) hipEventDestroy(e->fe_done);

@@ -1055,8 +1055,39 @@ static int ensure_fragments(ze_engine* e, hipStream_t s) {
     for (int li = 0; li < c.layers; ++li) {
         ze_text_layer& L = e->tl[li];
         L.qkv.wf = L.o.wf = L.gate_up.wf = nullptr;
+        L.qkv.wp = L.qkv.bias_p = nullptr;
     }
     e->lm_head_f = nullptr;
+    // row-streaming regime: the qkv rows permuted per head, so that M-RoPE + the KV append run as the projection's epilogue
+    if (hd == 128 && H % 64 == 0 && H / 64 >= 4 && nqkv % 128 == 0) {
+        const size_t per_layer = (size_t)nqkv * H + nqkv;
+        if (!e->arena_p) ZE_HIP(hipMalloc((void**)&e->arena_p, per_layer * c.layers * sizeof(bf16_t)));
+        if (!e->qkv_epi_dev) ZE_HIP(hipMalloc((void**)&e->qkv_epi_dev, sizeof(ze_qkv_epi) * c.layers));
+        std::vector<ze_qkv_epi> host(c.layers);
+        for (int li = 0; li < c.layers; ++li) {
+            ze_text_layer& L = e->tl[li];
+            bf16_t* wp = e->arena_p + per_layer * li;
+            bf16_t* bp = wp + (size_t)nqkv * H;
+            ze_launch_permute_qkv(L.qkv.w, L.qkv.ld, L.qkv.bias, nqkv / 128, H, wp, L.qkv.bias ? bp : nullptr, s);
+            L.qkv.wp = wp;
+            L.qkv.bias_p = L.qkv.bias ? bp : nullptr;
+            ze_qkv_epi& q = host[li];
+            memset(&q, 0, sizeof(q));
+            q.st = e->st_dev;
+            q.seq_ids = e->bseq;
+            q.cosT = e->cosT;
+            q.sinT = e->sinT;
+            q.kcache = e->kc(li, 0);
+            q.vcache = e->vc(li, 0);
+            q.cache_seq_stride = (size_t)c.kv_heads * c.max_ctx * hd;
+            q.max_ctx = c.max_ctx;
+            q.heads = c.heads;
+            q.kv_heads = c.kv_heads;
+        }
+        ZE_HIP(hipMemcpyAsync(e->qkv_epi_dev, host.data(), sizeof(ze_qkv_epi) * c.layers, hipMemcpyHostToDevice, s));
+        ZE_HIP(hipStreamSynchronize(s));  // (host is a local)
+        ZE_KCHECK();
+    }
     if (ok) {
         const size_t per_layer = (size_t)(nqkv + 2 * ip) * H + (size_t)H * nq;
         const size_t total = per_layer * c.layers + (size_t)c.vocab * H;
@@ -1185,10 +1216,16 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
                                        e->kc(li, 0), e->vc(li, 0), seq_stride, c.max_ctx, s, w8 ? L.qkv.scale8 : nullptr,
                                        a8q ? e->ty8_scale : nullptr);
         } else {
-            if (tiled) ze_launch_gemm_wide(ZE_EPI_NONE, e->by, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->bqkv, nqkv, n, nqkv, H, ws, s);
-            else ze_launch_gemm_stream(ZE_EPI_NONE, e->by, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->bqkv, nqkv, n, nqkv, H, ws, s);
-            ze_launch_rope_kv_batch(e->bqkv, n, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(li, 0),
-                                    e->vc(li, 0), seq_stride, c.max_ctx, s);
+            // row streaming: projection + M-RoPE + KV append in ONE launch on the permuted rows (same bits as the pair of
+            // launches below; knob 13 = 2 keeps the pair, for A/B runs and the bit-equality test)
+            if (tiled && L.qkv.wp && ze_gemv_knobs[13] != 2) {
+                ze_launch_gemm_qkv_rope(e->by, H, L.qkv.wp, H, L.qkv.bias_p, e->qkv_epi_dev + li, e->bqkv, nqkv, n, nqkv, H, s);
+            } else {
+                if (tiled) ze_launch_gemm_wide(ZE_EPI_NONE, e->by, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->bqkv, nqkv, n, nqkv, H, ws, s);
+                else ze_launch_gemm_stream(ZE_EPI_NONE, e->by, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->bqkv, nqkv, n, nqkv, H, ws, s);
+                ze_launch_rope_kv_batch(e->bqkv, n, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(li, 0),
+                                        e->vc(li, 0), seq_stride, c.max_ctx, s);
+            }
         }
         launch_batch_attention(e, li, n, fr, s);
         if (fr && ze_gemv_knobs[9] != 1) {
@@ -1968,6 +2005,8 @@ extern "C" int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters
             case 0:
                 if (fr) ze_launch_qkv_rope_oneshot(e->by, L.qkv.wf, L.qkv.bias, e->bqkv, nqkv, n, H, c.heads, c.kv_heads, e->cosT, e->sinT,
                                                    e->st_dev, e->bseq, e->kc(li, 0), e->vc(li, 0), seq_stride, c.max_ctx, s);
+                else if (tiled && L.qkv.wp && ze_gemv_knobs[13] != 2)
+                    ze_launch_gemm_qkv_rope(e->by, H, L.qkv.wp, H, L.qkv.bias_p, e->qkv_epi_dev + li, e->bqkv, nqkv, n, nqkv, H, s);
                 else if (tiled) ze_launch_gemm_wide(ZE_EPI_NONE, e->by, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->bqkv, nqkv, n, nqkv, H, ws, s);
                 else ze_launch_gemm_stream(ZE_EPI_NONE, e->by, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->bqkv, nqkv, n, nqkv, H, ws, s);
                 bytes = (double)nqkv * H * 2;

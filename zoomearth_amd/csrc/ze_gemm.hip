@@ -155,7 +155,7 @@ __device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / (16 * WM)][BN / (1
         }
     }
 
-    // ---------------- wide-store epilogue (LDS_EPI; bm0 = 0, c_rows unused): the MFMA result layout gives a lane four ROWS of
+    // ---------------- wide-store epilogue (LDS_EPI; c_rows unused): the MFMA result layout gives a lane four ROWS of
     // one column, so the plain epilogue below stores 2-byte values 32 B at a time (and loads the residual the same way): at
     // 256 rows it cost the decode projections 6-10 us.  Here the rounded values cross the (idle) staging LDS once and leave
     // as 16-byte row pieces; the arithmetic and its order of roundings are those of the plain epilogue, value for value.
@@ -195,11 +195,12 @@ __device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / (16 * WM)][BN / (1
         constexpr int PPR = OW * EB / 16;  // 16-byte pieces per row
         const int oc0 = (EPI == ZE_EPI_SWIGLU) ? bn0 / 2 : bn0, on = (EPI == ZE_EPI_SWIGLU) ? N / 2 : N;
         for (int pc = tid; pc < BM * PPR; pc += NT) {
-            const int row = pc / PPR, c16 = pc % PPR;
+            const int lrow = pc / PPR, c16 = pc % PPR;
+            const int row = bm0 + lrow;  // (bm0 = 0 for the tiles that take every row; the 192-row tiles have two row tiles)
             if (row >= M) continue;
             const int col = oc0 + c16 * (16 / EB);  // first output column of the piece
             if (col >= on) continue;
-            uint4 v = *reinterpret_cast<const uint4*>(smem + row * ROWB + c16 * 16);
+            uint4 v = *reinterpret_cast<const uint4*>(smem + lrow * ROWB + c16 * 16);
             if (EPI == ZE_EPI_RESIDUAL) {  // out = bf16(residual + value), per element as the plain epilogue
                 const uint4 rr = *reinterpret_cast<const uint4*>(R + (size_t)row * ldr + col);
                 const uint32_t* pv = reinterpret_cast<const uint32_t*>(&v);
@@ -215,6 +216,58 @@ __device__ __forceinline__ void gemm_finish(f32x4 (&acc)[BM / (16 * WM)][BN / (1
             }
             if (EPI == ZE_EPI_F32) *reinterpret_cast<uint4*>(reinterpret_cast<float*>(C) + (size_t)row * ldc + col) = v;
             else *reinterpret_cast<uint4*>(C + (size_t)row * ldc + col) = v;
+        }
+        return;
+    }
+    // ---------------- qkv projection of a decode step + M-RoPE + KV append (ze_kernels.h: ZE_EPI_QKV_ROPE): tiles j, j + 1 of a
+    // wave hold dims d and d + 64 of one head (permuted weight rows); R carries the device-resident ze_qkv_epi
+    if constexpr (EPI == ZE_EPI_QKV_ROPE) {
+        static_assert(EPI != ZE_EPI_QKV_ROPE || TN % 2 == 0, "the rotate_half partners are two 16-column tiles of a wave");
+        const ze_qkv_epi* __restrict__ qa = reinterpret_cast<const ze_qkv_epi*>(R);
+        const ze_seq_dev* __restrict__ st = qa->st;
+        const int* __restrict__ seq_ids = qa->seq_ids;
+        const bf16_t* __restrict__ cosT = qa->cosT;
+        const bf16_t* __restrict__ sinT = qa->sinT;
+        const int heads = qa->heads, kvh = qa->kv_heads, max_ctx = qa->max_ctx;
+        const size_t sstride = qa->cache_seq_stride;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            int seq[4], ctx[4], pos[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = min(bm0 + wm0 + i * 16 + fq * 4 + r, M - 1);
+                seq[r] = seq_ids[row];
+                ctx[r] = st[seq[r]].ctx;
+                pos[r] = ctx[r] + st[seq[r]].rope_delta;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; j += 2) {
+                const int pcol = bn0 + wn0 + j * 16 + fr;  // permuted column of the first partner
+                if (pcol >= N) continue;
+                const int head = pcol >> 7, d = ((pcol & 127) >> 5) * 16 + fr;  // dims d and d + 64 of `head`
+                const float b1 = bias ? bf16_to_f32(bias[pcol]) : 0.f, b2 = bias ? bf16_to_f32(bias[pcol + 16]) : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = bm0 + wm0 + i * 16 + fq * 4 + r;
+                    if (row >= M) continue;
+                    const float x1 = bf16_round(acc[i][j][r] + b1), x2 = bf16_round(acc[i][j + 1][r] + b2);
+                    bf16_t o1, o2;
+                    if (head < heads + kvh) {
+                        const float c = bf16_to_f32(cosT[(size_t)pos[r] * 64 + d]), sn = bf16_to_f32(sinT[(size_t)pos[r] * 64 + d]);
+                        o1 = f32_to_bf16(bf16_round(x1 * c) + bf16_round(-x2 * sn));
+                        o2 = f32_to_bf16(bf16_round(x2 * c) + bf16_round(x1 * sn));
+                    } else {
+                        o1 = f32_to_bf16(x1);
+                        o2 = f32_to_bf16(x2);
+                    }
+                    bf16_t* dst;
+                    if (head < heads) dst = C + (size_t)row * ldc + head * 128;
+                    else if (head < heads + kvh) dst = qa->kcache + seq[r] * sstride + ((size_t)(head - heads) * max_ctx + ctx[r]) * 128;
+                    else dst = qa->vcache + seq[r] * sstride + ((size_t)(head - heads - kvh) * max_ctx + ctx[r]) * 128;
+                    dst[d] = o1;
+                    dst[d + 64] = o2;
+                }
+            }
         }
         return;
     }
@@ -431,7 +484,7 @@ __device__ __forceinline__ void ring_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int STAGES, int EPI, int WM = 2, int WN = 2, bool SPREAD = false>
+template <int BM, int BN, int STAGES, int EPI, int WM = 2, int WN = 2, bool SPREAD = false, bool WIDE_EPI = false>
 __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
                                                    int ldw, const bf16_t* __restrict__ bias,
                                                    const bf16_t* __restrict__ R, int ldr, bf16_t* __restrict__ C,
@@ -554,7 +607,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
         }
     }
     __syncthreads();  // the tail reuses the staging LDS
-    gemm_finish<BM, BN, EPI, WM, WN>(acc, smem, bias, R, ldr, C, ldc, c_rows, M, N, ksplit, ks, bid, nwg, bm0, bn0, slab, tickets);
+    gemm_finish<BM, BN, EPI, WM, WN, WIDE_EPI>(acc, smem, bias, R, ldr, C, ldc, c_rows, M, N, ksplit, ks, bid, nwg, bm0, bn0, slab, tickets);
 }
 
 
@@ -1402,7 +1455,7 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
 // The split-K workspace (fp32 slabs + per-tile tickets) belongs to the calling engine and travels with every call
 // (ze_gemm_ws); the launch macros below name its two pointers g_slab / g_tickets.
 // one ring instantiation, every epilogue
-template <int BM, int BN, int ST, int WM, int WN, bool SPR>
+template <int BM, int BN, int ST, int WM, int WN, bool SPR, bool WIDE = false, bool QKV = false>
 static void launch_ring_variant(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,
                                 const bf16_t* R, int ldr, bf16_t* C, int ldc, const int* c_rows, int M, int N, int K,
                                 hipStream_t s, int ksplit = 1, const ze_gemm_ws& ws = ze_gemm_ws()) {
@@ -1414,19 +1467,25 @@ static void launch_ring_variant(int epi, const bf16_t* A, int lda, const bf16_t*
     do {                                                                                                            \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<BM, BN, ST, E, WM, WN, SPR>),            \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<BM, BN, ST, E, WM, WN, SPR, WIDE>),      \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL((k_gemm_ring<BM, BN, ST, E, WM, WN, SPR>), dim3(grid), dim3(64 * WM * WN), lds, s, A,    \
+        hipLaunchKernelGGL((k_gemm_ring<BM, BN, ST, E, WM, WN, SPR, WIDE>), dim3(grid), dim3(64 * WM * WN), lds, s, A, \
                            lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, ksplit, g_slab, g_tickets);          \
     } while (0)
-    switch (epi) {
-        case ZE_EPI_NONE: ZE_RINGV_LAUNCH(ZE_EPI_NONE); break;
-        case ZE_EPI_GELU: ZE_RINGV_LAUNCH(ZE_EPI_GELU); break;
-        case ZE_EPI_RESIDUAL: ZE_RINGV_LAUNCH(ZE_EPI_RESIDUAL); break;
-        case ZE_EPI_SWIGLU: ZE_RINGV_LAUNCH(ZE_EPI_SWIGLU); break;
-        case ZE_EPI_F32: ZE_RINGV_LAUNCH(ZE_EPI_F32); break;
+    if constexpr (QKV) {   // (the decode step's qkv projection with rope + KV append)
+        if (epi == ZE_EPI_QKV_ROPE) ZE_RINGV_LAUNCH(ZE_EPI_QKV_ROPE);
+    } else if constexpr (WIDE) {  // (the wide-store epilogue: SwiGLU of the batched decode step's gate/up only)
+        if (epi == ZE_EPI_SWIGLU) ZE_RINGV_LAUNCH(ZE_EPI_SWIGLU);
+    } else {
+        switch (epi) {
+            case ZE_EPI_NONE: ZE_RINGV_LAUNCH(ZE_EPI_NONE); break;
+            case ZE_EPI_GELU: ZE_RINGV_LAUNCH(ZE_EPI_GELU); break;
+            case ZE_EPI_RESIDUAL: ZE_RINGV_LAUNCH(ZE_EPI_RESIDUAL); break;
+            case ZE_EPI_SWIGLU: ZE_RINGV_LAUNCH(ZE_EPI_SWIGLU); break;
+            case ZE_EPI_F32: ZE_RINGV_LAUNCH(ZE_EPI_F32); break;
+        }
     }
 #undef ZE_RINGV_LAUNCH
 }
@@ -1793,7 +1852,7 @@ static int stream_ksplit(int N, int K) {
 
 // long-K projection, more than 64 rows: big tiles on the slices of the one-launch form, then the chip-wide reduction;
 // false = does not apply
-template <int BM, int BN, int ST, bool SPR>
+template <int BM, int BN, int ST, bool SPR, int WM = 2, int WN = 4>
 static bool launch_splitk_two(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
                               int ldr, bf16_t* C, int ldc, int M, int N, int K, const ze_gemm_ws& ws, hipStream_t s) {
     if (epi != ZE_EPI_RESIDUAL && epi != ZE_EPI_NONE) return false;
@@ -1803,13 +1862,42 @@ static bool launch_splitk_two(int epi, const bf16_t* A, int lda, const bf16_t* W
         return false;
     ze_gemm_ws slabs_only = ws;
     slabs_only.tickets = nullptr;
-    launch_ring_variant<BM, BN, ST, 2, 4, SPR>(ZE_EPI_NONE, A, lda, W, ldw, nullptr, nullptr, 0, C, ldc, nullptr, M, N, K, s, ksplit, slabs_only);
-    const int grid = nwg * (BM / 32) * (BN / 64);
+    launch_ring_variant<BM, BN, ST, WM, WN, SPR>(ZE_EPI_NONE, A, lda, W, ldw, nullptr, nullptr, 0, C, ldc, nullptr, M, N, K, s, ksplit, slabs_only);
+    const int grid = nwg * (BM / (16 * WM)) * (BN / (16 * WN));
     if (epi == ZE_EPI_RESIDUAL)
-        hipLaunchKernelGGL((k_splitk_reduce<BM, BN, 2, 4, ZE_EPI_RESIDUAL>), dim3(grid), dim3(512), 0, s, ws.slab, ksplit, bias, R, ldr, C, ldc, M, N);
+        hipLaunchKernelGGL((k_splitk_reduce<BM, BN, WM, WN, ZE_EPI_RESIDUAL>), dim3(grid), dim3(64 * WM * WN), 0, s, ws.slab, ksplit, bias, R, ldr, C, ldc, M, N);
     else
-        hipLaunchKernelGGL((k_splitk_reduce<BM, BN, 2, 4, ZE_EPI_NONE>), dim3(grid), dim3(512), 0, s, ws.slab, ksplit, bias, R, ldr, C, ldc, M, N);
+        hipLaunchKernelGGL((k_splitk_reduce<BM, BN, WM, WN, ZE_EPI_NONE>), dim3(grid), dim3(64 * WM * WN), 0, s, ws.slab, ksplit, bias, R, ldr, C, ldc, M, N);
     return true;
+}
+
+// dst row p of every 128-row head <- src row head * 128 + dim(p): blocks of 32 = [d0 .. d0 + 15 | 64 + d0 .. 64 + d0 + 15]
+__global__ void __launch_bounds__(256) k_permute_qkv(const bf16_t* __restrict__ W, int ldw, const bf16_t* __restrict__ bias, int K,
+                                                     bf16_t* __restrict__ Wp, bf16_t* __restrict__ bias_p) {
+    const int p = blockIdx.x, w = p & 127, i = w & 31;
+    const int dim = i < 16 ? (w >> 5) * 16 + i : 64 + (w >> 5) * 16 + (i - 16);
+    const int src = (p & ~127) + dim;
+    for (int c = threadIdx.x * 8; c < K; c += 256 * 8)
+        *reinterpret_cast<uint4*>(Wp + (size_t)p * K + c) = *reinterpret_cast<const uint4*>(W + (size_t)src * ldw + c);
+    if (threadIdx.x == 0 && bias && bias_p) bias_p[p] = bias[src];
+}
+void ze_launch_permute_qkv(const bf16_t* W, int ldw, const bf16_t* bias, int n_heads_total, int K, bf16_t* Wp, bf16_t* bias_p,
+                           hipStream_t s) {
+    if (n_heads_total <= 0) return;
+    k_permute_qkv<<<n_heads_total * 128, 256, 0, s>>>(W, ldw, bias, K, Wp, bias_p);
+}
+
+// The tile follows ze_launch_gemm's choice for these shapes (64 x 64 up to one round of workgroups, 64 x 128 beyond): K in
+// sequence on both, so a chain's bits do not depend on the row count -- and equal the unfused pair of launches.
+void ze_launch_gemm_qkv_rope(const bf16_t* A, int lda, const bf16_t* Wp, int ldw, const bf16_t* bias_p, const ze_qkv_epi* dev_args,
+                             bf16_t* C, int ldc, int M, int N, int K, hipStream_t s) {
+    if (M <= 0 || N <= 0) return;
+    const long b64 = (long)ze_cdiv(M, 64) * ze_cdiv(N, 64);
+    const bf16_t* R = reinterpret_cast<const bf16_t*>(dev_args);
+    if (b64 <= 256)
+        launch_ring_variant<64, 64, 4, 4, 2, false, false, true>(ZE_EPI_QKV_ROPE, A, lda, Wp, ldw, bias_p, R, 0, C, ldc, nullptr, M, N, K, s);
+    else
+        launch_ring_variant<64, 128, 4, 2, 4, false, false, true>(ZE_EPI_QKV_ROPE, A, lda, Wp, ldw, bias_p, R, 0, C, ldc, nullptr, M, N, K, s);
 }
 
 void ze_launch_gemm_p8(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R, int ldr,
@@ -1853,6 +1941,10 @@ void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int
         // launch on 64 x 64 tiles (with 128 x 256 tiles at 217 / 256 rows: 32.9 / 34.4 -- 128 workgroups, half the chip).  Same
         // slices, same order of additions: the same bits whatever the form.  knob 15 = 6: one launch at every row count
         if (ze_gemv_knobs[15] != 6) {
+            // 257 .. 384 rows: 192 x 128 tiles -- two row tiles instead of three of 128 (no wasted third), 256 workgroups
+            // instead of 192 (every CU), 17 % fewer bytes staged per workgroup; knob 15 = 4: the 128 x 256 tiles there too
+            if (M > 256 && M <= 384 && ze_gemv_knobs[15] != 4 &&
+                launch_splitk_two<192, 128, 3, false, 4, 2>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
             if (M > 256 && launch_splitk_two<128, 256, 3, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
             if (M > 128 && M <= 256 && launch_splitk_two<128, 128, 4, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
             if (M > 64 && M <= 128 && launch_splitk_two<64, 128, 4, false>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
@@ -1882,6 +1974,16 @@ void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int
             const int mb = std::min(blk, M - r0);
             const bf16_t* Ab = A + (size_t)r0 * lda;
             bf16_t* Cb = C + (size_t)r0 * crow;
+            // 257 .. 384 rows: 192 x 192 tiles on the ring (two row tiles x 115 column tiles = 230 workgroups, one round): a
+            // workgroup stages (192 + 192) rows per K-step for 192 x 192 outputs -- 96 FLOP per staged byte against 77 for
+            // the 384 x 96 weight-streaming tile, which re-reads ALL the activations in every workgroup.  Same K order per
+            // output element: the same bits.  knob 15 = 4: the weight-streaming tile there too
+            if (mb > 256 && mb <= 384 && epi == ZE_EPI_SWIGLU && v != 4 && r0 == 0 && M <= 384) {
+                // (the refill DMAs spread between the rows of MFMAs: 40.6 against 41.6 us at 344 rows)
+                launch_ring_variant<192, 192, 3, 4, 2, true, true>(epi, Ab, lda, W, ldw, bias, R, ldr, Cb, ldc, nullptr, mb, N, K, s);
+                continue;
+            }
+            // (tried for 385 .. 512 rows and dropped: 256 x 192 tiles in two stages, 61.9 against 57.4 us at 440 rows)
             if (mb > 384) launch_wstream_one<512, 96, 2, 6, 32, ZE_EPI_SWIGLU>(Ab, lda, W, ldw, bias, R, ldr, Cb, ldc, mb, N, K, 1, ws, s);
             else if (mb > 256) launch_wstream_one<384, 96, 2, 8, 32, ZE_EPI_SWIGLU>(Ab, lda, W, ldw, bias, R, ldr, Cb, ldc, mb, N, K, 1, ws, s);
             else if (mb > 128) done = launch_wstream<256, 96, 3, 8>(epi, Ab, lda, W, ldw, bias, R, ldr, Cb, ldc, mb, N, K, ws, s);

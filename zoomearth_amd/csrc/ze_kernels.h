@@ -3,7 +3,7 @@
 #include "ze_common.h"
 
 // GEMM epilogues
-enum { ZE_EPI_NONE = 0, ZE_EPI_GELU = 1, ZE_EPI_RESIDUAL = 2, ZE_EPI_SWIGLU = 3, ZE_EPI_F32 = 4 };
+enum { ZE_EPI_NONE = 0, ZE_EPI_GELU = 1, ZE_EPI_RESIDUAL = 2, ZE_EPI_SWIGLU = 3, ZE_EPI_F32 = 4, ZE_EPI_QKV_ROPE = 5 };
 // decode GEMV epilogues
 enum { ZE_GV_QKV_ROPE = 0, ZE_GV_RESIDUAL = 1, ZE_GV_SWIGLU = 2, ZE_GV_LOGITS = 3, ZE_GV_PLAIN = 4 };
 
@@ -86,6 +86,28 @@ void ze_launch_embed_rows(const int* src, const bf16_t* embed, const bf16_t* ima
                           int hidden, hipStream_t s);
 void ze_launch_scatter_rows(const bf16_t* src, int lds_, const int* dst_idx, bf16_t* dst, int ldd, int rows, int cols,
                             hipStream_t s);
+
+// ---- qkv projection of the batched decode step in the row-streaming regime with M-RoPE + KV append as its epilogue
+// (ZE_EPI_QKV_ROPE; removes the stand-alone k_rope_kv_batch launch).  The weight rows of every 128-wide head are PERMUTED in
+// blocks of 32: [d0 .. d0+15 | 64+d0 .. 64+d0+15] for d0 = 0, 16, 32, 48 (ze_launch_permute_qkv; the bias likewise), so the two
+// 16-column MFMA tiles a wave holds side by side are the rotate_half partners (d, d + 64) of the same rows and lanes -- the pairing
+// the SwiGLU epilogue uses for gate / up.  Per element the arithmetic is k_rope_kv_batch's on the bf16-rounded projection:
+// bf16(bf16(x1 c) + bf16(-x2 s)), bf16(bf16(x2 c) + bf16(x1 s)) with the chain's cos / sin at position ctx + rope_delta; q heads
+// go to C (original column order), k / v heads into the caches at the chain's ctx.  Device-resident per layer (one pointer as a
+// kernel argument, in the slot of the unused residual pointer).
+struct ze_qkv_epi {
+    const ze_seq_dev* st;
+    const int* seq_ids;
+    const bf16_t* cosT;
+    const bf16_t* sinT;
+    bf16_t* kcache;  // of this layer, chain 0
+    bf16_t* vcache;
+    size_t cache_seq_stride;
+    int max_ctx, heads, kv_heads, pad_;
+};
+void ze_launch_permute_qkv(const bf16_t* W, int ldw, const bf16_t* bias, int n_heads_total, int K, bf16_t* Wp, bf16_t* bias_p, hipStream_t s);
+void ze_launch_gemm_qkv_rope(const bf16_t* A, int lda, const bf16_t* Wp, int ldw, const bf16_t* bias_p, const ze_qkv_epi* dev_args,
+                             bf16_t* C, int ldc, int M, int N, int K, hipStream_t s);
 
 // ---- GEMM (prefill / ViT)
 void ze_launch_gemm(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
