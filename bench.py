@@ -43,13 +43,12 @@ L_TEXT_A, L_TEXT_B, N1, N2, PENALTY = 21, 455, 192, 96, 1.05  # 21 + 455 = 476 t
 HBM_PEAK_GBS = 8000.0
 BATCH_KERNELS = {0: "qkv", 1: "o_proj", 2: "gate_up", 3: "down", 4: "lm_head", 5: "attention", 6: "rmsnorm", 7: "rope_kv"}
 BATCH_KERNEL_NAMES_WIDE = {
-    0: "k_gemm_ring (row-streaming decode qkv projection, rows = chains)",
+    0: "k_gemm_ring<64,64,QKV_ROPE> (row-streaming decode qkv projection + M-RoPE + KV append in one launch, rows = chains)",
     1: "k_gemm_ring (row-streaming decode o projection + residual)",
-    2: "k_gemm_wstream<256,96,SWIGLU> (row-streaming decode gate/up projection: all chains' rows per workgroup, weights prefetched eight K-steps deep in registers)",
-    3: "k_gemm_ring<64,64,4,RESIDUAL> split-K x 8 (row-streaming decode down projection)",
+    2: "k_gemm_ring<192,192,SWIGLU> at 257-384 chains, k_gemm_wstream<BM,96,SWIGLU> otherwise (row-streaming decode gate/up projection)",
+    3: "k_gemm_ring split-K x 8 + k_splitk_reduce (row-streaming decode down projection; 192 x 128 tiles at 257-384 chains)",
     4: "k_gemm_wstream / k_gemm_ring<256,256,F32> (row-streaming decode lm_head)",
     5: "k_attn_decode_wave<8> (batched decode attention: every wave streams 16 keys of each 64-key round, K rows straight into MFMA registers, V rows through its own LDS stages)",
-    7: "k_rope_kv_batch (M-RoPE + KV append of the row-streaming family)",
 }
 BATCH_KERNEL_NAMES = {
     0: "k_gemm_oneshot<QKV,4> (batched decode qkv projection + M-RoPE + KV append, sixteen waves per workgroup)",
@@ -634,11 +633,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     use_dist = world > 1 or os.environ.get("ZE_BENCH_FORCE_DIST") == "1"  # the env flag exercises RCCL at N=1
+    # ZE_DIST_BACKEND=gloo: the same N > 1 code path (sharding, the weight broadcast into ranks that never filled their arena, the
+    # barriers, the MAX / SUM reductions of the report) with the ranks SHARING a GPU -- RCCL wants one rank per GPU, and the
+    # builder's box has one: tests/test_gpu_bench_contract.py runs `--gpus 2` this way.  Default: nccl = RCCL.
+    backend = os.environ.get("ZE_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
+    red_dev = f"cuda:{local}" if backend == "nccl" else "cpu"  # where the report's reductions live
 
     from zoomearth_amd.accel import broadcast_engine_weights, shard_by_tile
     from zoomearth_amd.config import ModelConfig
@@ -655,7 +664,8 @@ def main():
     e = Engine(cfg, device=local, max_seqs=chains, max_ctx=2048, max_patches=max(4096, 1400 * min(max(chains, 64 if want64 else 1), 40)),
                max_prefill_rows=(int(os.environ.get("ZE_PREFILL_ROWS", str(32 * 832 if chains > 64 else 16 * 832))) if chains > 1 else 0),
                max_tile_side=max(args.tile, 1024))
-    if rank == 0 or os.environ.get("ZE_BENCH_EVERY_RANK_FILLS") == "1":
+    filled_here = rank == 0 or os.environ.get("ZE_BENCH_EVERY_RANK_FILLS") == "1"
+    if filled_here:
         e.fill_synthetic(seed=0, std=0.02)
     for kv in os.environ.get("ZE_TUNE", "").split(","):  # measurement-only A/B knobs, e.g. ZE_TUNE=2:64
         if ":" in kv:
@@ -763,13 +773,13 @@ def main():
     for en in engines[1:]:
         for k, v in en.phase_timers(enable=False).items():
             phases[k] += v
-    per_rank = [[len(mine), my_dt]]
+    per_rank = [[len(mine), my_dt, 1.0 if filled_here else 0.0]]
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        g = torch.zeros((world, 2), dtype=torch.float64, device=f"cuda:{local}")
-        g[rank, 0], g[rank, 1] = len(mine), my_dt
+        g = torch.zeros((world, 3), dtype=torch.float64, device=red_dev)
+        g[rank, 0], g[rank, 1], g[rank, 2] = len(mine), my_dt, 1.0 if filled_here else 0.0
         dist.all_reduce(g, op=dist.ReduceOp.SUM)
         per_rank = g.cpu().tolist()
 
@@ -785,8 +795,8 @@ def main():
         names = BATCH_KERNEL_NAMES_WIDE if wide else BATCH_KERNEL_NAMES
         rows = {}
         for which in sorted(BATCH_KERNELS):
-            if which == 7 and not wide:
-                continue  # (the fragment family folds rope + KV append into the qkv launch)
+            if which == 7:
+                continue  # (both families fold rope + KV append into the qkv launch: round 4 for the row-streaming one)
             u, by = e.profile_batch_kernel(which, n, iters=72)
             rows[BATCH_KERNELS[which]] = {"us": round(u, 2), "GBps": round(by / (u * 1e-6) / 1e9, 1), "bytes": by}
         per_step = {k: v["us"] * (2 if k == "rmsnorm" else 1) for k, v in rows.items() if k != "lm_head"}
@@ -824,6 +834,107 @@ def main():
                 obj["step_kernels"]["attention"] = {"us": round(u2, 2), "GBps": round(ach2, 1)}
         e.set_decode_regime(-1)
         return obj
+
+    def live_like_contexts(n):
+        """The stream's end state holds finished stage-2 chains (~1416 cached rows each); a LIVE step holds two stage-1 chains
+        (802 .. 994 rows) for every stage-2 chain (1320 .. 1416): mean ~1055.  Cut the first n chains back to lengths drawn like
+        that before the decode kernels are timed (the roofline launch ran on the contexts the stream left
+        behind).  Returns the mean context of the n chains."""
+        tot = 0
+        for s_ in range(n):
+            want = (L_TEXT_A + 2 + 324 + L_TEXT_B + (s_ * 37) % N1) if s_ % 3 != 2 else (1320 + (s_ * 53) % N2)
+            have = e.seq_len(s_)
+            if have > want:
+                e.seq_truncate(s_, want)
+                have = want
+            tot += have
+        return tot / max(1, n)
+
+    def stream_rooflines(st, roof, live, n_q_rank, wall_s):
+        """The whole-stream roofline objects of the line, from ISOLATED kernel-time accounting -- the stream's own
+        phase timers sum two lanes' overlapping stream time and cannot be turned into a fraction:
+          decode   the step's kernels timed alone at the mean live-chain count on live-like contexts (batch_roofline): decode
+                   steps x (layers x layer_us + lm_head) per question, against the algorithmic bytes of those steps at 8 TB/s
+                   (weights once per step for all chains of the step + every chain's K/V rows: SURVEY 8d's B_decode);
+          prefill  a replay of representative admission passes alone on the GPU (16 chains x 802 new rows, then 330 more rows
+          / vit    behind a cached prompt) and of a 24-image ViT call, scaled to the rows / patches the stream actually executed
+                   (scheduler stats), against the FLOPs of those rows at 2.5 PFLOP/s;
+          question SURVEY 8d's formula at the measured mean batch: T_roof = 12.8 TFLOP / 2.5 PFLOP/s + (6.171 GB x 288 / chains
+                   + 11.2 GB) / 8 TB/s against the measured wall time per question of this GPU."""
+        import torch
+        cfgt = cfg.text
+        steps_total = max(1, st.get("steps", 1))
+        mean_chains = st.get("chain_steps", 0) / steps_total
+        # ---- decode
+        step_us = cfgt.num_hidden_layers * roof["layer_us"] + roof["step_kernels"]["lm_head"]["us"]
+        dec_ms_q = steps_total * step_us / 1000.0 / n_q_rank
+        w_bytes = 2.0 * (2774532096 + 311164928)
+        kv_row = 36864.0
+        kv_bytes_q = kv_row * (N1 * (L_TEXT_A + 2 + 324 + L_TEXT_B + N1 / 2.0) + N2 * (1320 + N2 / 2.0))
+        dec_bytes_q = w_bytes * (N1 + N2) / max(1.0, mean_chains) + kv_bytes_q
+        dec_roof_ms = dec_bytes_q / (HBM_PEAK_GBS * 1e9) * 1000.0
+        # ---- replay: prefill passes and a ViT call alone on the GPU
+        view = next(iter(dev.values())).resize((512, 512))
+        pv, grid = e.preprocess_image(view.tensor())
+        n_img = grid[1] * grid[2] // 4
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        k_img = 24 if 24 * pv.shape[0] <= e.max_patches else max(1, e.max_patches // pv.shape[0])
+        pvs = torch.cat([pv] * k_img).contiguous()
+        e.vit_forward(pvs, [grid] * k_img)  # warm-up
+        ev[0].record()
+        feats = e.vit_forward(pvs, [grid] * k_img)
+        ev[1].record()
+        nrep = min(16, e.max_seqs)
+        ids1 = [question_ids(cfg, 77_000 + c, n_img) for c in range(nrep)]
+        extra = [[1000 + c] * 4 + [cfg.vision_start_token_id] + [cfg.image_token_id] * n_img + [cfg.vision_end_token_id] for c in range(nrep)]
+        pl = [e.rope_index(ids1[c] + extra[c], [grid, grid]) for c in range(nrep)]
+        emb = feats[:n_img]
+
+        def passes():
+            for c in range(nrep):
+                e.seq_reset(c)
+            ev[2].record()
+            e.prefill_batch(list(range(nrep)), ids1, [emb] * nrep, [pl[c][0][:, :len(ids1[c])] for c in range(nrep)], [pl[c][1] for c in range(nrep)])
+            ev[3].record()
+            e.prefill_batch(list(range(nrep)), extra, [emb] * nrep, [pl[c][0][:, len(ids1[c]):] for c in range(nrep)], [pl[c][1] for c in range(nrep)])
+            ev[4].record()
+        passes()
+        passes()
+        torch.cuda.synchronize()
+        vit_ms_img = ev[0].elapsed_time(ev[1]) / k_img
+        rows_a, rows_b = sum(len(x) for x in ids1), sum(len(x) for x in extra)
+        pre_ms_row = (ev[2].elapsed_time(ev[3]) + ev[3].elapsed_time(ev[4])) / (rows_a + rows_b)
+        imgs_q = st.get("vit_images", 0) / n_q_rank
+        patches_q = st.get("vit_patches", 0) / n_q_rank
+        rows_q = st.get("prefill_rows", 0) / n_q_rank
+        vit_ms_q = vit_ms_img * imgs_q
+        pre_ms_q = pre_ms_row * rows_q
+        f_vit_q = patches_q * 1.2813e9 + imgs_q * 45.0e9          # SURVEY 8d: per patch 1.2813 GFLOP, attention 45 GFLOP per 36 x 36 view
+        f_pre_q = rows_q * (2.0 * 2774532096 + 36 * 4 * 2048 * 870.0)  # linear layers + causal attention at the rows' mean context
+        mfma = 2500.0e12
+        wall_ms_q = 1000.0 * wall_s / n_q_rank
+        t_roof_ms = (12.8e12 / mfma + (w_bytes * (N1 + N2) / max(1.0, mean_chains) + 11.2e9) / (HBM_PEAK_GBS * 1e9)) * 1000.0
+        iso = vit_ms_q + pre_ms_q + dec_ms_q
+        return {
+            "note": ("isolated kernel-time accounting (the kernels of each phase timed ALONE on this GPU, scaled to the work the stream "
+                     "executed); the stream's own phase timers overlap two lanes and several HIP streams"),
+            "vit": {"bound": "mfma", "ms_per_question": round(vit_ms_q, 3), "images_per_question": round(imgs_q, 3),
+                    "achieved_TFLOPs": round(f_vit_q / (vit_ms_q * 1e-3) / 1e12, 1) if vit_ms_q > 0 else None, "peak_TFLOPs": 2500.0,
+                    "frac": (f_vit_q / mfma) / (vit_ms_q * 1e-3) if vit_ms_q > 0 else None,
+                    "replay": f"{k_img} views of 36 x 36 patches in one call: {vit_ms_img:.3f} ms per image"},
+            "prefill": {"bound": "mfma", "ms_per_question": round(pre_ms_q, 3), "rows_per_question": round(rows_q, 1),
+                        "achieved_TFLOPs": round(f_pre_q / (pre_ms_q * 1e-3) / 1e12, 1) if pre_ms_q > 0 else None, "peak_TFLOPs": 2500.0,
+                        "frac": (f_pre_q / mfma) / (pre_ms_q * 1e-3) if pre_ms_q > 0 else None,
+                        "replay": f"{nrep} chains x {len(ids1[0])} new rows, then {len(extra[0])} rows behind the cached prompt: {1000 * pre_ms_row:.2f} us per row"},
+            "decode": {"bound": "hbm", "ms_per_question": round(dec_ms_q, 3), "step_us_at_mean_chains": round(step_us, 1),
+                       "mean_chains_per_step": round(mean_chains, 1), "algorithmic_GB_per_question": round(dec_bytes_q / 1e9, 2),
+                       "achieved_GBs": round(dec_bytes_q / (dec_ms_q * 1e-3) / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
+                       "frac": dec_roof_ms / dec_ms_q},
+            "isolated_ms_per_question": round(iso, 3),
+            "question": {"roofline_ms": round(t_roof_ms, 3), "measured_ms": round(wall_ms_q, 3), "frac": t_roof_ms / wall_ms_q,
+                         "formula": "SURVEY 8d: 12.8 TFLOP / 2.5 PFLOP/s + (6.171 GB x 288 / mean chains + 11.2 GB) / 8 TB/s",
+                         "gpu_busy_with_isolated_kernel_time": round(iso / wall_ms_q, 3)},
+        }
 
     def committed_traffic(section, kernel, alg_bytes=None):
         """HBM bytes per launch from the PMC passes of the latest committed profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
@@ -933,6 +1044,7 @@ def main():
                        "weight_broadcast_s": round(bcast_s, 4)},
             "weight_broadcast_s": round(bcast_s, 4),
             "per_rank": {"questions": [int(r[0]) for r in per_rank], "seconds": [round(r[1], 3) for r in per_rank],
+                         "filled_own_weights": [bool(r[2]) for r in per_rank], "dist_backend": backend if use_dist else None,
                          "imbalance": round(max(r[1] for r in per_rank) / max(1e-9, float(np.mean([r[1] for r in per_rank]))), 4)},
             "tile_upload_ms": round(1000.0 * upload_stats["s"] / n_up, 3),
             "tile_upload_note": (f"one {args.tile}x{args.tile}x3 u8 tile, pinned host memory -> HBM (ze_tile_upload), per TILE, "
@@ -948,7 +1060,14 @@ def main():
             line["scheduler"] = st
             if args.model == "3b" and not args.fp8:
                 live = int(min(SLOTS, max(1, round(line["mean_chains_per_step"]))))
+                mean_ctx = live_like_contexts(live)
                 line["roofline"] = batch_roofline(live, shared=(10, 347))
+                line["roofline"]["contexts"] = (f"the {live} chains cut back to live-like lengths before the launch (two stage-1 chains of "
+                                                f"802-994 rows per stage-2 chain of 1320-1416): mean {mean_ctx:.0f} rows")
+                try:
+                    line["roofline_phases"] = stream_rooflines(st, line["roofline"], live, max(1, len(mine)), my_dt)
+                except Exception as ex:  # the line must not die on its annex
+                    line["roofline_phases"] = {"error": f"{type(ex).__name__}: {ex}"}
         if args.model == "3b" and not args.fp8 and not stream:
             if B == 1:
                 pm = line["phase_ms_per_question"]

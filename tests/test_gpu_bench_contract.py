@@ -45,6 +45,16 @@ def test_bench_line_contract():
     assert d["value"] > 10.0
     check_roofline(d["roofline"])
     assert d["roofline"]["chains"] >= 1 and "decode" in d["roofline"]["kernel"]
+    # the stream's own whole-question roofline (isolated kernel-time accounting; SURVEY 8d's formula at the measured batch)
+    rp = d["roofline_phases"]
+    assert "error" not in rp, rp
+    assert rp["decode"]["bound"] == "hbm" and rp["vit"]["bound"] == "mfma" and rp["prefill"]["bound"] == "mfma"
+    for k in ("vit", "prefill", "decode"):
+        assert 0 < rp[k]["frac"] < 1 and rp[k]["ms_per_question"] > 0, (k, rp[k])
+    assert 0 < rp["question"]["frac"] < 1 and rp["question"]["measured_ms"] > rp["question"]["roofline_ms"] > 0
+    assert abs(rp["question"]["measured_ms"] - 1000.0 / d["value"]) < 0.02 * rp["question"]["measured_ms"]
+    assert abs(rp["isolated_ms_per_question"] - sum(rp[k]["ms_per_question"] for k in ("vit", "prefill", "decode"))) < 0.01
+    assert d["per_rank"]["filled_own_weights"] == [True]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "threads", "kind", "sample"):
         assert k in c, k
@@ -86,3 +96,20 @@ def test_bench_runs_the_collective_path_on_one_rank():
                   ZE_BENCH_FORCE_DIST="1", MASTER_PORT="29577")
     assert d["n_gpus"] == 1 and d["weight_broadcast_s"] > 0 and d["per_rank"]["questions"] == [64]
     assert d["value"] > 5.0
+
+
+def test_bench_two_ranks_share_the_gpu_over_gloo():
+    """the N > 1 branch of bench.py had never executed anywhere (RCCL wants one rank per GPU and no multi-GPU box
+    has been available).  `ZE_DIST_BACKEND=gloo` runs the same code with both ranks on this box's one GPU: `--gpus 2` spawns the
+    ranks itself (before anything touches the GPU), the question table of 2 x 64 questions is sharded by tile, rank 1 never
+    fills its weights and receives the packed arena by broadcast, the report is reduced over the ranks (MAX of the times, SUM of
+    the per-rank rows) and rank 0 alone prints the line."""
+    d = run_bench("--gpus", "2", "--steps", "1", "--warmup", "1", "--lanes", "1", "--slots", "96", "--no-cpu-baseline",
+                  "--no-batch64", "--no-configs1", ZE_DIST_BACKEND="gloo")
+    assert d["n_gpus"] == 2 and d["per_rank"]["dist_backend"] == "gloo"
+    assert len(d["per_rank"]["questions"]) == 2 and sum(d["per_rank"]["questions"]) == 128
+    assert min(d["per_rank"]["questions"]) >= 40                      # tile-level LPT: close to 64 / 64
+    assert d["per_rank"]["filled_own_weights"] == [True, False] and d["weight_broadcast_s"] > 0
+    assert d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert abs(d["value"] - 128 * 1000.0 / (d["ms_per_step"] * 1)) < 1e-6 * d["value"]   # all questions / the slowest rank's time
+    assert d["ms_per_step"] >= 1000.0 * max(d["per_rank"]["seconds"]) * 0.999 and d["value"] > 3.0

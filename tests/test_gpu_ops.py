@@ -302,6 +302,29 @@ def test_attention_every_instantiation(tiny_engine, d, heads, kvh, t, causal):
     assert np.abs(got - want).max() <= 2.0 ** -6 * max(1.0, np.abs(want).max()), np.abs(got - want).max()
 
 
+@pytest.mark.parametrize("d,heads,kvh,cu,causal", [(128, 4, 2, [0, 500], True), (128, 16, 2, [0, 130, 131, 400, 1202], True),
+                                                    (80, 4, 4, [0, 1296], False), (80, 2, 2, [0, 64, 128, 144, 400], False),
+                                                    (128, 4, 4, [0, 700], False), (80, 2, 2, [0, 333], True)])
+def test_attention_two_query_tiles_per_wave_give_the_same_bits(tiny_engine, d, heads, kvh, cu, causal):
+    """The long-segment form of the flash kernel (128-query tiles: two 16-query tiles per wave, every K / V^T fragment read from
+    LDS feeds two MFMAs) against the 64-query form (ze_tune knob 1 = 9): a row's arithmetic does not depend on the tile it sits
+    in -- same key tiles, same online softmax -- so the outputs are the same bits (what keeps prefix reuse and cross-chain
+    prefill exact), for ragged segments, segment ends inside a tile, GQA and both head sizes."""
+    t = cu[-1]
+    q, k, v = rnd(26, (t, heads, d)), rnd(27, (t, kvh, d)), rnd(28, (t, kvh, d))
+    dq, dk, dv = to_dev_bf16(q), to_dev_bf16(k), to_dev_bf16(v)
+    two = tiny_engine.op_attention(dq, dk, dv, cu, causal)
+    try:
+        tiny_engine.lib.ze_tune(1, 9)
+        one = tiny_engine.op_attention(dq, dk, dv, cu, causal)
+    finally:
+        tiny_engine.lib.ze_tune(1, 0)
+    assert torch.equal(one, two)
+    want = ref_attention(q, k, v, cu, causal)
+    got = two.float().cpu().numpy()
+    assert np.abs(got - want).max() <= 2.0 ** -6 * max(1.0, np.abs(want).max())
+
+
 @pytest.mark.parametrize("m,n,k,bias,act", [
     (200, 256, 64, True, 0), (300, 520, 128, False, 0), (777, 1000, 640, True, 0), (600, 1024, 192, False, 4),
     (1000, 2560, 2048, True, 0), (2304, 4096, 2048, False, 4), (513, 257 * 8, 320, True, 0), (4096, 2048, 2752, False, 0),

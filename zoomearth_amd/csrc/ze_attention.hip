@@ -50,7 +50,10 @@ __device__ __forceinline__ int fa_off(int row, int ch) { return 256 * row + 16 *
 //     (global loads of tile t+1 are issued before the products of tile t, written to LDS after).
 // D = 128 (LLM, causal GQA) and D = 80 (ViT; rows padded to 128 in LDS, the pad chunks are zero).
 // BKV: keys per iteration (64, or 128: half the barriers and load-latency exposures of a long causal prefill)
-template <int D, int CAUSAL, int BKV>
+// QT: 16-query tiles per wave (1: 64 queries per workgroup; 2: 128 -- every K and V^T fragment read from LDS feeds TWO MFMAs:
+// the kernel is bound by its LDS fragment reads, one per MFMA with QT = 1).  A query's arithmetic does not depend on QT: the
+// same key tiles in the same order, the same online softmax -- bit-identical rows.
+template <int D, int CAUSAL, int BKV, int QT = 1>
 __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q, int q_rs, int q_hs,
                                                     const bf16_t* __restrict__ k, int k_rs, int k_hs,
                                                     const bf16_t* __restrict__ v, int v_rs, int v_hs,
@@ -74,22 +77,31 @@ __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q
     const int head = blockIdx.y, kvh = head / group;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    const int qi = q0 + wid * 16 + fr;  // the query of this lane (column of S^T / O^T)
+    int qi[QT];  // the queries of this lane (columns of S^T / O^T), one per query tile of the wave
+#pragma unroll
+    for (int t = 0; t < QT; ++t) qi[t] = q0 + (wid * QT + t) * 16 + fr;
 
     // Q^T fragments: lane (n = fr, k-group fq) holds d = ks*32 + fq*8 .. +7 of its query
-    bf16x8 qf[KS];
+    bf16x8 qf[QT][KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        uint4 val = make_uint4(0, 0, 0, 0);
-        const int ch = ks * 4 + fq;
-        if (qi < q1 && ch < DCH) val = *reinterpret_cast<const uint4*>(q + (size_t)qi * q_rs + (size_t)head * q_hs + ch * 8);
-        qf[ks] = *reinterpret_cast<const bf16x8*>(&val);
-    }
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            uint4 val = make_uint4(0, 0, 0, 0);
+            const int ch = ks * 4 + fq;
+            if (qi[t] < q1 && ch < DCH) val = *reinterpret_cast<const uint4*>(q + (size_t)qi[t] * q_rs + (size_t)head * q_hs + ch * 8);
+            qf[t][ks] = *reinterpret_cast<const bf16x8*>(&val);
+        }
 
-    f32x4 oacc[NV];
+    f32x4 oacc[QT][NV];
+    float m_run[QT], l_run[QT];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) oacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
+    for (int t = 0; t < QT; ++t) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) oacc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m_run[t] = -INFINITY;
+        l_run[t] = 0.f;
+    }
     int kv_hi = kv1;
     if (CAUSAL) kv_hi = min(kv1, q1 + q_pos_offset);  // keys beyond the last query position are never visible
     const int ntile = (kv_hi - kv0 + BKV - 1) / BKV;
@@ -139,74 +151,86 @@ __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q
         const uint8_t* kb = smem + (t & 1) * 2 * TILE_B;
         const uint8_t* vb = kb + TILE_B;
         if (t + 1 < ntile) stage_load(kt + BKV);
-        // ---- S^T = K Q^T : NKT key tiles x KS steps
-        f32x4 sacc[NKT];
+        // ---- S^T = K Q^T : NKT key tiles x KS steps; one K fragment read feeds the QT query tiles
+        f32x4 sacc[QT][NKT];
 #pragma unroll
-        for (int n = 0; n < NKT; ++n) sacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < QT; ++u)
+#pragma unroll
+            for (int n = 0; n < NKT; ++n) sacc[u][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int n = 0; n < NKT; ++n) {
                 const uint4 ka = *reinterpret_cast<const uint4*>(kb + fa_off(n * 16 + fr, ks * 4 + fq));
-                sacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&ka), qf[ks], sacc[n],
-                                                                 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < QT; ++u)
+                    sacc[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&ka), qf[u][ks], sacc[u][n],
+                                                                        0, 0, 0);
             }
         }
-        // ---- mask + online softmax for query qi: keys kt + n*16 + fq*4 + r
-        float p[NKT][4];
-        float mx = -INFINITY;
+        // ---- mask + online softmax per query: keys kt + n*16 + fq*4 + r
         // (The library is compiled with -fno-slp-vectorize: with hipcc's SLP vectoriser on, the D = 80 instantiations
         //  produced wrong rows -- first seen behind a fast path that skipped this compare + select pair on fully
         //  visible tiles, then in the plain D = 80 causal kernel; tools/check_attn.py and
-        //  test_attention_every_instantiation pin all four instantiations.  The fast path was worth 10 % of the
+        //  test_attention_every_instantiation pin every instantiation.  The fast path was worth 10 % of the
         //  kernel = 0.2 ms per question and is not worth re-validating.)
+        uint32_t pw[QT][NKT][2];  // the probabilities, packed to bf16 pairs (keys fq*4 + 0,1 | 2,3 of key tile n)
 #pragma unroll
-        for (int n = 0; n < NKT; ++n)
+        for (int u = 0; u < QT; ++u) {
+            float p[NKT][4];
+            float mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kj = kt + n * 16 + fq * 4 + r;
-                bool ok = kj < kv_hi;
-                if (CAUSAL) ok = ok && (kj <= qi + q_pos_offset);
-                const float sv = ok ? sacc[n][r] * scale_log2e : -INFINITY;
-                p[n][r] = sv;
-                mx = fmaxf(mx, sv);
+            for (int n = 0; n < NKT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kj = kt + n * 16 + fq * 4 + r;
+                    bool ok = kj < kv_hi;
+                    if (CAUSAL) ok = ok && (kj <= qi[u] + q_pos_offset);
+                    const float sv = ok ? sacc[u][n][r] * scale_log2e : -INFINITY;
+                    p[n][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[u], mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = exp2f(m_run[u] - m_use);  // m_run = -inf -> 0
+            float rs = 0.f;
+#pragma unroll
+            for (int n = 0; n < NKT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(p[n][r] - m_use);  // raw v_exp_f32: arguments <= 0, results in [0, 1]
+                    p[n][r] = e;
+                    rs += e;
+                }
+            rs += __shfl_xor(rs, 16, 64);
+            rs += __shfl_xor(rs, 32, 64);
+            l_run[u] = l_run[u] * alpha + rs;
+            m_run[u] = m_new;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                oacc[u][j][0] *= alpha;
+                oacc[u][j][1] *= alpha;
+                oacc[u][j][2] *= alpha;
+                oacc[u][j][3] *= alpha;
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = exp2f(m_run - m_use);  // m_run = -inf -> 0
-        float rs = 0.f;
 #pragma unroll
-        for (int n = 0; n < NKT; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __builtin_amdgcn_exp2f(p[n][r] - m_use);  // raw v_exp_f32: arguments <= 0, results in [0, 1]
-                p[n][r] = e;
-                rs += e;
+            for (int n = 0; n < NKT; ++n) {
+                pw[u][n][0] = fa_pack_bf16(p[n][0], p[n][1]);
+                pw[u][n][1] = fa_pack_bf16(p[n][2], p[n][3]);
             }
-        rs += __shfl_xor(rs, 16, 64);
-        rs += __shfl_xor(rs, 32, 64);
-        l_run = l_run * alpha + rs;
-        m_run = m_new;
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            oacc[j][0] *= alpha;
-            oacc[j][1] *= alpha;
-            oacc[j][2] *= alpha;
-            oacc[j][3] *= alpha;
         }
-        // ---- O^T += V^T P^T : per 32-key step the lane's 8 keys are (ks*32 + fq*4 + 0..3) and (ks*32 + 16 + fq*4 + 0..3)
+        // ---- O^T += V^T P^T : per 32-key step the lane's 8 keys are (ks*32 + fq*4 + 0..3) and (ks*32 + 16 + fq*4 + 0..3);
+        // one V^T fragment (two transposed reads) feeds the QT query tiles
 #pragma unroll
         for (int ks = 0; ks < BKV / 32; ++ks) {
-            uint32_t pw[4];
+            bf16x8 pb[QT];
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                pw[2 * h2] = fa_pack_bf16(p[2 * ks + h2][0], p[2 * ks + h2][1]);
-                pw[2 * h2 + 1] = fa_pack_bf16(p[2 * ks + h2][2], p[2 * ks + h2][3]);
+            for (int u = 0; u < QT; ++u) {
+                const uint4 pq = make_uint4(pw[u][2 * ks][0], pw[u][2 * ks][1], pw[u][2 * ks + 1][0], pw[u][2 * ks + 1][1]);
+                pb[u] = *reinterpret_cast<const bf16x8*>(&pq);
             }
-            const uint4 pq = make_uint4(pw[0], pw[1], pw[2], pw[3]);
-            const bf16x8 pb = *reinterpret_cast<const bf16x8*>(&pq);
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 // block of 4 keys x 16 d: lane 4q+p of the 16-lane group addresses key row (r0 + q), d = j*16 + 4p .. +3
@@ -219,49 +243,62 @@ __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q
                     (__attribute__((address_space(3))) v4s*)(vb + fa_off(r0b + tq, ch) + half));
                 typedef short v8s __attribute__((ext_vector_type(8)));
                 const v8s va = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&va), pb, oacc[j], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < QT; ++u)
+                    oacc[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&va), pb[u], oacc[u][j], 0, 0, 0);
             }
         }
         if (t + 1 < ntile) stage_write((t + 1) & 1, kt + BKV);
         __syncthreads();
     }
     // ---- normalise and store: lane holds O[qi][j*16 + fq*4 .. +3]
-    if (qi < q1) {
-        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            uint2 w;
-            w.x = pack_bf16x2(oacc[j][0] * inv, oacc[j][1] * inv);
-            w.y = pack_bf16x2(oacc[j][2] * inv, oacc[j][3] * inv);
-            *reinterpret_cast<uint2*>(o + (size_t)qi * o_rs + (size_t)head * o_hs + j * 16 + fq * 4) = w;
+    for (int u = 0; u < QT; ++u)
+        if (qi[u] < q1) {
+            const float inv = l_run[u] > 0.f ? 1.0f / l_run[u] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                uint2 w;
+                w.x = pack_bf16x2(oacc[u][j][0] * inv, oacc[u][j][1] * inv);
+                w.y = pack_bf16x2(oacc[u][j][2] * inv, oacc[u][j][3] * inv);
+                *reinterpret_cast<uint2*>(o + (size_t)qi[u] * o_rs + (size_t)head * o_hs + j * 16 + fq * 4) = w;
+            }
         }
-    }
 }
 
 void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_rs, int q_hs, const bf16_t* k, int k_rs,
                           int k_hs, const bf16_t* v, int v_rs, int v_hs, bf16_t* o, int o_rs, int o_hs,
                           const int4* tiles, int n_tiles, int heads, int group, float scale, int q_pos_offset,
-                          hipStream_t s, const int* tile_aux, size_t kv_seq_stride) {
+                          hipStream_t s, const int* tile_aux, size_t kv_seq_stride, int q_tile) {
     if (n_tiles == 0) return;
     const float sl = scale * 1.4426950408889634f;
     dim3 grid(n_tiles, heads);
-#define FA_LAUNCH(DD, CC)                                                                                      \
+#define FA_LAUNCH(DD, CC, QQ)                                                                                      \
     do {                                                                                                          \
         constexpr int BKV_ = (CC) ? ZE_FA_CAUSAL_BKV : 64;                                                        \
         constexpr int LDS_ = 4 * BKV_ * 256;                                                                      \
         static bool attr_set = false;                                                                             \
         if (!attr_set) {                                                                                          \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn<DD, CC, BKV_>),                       \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn<DD, CC, BKV_, QQ>),                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_);                                \
             attr_set = true;                                                                                      \
         }                                                                                                         \
-        hipLaunchKernelGGL((k_flash_attn<DD, CC, BKV_>), grid, dim3(256), LDS_, s, q, q_rs, q_hs, k, k_rs, k_hs, v, v_rs, \
+        hipLaunchKernelGGL((k_flash_attn<DD, CC, BKV_, QQ>), grid, dim3(256), LDS_, s, q, q_rs, q_hs, k, k_rs, k_hs, v, v_rs, \
                            v_hs, o, o_rs, o_hs, tiles, group, sl, q_pos_offset, tile_aux, kv_seq_stride);          \
     } while (0)
+    // q_tile: the query rows a tile of the caller's list spans at most -- 64 (one 16-query tile per wave) or 128 (two)
+    if (q_tile > 64) {
+        if (D == 80) {
+            if (causal) FA_LAUNCH(80, 1, 2); else FA_LAUNCH(80, 0, 2);
+        } else {
+            if (causal) FA_LAUNCH(128, 1, 2); else FA_LAUNCH(128, 0, 2);
+        }
+        return;
+    }
     if (D == 80) {
-        if (causal) FA_LAUNCH(80, 1); else FA_LAUNCH(80, 0);
+        if (causal) FA_LAUNCH(80, 1, 1); else FA_LAUNCH(80, 0, 1);
     } else {
-        if (causal) FA_LAUNCH(128, 1); else FA_LAUNCH(128, 0);
+        if (causal) FA_LAUNCH(128, 1, 1); else FA_LAUNCH(128, 0, 1);
     }
 #undef FA_LAUNCH
 }

@@ -212,13 +212,13 @@ extern "C" int ze_rope_index(const ze_config* cfg, const int32_t* input_ids, int
 
 // ================================================================== attention tile lists
 // one tile = up to 64 query rows of one segment against that segment's keys
-static int build_tiles(const int32_t* cu, int n_seg, int* out /* int4 rows */, int cap_tiles) {
+static int build_tiles(const int32_t* cu, int n_seg, int* out /* int4 rows */, int cap_tiles, int bq = 64) {
     int n = 0;
     for (int sgi = 0; sgi < n_seg; ++sgi)
-        for (int q0 = cu[sgi]; q0 < cu[sgi + 1]; q0 += 64) {
+        for (int q0 = cu[sgi]; q0 < cu[sgi + 1]; q0 += bq) {
             if (n >= cap_tiles) return -1;
             out[4 * n + 0] = q0;
-            out[4 * n + 1] = std::min(q0 + 64, cu[sgi + 1]);
+            out[4 * n + 1] = std::min(q0 + bq, cu[sgi + 1]);
             out[4 * n + 2] = cu[sgi];
             out[4 * n + 3] = cu[sgi + 1];
             ++n;
@@ -265,7 +265,9 @@ extern "C" int ze_vit_forward(ze_engine* e, const float* pixel_values, const int
     }
     const int ntw = build_tiles(cu_win.data(), (int)cu_win.size() - 1, tw, n);
     int* tf = tw + 4 * ntw;
-    const int ntf = build_tiles(cu_full.data(), (int)cu_full.size() - 1, tf, n);
+    // (the full-attention blocks: segments of a whole image -- 128-query tiles, two per wave; ze_tune knob 1 = 9: 64)
+    const int bq_full = ze_gemv_knobs[1] == 9 ? 64 : ZE_FA_BQ_LONG;
+    const int ntf = build_tiles(cu_full.data(), (int)cu_full.size() - 1, tf, n, bq_full);
     if (ntw < 0 || ntf < 0) return ze_fail(e, ZE_ERR_NOMEM, "attention tile list overflow");
     // rotary: inv_freq over dim = head_dim/2 -> half/2 frequencies per axis (HF:...:125-134, 441-446)
     const int nf = half / 2;
@@ -306,7 +308,8 @@ extern "C" int ze_vit_forward(ze_engine* e, const float* pixel_values, const int
                        3 * vh, vh, s);
         ze_launch_vision_rope(e->vqkv, e->vcos, e->vsin, n, nh, hd, s);
         ze_launch_flash_attn(hd, 0, e->vqkv, 3 * vh, hd, e->vqkv + vh, 3 * vh, hd, e->vqkv + 2 * vh, 3 * vh, hd, e->vo,
-                             vh, hd, full ? e->vtiles_full : e->vtiles_win, full ? ntf : ntw, nh, 1, scale, 0, s);
+                             vh, hd, full ? e->vtiles_full : e->vtiles_win, full ? ntf : ntw, nh, 1, scale, 0, s, nullptr, 0,
+                             full ? bq_full : 64);
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->vo, vh, b.proj.w, b.proj.ld, b.proj.bias, e->vh, vh, e->vh, vh, nullptr, n,
                        vh, vh, s);
         ze_launch_rmsnorm(e->vh, vh, b.norm2, e->vy, vh, n, vh, 1e-6f, s);
@@ -546,9 +549,13 @@ static int prefill_impl(ze_engine* e, int seq, const int32_t* input_ids, int len
         return ze_fail(e, ZE_ERR_MISMATCH, "Image features and image tokens do not match, tokens: " +
                                                std::to_string(img) + ", features: " + std::to_string(n_image_rows));
     int nt = 0;
-    for (int q0 = 0; q0 < len; q0 += 64, ++nt) {
+    // query rows per attention tile: 64.  (128 -- two query tiles per wave, half the LDS fragment reads per MFMA -- is what the
+    // ViT's full-attention blocks run, D = 80; at D = 128 that form needs 280 VGPRs, ONE workgroup per CU instead of two, and the
+    // batched prefill pass took 120.5 instead of 116.9 ms: ze_tune knob 1 = 8 selects it for A/B runs.  Same bits either way.)
+    const int bq = ze_gemv_knobs[1] == 8 ? ZE_FA_BQ_LONG : 64;
+    for (int q0 = 0; q0 < len; q0 += bq, ++nt) {
         tiles[4 * nt + 0] = q0;
-        tiles[4 * nt + 1] = std::min(q0 + 64, len);
+        tiles[4 * nt + 1] = std::min(q0 + bq, len);
         tiles[4 * nt + 2] = 0;
         tiles[4 * nt + 3] = past + len;
     }
@@ -567,7 +574,7 @@ static int prefill_impl(ze_engine* e, int seq, const int32_t* input_ids, int len
                            e->kc(li, seq), e->vc(li, seq), c.max_ctx, past, nullptr, 0, s);
         ze_launch_flash_attn(hd, 1, e->tqkv, nqkv, hd, e->kc(li, seq), hd, c.max_ctx * hd, e->vc(li, seq), hd,
                              c.max_ctx * hd, e->to, nq, hd, e->ttiles, nt, c.heads, c.heads / c.kv_heads, scale, past,
-                             s);
+                             s, nullptr, 0, bq);
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, len, H, nq, s);
         prefill_norm_gemm(e, L.post_norm, L.gate_up, nullptr, ZE_EPI_SWIGLU, e->ta, e->text_ipad, len, 2 * e->text_ipad, s);
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, nullptr,
@@ -654,6 +661,10 @@ extern "C" int ze_prefill_batch(ze_engine* e, const int32_t* seqs, int n, const 
     int* row_aux = pos + 3 * total;
     int* tiles = row_aux + 2 * total;
     int img = 0, nt = 0, row0 = 0, img_expected = 0;
+    // query rows per attention tile: 64.  (128 -- two query tiles per wave, half the LDS fragment reads per MFMA -- is what the
+    // ViT's full-attention blocks run, D = 80; at D = 128 that form needs 280 VGPRs, ONE workgroup per CU instead of two, and the
+    // batched prefill pass took 120.5 instead of 116.9 ms: ze_tune knob 1 = 8 selects it for A/B runs.  Same bits either way.)
+    const int bq = ze_gemv_knobs[1] == 8 ? ZE_FA_BQ_LONG : 64;
     std::vector<int> tile_aux;
     for (int i = 0; i < n; ++i) {
         const int seq = seqs[i], len = lens[i], past = e->ctx_host[seq];
@@ -680,9 +691,9 @@ extern "C" int ze_prefill_batch(ze_engine* e, const int32_t* seqs, int n, const 
             return ze_fail(e, ZE_ERR_MISMATCH, "Image features and image tokens do not match, tokens: " +
                                                    std::to_string(img_chain) + ", features: " + std::to_string(want));
         img_expected += want;
-        for (int q0 = 0; q0 < len; q0 += 64, ++nt) {
+        for (int q0 = 0; q0 < len; q0 += bq, ++nt) {
             tiles[4 * nt + 0] = row0 + q0;
-            tiles[4 * nt + 1] = row0 + std::min(q0 + 64, len);
+            tiles[4 * nt + 1] = row0 + std::min(q0 + bq, len);
             tiles[4 * nt + 2] = 0;
             tiles[4 * nt + 3] = past + len;
             tile_aux.push_back(seq);
@@ -711,7 +722,7 @@ extern "C" int ze_prefill_batch(ze_engine* e, const int32_t* seqs, int n, const 
                            e->vc(li, 0), c.max_ctx, 0, e->trow_aux, seq_stride, s);
         ze_launch_flash_attn(hd, 1, e->tqkv, nqkv, hd, e->kc(li, 0), hd, c.max_ctx * hd, e->vc(li, 0), hd,
                              c.max_ctx * hd, e->to, nq, hd, e->ttiles, nt, c.heads, c.heads / c.kv_heads, scale, 0, s,
-                             e->ttile_aux, seq_stride);
+                             e->ttile_aux, seq_stride, bq);
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, total, H, nq, s);
         prefill_norm_gemm(e, L.post_norm, L.gate_up, nullptr, ZE_EPI_SWIGLU, e->ta, e->text_ipad, total, 2 * e->text_ipad, s);
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, nullptr,
@@ -1618,7 +1629,8 @@ extern "C" int ze_op_attention(ze_engine* e, const void* q, const void* k, const
     hipSetDevice(e->device);
     hipStream_t s = (hipStream_t)stream;
     std::vector<int> tiles((size_t)4 * (T / 64 + n_seg + 2));
-    const int nt = build_tiles(cu, n_seg, tiles.data(), (int)tiles.size() / 4);
+    const int bq = ze_gemv_knobs[1] == 9 ? 64 : ZE_FA_BQ_LONG;  // (two query tiles per wave unless knob 1 = 9: the unit op covers both forms)
+    const int nt = build_tiles(cu, n_seg, tiles.data(), (int)tiles.size() / 4, bq);
     if (nt < 0) return ze_fail(e, ZE_ERR_NOMEM, "tile overflow");
     int4* dt = nullptr;
     ZE_HIP(hipMalloc((void**)&dt, (size_t)std::max(nt, 1) * 16));
@@ -1626,7 +1638,7 @@ extern "C" int ze_op_attention(ze_engine* e, const void* q, const void* k, const
     // causal inside each segment: key j visible to query i iff j <= i (absolute row indices, offset 0)
     ze_launch_flash_attn(D, causal, (const bf16_t*)q, heads * D, D, (const bf16_t*)k, kv_heads * D, D,
                          (const bf16_t*)v, kv_heads * D, D, (bf16_t*)o, heads * D, D, dt, nt, heads, heads / kv_heads,
-                         1.0f / sqrtf((float)D), 0, s);
+                         1.0f / sqrtf((float)D), 0, s, nullptr, 0, bq);
     hipError_t le = hipGetLastError();
     hipStreamSynchronize(s);
     hipFree(dt);

@@ -351,6 +351,8 @@ class ChainScheduler:
             grids = [it[1][1] for it in items[i:j]]
             feats = e.vit_forward((torch.cat(pvs) if len(pvs) > 1 else pvs[0]).contiguous(), grids)
             self.stats["vit_calls"] += 1
+            self.stats["vit_images"] = self.stats.get("vit_images", 0) + len(grids)
+            self.stats["vit_patches"] = self.stats.get("vit_patches", 0) + int(n)
             off = 0
             mu = self.model.config.vision.spatial_merge_size ** 2
             for (key, (_, g)) in items[i:j]:
