@@ -118,15 +118,19 @@ def evaluation_metrics(data_path):
     r = score_records(records)
     n = r["total"]
     print("\n" + "=" * 50 + "\nEvaluating dataset: LRS-GRO\n" + "=" * 50)
+    print("Processing evaluations...")
     if not HAVE_WORDNET:
-        print("(nltk/WordNet not installed: synonym credit from the bundled WordNet subset src/eval/synsets_lite.json only)")
+        import sys
+        print("(nltk/WordNet not installed: synonym credit from the bundled WordNet subset src/eval/synsets_lite.json only)",
+              file=sys.stderr)  # (stderr: stdout is the reference's report, line for line -- tests/golden/eval_report.json)
     print("\n--- Evaluation Results ---")
     print(f"Total Correct (stage 1): {r['correct1']}")
     print(f"Total Correct (stage 2): {r['correct2']}")
     print(f"Total Incorrect (stage 1): {n - r['correct1']}")
     print(f"Total Incorrect (stage 2): {n - r['correct2']}")
     print(f"Total Samples: {n}")
-    print("-" * 25 + "\nType-wise Accuracies:")
+    # (the reference prints an empty category section, /root/reference/src/eval/eval.py:105-107: kept, line for line)
+    print("-" * 25 + "\nCategory-wise Accuracies:\n" + "-" * 25 + "\nType-wise Accuracies:")
     for t in sorted(r["by_type"]):
         cnt, a, b = r["by_type"][t]
         print(f"{t:<15}: {100.0 * a / cnt:.2f}% -> {100.0 * b / cnt:.2f}%")
@@ -134,6 +138,8 @@ def evaluation_metrics(data_path):
     if n:
         print(f"Overall Accuracy (OA, stage 1): {100.0 * r['correct1'] / n:.2f}%")
         print(f"Overall Accuracy (OA, stage 2): {100.0 * r['correct2'] / n:.2f}%")
+        # the reference's counter `total_correct_call` is never incremented (:49, :124): the line always reads 0.0000 %
+        print(f"Tool use accuracy: {100.0 * r.get('correct_call', 0) / n:.4f}%")
         print(f"Overall: {100.0 * r['correct1'] / n:.2f}% -> {100.0 * r['correct2'] / n:.2f}%")
     else:
         print("Overall Accuracy (OA): N/A (No samples found)")
