@@ -15,7 +15,7 @@ echo "Infering model: $model_name on LRS-GRO!"
 echo "Experiment name: $exp_name!"
 if [ "$NGPU" -gt 1 ]; then
   python -m torch.distributed.run --nnodes=1 --nproc-per-node "$NGPU" --master-addr 127.0.0.1 --master-port "${MASTER_PORT:-29511}" \
-    src/infer.py --model_name "$model_name" --exp_name "$exp_name" ${EXTRA_ARGS:-}
+    src/infer.py --model_name "$model_name" --exp_name "$exp_name" --steal ${EXTRA_ARGS:-}
   python -c "from zoomearth_amd.accel import merge_results; print(merge_results('results/$exp_name', $NGPU, 'results/$exp_name.jsonl'), 'records merged')"
 else
   python src/infer.py --model_name "$model_name" --exp_name "$exp_name" ${EXTRA_ARGS:-}

@@ -63,7 +63,8 @@ def done_question_ids(path):
 
 
 def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir="./image/", max_new_tokens=1024,
-                    batch_size=BATCH_SIZE, max_ctx=4096, do_sample=True, resume=False, decode_workers=3, decode_ahead=6, lanes=1):
+                    batch_size=BATCH_SIZE, max_ctx=4096, do_sample=True, resume=False, decode_workers=3, decode_ahead=6, lanes=1,
+                    steal=False):
     # capacity: the stage-2 prompt holds the stage-1 prompt, its output and a second image (<= ~3200 tokens at the
     # default budgets); prefill passes of up to 16 prompts share their GEMMs
     # one rank per GPU (torchrun / accelerate launch): rank 0 reads the checkpoint, the others receive the packed weight
@@ -115,14 +116,30 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
         p = ZoomEarthProcessor(processor.tokenizer, processor.min_pixels, processor.max_pixels, processor.merge_size, engine=m.engine)
         procs.append(p)
     samples = [(i, sample) for i, sample in enumerate(s for examples in dl for s in examples)]
-    lane_of, work = {}, [[] for _ in range(lanes)]
+    # the rank's questions as TILE GROUPS (the loader lists a tile's questions together), dealt to the lanes whole
+    groups = []
+    for idx, sample in samples:
+        if groups and groups[-1][0] == sample["image_name"]:
+            groups[-1][1].append((idx, sample))
+        else:
+            groups.append((sample["image_name"], [(idx, sample)]))
+    work = [[(g, name, items) for g, (name, items) in enumerate(groups) if g % lanes == ln] for ln in range(lanes)]
     done, lock, next_out, errors = {}, threading.Lock(), [0], []
     for idx, sample in samples:
         if sample.get("question_id") in skip:
             done[idx] = (sample, None)  # recorded by an earlier run
-            continue
-        ln = lane_of.setdefault(sample["image_name"], len(lane_of) % lanes)
-        work[ln].append((idx, sample))
+    extra_idx = [len(samples)]  # records of STOLEN tiles follow the rank's own, in the order they were taken
+    # --steal: tile-level work stealing for the drain tail (accel.TileClaims).  Every rank knows every rank's LPT
+    # list (shard_by_tile is deterministic); a claim flag per tile in a TCPStore decides who runs it.  Off with --resume (a
+    # stolen tile's records live in the thief's file) and for a single rank.
+    claims = None
+    if steal and world > 1 and not resume:
+        from zoomearth_amd.accel import TileClaims, shard_by_tile, tile_groups
+        ds_all = dl.dl.dataset
+        names_all = list(ds_all["image_name"]) if not isinstance(ds_all, list) else [r["image_name"] for r in ds_all]
+        lists = [tile_groups(names_all, shard_by_tile(names_all, r, world)) for r in range(world)]
+        assert [n for n, _ in lists[accelerator.process_index]] == [n for n, _ in groups], "the loader's order is the LPT list's"
+        claims = TileClaims.connect(accelerator.process_index, world, lists)
     bar = tqdm(total=len(samples), desc="Evaluating")
 
     def flush():  # records leave in the rank's dataset order, whatever order (and on whatever lane) the chains finish
@@ -139,7 +156,7 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
     def run_lane(ln):
         m, proc, todo = models[ln], procs[ln], work[ln]
         # the lane's questions arrive grouped by tile: decode the next tiles while the current one is being questioned
-        tiles = TilePrefetcher([tile_path(s["image_name"]) for _, s in todo], m.engine, depth=decode_ahead, workers=decode_workers)
+        tiles = TilePrefetcher([tile_path(name) for _, name, _items in todo], m.engine, depth=decode_ahead, workers=decode_workers)
         sched = ChainScheduler(m, proc, do_sample=do_sample, temperature=0.01 if do_sample else None, burst=8,
                                min_admit=max(1, batch_size // 2), max_wait_bursts=12)
 
@@ -147,22 +164,63 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
             with lock:
                 done[idx] = (sample, r)
 
-        view_of = (None, None, None)  # (tile path, view, scale): every question of a tile looks at the same <=512-px view
-        for idx, sample in todo:
-            path = tile_path(sample["image_name"])
-            # keep the queue short (tiles stay resident only while needed) -- and while the next tile is still being
-            # decoded, advance the chains that are already in: the GPU never idles behind a decode
-            while len(sched.waiting) >= batch_size or (sched.busy() and not tiles.ready(path)):
-                sched.step()
-                flush()
+        def submit(idx, sample, tile, view, scale):
             try:
-                tile = tiles.get(path)
-                if view_of[0] != path:
-                    view_of = (path,) + tuple(H.resize_image(tile))
                 H.submit_zoom_chain(sched, sample["question"], tile, lambda r, idx=idx, sample=sample: finish(idx, sample, r),
-                                    view=view_of[1], scale=view_of[2], stream_id=stream_of(sample), max_new_tokens=max_new_tokens)
+                                    view=view, scale=scale, stream_id=stream_of(sample), max_new_tokens=max_new_tokens)
             except Exception as ex:  # keep going; the record marks the failure
                 finish(idx, sample, dict(output1=f"Error: {ex}", output2="", error=True))
+
+        for g, name, items in todo:
+            path = tile_path(name)
+            if claims is not None and not claims.claim(accelerator.process_index, g):
+                tiles.skip(path)                       # another rank took this tile off the back of the list: its file has it
+                for idx, sample in items:
+                    finish(idx, sample, None)
+                continue
+            view = None  # (view, scale): every question of a tile looks at the same <=512-px view
+            for idx, sample in items:
+                if idx in done:                        # recorded by an earlier run (--resume)
+                    continue
+                # keep the queue short (tiles stay resident only while needed) -- and while the next tile is still being
+                # decoded, advance the chains that are already in: the GPU never idles behind a decode
+                while len(sched.waiting) >= batch_size or (sched.busy() and not tiles.ready(path)):
+                    sched.step()
+                    flush()
+                try:
+                    tile = tiles.get(path)
+                    if view is None:
+                        view = tuple(H.resize_image(tile))
+                except Exception as ex:
+                    finish(idx, sample, dict(output1=f"Error: {ex}", output2="", error=True))
+                    continue
+                submit(idx, sample, tile, view[0], view[1])
+        # the lane's own list is through: whole tiles of other ranks, from the back of their lists, while the tail drains
+        while claims is not None:
+            while len(sched.waiting) >= batch_size:
+                sched.step()
+                flush()
+            with lock:
+                took = claims.steal()
+            if took is None:
+                break
+            name, idxs = claims.lists[took[0]][took[1]]
+            try:
+                from zoomearth_amd.image import DeviceImage
+                tile = DeviceImage.open(tile_path(name), m.engine)
+                view = tuple(H.resize_image(tile))
+            except Exception as ex:
+                tile, view, err = None, None, ex
+            for j in idxs:
+                sample = ds_all[j]
+                with lock:
+                    idx = extra_idx[0]
+                    extra_idx[0] += 1
+                    bar.total += 1
+                if tile is None:
+                    finish(idx, sample, dict(output1=f"Error: {err}", output2="", error=True))
+                else:
+                    submit(idx, sample, tile, view[0], view[1])
         while sched.busy():
             sched.step()
             flush()
@@ -191,6 +249,8 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
     flush()
     bar.close()
     fout.close()
+    if claims is not None:
+        claims.finish()
     for m in models[1:]:
         m.engine.close()
     accelerator.wait_for_everyone()
@@ -204,6 +264,7 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
         for k, v in (st or {}).items():
             stats[k] = stats.get(k, 0) + v
     stats["lanes"] = lanes
+    stats["stolen_tiles"] = claims.stolen if claims is not None else 0
     return stats
 
 
@@ -232,9 +293,12 @@ if __name__ == "__main__":
     parser.add_argument("--lanes", type=int, default=1, help="engines per GPU, each with its own scheduler thread and --batch_size "
                                                              "chain slots: the prefill rounds of one overlap the decode bursts of the "
                                                              "other (2 x 512 slots answer 13 %% more questions/s than 1 x 512)")
+    parser.add_argument("--steal", action="store_true", default=os.environ.get("ZE_STEAL") == "1",
+                        help="several ranks: a rank whose own tiles are through takes whole tiles off the back of the other ranks' "
+                             "lists (one claim flag per tile in a TCPStore on MASTER_PORT + 17; needs the ranks to run at once)")
     parser.add_argument("--decode_workers", type=int, default=3, help="tile decode threads per lane")
     parser.add_argument("--decode_ahead", type=int, default=6, help="tiles decoded ahead of the one in use (75 MB pinned each)")
     args = parser.parse_args()
     eval_model_lora(args.model_name, args.exp_name, args.dataset, args.image_dir, args.max_new_tokens, args.batch_size,
                     args.max_ctx, do_sample=not args.greedy, resume=args.resume, decode_workers=args.decode_workers,
-                    decode_ahead=args.decode_ahead, lanes=args.lanes)
+                    decode_ahead=args.decode_ahead, lanes=args.lanes, steal=args.steal)

@@ -233,7 +233,7 @@ def test_two_concurrent_ranks_receive_the_weights_by_broadcast(workdir):
         cmd = [sys.executable, "src/infer.py", "--model_name", ck, "--exp_name", "bc_", "--max_new_tokens", "14",
                "--max_ctx", "2048", "--batch_size", "4"]
         env = dict(os.environ, PYTHONPATH=ROOT, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), ZE_DIST_BACKEND="gloo")
+                   MASTER_PORT=str(port), ZE_DIST_BACKEND="gloo", ZE_STEAL="1")  # (+ tile work stealing over a TCPStore)
         procs.append(subprocess.Popen(cmd, cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=900) for p in procs]
     for p, (so, se) in zip(procs, outs):

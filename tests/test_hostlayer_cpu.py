@@ -163,6 +163,55 @@ def test_two_process_gloo_sharding_and_broadcast(tmp_path):
     assert "OK" in outs[0]
 
 
+STEAL_WORKER = """
+import json, os, sys, time
+sys.path.insert(0, sys.argv[1])
+from zoomearth_amd.accel import TileClaims, shard_by_tile, tile_groups
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+names = [f"tile{t:03d}.tif" for t in range(40) for _ in range(3 + (t * 7) % 9)]
+lists = [tile_groups(names, shard_by_tile(names, r, world)) for r in range(world)]
+claims = TileClaims.connect(rank, world, lists)
+mine = []
+for pos, (tile, idx) in enumerate(lists[rank]):          # own tiles, front to back; rank 2 is ten times slower per question
+    if claims.claim(rank, pos):
+        mine.append((rank, pos, tile, len(idx)))
+        time.sleep((0.02 if rank == 2 else 0.002) * len(idx))
+while True:                                              # own list exhausted: whole tiles of the others, from the back
+    t = claims.steal()
+    if t is None:
+        break
+    tile, idx = lists[t[0]][t[1]]
+    mine.append((t[0], t[1], tile, len(idx)))
+    time.sleep(0.002 * len(idx))
+claims.finish()
+print("RESULT " + json.dumps(dict(rank=rank, tiles=mine, stolen=claims.stolen, questions=len(names))), flush=True)
+"""
+
+
+def test_tile_work_stealing_covers_every_tile_exactly_once(tmp_path):
+    """accel.TileClaims (work stealing of whole tiles for the drain tail): three processes over a TCPStore, the
+    static LPT lists as the starting point, rank 2 ten times slower.  Every tile is processed exactly once, never split; the
+    fast ranks take tiles off the slow rank's list from the back; nobody steals while its own list still has work."""
+    script = tmp_path / "steal_worker.py"
+    script.write_text(STEAL_WORKER)
+    port = 29900 + os.getpid() % 90
+    procs = []
+    for r in range(3):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    res = [json.loads(next(ln for ln in o.splitlines() if ln.startswith("RESULT "))[7:]) for o in outs]
+    done = [tuple(t[:3]) for r in res for t in r["tiles"]]
+    assert len(done) == len(set(done)) == 40                                  # every tile once
+    assert sum(t[3] for r in res for t in r["tiles"]) == res[0]["questions"]    # every question once
+    by = {r["rank"]: r for r in res}
+    assert by[2]["stolen"] == 0 and by[0]["stolen"] + by[1]["stolen"] >= 2       # the fast ranks relieve the slow one
+    stolen_from_2 = sorted(t[1] for r in (by[0], by[1]) for t in r["tiles"] if t[0] == 2)
+    own_2 = sorted(t[1] for t in by[2]["tiles"])
+    assert own_2 and stolen_from_2 and max(own_2) < min(stolen_from_2)          # owner from the front, thieves from the back
+
+
 def test_scorer(tmp_path):
     import importlib.util
     spec = importlib.util.spec_from_file_location("ze_eval", os.path.join(ROOT, "src", "eval", "eval.py"))

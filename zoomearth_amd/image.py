@@ -172,6 +172,7 @@ class TilePrefetcher:
         self._busy = 0            # decodes in progress
         self._current = (None, None)
         self._cv = threading.Condition()
+        self._skipped = set()     # tiles the caller will not ask for after all (claimed by another rank: accel.TileClaims)
         self._in_copy = []        # (event, pinned buffer) of uploads that may still be running
         self._pinned = []         # free pinned staging buffers, reused tile after tile (hipHostMalloc of 75 MB per tile costs
         #                           more than the decode itself and serialises with the GPU's work)
@@ -188,6 +189,8 @@ class TilePrefetcher:
                    and len(self._ready) + self._busy < self._depth):
                 path = self._order[self._next]
                 self._next += 1
+                if path in self._skipped:
+                    continue
                 self._busy += 1
                 threading.Thread(target=self._work, args=(path,), daemon=True).start()
 
@@ -217,11 +220,27 @@ class TilePrefetcher:
         except Exception as ex:  # surfaced by get()
             arr = ex
         with self._cv:
-            self._ready[path] = arr
+            if path in self._skipped:     # skipped while it was being decoded: the staging buffer goes back to the pool
+                buf = getattr(arr, "_ze_pool_buffer", None)
+                if buf is not None:
+                    self._pinned.append(buf)
+            else:
+                self._ready[path] = arr
             self._busy -= 1
             self.decodes += 1
             self.decode_s += time.perf_counter() - t0
             self._cv.notify_all()
+        self._kick()
+
+    def skip(self, path: str) -> None:
+        """The caller will not get() this tile (work stealing: another rank claimed it): a copy decoded ahead is dropped and its
+        place in the look-ahead window goes to the next tile."""
+        with self._cv:
+            self._skipped.add(path)
+            arr = self._ready.pop(path, None)
+            buf = getattr(arr, "_ze_pool_buffer", None) if arr is not None else None
+            if buf is not None:
+                self._pinned.append(buf)
         self._kick()
 
     def ready(self, path: str) -> bool:
