@@ -682,7 +682,7 @@ def main():
     engines = [e]
     for _ in range(1, max(1, args.lanes) if stream else 1):  # further lanes: engines of their own, weights copied on the device
         e2 = Engine(cfg, device=local, max_seqs=chains, max_ctx=2048, max_patches=max(4096, 1400 * min(chains, 40)),
-                    max_prefill_rows=int(os.environ.get("ZE_PREFILL_ROWS", str(16 * 832))), max_tile_side=max(args.tile, 1024))
+                    max_prefill_rows=int(os.environ.get("ZE_PREFILL_ROWS", str(32 * 832))), max_tile_side=max(args.tile, 1024))
         e2.weights_arena().copy_(e.weights_arena())
         torch.cuda.synchronize()
         e2.weights_invalidate()

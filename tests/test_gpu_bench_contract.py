@@ -96,6 +96,11 @@ def test_bench_runs_the_collective_path_on_one_rank():
                   ZE_BENCH_FORCE_DIST="1", MASTER_PORT="29577")
     assert d["n_gpus"] == 1 and d["weight_broadcast_s"] > 0 and d["per_rank"]["questions"] == [64]
     assert d["value"] > 5.0
+    # the xGMI-shaped form of the broadcast (scatter + in-place all-gather + tail broadcast) on the same one-rank RCCL
+    # communicator: no peer to scatter to, but ncclAllGather in place on the 7.5-GB arena and the tail broadcast run on RCCL
+    d = run_bench("--gpus", "1", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-batch64", "--no-configs1",
+                  ZE_BENCH_FORCE_DIST="1", MASTER_PORT="29578", ZE_BCAST="scatter_allgather")
+    assert d["weight_broadcast_s"] > 0 and d["per_rank"]["questions"] == [64] and d["value"] > 5.0
 
 
 def test_bench_two_ranks_share_the_gpu_over_gloo():

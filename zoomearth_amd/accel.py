@@ -144,7 +144,7 @@ def scatter_allgather_broadcast(arena, src: int, dist, align: int = 256) -> None
     world, rank = dist.get_world_size(), dist.get_rank()
     n = arena.numel()
     piece = (n // world) // align * align
-    if piece == 0 or world == 1:
+    if piece == 0:
         dist.broadcast(arena, src=src)
         return
     body = arena[: piece * world]
@@ -154,8 +154,9 @@ def scatter_allgather_broadcast(arena, src: int, dist, align: int = 256) -> None
         ops = [dist.P2POp(dist.isend, body[r * piece:(r + 1) * piece], r) for r in range(world) if r != src]
     else:
         ops = [dist.P2POp(dist.irecv, mine, src)]
-    for w in dist.batch_isend_irecv(ops):
-        w.wait()
+    if ops:  # (a one-rank communicator -- the RCCL smoke run of tests/test_gpu_bench_contract.py -- has no peer to send to)
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
     # 2. all-gather the pieces in place (the piece of rank r already sits at offset r * piece of its own arena)
     if arena.is_cuda:
         dist.all_gather_into_tensor(body, mine)
