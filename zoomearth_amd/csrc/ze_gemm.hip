@@ -629,7 +629,88 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
 // one row's waves issue MFMAs the other's read fragments and issue DMAs (cdna_hip_programming.md, the 256^2 8-phase
 // template).  A staged half-tile is read one phase after the wait + barrier that retire it.  Per output element the MFMAs and
 // their K order are k_gemm_ring's: identical bits.
+// Wide-store epilogue of k_gemm_p8 (round 4).  The MFMA result layout gives a lane four ROWS of one column, so the plain
+// epilogue (gemm_finish) leaves a 256 x 256 tile as 128 two-byte stores per lane, 32 B of a row per wave-instruction -- for the
+// ViT's K = 1280 that is a fifth of a tile's time.  The staging LDS holds the NEXT tile's first half-tiles by now, so every wave
+// gets 4 KB of its own behind the two K-tile buffers (128 KB + 8 x 4 KB <= 160 KB): its 128 x 64 outputs cross that scratch in
+// four chunks of 32 rows -- written as the accumulators hold them, read back as 16-byte row pieces (XOR-swizzled by the row:
+// conflict-free both ways) -- and leave as 64 lanes x 16 B = eight whole 128-byte rows per wave-instruction.  No workgroup
+// barrier: a wave's LDS operations execute in order.  Values, roundings and their order are the plain epilogue's, element for
+// element (bias, bf16 rounding, GELU, residual add in fp32 on the rounded value, SwiGLU on rounded gate / up): same bits.
 template <int EPI>
+__device__ __forceinline__ void p8_finish_wide(f32x4 (&acc)[8][4], uint8_t* scratch, const bf16_t* __restrict__ bias,
+                                               const bf16_t* __restrict__ R, int ldr, bf16_t* __restrict__ C, int ldc,
+                                               const int* __restrict__ c_rows, int M, int N, int row_base, int col_base, int lane) {
+    constexpr bool SW = EPI == ZE_EPI_SWIGLU;
+    constexpr int OW = SW ? 32 : 64;          // output columns of the wave's tile
+    constexpr int PPR = OW / 8;               // 16-byte pieces per output row
+    const int fr = lane & 15, fq = lane >> 4;
+    float b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ncol = col_base + j * 16 + fr;
+        b[j] = (bias && ncol < N) ? bf16_to_f32(bias[ncol]) : 0.f;
+    }
+    const int ocol_base = SW ? col_base / 2 : col_base, on = SW ? N / 2 : N;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        // ---- 32 rows x OW columns into the scratch: element (lrow, col) at lrow * 128 + ((col * 2) ^ ((lrow & 7) << 4))
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = 2 * c + ii;
+#pragma unroll
+            for (int j = 0; j < 4; j += (SW ? 2 : 1)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int lrow = ii * 16 + fq * 4 + r;
+                    float v;
+                    int col;
+                    if (SW) {
+                        const float g = bf16_round(acc[i][j][r] + b[j]);
+                        const float u = bf16_round(acc[i][j + 1][r] + b[j + 1]);
+                        v = bf16_round(silu_f(g)) * u;
+                        col = (j / 2) * 16 + fr;
+                    } else {
+                        v = bf16_round(acc[i][j][r] + b[j]);
+                        if (EPI == ZE_EPI_GELU) v = gelu_erf(v);
+                        col = j * 16 + fr;
+                    }
+                    *reinterpret_cast<bf16_t*>(scratch + lrow * 128 + ((col * 2) ^ ((lrow & 7) << 4))) = f32_to_bf16(v);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ---- back as 16-byte row pieces: 64 lanes = (64 / PPR) rows per instruction
+        constexpr int RPI = 64 / PPR;  // rows per wave-instruction (8, or 16 for the 32-column SwiGLU tile)
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int lrow = it * RPI + lane / PPR, piece = lane % PPR;
+            uint4 v = *reinterpret_cast<const uint4*>(scratch + lrow * 128 + ((piece ^ (lrow & 7)) << 4));
+            const int row = row_base + c * 32 + lrow;
+            const int col = ocol_base + piece * 8;
+            if (row < M && col < on) {
+                const int orow = c_rows ? c_rows[row] : row;
+                if (EPI == ZE_EPI_RESIDUAL) {  // out = bf16(residual + value), per element as the plain epilogue
+                    const uint4 rr = *reinterpret_cast<const uint4*>(R + (size_t)row * ldr + col);
+                    const uint32_t* pv = reinterpret_cast<const uint32_t*>(&v);
+                    const uint32_t* pr = reinterpret_cast<const uint32_t*>(&rr);
+                    uint32_t o[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float lo = __uint_as_float(pr[q] << 16) + __uint_as_float(pv[q] << 16);
+                        const float hi = __uint_as_float(pr[q] & 0xffff0000u) + __uint_as_float(pv[q] & 0xffff0000u);
+                        o[q] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+                    }
+                    v = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+                *reinterpret_cast<uint4*>(C + (size_t)orow * ldc + col) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads are back before the next chunk overwrites the scratch
+    }
+}
+
+template <int EPI, bool WIDE = false>
 __global__ void __launch_bounds__(512) k_gemm_p8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
                                                  const bf16_t* __restrict__ bias, const bf16_t* __restrict__ R, int ldr,
                                                  bf16_t* __restrict__ C, int ldc, const int* __restrict__ c_rows, int M, int N,
@@ -795,7 +876,10 @@ __global__ void __launch_bounds__(512) k_gemm_p8(const bf16_t* __restrict__ A, i
             sources();
             prologue();
         }
-        gemm_finish<BM, BN, EPI, 2, 4>(acc, smem, bias, R, ldr, C, ldc, c_rows, M, N, 1, 0, done_bid, nwg, done_bm0, done_bn0, nullptr, nullptr);
+        if constexpr (WIDE && EPI != ZE_EPI_F32)
+            p8_finish_wide<EPI>(acc, smem + 2 * BUF + wid * 4096, bias, R, ldr, C, ldc, c_rows, M, N, done_bm0 + wr * 128, done_bn0 + wc * 64, lane);
+        else
+            gemm_finish<BM, BN, EPI, 2, 4>(acc, smem, bias, R, ldr, C, ldc, c_rows, M, N, 1, 0, done_bid, nwg, done_bm0, done_bn0, nullptr, nullptr);
         if (!more) break;
     }
 }
@@ -811,22 +895,36 @@ static void launch_p8(int epi, const bf16_t* A, int lda, const bf16_t* W, int ld
     }
     const int tiles = ze_cdiv(M, 256) * ze_cdiv(N, 256);
     const int grid = ze_gemv_knobs[7] == 9 ? tiles : std::min(tiles, cus);  // (knob 7 = 9: one tile per workgroup, for A/B runs)
-    const size_t lds = 128 * 1024;
-#define ZE_P8_LAUNCH(E)                                                                                                        \
+    // the wide-store epilogue (p8_finish_wide: 16-byte row pieces through 4 KB of LDS per wave) wherever rows are 16-byte
+    // aligned; knob 7 = 10: the plain two-byte epilogue, for A/B runs and the bit-equality test
+    const bool sw = epi == ZE_EPI_SWIGLU;
+    const bool wide = ze_gemv_knobs[7] != 10 && epi != ZE_EPI_F32 && (ldc % 8) == 0 && ((size_t)C % 16) == 0 && ((sw ? N / 2 : N) % 8) == 0 &&
+                      (epi != ZE_EPI_RESIDUAL || ((ldr % 8) == 0 && ((size_t)R % 16) == 0));
+    const size_t lds = wide ? (128 + 32) * 1024 : 128 * 1024;
+#define ZE_P8_LAUNCH(E, WD)                                                                                                    \
     do {                                                                                                                       \
         static bool attr_set = false;                                                                                          \
         if (!attr_set) {                                                                                                       \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_p8<E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_p8<E, WD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr_set = true;                                                                                                   \
         }                                                                                                                      \
-        hipLaunchKernelGGL((k_gemm_p8<E>), dim3(grid), dim3(512), lds, s, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K); \
+        hipLaunchKernelGGL((k_gemm_p8<E, WD>), dim3(grid), dim3(512), lds, s, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K); \
     } while (0)
+    if (wide) {
+        switch (epi) {
+            case ZE_EPI_NONE: ZE_P8_LAUNCH(ZE_EPI_NONE, true); break;
+            case ZE_EPI_GELU: ZE_P8_LAUNCH(ZE_EPI_GELU, true); break;
+            case ZE_EPI_RESIDUAL: ZE_P8_LAUNCH(ZE_EPI_RESIDUAL, true); break;
+            case ZE_EPI_SWIGLU: ZE_P8_LAUNCH(ZE_EPI_SWIGLU, true); break;
+        }
+        return;
+    }
     switch (epi) {
-        case ZE_EPI_NONE: ZE_P8_LAUNCH(ZE_EPI_NONE); break;
-        case ZE_EPI_GELU: ZE_P8_LAUNCH(ZE_EPI_GELU); break;
-        case ZE_EPI_RESIDUAL: ZE_P8_LAUNCH(ZE_EPI_RESIDUAL); break;
-        case ZE_EPI_SWIGLU: ZE_P8_LAUNCH(ZE_EPI_SWIGLU); break;
-        case ZE_EPI_F32: ZE_P8_LAUNCH(ZE_EPI_F32); break;
+        case ZE_EPI_NONE: ZE_P8_LAUNCH(ZE_EPI_NONE, false); break;
+        case ZE_EPI_GELU: ZE_P8_LAUNCH(ZE_EPI_GELU, false); break;
+        case ZE_EPI_RESIDUAL: ZE_P8_LAUNCH(ZE_EPI_RESIDUAL, false); break;
+        case ZE_EPI_SWIGLU: ZE_P8_LAUNCH(ZE_EPI_SWIGLU, false); break;
+        case ZE_EPI_F32: ZE_P8_LAUNCH(ZE_EPI_F32, false); break;
     }
 #undef ZE_P8_LAUNCH
 }
