@@ -641,9 +641,13 @@ template <int EPI>
 __device__ __forceinline__ void p8_finish_wide(f32x4 (&acc)[8][4], uint8_t* scratch, const bf16_t* __restrict__ bias,
                                                const bf16_t* __restrict__ R, int ldr, bf16_t* __restrict__ C, int ldc,
                                                const int* __restrict__ c_rows, int M, int N, int row_base, int col_base, int lane) {
-    constexpr bool SW = EPI == ZE_EPI_SWIGLU;
+    constexpr bool SW = EPI == ZE_EPI_SWIGLU, F32 = EPI == ZE_EPI_F32;
+    constexpr int EB = F32 ? 4 : 2;           // bytes per output element (F32: the fp32 copy of the bf16-rounded logit)
     constexpr int OW = SW ? 32 : 64;          // output columns of the wave's tile
-    constexpr int PPR = OW / 8;               // 16-byte pieces per output row
+    constexpr int ROWB = OW * EB;             // bytes per staged row: 64 (SwiGLU), 128, or 256 (fp32)
+    constexpr int PPR = ROWB / 16;            // 16-byte pieces per output row
+    constexpr int CR = 4096 / ROWB > 32 ? 32 : 4096 / ROWB;  // rows per chunk: 32 (16 for fp32): one or two 16-row MFMA tiles
+    constexpr int TI = CR / 16;               // row tiles per chunk
     const int fr = lane & 15, fq = lane >> 4;
     float b[4];
 #pragma unroll
@@ -653,16 +657,17 @@ __device__ __forceinline__ void p8_finish_wide(f32x4 (&acc)[8][4], uint8_t* scra
     }
     const int ocol_base = SW ? col_base / 2 : col_base, on = SW ? N / 2 : N;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        // ---- 32 rows x OW columns into the scratch: element (lrow, col) at lrow * 128 + ((col * 2) ^ ((lrow & 7) << 4))
+    for (int c = 0; c < 128 / CR; ++c) {
+        // ---- CR rows x OW columns into the scratch: element (lrow, col) at lrow * ROWB + ((col * EB) ^ swizzle(lrow) << 4)
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            const int i = 2 * c + ii;
+        for (int ii = 0; ii < TI; ++ii) {
+            const int i = TI * c + ii;
 #pragma unroll
             for (int j = 0; j < 4; j += (SW ? 2 : 1)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int lrow = ii * 16 + fq * 4 + r;
+                    const int swz = (lrow & (PPR - 1)) << 4;
                     float v;
                     int col;
                     if (SW) {
@@ -675,19 +680,20 @@ __device__ __forceinline__ void p8_finish_wide(f32x4 (&acc)[8][4], uint8_t* scra
                         if (EPI == ZE_EPI_GELU) v = gelu_erf(v);
                         col = j * 16 + fr;
                     }
-                    *reinterpret_cast<bf16_t*>(scratch + lrow * 128 + ((col * 2) ^ ((lrow & 7) << 4))) = f32_to_bf16(v);
+                    if (F32) *reinterpret_cast<float*>(scratch + lrow * ROWB + ((col * 4) ^ swz)) = v;
+                    else *reinterpret_cast<bf16_t*>(scratch + lrow * ROWB + ((col * 2) ^ swz)) = f32_to_bf16(v);
                 }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // ---- back as 16-byte row pieces: 64 lanes = (64 / PPR) rows per instruction
-        constexpr int RPI = 64 / PPR;  // rows per wave-instruction (8, or 16 for the 32-column SwiGLU tile)
+        constexpr int RPI = 64 / PPR;  // rows per wave-instruction: 16 (SwiGLU), 8, or 4 (fp32)
 #pragma unroll
-        for (int it = 0; it < 32 / RPI; ++it) {
+        for (int it = 0; it < CR / RPI; ++it) {
             const int lrow = it * RPI + lane / PPR, piece = lane % PPR;
-            uint4 v = *reinterpret_cast<const uint4*>(scratch + lrow * 128 + ((piece ^ (lrow & 7)) << 4));
-            const int row = row_base + c * 32 + lrow;
-            const int col = ocol_base + piece * 8;
+            uint4 v = *reinterpret_cast<const uint4*>(scratch + lrow * ROWB + ((piece ^ (lrow & (PPR - 1))) << 4));
+            const int row = row_base + c * CR + lrow;
+            const int col = ocol_base + piece * (16 / EB);
             if (row < M && col < on) {
                 const int orow = c_rows ? c_rows[row] : row;
                 if (EPI == ZE_EPI_RESIDUAL) {  // out = bf16(residual + value), per element as the plain epilogue
@@ -703,7 +709,8 @@ __device__ __forceinline__ void p8_finish_wide(f32x4 (&acc)[8][4], uint8_t* scra
                     }
                     v = make_uint4(o[0], o[1], o[2], o[3]);
                 }
-                *reinterpret_cast<uint4*>(C + (size_t)orow * ldc + col) = v;
+                if (F32) *reinterpret_cast<uint4*>(reinterpret_cast<float*>(C) + (size_t)orow * ldc + col) = v;
+                else *reinterpret_cast<uint4*>(C + (size_t)orow * ldc + col) = v;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads are back before the next chunk overwrites the scratch
@@ -876,7 +883,7 @@ __global__ void __launch_bounds__(512) k_gemm_p8(const bf16_t* __restrict__ A, i
             sources();
             prologue();
         }
-        if constexpr (WIDE && EPI != ZE_EPI_F32)
+        if constexpr (WIDE)
             p8_finish_wide<EPI>(acc, smem + 2 * BUF + wid * 4096, bias, R, ldr, C, ldc, c_rows, M, N, done_bm0 + wr * 128, done_bn0 + wc * 64, lane);
         else
             gemm_finish<BM, BN, EPI, 2, 4>(acc, smem, bias, R, ldr, C, ldc, c_rows, M, N, 1, 0, done_bid, nwg, done_bm0, done_bn0, nullptr, nullptr);
@@ -898,7 +905,7 @@ static void launch_p8(int epi, const bf16_t* A, int lda, const bf16_t* W, int ld
     // the wide-store epilogue (p8_finish_wide: 16-byte row pieces through 4 KB of LDS per wave) wherever rows are 16-byte
     // aligned; knob 7 = 10: the plain two-byte epilogue, for A/B runs and the bit-equality test
     const bool sw = epi == ZE_EPI_SWIGLU;
-    const bool wide = ze_gemv_knobs[7] != 10 && epi != ZE_EPI_F32 && (ldc % 8) == 0 && ((size_t)C % 16) == 0 && ((sw ? N / 2 : N) % 8) == 0 &&
+    const bool wide = ze_gemv_knobs[7] != 10 && (ldc % 8) == 0 && ((size_t)C % 16) == 0 && ((sw ? N / 2 : N) % 8) == 0 &&
                       (epi != ZE_EPI_RESIDUAL || ((ldr % 8) == 0 && ((size_t)R % 16) == 0));
     const size_t lds = wide ? (128 + 32) * 1024 : 128 * 1024;
 #define ZE_P8_LAUNCH(E, WD)                                                                                                    \
@@ -916,6 +923,7 @@ static void launch_p8(int epi, const bf16_t* A, int lda, const bf16_t* W, int ld
             case ZE_EPI_GELU: ZE_P8_LAUNCH(ZE_EPI_GELU, true); break;
             case ZE_EPI_RESIDUAL: ZE_P8_LAUNCH(ZE_EPI_RESIDUAL, true); break;
             case ZE_EPI_SWIGLU: ZE_P8_LAUNCH(ZE_EPI_SWIGLU, true); break;
+            case ZE_EPI_F32: ZE_P8_LAUNCH(ZE_EPI_F32, true); break;
         }
         return;
     }
@@ -1574,9 +1582,30 @@ static void launch_ring_variant(int epi, const bf16_t* A, int lda, const bf16_t*
     } while (0)
     if constexpr (QKV) {   // (the decode step's qkv projection with rope + KV append)
         if (epi == ZE_EPI_QKV_ROPE) ZE_RINGV_LAUNCH(ZE_EPI_QKV_ROPE);
-    } else if constexpr (WIDE) {  // (the wide-store epilogue: SwiGLU of the batched decode step's gate/up only)
-        if (epi == ZE_EPI_SWIGLU) ZE_RINGV_LAUNCH(ZE_EPI_SWIGLU);
+    } else if constexpr (WIDE) {  // the wide-store epilogue (gemm_finish LDS_EPI): 16-byte row pieces through the idle staging LDS
+        switch (epi) {
+            case ZE_EPI_NONE: ZE_RINGV_LAUNCH(ZE_EPI_NONE); break;
+            case ZE_EPI_GELU: ZE_RINGV_LAUNCH(ZE_EPI_GELU); break;
+            case ZE_EPI_RESIDUAL: ZE_RINGV_LAUNCH(ZE_EPI_RESIDUAL); break;
+            case ZE_EPI_SWIGLU: ZE_RINGV_LAUNCH(ZE_EPI_SWIGLU); break;
+            case ZE_EPI_F32: ZE_RINGV_LAUNCH(ZE_EPI_F32); break;
+        }
     } else {
+        // Every caller without a row scatter and with 16-byte-aligned rows takes the wide-store instantiation of the same tile
+        // (round 4: the two-byte stores of the plain epilogue were a fifth of a 256 x 256 tile's time at K = 1280; same values,
+        // same roundings: the same bits).  knob 7 = 10: plain epilogue everywhere, for A/B runs.  Not for slab-only split-K
+        // launches (no epilogue runs) and not where the staged tile would not fit the ring's LDS.
+        {
+            const bool sw = epi == ZE_EPI_SWIGLU, f32 = epi == ZE_EPI_F32;
+            const size_t stage_b = (size_t)BM * ((sw ? BN / 2 : BN) * (f32 ? 4 : 2) + 16);
+            const bool wide_ok = ze_gemv_knobs[7] != 10 && c_rows == nullptr && !(ksplit > 1 && g_tickets == nullptr) && stage_b <= lds &&
+                                 (ldc % 8) == 0 && ((size_t)C % 16) == 0 && ((sw ? N / 2 : N) % 8) == 0 && (!sw || BN % 32 == 0) &&
+                                 (epi != ZE_EPI_RESIDUAL || ((ldr % 8) == 0 && ((size_t)R % 16) == 0)) && epi != ZE_EPI_QKV_ROPE;
+            if (wide_ok) {
+                launch_ring_variant<BM, BN, ST, WM, WN, SPR, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, ksplit, ws);
+                return;
+            }
+        }
         switch (epi) {
             case ZE_EPI_NONE: ZE_RINGV_LAUNCH(ZE_EPI_NONE); break;
             case ZE_EPI_GELU: ZE_RINGV_LAUNCH(ZE_EPI_GELU); break;
