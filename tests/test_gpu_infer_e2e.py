@@ -244,7 +244,11 @@ def test_two_concurrent_ranks_receive_the_weights_by_broadcast(workdir):
     run([sys.executable, "src/infer.py", "--model_name", "ckpt", "--exp_name", "bcone_", "--max_new_tokens", "14", "--max_ctx",
          "2048", "--batch_size", "4"], d)
     merged, single = load(d / "results" / "bc_merged.jsonl"), load(d / "results" / "bcone_0.jsonl")
-    assert n == len(rows) and len(load(d / "results" / "bc_1.jsonl")) > 0
+    # (with --steal a rank that is through early takes whole tiles off the other's list: on this 5-tile dataset rank 1 may be
+    #  left with nothing -- what must hold is that every question is answered exactly once, by whoever ran its tile)
+    parts = [load(d / "results" / f"bc_{r}.jsonl") for r in (0, 1)]
+    assert n == len(rows) == len(parts[0]) + len(parts[1])
+    assert not ({r["image"] for r in parts[0]} & {r["image"] for r in parts[1]})   # a tile never splits
     assert merged == sorted(single, key=lambda r: r["question_id"])
     # a rank without the weight file and without the broadcast fails loudly
     r = subprocess.run([sys.executable, "src/infer.py", "--model_name", "ckpt_bare", "--exp_name", "x_"], cwd=d,

@@ -24,6 +24,13 @@ KEYS = {
     "batch64": {"attention": "k_attn_decode_wave<8>", "gate_up": "k_gemm_skinny<6, 3", "down": "k_gemm_ring<64, 64, 4, 2, 4, 2, false>"},
 }
 SECTION = {"configs1": "configs1", "wide": "stream", "wide_shared": "stream_shared", "batch64": "batch64"}
+if ROUND >= 4:  # round 4: the stream's rows at the line's own chain count (376) and every GEMM of the layer
+    del KEYS["wide"], KEYS["wide_shared"]
+    KEYS["wide376"] = {"attention": "k_attn_decode_wave<8>", "gate_up": "k_gemm_ring<192, 192, 3, 3",
+                       "down": ("k_gemm_ring<192, 128, 3, 0", "k_splitk_reduce<192, 128"),
+                       "qkv": "k_gemm_ring<64, 64, 4, 5", "o_proj": "k_gemm_ring<64, 64, 4, 2, 4, 2, false, true"}
+    KEYS["wide376_shared"] = {"attention": "k_attn_decode_wave<8>"}
+    SECTION.update(wide376="stream", wide376_shared="stream_shared")
 
 
 def rows(name, source=None):
