@@ -269,10 +269,13 @@ __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q
 void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_rs, int q_hs, const bf16_t* k, int k_rs,
                           int k_hs, const bf16_t* v, int v_rs, int v_hs, bf16_t* o, int o_rs, int o_hs,
                           const int4* tiles, int n_tiles, int heads, int group, float scale, int q_pos_offset,
-                          hipStream_t s, const int* tile_aux, size_t kv_seq_stride, int q_tile) {
+                          hipStream_t s, const int* tile_aux, size_t kv_seq_stride, int q_tile, int max_kv) {
     if (n_tiles == 0) return;
     const float sl = scale * 1.4426950408889634f;
     dim3 grid(n_tiles, heads);
+    // max_kv: the longest key range of any tile of the list, 0 = unknown.  A list whose tiles all fit ONE key tile (the ViT's
+    // window blocks: segments of at most 64 tokens) never touches the second K / V buffer: half the LDS, so three workgroups
+    // per CU instead of two -- these launches are thousands of short-lived workgroups bound by their own latency
 #define FA_LAUNCH(DD, CC, QQ)                                                                                      \
     do {                                                                                                          \
         constexpr int BKV_ = (CC) ? ZE_FA_CAUSAL_BKV : 64;                                                        \
@@ -283,7 +286,8 @@ void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_rs, int q_hs
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_);                                \
             attr_set = true;                                                                                      \
         }                                                                                                         \
-        hipLaunchKernelGGL((k_flash_attn<DD, CC, BKV_, QQ>), grid, dim3(256), LDS_, s, q, q_rs, q_hs, k, k_rs, k_hs, v, v_rs, \
+        const int lds_ = (max_kv > 0 && max_kv <= BKV_) ? LDS_ / 2 : LDS_;                                        \
+        hipLaunchKernelGGL((k_flash_attn<DD, CC, BKV_, QQ>), grid, dim3(256), lds_, s, q, q_rs, q_hs, k, k_rs, k_hs, v, v_rs, \
                            v_hs, o, o_rs, o_hs, tiles, group, sl, q_pos_offset, tile_aux, kv_seq_stride);          \
     } while (0)
     // q_tile: the query rows a tile of the caller's list spans at most -- 64 (one 16-query tile per wave) or 128 (two)

@@ -265,6 +265,8 @@ extern "C" int ze_vit_forward(ze_engine* e, const float* pixel_values, const int
     }
     const int ntw = build_tiles(cu_win.data(), (int)cu_win.size() - 1, tw, n);
     int* tf = tw + 4 * ntw;
+    int max_win = 0;  // longest window segment (64 tokens for 112-px windows of 14-px patches)
+    for (size_t i = 1; i < cu_win.size(); ++i) max_win = std::max(max_win, cu_win[i] - cu_win[i - 1]);
     // (the full-attention blocks: segments of a whole image -- 128-query tiles, two per wave; ze_tune knob 1 = 9: 64)
     const int bq_full = ze_gemv_knobs[1] == 9 ? 64 : ZE_FA_BQ_LONG;
     const int ntf = build_tiles(cu_full.data(), (int)cu_full.size() - 1, tf, n, bq_full);
@@ -309,7 +311,7 @@ extern "C" int ze_vit_forward(ze_engine* e, const float* pixel_values, const int
         ze_launch_vision_rope(e->vqkv, e->vcos, e->vsin, n, nh, hd, s);
         ze_launch_flash_attn(hd, 0, e->vqkv, 3 * vh, hd, e->vqkv + vh, 3 * vh, hd, e->vqkv + 2 * vh, 3 * vh, hd, e->vo,
                              vh, hd, full ? e->vtiles_full : e->vtiles_win, full ? ntf : ntw, nh, 1, scale, 0, s, nullptr, 0,
-                             full ? bq_full : 64);
+                             full ? bq_full : 64, full ? 0 : max_win);
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->vo, vh, b.proj.w, b.proj.ld, b.proj.bias, e->vh, vh, e->vh, vh, nullptr, n,
                        vh, vh, s);
         ze_launch_rmsnorm(e->vh, vh, b.norm2, e->vy, vh, n, vh, 1e-6f, s);

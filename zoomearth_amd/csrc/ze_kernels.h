@@ -177,7 +177,7 @@ void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_row_stride, 
                           int k_row_stride, int k_head_stride, const bf16_t* v, int v_row_stride, int v_head_stride,
                           bf16_t* o, int o_row_stride, int o_head_stride, const int4* tiles, int n_tiles, int heads,
                           int group, float scale, int q_pos_offset, hipStream_t s, const int* tile_aux = nullptr,
-                          size_t kv_seq_stride = 0, int q_tile = 64);
+                          size_t kv_seq_stride = 0, int q_tile = 64, int max_kv = 0);
 // q_tile: the most query rows a tile of the list spans -- 64 (default) or ZE_FA_BQ_LONG = 128, where every wave holds two
 // 16-query tiles and each K / V^T fragment it reads from LDS feeds two MFMAs (long segments: the prefill, the ViT's
 // full-attention blocks); a row's bits do not depend on the choice
