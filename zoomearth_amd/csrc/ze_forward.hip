@@ -582,19 +582,26 @@ static int prefill_impl(ze_engine* e, int seq, const int32_t* input_ids, int len
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, nullptr,
                        len, H, e->text_ipad, s);
     }
-    // last position: final norm fused into the lm_head GEMV (logits_to_keep = 1, HF:...:1386-1387)
-    ze_gemv_args a;
-    memset(&a, 0, sizeof(a));
-    a.W = e->lm_head;
-    a.ldw = H;
-    a.N = c.vocab;
-    a.K = H;
-    a.x = e->th + (size_t)(len - 1) * H;
-    a.norm_w = e->final_norm;
-    a.eps = c.rms_eps;
-    a.out_f32 = e->dlogits + (size_t)seq * c.vocab;
-    a.D = hd;
-    ze_launch_gemv(ZE_GV_LOGITS, a, s);
+    // last position: final norm fused into the lm_head stream (logits_to_keep = 1, HF:...:1386-1387) -- the kernel of the
+    // batched pass with one chain, so the first token does not depend on how the chain was prefilled
+    {
+        const bf16_t* xr = e->th + (size_t)(len - 1) * H;
+        float* lo = e->dlogits + (size_t)seq * c.vocab;
+        if (!ze_launch_logits_rows(e->lm_head, H, c.vocab, H, e->final_norm, c.rms_eps, &xr, &lo, 1, s)) {
+            ze_gemv_args a;
+            memset(&a, 0, sizeof(a));
+            a.W = e->lm_head;
+            a.ldw = H;
+            a.N = c.vocab;
+            a.K = H;
+            a.x = xr;
+            a.norm_w = e->final_norm;
+            a.eps = c.rms_eps;
+            a.out_f32 = lo;
+            a.D = hd;
+            ze_launch_gemv(ZE_GV_LOGITS, a, s);
+        }
+    }
     if (out_logps && len > 1) {
         // every position: final norm, lm_head GEMM in row chunks (bf16 logits as HF's lm_head gives them), then the
         // log-softmax pick of the next id.  The logits live in the (now free) MLP activation workspace.
@@ -730,22 +737,33 @@ extern "C" int ze_prefill_batch(ze_engine* e, const int32_t* seqs, int n, const 
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, nullptr,
                        total, H, e->text_ipad, s);
     }
-    // last position of every chain: final norm fused into the lm_head GEMV, exactly as ze_prefill does it
-    row0 = 0;
-    for (int i = 0; i < n; ++i) {
-        ze_gemv_args a;
-        memset(&a, 0, sizeof(a));
-        a.W = e->lm_head;
-        a.ldw = H;
-        a.N = c.vocab;
-        a.K = H;
-        a.x = e->th + (size_t)(row0 + lens[i] - 1) * H;
-        a.norm_w = e->final_norm;
-        a.eps = c.rms_eps;
-        a.out_f32 = e->dlogits + (size_t)seqs[i] * c.vocab;
-        a.D = hd;
-        ze_launch_gemv(ZE_GV_LOGITS, a, s);
-        row0 += lens[i];
+    // last position of every chain: final norm + lm_head, the weight matrix streamed once per EIGHT chains (ze_gemv_logits.hip;
+    // per chain the arithmetic -- and the kernel -- of ze_prefill)
+    {
+        std::vector<const bf16_t*> xr(n);
+        std::vector<float*> lo(n);
+        row0 = 0;
+        for (int i = 0; i < n; ++i) {
+            xr[i] = e->th + (size_t)(row0 + lens[i] - 1) * H;
+            lo[i] = e->dlogits + (size_t)seqs[i] * c.vocab;
+            row0 += lens[i];
+        }
+        if (!ze_launch_logits_rows(e->lm_head, H, c.vocab, H, e->final_norm, c.rms_eps, xr.data(), lo.data(), n, s)) {
+            for (int i = 0; i < n; ++i) {
+                ze_gemv_args a;
+                memset(&a, 0, sizeof(a));
+                a.W = e->lm_head;
+                a.ldw = H;
+                a.N = c.vocab;
+                a.K = H;
+                a.x = xr[i];
+                a.norm_w = e->final_norm;
+                a.eps = c.rms_eps;
+                a.out_f32 = lo[i];
+                a.D = hd;
+                ze_launch_gemv(ZE_GV_LOGITS, a, s);
+            }
+        }
     }
     ze_timer_end(e, th, s);
     ZE_KCHECK();

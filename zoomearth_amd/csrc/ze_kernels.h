@@ -167,6 +167,10 @@ struct ze_gemv_args {
 };
 // returns false when x[K] does not fit the LDS stage
 bool ze_launch_gemv(int epi, const ze_gemv_args& a, hipStream_t s);
+// fp32 logits of the last hidden rows of n chains in one pass over the lm_head per eight chains (ze_gemv_logits.hip: the
+// prefill paths; final RMSNorm fused); false = shape not covered, the caller launches the single-chain GEMV per chain
+bool ze_launch_logits_rows(const bf16_t* W, int ldw, int N, int K, const bf16_t* norm_w, float eps, const bf16_t* const* x_rows,
+                           float* const* out_rows, int n, hipStream_t s);
 // per-row power-of-two-scale E4M3 quantisation of a bf16 matrix [rows, ld] (cols valid): writes the fp8 bytes
 // [rows, ld8], the scales, and REPLACES the bf16 values by the dequantised ones (exactly representable)
 void ze_launch_quantize_rows(bf16_t* w, int rows, int cols, int ld, uint8_t* q, int ld8, float* scale, hipStream_t s);
