@@ -317,9 +317,11 @@ def test_attention_two_query_tiles_per_wave_give_the_same_bits(tiny_engine, d, h
     try:
         tiny_engine.lib.ze_tune(1, 9)
         one = tiny_engine.op_attention(dq, dk, dv, cu, causal)
+        tiny_engine.lib.ze_tune(1, 7)   # D = 128 causal: the register-staged form instead of the LDS-DMA staging (two query tiles)
+        reg = tiny_engine.op_attention(dq, dk, dv, cu, causal)
     finally:
         tiny_engine.lib.ze_tune(1, 0)
-    assert torch.equal(one, two)
+    assert torch.equal(one, two) and torch.equal(reg, two)
     want = ref_attention(q, k, v, cu, causal)
     got = two.float().cpu().numpy()
     assert np.abs(got - want).max() <= 2.0 ** -6 * max(1.0, np.abs(want).max())

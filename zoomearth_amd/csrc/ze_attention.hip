@@ -53,7 +53,10 @@ __device__ __forceinline__ int fa_off(int row, int ch) { return 256 * row + 16 *
 // QT: 16-query tiles per wave (1: 64 queries per workgroup; 2: 128 -- every K and V^T fragment read from LDS feeds TWO MFMAs:
 // the kernel is bound by its LDS fragment reads, one per MFMA with QT = 1).  A query's arithmetic does not depend on QT: the
 // same key tiles in the same order, the same online softmax -- bit-identical rows.
-template <int D, int CAUSAL, int BKV, int QT = 1>
+// DMA (D = 128 only: a cache row is one whole 256-byte LDS row): K / V tiles go from global memory straight into the LDS image
+// by `global_load_lds_dwordx4` -- the swizzle on the SOURCE chunk, as the decode kernels stage them -- instead of through 32
+// staging registers and a ds_write phase; keys past the end re-read the last valid row (finite; masked out of the softmax).
+template <int D, int CAUSAL, int BKV, int QT = 1, bool DMA = false>
 __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q, int q_rs, int q_hs,
                                                     const bf16_t* __restrict__ k, int k_rs, int k_hs,
                                                     const bf16_t* __restrict__ v, int v_rs, int v_hs,
@@ -140,9 +143,38 @@ __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q
             }
         }
     };
+    static_assert(!DMA || (D == 128 && BKV == 64), "the LDS-DMA staging moves whole 256-byte rows of 64-key tiles");
+    const unsigned smem_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem);
+    const int wid_u = __builtin_amdgcn_readfirstlane(wid);
+    // this wave's 4 of the 16 one-KiB pieces of the K image and of the V image (piece p = rows 4p .. 4p + 3)
+    auto stage_dma = [&](int buf, int kt) {
+        const unsigned kimg = smem_lds + (unsigned)buf * 2u * TILE_B, vimg = kimg + TILE_B;
+        const int r4 = lane >> 4, pos = lane & 15;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int pc = wid_u * 4 + g;
+            const int row = 4 * pc + r4;
+            const int ch = pos ^ ((r4 << 2) | (pc & 3));
+            const int keyc = min(kt + row, kv_hi - 1);
+            const bf16_t* ksrc = k + (size_t)keyc * k_rs + (size_t)kvh * k_hs + ch * 8;
+            const bf16_t* vsrc = v + (size_t)keyc * v_rs + (size_t)kvh * v_hs + ch * 8;
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(ksrc), "v"(vsrc), "s"(kimg + (unsigned)pc * 1024u), "s"(vimg + (unsigned)pc * 1024u)
+                : "memory");
+        }
+    };
     if (ntile > 0) {
-        stage_load(kv0);
-        stage_write(0, kv0);
+        if constexpr (DMA) {
+            stage_dma(0, kv0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            stage_load(kv0);
+            stage_write(0, kv0);
+        }
     }
     __syncthreads();
 
@@ -150,7 +182,10 @@ __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q
         const int kt = kv0 + t * BKV;
         const uint8_t* kb = smem + (t & 1) * 2 * TILE_B;
         const uint8_t* vb = kb + TILE_B;
-        if (t + 1 < ntile) stage_load(kt + BKV);
+        if (t + 1 < ntile) {
+            if constexpr (DMA) stage_dma((t + 1) & 1, kt + BKV);  // lands during the products of tile t
+            else stage_load(kt + BKV);
+        }
         // ---- S^T = K Q^T : NKT key tiles x KS steps; one K fragment read feeds the QT query tiles
         f32x4 sacc[QT][NKT];
 #pragma unroll
@@ -248,7 +283,8 @@ __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q
                     oacc[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&va), pb[u], oacc[u][j], 0, 0, 0);
             }
         }
-        if (t + 1 < ntile) stage_write((t + 1) & 1, kt + BKV);
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t + 1 have landed
+        else if (t + 1 < ntile) stage_write((t + 1) & 1, kt + BKV);
         __syncthreads();
     }
     // ---- normalise and store: lane holds O[qi][j*16 + fq*4 .. +3]
@@ -276,20 +312,30 @@ void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_rs, int q_hs
     // max_kv: the longest key range of any tile of the list, 0 = unknown.  A list whose tiles all fit ONE key tile (the ViT's
     // window blocks: segments of at most 64 tokens) never touches the second K / V buffer: half the LDS, so three workgroups
     // per CU instead of two -- these launches are thousands of short-lived workgroups bound by their own latency
-#define FA_LAUNCH(DD, CC, QQ)                                                                                      \
+#define FA_LAUNCH_(DD, CC, QQ, DM)                                                                                 \
     do {                                                                                                          \
         constexpr int BKV_ = (CC) ? ZE_FA_CAUSAL_BKV : 64;                                                        \
         constexpr int LDS_ = 4 * BKV_ * 256;                                                                      \
         static bool attr_set = false;                                                                             \
         if (!attr_set) {                                                                                          \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn<DD, CC, BKV_, QQ>),                   \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn<DD, CC, BKV_, QQ, DM>),               \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_);                                \
             attr_set = true;                                                                                      \
         }                                                                                                         \
         const int lds_ = (max_kv > 0 && max_kv <= BKV_) ? LDS_ / 2 : LDS_;                                        \
-        hipLaunchKernelGGL((k_flash_attn<DD, CC, BKV_, QQ>), grid, dim3(256), lds_, s, q, q_rs, q_hs, k, k_rs, k_hs, v, v_rs, \
+        hipLaunchKernelGGL((k_flash_attn<DD, CC, BKV_, QQ, DM>), grid, dim3(256), lds_, s, q, q_rs, q_hs, k, k_rs, k_hs, v, v_rs, \
                            v_hs, o, o_rs, o_hs, tiles, group, sl, q_pos_offset, tile_aux, kv_seq_stride);          \
     } while (0)
+#define FA_LAUNCH(DD, CC, QQ) FA_LAUNCH_(DD, CC, QQ, false)
+    // D = 128 causal (the prefill: K / V rows are whole 256-byte cache rows, 16-byte aligned): the LDS-DMA staging form;
+    // ze_tune knob 1 = 7 keeps the register-staged form for A/B runs and the bit-equality test
+    extern int ze_gemv_knobs[16];
+    if (D == 128 && causal && ZE_FA_CAUSAL_BKV == 64 && ze_gemv_knobs[1] != 7 && k_rs % 8 == 0 && v_rs % 8 == 0 && k_hs % 8 == 0 &&
+        v_hs % 8 == 0 && ((size_t)k % 16) == 0 && ((size_t)v % 16) == 0 && kv_seq_stride % 8 == 0) {
+        if (q_tile > 64) FA_LAUNCH_(128, 1, 2, true);
+        else FA_LAUNCH_(128, 1, 1, true);
+        return;
+    }
     // q_tile: the query rows a tile of the caller's list spans at most -- 64 (one 16-query tile per wave) or 128 (two)
     if (q_tile > 64) {
         if (D == 80) {
@@ -305,4 +351,5 @@ void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_rs, int q_hs
         if (causal) FA_LAUNCH(128, 1, 1); else FA_LAUNCH(128, 0, 1);
     }
 #undef FA_LAUNCH
+#undef FA_LAUNCH_
 }

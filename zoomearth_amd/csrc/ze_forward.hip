@@ -551,10 +551,11 @@ static int prefill_impl(ze_engine* e, int seq, const int32_t* input_ids, int len
         return ze_fail(e, ZE_ERR_MISMATCH, "Image features and image tokens do not match, tokens: " +
                                                std::to_string(img) + ", features: " + std::to_string(n_image_rows));
     int nt = 0;
-    // query rows per attention tile: 64.  (128 -- two query tiles per wave, half the LDS fragment reads per MFMA -- is what the
-    // ViT's full-attention blocks run, D = 80; at D = 128 that form needs 280 VGPRs, ONE workgroup per CU instead of two, and the
-    // batched prefill pass took 120.5 instead of 116.9 ms: ze_tune knob 1 = 8 selects it for A/B runs.  Same bits either way.)
-    const int bq = ze_gemv_knobs[1] == 8 ? ZE_FA_BQ_LONG : 64;
+    // query rows per attention tile: 128 -- two query tiles per wave, half the LDS fragment reads per MFMA -- on the LDS-DMA
+    // staging form of the kernel (no staging registers: 248 VGPRs, two workgroups per CU; with register staging the same tile
+    // needs 280 and lost: 120.5 against 116.9 ms per pass pair).  16-chain pass pair: register-staged 64-row tiles 107.0 ms,
+    // DMA 64-row 105.3, DMA 128-row 104.3.  ze_tune knob 1 = 9: 64-row tiles, 7: the register-staged form.  Same bits either way.
+    const int bq = (ze_gemv_knobs[1] == 9 || ze_gemv_knobs[1] == 7) ? 64 : ZE_FA_BQ_LONG;
     for (int q0 = 0; q0 < len; q0 += bq, ++nt) {
         tiles[4 * nt + 0] = q0;
         tiles[4 * nt + 1] = std::min(q0 + bq, len);
@@ -670,10 +671,11 @@ extern "C" int ze_prefill_batch(ze_engine* e, const int32_t* seqs, int n, const 
     int* row_aux = pos + 3 * total;
     int* tiles = row_aux + 2 * total;
     int img = 0, nt = 0, row0 = 0, img_expected = 0;
-    // query rows per attention tile: 64.  (128 -- two query tiles per wave, half the LDS fragment reads per MFMA -- is what the
-    // ViT's full-attention blocks run, D = 80; at D = 128 that form needs 280 VGPRs, ONE workgroup per CU instead of two, and the
-    // batched prefill pass took 120.5 instead of 116.9 ms: ze_tune knob 1 = 8 selects it for A/B runs.  Same bits either way.)
-    const int bq = ze_gemv_knobs[1] == 8 ? ZE_FA_BQ_LONG : 64;
+    // query rows per attention tile: 128 -- two query tiles per wave, half the LDS fragment reads per MFMA -- on the LDS-DMA
+    // staging form of the kernel (no staging registers: 248 VGPRs, two workgroups per CU; with register staging the same tile
+    // needs 280 and lost: 120.5 against 116.9 ms per pass pair).  16-chain pass pair: register-staged 64-row tiles 107.0 ms,
+    // DMA 64-row 105.3, DMA 128-row 104.3.  ze_tune knob 1 = 9: 64-row tiles, 7: the register-staged form.  Same bits either way.
+    const int bq = (ze_gemv_knobs[1] == 9 || ze_gemv_knobs[1] == 7) ? 64 : ZE_FA_BQ_LONG;
     std::vector<int> tile_aux;
     for (int i = 0; i < n; ++i) {
         const int seq = seqs[i], len = lens[i], past = e->ctx_host[seq];
