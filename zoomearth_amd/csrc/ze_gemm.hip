@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
     constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN), NT = 64 * WM * WN;
     constexpr int STAGE_BYTES = (BM + BN) * 128;
     constexpr int LPW = (BM + BN) / 8 / (WM * WN);  // DMA instructions per wave per stage
-    static_assert(STAGES >= 2 && STAGES <= 8 && 6 * LPW < 64, "ring depth");
+    static_assert(STAGES >= 2 && STAGES <= 8 && (STAGES > 4 ? 6 : 2) * LPW < 64, "ring depth (vmcnt is a 6-bit counter)");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
@@ -2111,6 +2111,8 @@ void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int
                 continue;
             }
             // (tried for 385 .. 512 rows and dropped: 256 x 192 tiles in two stages, 61.9 against 57.4 us at 440 rows)
+            // (tried for 385 .. 448 rows and dropped: 224 x 192 tiles on FOUR waves of 112 x 96 outputs -- the only wave grid that
+            //  divides 224 rows and keeps the SwiGLU pairs in a wave -- 67.0 against 56.8 us at 440 rows)
             if (mb > 384) launch_wstream_one<512, 96, 2, 6, 32, ZE_EPI_SWIGLU>(Ab, lda, W, ldw, bias, R, ldr, Cb, ldc, mb, N, K, 1, ws, s);
             else if (mb > 256) launch_wstream_one<384, 96, 2, 8, 32, ZE_EPI_SWIGLU>(Ab, lda, W, ldw, bias, R, ldr, Cb, ldc, mb, N, K, 1, ws, s);
             else if (mb > 128) done = launch_wstream<256, 96, 3, 8>(epi, Ab, lda, W, ldw, bias, R, ldr, Cb, ldc, mb, N, K, ws, s);
