@@ -450,6 +450,17 @@ class ChainScheduler:
         self._ready = self._ready[keep_from:]
         self._pass_done = self._pass_done[keep_from:]
 
+    # histogram of the decode steps by their live-chain count (the row count of the step's GEMMs picks their tiles: which
+    # buckets the stream spends its steps in says which tile is worth work); keys `steps_le_<bound>`
+    _ROW_BOUNDS = (64, 128, 192, 256, 320, 384, 416, 448, 512, 640, 768)
+
+    def _tally_step_rows(self, ran: int, n: int) -> None:
+        if ran <= 0:
+            return
+        b = next((x for x in self._ROW_BOUNDS if n <= x), None)
+        k = f"steps_le_{b}" if b is not None else "steps_gt_768"
+        self.stats[k] = self.stats.get(k, 0) + ran
+
     # -- one burst of decode steps for every live chain, then retire the finished ones
     def _burst(self) -> None:
         e = self.engine
@@ -460,6 +471,7 @@ class ChainScheduler:
         self.stats["bursts"] += 1
         self.stats["steps"] += ran
         self.stats["chain_steps"] += ran * len(slots)
+        self._tally_step_rows(ran, len(slots))
         for slot, ng, f in zip(slots, n_gen, fin):
             l = self.live[slot]
             l.produced = ng
@@ -482,6 +494,7 @@ class ChainScheduler:
         self.stats["bursts"] += 1
         self.stats["steps"] += ran
         self.stats["chain_steps"] += ran * len(slots)
+        self._tally_step_rows(ran, len(slots))
         with self._side_stream():   # (the callbacks of finished chains crop / resize on the front-end's stream)
             for slot, ng, f in zip(slots, n_gen, fin):
                 l = self.live[slot]
