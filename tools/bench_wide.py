@@ -1,6 +1,6 @@
 """Per-kernel device time of the batched decode step in the row-streaming regime (ze_profile_batch_kernel, HIP events, the 36
 layers' real weights in rotation) on the 3B shape at several chain counts, for a list of ze_tune settings.
-usage: python tools/bench_wide.py [slots=256] [tune ...]     e.g. ... 256 "" 15:99 15:3"""
+usage: python tools/bench_wide.py [slots=256] [tune ...]     e.g. ... 256 "" 15:99 15:3   (ZE_COUNTS=512,580,640: the chain counts)"""
 import os
 import sys
 
@@ -43,7 +43,8 @@ for tune in tunes:
     for kv in tune.split(","):
         if ":" in kv:
             e.lib.ze_tune(int(kv.split(":")[0]), int(kv.split(":")[1]))
-    for n in sorted({min(64, B), min(128, B), min(217, B), min(256, B), min(261, B), min(344, B), min(384, B), min(440, B), B}):
+    counts = [int(x) for x in os.environ.get("ZE_COUNTS", "64,128,217,256,261,344,384,440").split(",")] + [B]
+    for n in sorted({min(c, B) for c in counts}):
         row = []
         for w in (0, 1, 2, 3, 4, 5):
             us, by = e.profile_batch_kernel(w, n, 72)

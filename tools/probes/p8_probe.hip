@@ -2,7 +2,8 @@
 // loop restated here with ABLATIONS selected by a template parameter; results of the ablated forms are wrong by design --
 // only the clock is read).  P = 0: the loop as shipped; 1: one MFMA of each quadrant's sixteen; 2: no fragment reads inside the
 // loop; 3: no LDS-DMA inside the loop; 4: no barrier behind a quadrant's MFMAs; 5: no s_setprio; 6: both wave rows in lockstep;
-// 7: MFMAs only (no reads, no DMA); 8: reads + DMA + barriers, no MFMA at all.
+// 7: MFMAs only (no reads, no DMA); 8: reads + DMA + barriers, no MFMA at all; 9: the DMA pieces issued from inside the MFMA clusters
+// (a candidate schedule, not an ablation).
 // Build: hipcc --offload-arch=gfx950 -O3 -o /tmp/p8_probe tools/probes/p8_probe.hip ; run: /tmp/p8_probe [M N K]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,7 +35,8 @@ __global__ void __launch_bounds__(512) k_p8(const bf16_t* __restrict__ A, int ld
     const int fr = lane & 15, fq = lane >> 4;
     const int nk = K / GEMM_BK;
     const unsigned smem_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem);
-    constexpr bool DMA = P != 3 && P != 7, READS = P != 2 && P != 7, BAR2 = P != 4, PRIO = P != 5, SKEW = P != 6;
+    constexpr bool INMFMA = P == 9;
+    constexpr bool DMA = P != 3 && P != 7 && P != 9, READS = P != 2 && P != 7, BAR2 = P != 4, PRIO = P != 5, SKEW = P != 6;
 
     int bm0 = 0, bn0 = 0, bid = 0;
     auto place = [&](int tile) {
@@ -57,18 +59,19 @@ __global__ void __launch_bounds__(512) k_p8(const bf16_t* __restrict__ A, int ld
                 offB[h][q] = (unsigned)(((size_t)rb * ldw + c * 8) * sizeof(bf16_t));
             }
     };
-    auto stage = [&](int slot, int t) {
-        const unsigned dst = smem_lds + (t & 1) * BUF + slot * HALF + wid * 2048;
+    auto stage_piece = [&](int slot, int t, int q) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_lds + (t & 1) * BUF + slot * HALF + wid * 2048);
         const bf16_t* base = (slot < 2 ? A : W) + (size_t)t * GEMM_BK;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const unsigned off = slot == 0 ? offA[0][q] : slot == 1 ? offA[1][q] : slot == 2 ? offB[0][q] : offB[1][q];
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep)
-                         : "v"(off), "s"(dst + q * 1024), "s"(base)
-                         : "memory");
-        }
+        const unsigned off = slot == 0 ? offA[0][q] : slot == 1 ? offA[1][q] : slot == 2 ? offB[0][q] : offB[1][q];
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(off), "s"(dst + q * 1024), "s"(base)
+                     : "memory");
+    };
+    auto stage = [&](int slot, int t) {
+        stage_piece(slot, t, 0);
+        stage_piece(slot, t, 1);
     };
     auto prologue = [&]() {
         stage(0, 0);
@@ -102,7 +105,9 @@ __global__ void __launch_bounds__(512) k_p8(const bf16_t* __restrict__ A, int ld
             f[1][j] = *reinterpret_cast<const bf16x8*>(p + boff1 + j * 2048);
         }
     };
-    auto quadrant = [&](int mh, int nh, const bf16x8 (&f)[2][2]) {
+    // (P = 9: the phase's two DMA pieces go out from INSIDE the cluster of MFMAs -- behind the 4th and the 10th -- instead of in
+    //  front of the phase's first barrier; slot < 0: nothing to stage)
+    auto quadrant = [&](int mh, int nh, const bf16x8 (&f)[2][2], int slot = -1, int tt = 0) {
         if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -113,6 +118,11 @@ __global__ void __launch_bounds__(512) k_p8(const bf16_t* __restrict__ A, int ld
                     if (P == 8) continue;
                     if (P == 1 && (kk | i | j)) continue;
                     acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][i], f[kk][j], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+                    if (P == 9 && slot >= 0) {
+                        const int n = kk * 8 + i * 2 + j;
+                        if (n == 3) stage_piece(slot, tt, 0);
+                        if (n == 9) stage_piece(slot, tt, 1);
+                    }
                 }
         if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
@@ -150,7 +160,7 @@ __global__ void __launch_bounds__(512) k_p8(const bf16_t* __restrict__ A, int ld
             if (DMA && t + 1 < nk) stage(1, t + 1);
             if (READS) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            quadrant(0, 0, fb0);
+            quadrant(0, 0, fb0, (INMFMA && t + 1 < nk) ? 1 : -1, t + 1);
             if (P == 8) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sink(fa[0][i]), sink(fa[1][i]);
@@ -161,14 +171,14 @@ __global__ void __launch_bounds__(512) k_p8(const bf16_t* __restrict__ A, int ld
             if (READS) read_b(fb1, b, 1);
             if (DMA && t + 2 < nk) stage(0, t + 2);
             __builtin_amdgcn_s_barrier();
-            quadrant(0, 1, fb1);
+            quadrant(0, 1, fb1, (INMFMA && t + 2 < nk) ? 0 : -1, t + 2);
             if (P == 8) sink(fb1[0][0]), sink(fb1[0][1]), sink(fb1[1][0]), sink(fb1[1][1]);
             if (BAR2) __builtin_amdgcn_s_barrier();
             // ---- phase 3
             if (READS) read_a(b, 1);
             if (DMA && t + 2 < nk) stage(2, t + 2);
             __builtin_amdgcn_s_barrier();
-            quadrant(1, 1, fb1);
+            quadrant(1, 1, fb1, (INMFMA && t + 2 < nk) ? 2 : -1, t + 2);
             if (P == 8) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sink(fa[0][i]), sink(fa[1][i]);
@@ -183,8 +193,12 @@ __global__ void __launch_bounds__(512) k_p8(const bf16_t* __restrict__ A, int ld
                     ring_wait<0>();
                 }
             }
+            if (INMFMA) {  // outstanding at this point: A-half 1 (t+1), A-half 0 (t+2), W-half 0 (t+2); W-half 1 (t+1) has to be back
+                if (t + 2 < nk) ring_wait<6>();
+                else ring_wait<0>();
+            }
             __builtin_amdgcn_s_barrier();
-            quadrant(1, 0, fb0);
+            quadrant(1, 0, fb0, (INMFMA && t + 2 < nk) ? 3 : -1, t + 2);
             if (BAR2) __builtin_amdgcn_s_barrier();
         }
         if (SKEW && wr == 0) __builtin_amdgcn_s_barrier();
@@ -249,7 +263,8 @@ int main(int argc, char** argv) {
     const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
     const double ktiles_per_wg = (double)tiles / (tiles < 256 ? tiles : 256) * (K / 64);
     const char* names[] = {"as shipped", "1 MFMA of 16 per quadrant", "no fragment reads in the loop", "no LDS-DMA in the loop",
-                           "no barrier behind the MFMAs", "no s_setprio", "wave rows in lockstep", "MFMAs only", "no MFMA (reads + DMA + barriers)"};
+                           "no barrier behind the MFMAs", "no s_setprio", "wave rows in lockstep", "MFMAs only", "no MFMA (reads + DMA + barriers)",
+                           "DMA pieces from inside the MFMA clusters"};
 #define RUN(P)                                                                                                                 \
     do {                                                                                                                       \
         const float us = run<P>(A, W, C, M, N, K, 10);                                                                         \
@@ -257,6 +272,6 @@ int main(int argc, char** argv) {
                fl / us / 1e6, us / ktiles_per_wg);                                                                             \
     } while (0)
     printf("M=%d N=%d K=%d: %d tiles, %.1f K-tiles per workgroup\n", M, N, K, tiles, ktiles_per_wg);
-    RUN(0); RUN(1); RUN(2); RUN(3); RUN(4); RUN(5); RUN(6); RUN(7); RUN(8); RUN(0);
+    RUN(0); RUN(1); RUN(2); RUN(3); RUN(4); RUN(5); RUN(6); RUN(7); RUN(8); RUN(9); RUN(0); RUN(9); RUN(0); RUN(9);
     return 0;
 }

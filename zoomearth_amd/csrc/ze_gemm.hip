@@ -478,23 +478,54 @@ __device__ __forceinline__ void ring_issue_one(const bf16_t* __restrict__ G, int
         : "memory");
 }
 
+// K-steps of 32 (k_gemm_ring<..., BK = 32>): a stage image row is 64 B -- exactly the 16 x 32 operand of one MFMA per 16 rows --
+// and a 1-KiB piece is 16 rows x 64 B of the image [A rows | W rows] (lane l -> row l >> 2, chunk l & 3).  The 16-B chunk is
+// XOR-ed with (-(row >> 2)) & 3 on the source address and on the fragment read: the four 16-lane groups of a ds_read_b128 then
+// touch 16 distinct 16-B slots of the 256-B bank row (rows r, r + 4, r + 8, r + 12 share the slots 4 (r & 3) .. + 3; a group
+// holds one of them with each of two chunk indices, and the table 0, 3, 2, 1 separates all four).  `piece` is wave-uniform.
+template <int BM>
+__device__ __forceinline__ void ring_issue32_one(const bf16_t* __restrict__ A, int lda, int bm0, int mmax,
+                                                 const bf16_t* __restrict__ W, int ldw, int bn0, int nmax, int k0,
+                                                 unsigned lds_img, int piece, int lane) {
+    const bool is_a = piece < BM / 16;
+    const bf16_t* G = is_a ? A : W;
+    const int ld = is_a ? lda : ldw, row0 = is_a ? bm0 : bn0, rmax = is_a ? mmax : nmax;
+    const int row = (is_a ? piece : piece - BM / 16) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((-(row >> 2)) & 3);
+    const bf16_t* src = G + (size_t)min(row0 + row, rmax) * ld + k0 + c * 8;
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_img + piece * 1024)
+        : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void ring_wait() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int STAGES, int EPI, int WM = 2, int WN = 2, bool SPREAD = false, bool WIDE_EPI = false>
+template <int BM, int BN, int STAGES, int EPI, int WM = 2, int WN = 2, bool SPREAD = false, bool WIDE_EPI = false, int BK = GEMM_BK>
 __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
                                                    int ldw, const bf16_t* __restrict__ bias,
                                                    const bf16_t* __restrict__ R, int ldr, bf16_t* __restrict__ C,
                                                    int ldc, const int* __restrict__ c_rows, int M, int N, int K,
                                                    int ksplit, float* __restrict__ slab,
                                                    unsigned* __restrict__ tickets) {
+    // BK = 32 (round 4): K-steps of HALF the depth, so a stage of a 320 x 192 tile is 32 KB and four of them fit the LDS -- the
+    // decode step's gate/up at 513 .. 640 chains as two row tiles x 115 column tiles in ONE round (ze_launch_gemm_wide).  Per
+    // output element the same MFMAs over the same ascending 32-element K chunks: the same bits as BK = 64.
+    static_assert(BK == 64 || BK == 32, "K-step");
     constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN), NT = 64 * WM * WN;
-    constexpr int STAGE_BYTES = (BM + BN) * 128;
-    constexpr int LPW = (BM + BN) / 8 / (WM * WN);  // DMA instructions per wave per stage
-    static_assert(STAGES >= 2 && STAGES <= 8 && (STAGES > 4 ? 6 : 2) * LPW < 64, "ring depth (vmcnt is a 6-bit counter)");
+    constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+    constexpr int LPW = (BM + BN) * BK * 2 / 1024 / (WM * WN);  // DMA instructions per wave per stage
+    // (BK = 32 only: REM waves carry one piece more -- 320 x 128 is 28 pieces, 384 x 192 is 36, on eight waves -- and count it
+    //  in their own waits; wid is wave-uniform, so the branch costs a scalar compare)
+    constexpr int REM = (BM + BN) * BK * 2 / 1024 % (WM * WN);
+    static_assert((REM == 0 || BK == 32) && BM % 16 == 0 && BN % 16 == 0, "a stage's pieces divide evenly among the waves");
+    static_assert(STAGES >= 2 && STAGES <= 8 && (STAGES > 4 ? 6 : 2) * (LPW + (REM ? 1 : 0)) < 64, "ring depth (vmcnt is a 6-bit counter)");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
@@ -521,8 +552,9 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk_all = K / GEMM_BK;
-    const int nk_per = (nk_all + ksplit - 1) / ksplit;
+    // (the K slices of a split are cut in 64-element K-tiles whatever the K-step: the same slices, the same bits)
+    const int nk_all = K / BK;
+    const int nk_per = (K / GEMM_BK + ksplit - 1) / ksplit * (GEMM_BK / BK);
     const int kt0 = ks * nk_per;
     const int nk = max(0, min(nk_all - kt0, nk_per));
 
@@ -531,9 +563,17 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
         (unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem);
     auto issue = [&](int kt) {
         const unsigned img = smem_lds + (kt % STAGES) * STAGE_BYTES;
-        const int k0 = (kt0 + kt) * GEMM_BK;
-        ring_issue<BM, NT>(A, lda, bm0, M - 1, k0, img, wid, lane);
-        ring_issue<BN, NT>(W, ldw, bn0, N - 1, k0, img + BM * 128, wid, lane);
+        const int k0 = (kt0 + kt) * BK;
+        if constexpr (BK == 32) {
+#pragma unroll
+            for (int g = 0; g < LPW; ++g)
+                ring_issue32_one<BM>(A, lda, bm0, M - 1, W, ldw, bn0, N - 1, k0, img, wid + g * (NT / 64), lane);
+            if (REM > 0 && wid < REM)
+                ring_issue32_one<BM>(A, lda, bm0, M - 1, W, ldw, bn0, N - 1, k0, img, wid + LPW * (NT / 64), lane);
+        } else {
+            ring_issue<BM, NT>(A, lda, bm0, M - 1, k0, img, wid, lane);
+            ring_issue<BN, NT>(W, ldw, bn0, N - 1, k0, img + BM * 128, wid, lane);
+        }
     };
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
@@ -553,6 +593,10 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
                 case 1: ring_wait<LPW>(); break;
                 default: ring_wait<0>(); break;
             }
+        } else if (REM > 0 && wid < REM) {
+            if (ahead >= 2) ring_wait<2 * (LPW + 1)>();
+            else if (ahead == 1) ring_wait<LPW + 1>();
+            else ring_wait<0>();
         } else {
             if (ahead >= 2) ring_wait<2 * LPW>();
             else if (ahead == 1) ring_wait<LPW>();
@@ -564,6 +608,33 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
         // for the length of the burst)
         const bool more = kt + STAGES - 1 < nk;
         if (!SPREAD && more) issue(kt + STAGES - 1);
+        if constexpr (BK == 32) {
+            const unsigned img_next = smem_lds + ((kt + STAGES - 1) % STAGES) * STAGE_BYTES;
+            const int k_next = (kt0 + kt + STAGES - 1) * BK;
+            const uint8_t* imgA = smem + (kt % STAGES) * STAGE_BYTES;
+            const uint8_t* imgB = imgA + BM * 64;
+            const int sw = (-(fr >> 2)) & 3;  // (tile and wave origins are multiples of 16 rows: the swizzle term is the lane's)
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(imgA + (wm0 + i * 16 + fr) * 64 + ((fq ^ sw) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(imgB + (wn0 + j * 16 + fr) * 64 + ((fq ^ sw) << 4));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                if (SPREAD && more) {
+#pragma unroll
+                    for (int pc = 0; pc < LPW; ++pc)
+                        if (pc * TM / LPW == i)
+                            ring_issue32_one<BM>(A, lda, bm0, M - 1, W, ldw, bn0, N - 1, k_next, img_next, wid + pc * (NT / 64), lane);
+                    if (REM > 0 && i == TM - 1 && wid < REM)
+                        ring_issue32_one<BM>(A, lda, bm0, M - 1, W, ldw, bn0, N - 1, k_next, img_next, wid + LPW * (NT / 64), lane);
+                }
+            }
+            continue;
+        }
         constexpr int LPA = BM / 8 / (WM * WN);  // pieces of the A image per wave
         const unsigned img_next = smem_lds + ((kt + STAGES - 1) % STAGES) * STAGE_BYTES;
         const int k_next = (kt0 + kt + STAGES - 1) * GEMM_BK;
@@ -1561,23 +1632,23 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
 // The split-K workspace (fp32 slabs + per-tile tickets) belongs to the calling engine and travels with every call
 // (ze_gemm_ws); the launch macros below name its two pointers g_slab / g_tickets.
 // one ring instantiation, every epilogue
-template <int BM, int BN, int ST, int WM, int WN, bool SPR, bool WIDE = false, bool QKV = false>
+template <int BM, int BN, int ST, int WM, int WN, bool SPR, bool WIDE = false, bool QKV = false, int BK = GEMM_BK>
 static void launch_ring_variant(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,
                                 const bf16_t* R, int ldr, bf16_t* C, int ldc, const int* c_rows, int M, int N, int K,
                                 hipStream_t s, int ksplit = 1, const ze_gemm_ws& ws = ze_gemm_ws()) {
     float* g_slab = ws.slab;
     unsigned* g_tickets = ws.tickets;
     const int grid = ze_cdiv(M, BM) * ze_cdiv(N, BN) * ksplit;
-    const size_t lds = (size_t)(BM + BN) * 128 * ST;
+    const size_t lds = (size_t)(BM + BN) * BK * 2 * ST;
 #define ZE_RINGV_LAUNCH(E)                                                                                          \
     do {                                                                                                            \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<BM, BN, ST, E, WM, WN, SPR, WIDE>),      \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<BM, BN, ST, E, WM, WN, SPR, WIDE, BK>),  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL((k_gemm_ring<BM, BN, ST, E, WM, WN, SPR, WIDE>), dim3(grid), dim3(64 * WM * WN), lds, s, A, \
+        hipLaunchKernelGGL((k_gemm_ring<BM, BN, ST, E, WM, WN, SPR, WIDE, BK>), dim3(grid), dim3(64 * WM * WN), lds, s, A, \
                            lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, ksplit, g_slab, g_tickets);          \
     } while (0)
     if constexpr (QKV) {   // (the decode step's qkv projection with rope + KV append)
@@ -1602,7 +1673,7 @@ static void launch_ring_variant(int epi, const bf16_t* A, int lda, const bf16_t*
                                  (ldc % 8) == 0 && ((size_t)C % 16) == 0 && ((sw ? N / 2 : N) % 8) == 0 && (!sw || BN % 32 == 0) &&
                                  (epi != ZE_EPI_RESIDUAL || ((ldr % 8) == 0 && ((size_t)R % 16) == 0)) && epi != ZE_EPI_QKV_ROPE;
             if (wide_ok) {
-                launch_ring_variant<BM, BN, ST, WM, WN, SPR, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, ksplit, ws);
+                launch_ring_variant<BM, BN, ST, WM, WN, SPR, true, false, BK>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, ksplit, ws);
                 return;
             }
         }
@@ -1979,7 +2050,7 @@ static int stream_ksplit(int N, int K) {
 
 // long-K projection, more than 64 rows: big tiles on the slices of the one-launch form, then the chip-wide reduction;
 // false = does not apply
-template <int BM, int BN, int ST, bool SPR, int WM = 2, int WN = 4>
+template <int BM, int BN, int ST, bool SPR, int WM = 2, int WN = 4, int BK = GEMM_BK>
 static bool launch_splitk_two(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
                               int ldr, bf16_t* C, int ldc, int M, int N, int K, const ze_gemm_ws& ws, hipStream_t s) {
     if (epi != ZE_EPI_RESIDUAL && epi != ZE_EPI_NONE) return false;
@@ -1989,7 +2060,7 @@ static bool launch_splitk_two(int epi, const bf16_t* A, int lda, const bf16_t* W
         return false;
     ze_gemm_ws slabs_only = ws;
     slabs_only.tickets = nullptr;
-    launch_ring_variant<BM, BN, ST, WM, WN, SPR>(ZE_EPI_NONE, A, lda, W, ldw, nullptr, nullptr, 0, C, ldc, nullptr, M, N, K, s, ksplit, slabs_only);
+    launch_ring_variant<BM, BN, ST, WM, WN, SPR, false, false, BK>(ZE_EPI_NONE, A, lda, W, ldw, nullptr, nullptr, 0, C, ldc, nullptr, M, N, K, s, ksplit, slabs_only);
     const int grid = nwg * (BM / (16 * WM)) * (BN / (16 * WN));
     if (epi == ZE_EPI_RESIDUAL)
         hipLaunchKernelGGL((k_splitk_reduce<BM, BN, WM, WN, ZE_EPI_RESIDUAL>), dim3(grid), dim3(64 * WM * WN), 0, s, ws.slab, ksplit, bias, R, ldr, C, ldc, M, N);
@@ -2053,6 +2124,7 @@ void ze_launch_gemm_stream(int epi, const bf16_t* A, int lda, const bf16_t* W, i
     launch_cfg<64, 64>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s, true, ws);
 }
 
+#define ze_ring32_from (ze_gemv_knobs[3] > 0 ? ze_gemv_knobs[3] : 512)  // knob 3: first row count (exclusive) of the 320 x 192 tiles
 void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
                          int ldr, bf16_t* C, int ldc, int M, int N, int K, const ze_gemm_ws& ws, hipStream_t s) {
     if (M <= 0 || N <= 0) return;
@@ -2072,6 +2144,13 @@ void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int
             // instead of 192 (every CU), 17 % fewer bytes staged per workgroup; knob 15 = 4: the 128 x 256 tiles there too
             if (M > 256 && M <= 384 && ze_gemv_knobs[15] != 4 &&
                 launch_splitk_two<192, 128, 3, false, 4, 2>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
+            // 513 .. 640 / 641 .. 768 rows: 320 x 128 / 384 x 128 tiles with K-steps of 32 (four stages): two row tiles x 16
+            // column tiles x 8 slices = 256 workgroups, one round, where five or six row tiles of 128 x 256 are 320 / 384
+            // workgroups -- a second round for a quarter / half of the chip.  knob 15 = 7: off
+            if (M > 512 && M <= 640 && ze_gemv_knobs[15] != 7 &&
+                launch_splitk_two<320, 128, 4, true, 4, 2, 32>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
+            if (M > 640 && M <= 768 && ze_gemv_knobs[15] != 7 &&
+                launch_splitk_two<384, 128, 4, true, 4, 2, 32>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
             if (M > 256 && launch_splitk_two<128, 256, 3, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
             if (M > 128 && M <= 256 && launch_splitk_two<128, 128, 4, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
             if (M > 64 && M <= 128 && launch_splitk_two<64, 128, 4, false>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
@@ -2096,6 +2175,18 @@ void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int
         done = true;
         // (gate/up: blocks of up to 512 rows on the 384- and 512-row instances -- a pass costs ~18 us whatever its rows and
         //  ~10 us per 128 rows on top, so 261 chains in one pass instead of a 256- and a 5-row pass; knob 15 = 5: 256 at most)
+        // 513 .. 640 rows (where the question stream spends most of its decode steps: two lanes x 768 slots): 320 x 192 tiles on
+        // the ring with K-steps of 32 -- four 32-KB stages, two row tiles x 115 column tiles = 230 workgroups in ONE round, 512
+        // staged rows per 320 x 192 outputs -- instead of a 512-row and a 128-row weight-streaming pass.  knob 15 = 7: off
+        if (epi == ZE_EPI_SWIGLU && M > ze_ring32_from && M <= 640 && v != 7 && v != 4) {
+            launch_ring_variant<320, 192, 4, 4, 2, true, true, false, 32>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s);
+            return;
+        }
+        // 641 .. 768 rows: 384 x 192 tiles the same way (four 36-KB stages, 96 x 96 outputs per wave)
+        if (epi == ZE_EPI_SWIGLU && M > 640 && M <= 768 && v != 7 && v != 4) {
+            launch_ring_variant<384, 192, 4, 4, 2, true, true, false, 32>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s);
+            return;
+        }
         const int blk = (epi == ZE_EPI_SWIGLU && K / GEMM_BK == 32 && v != 5) ? 512 : 256;
         for (int r0 = 0; r0 < M && done; r0 += blk) {
             const int mb = std::min(blk, M - r0);
