@@ -2092,7 +2092,9 @@ void ze_launch_gemm_qkv_rope(const bf16_t* A, int lda, const bf16_t* Wp, int ldw
     if (M <= 0 || N <= 0) return;
     const long b64 = (long)ze_cdiv(M, 64) * ze_cdiv(N, 64);
     const bf16_t* R = reinterpret_cast<const bf16_t*>(dev_args);
-    if (b64 <= 256)
+    // (two 64-KB workgroups share a CU: up to 512 tiles stay on 64 x 64 -- 16.4 against 20.8 us at 410 rows, 19.9 / 21.0 at 580, 20.9 /
+    //  22.7 at 768; knob 13 = 3: 64 x 128 from 257 tiles on, the rule before)
+    if (b64 <= (ze_gemv_knobs[13] == 3 ? 256 : 512))
         launch_ring_variant<64, 64, 4, 4, 2, false, false, true>(ZE_EPI_QKV_ROPE, A, lda, Wp, ldw, bias_p, R, 0, C, ldc, nullptr, M, N, K, s);
     else
         launch_ring_variant<64, 128, 4, 2, 4, false, false, true>(ZE_EPI_QKV_ROPE, A, lda, Wp, ldw, bias_p, R, 0, C, ldc, nullptr, M, N, K, s);
