@@ -865,9 +865,30 @@ def main():
         cfgt = cfg.text
         steps_total = max(1, st.get("steps", 1))
         mean_chains = st.get("chain_steps", 0) / steps_total
-        # ---- decode
+        # ---- decode: the steps are spread over a wide range of live-chain counts (two lanes x 768 slots fill and drain: most
+        # chain-steps run at 513-640 chains, the MEAN step has ~410), and the step's GEMMs pick their tiles by the row count --
+        # so the step is timed alone at a representative count of every bucket of the scheduler's histogram (`steps_le_<bound>`)
+        # and weighted by the steps the stream ran there; `step_us_at_mean_chains` stays for reference
         step_us = cfgt.num_hidden_layers * roof["layer_us"] + roof["step_kernels"]["lm_head"]["us"]
-        dec_ms_q = steps_total * step_us / 1000.0 / n_q_rank
+        buckets, dec_us_total, lo = [], 0.0, 1
+        for bound in (64, 128, 192, 256, 320, 384, 416, 448, 512, 640, 768):
+            nsteps = st.get(f"steps_le_{bound}", 0)
+            if nsteps > 0:
+                n_rep = int(min(e.max_seqs, (lo + bound) // 2))
+                if n_rep > 64:
+                    live_like_contexts(n_rep)
+                    rb = batch_roofline(n_rep, shared=(10, 347))
+                    us_b = cfgt.num_hidden_layers * rb["layer_us"] + rb["step_kernels"]["lm_head"]["us"]
+                else:   # (the drain tail: few chains on the row-streaming family's small-row kernels)
+                    rb = batch_roofline(max(n_rep, 65), shared=(10, 347))
+                    us_b = cfgt.num_hidden_layers * rb["layer_us"] + rb["step_kernels"]["lm_head"]["us"]
+                buckets.append({"chains": f"{lo}-{bound}", "timed_at": max(n_rep, 65) if n_rep <= 64 else n_rep, "steps": nsteps,
+                                "step_us": round(us_b, 1), "layer_us": rb["layer_us"]})
+                dec_us_total += nsteps * us_b
+            lo = bound + 1
+        if not buckets:
+            dec_us_total = steps_total * step_us
+        dec_ms_q = dec_us_total / 1000.0 / n_q_rank
         w_bytes = 2.0 * (2774532096 + 311164928)
         kv_row = 36864.0
         kv_bytes_q = kv_row * (N1 * (L_TEXT_A + 2 + 324 + L_TEXT_B + N1 / 2.0) + N2 * (1320 + N2 / 2.0))
@@ -927,6 +948,7 @@ def main():
                         "frac": (f_pre_q / mfma) / (pre_ms_q * 1e-3) if pre_ms_q > 0 else None,
                         "replay": f"{nrep} chains x {len(ids1[0])} new rows, then {len(extra[0])} rows behind the cached prompt: {1000 * pre_ms_row:.2f} us per row"},
             "decode": {"bound": "hbm", "ms_per_question": round(dec_ms_q, 3), "step_us_at_mean_chains": round(step_us, 1),
+                       "steps_by_live_chains": buckets,
                        "mean_chains_per_step": round(mean_chains, 1), "algorithmic_GB_per_question": round(dec_bytes_q / 1e9, 2),
                        "achieved_GBs": round(dec_bytes_q / (dec_ms_q * 1e-3) / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
                        "frac": dec_roof_ms / dec_ms_q},

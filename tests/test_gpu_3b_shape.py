@@ -158,7 +158,8 @@ def test_3b_layer_shape_row_streaming_at_the_headline_chain_counts():
     """bench.py's stream runs 2 x 768 chain slots, ~376 live chains per step.  Above 256 rows the step
     switches instances -- 384- / 512-row k_gemm_wstream passes for gate/up, the 128 x 256 two-launch down projection, the
     lm_head on ring tiles above 160 rows, the attention grid cut by live_parts -- and until round 4 none of that ran against
-    the oracle inside a model.  Here: an engine with 768 slots, `ze_decode_batch` at 1 / 261 / 384 / 512 / 768 ragged chains,
+    the oracle inside a model.  Here: an engine with 768 slots, `ze_decode_batch` at 1 / 261 / 384 / 512 / 600 / 768 ragged chains
+    (600, 768: gate/up and down on the 320- / 384-row ring tiles with K-steps of 32, where the stream runs most of its steps),
     two teacher-forced steps each, against the fp32 oracle (2 x the oracle's own bf16-vs-fp32 error), greedy token where
     the oracle's margin is decidable, chains 0 and 1 bit-identical alone and inside every batch."""
     from zoomearth_amd.engine import Engine
@@ -200,7 +201,7 @@ def test_3b_layer_shape_row_streaming_at_the_headline_chain_counts():
             e.seq_reset(c)
             e.prefill(c, ids[: lens[c]], emb, pos[:, : lens[c]], delta, want_logits=False)
         first = {}
-        for n in (1, 261, 384, 512, 768):
+        for n in (1, 261, 384, 512, 600, 768):
             chains = list(range(n))
             for c in chains:
                 e.seq_truncate(c, lens[c])

@@ -16,7 +16,7 @@ ROUND = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 P = f"r{ROUND:02d}"
 # bench.py's kernel keys -> substring of the kernel's name, per measured configuration (tools/pmc_kernel.py modes)
 KEYS = {
-    "configs1": {"gate_up": "k_gemv<2, 1, 1, 4, 16>", "down": "k_gemv<1, 1, 4, 4, 16>", "lm_head": "k_gemv<3, 2, 1, 4, 16>"},
+    "configs1": {"gate_up": "k_gemv<2, 1, 1, 4, 16>", "down": "k_gemv<1, 1, 4, ", "lm_head": "k_gemv<3, 2, 1, 4, 16>"},
     # (down at 220 chains = two launches: 128 x 128 tiles park the K slices, k_splitk_reduce adds them -- summed)
     "wide": {"attention": "k_attn_decode_wave<8>", "gate_up": "k_gemm_wstream<256, 96",
              "down": ("k_gemm_ring<128, 128, 4, 0, 2, 4, true>", "k_splitk_reduce<128, 128")},
@@ -24,14 +24,18 @@ KEYS = {
     "batch64": {"attention": "k_attn_decode_wave<8>", "gate_up": "k_gemm_skinny<6, 3", "down": "k_gemm_ring<64, 64, 4, 2, 4, 2, false>"},
 }
 SECTION = {"configs1": "configs1", "wide": "stream", "wide_shared": "stream_shared", "batch64": "batch64"}
-if ROUND >= 4:  # round 4: the stream's rows at the line's own chain count (376) and every GEMM of the layer
+if ROUND >= 4:  # round 4: the stream's rows at the line's own mean chain count (410) and every GEMM of the layer; 580 = the bucket
+    # (513-640 chains) in which the stream runs most of its chain-steps
     del KEYS["wide"], KEYS["wide_shared"]
-    KEYS["wide376"] = {"attention": "k_attn_decode_wave<8>", "gate_up": "k_gemm_ring<192, 192, 3, 3",
-                       "down": ("k_gemm_ring<192, 128, 3, 0", "k_splitk_reduce<192, 128"),
-                       "qkv": "k_gemm_ring<64, 64, 4, 5", "o_proj": "k_gemm_ring<64, 64, 4, 2, 4, 2, false, true"}
-    KEYS["wide376_shared"] = {"attention": "k_attn_decode_wave<8>"}
-    SECTION.update(wide376="stream", wide376_shared="stream_shared")
-
+    KEYS["wide410"] = {"attention": "k_attn_decode_wave<8>", "gate_up": "k_gemm_wstream<512, 96",
+                       "down": ("k_gemm_ring<128, 256, 3, 0, 2, 4, true, false", "k_splitk_reduce<128, 256"),  # (…, true, true: a prefill GEMM of the set-up)
+                       "qkv": "k_gemm_ring<64, 64, 4, 5", "o_proj": "k_gemm_ring<64, 64, 4, 2, 4, 2, false, true", "lm_head": "k_gemm_p8<4, true>"}
+    KEYS["wide410_shared"] = {"attention": "k_attn_decode_wave<8>"}
+    KEYS["wide580"] = {"attention": "k_attn_decode_wave<8>", "gate_up": "k_gemm_ring<320, 192, 4, 3",
+                       "down": ("k_gemm_ring<320, 128, 4, 0", "k_splitk_reduce<320, 128"),
+                       "qkv": "k_gemm_ring<64, 64, 4, 5", "o_proj": "k_gemm_ring<64, 128, 4, 2, 2, 4, false, true", "lm_head": "k_gemm_p8<4, true>"}
+    KEYS["wide580_shared"] = {"attention": "k_attn_decode_wave<8>"}
+    SECTION.update(wide410="stream", wide410_shared="stream_shared", wide580="stream580", wide580_shared="stream580_shared")
 
 def rows(name, source=None):
     with open(os.path.join(D, f"{P}_{name}")) as fh:
