@@ -328,8 +328,11 @@ def test_follow_up_on_decode_written_rows_matches_the_oracle(eng):
     assert float(np.abs(reused - fresh).max()) <= 2.0 * yard
 
 
-def test_per_wave_attention_kernel_is_batch_invariant_and_agrees_with_the_ring_kernel():
-    """k_attn_decode_wave (the default of the batched step) against k_attn_decode_stream (ze_tune knob 8 = 2): ragged
+@pytest.mark.parametrize("wave_knob", [0, 5, 6, 4])
+def test_per_wave_attention_kernel_is_batch_invariant_and_agrees_with_the_ring_kernel(wave_knob):
+    """(wave_knob 0: the shipped form of the per-wave kernel; 5 / 6: k_attn_decode_wave_long with 384- / 256-key parts, rounds
+    requested as earlier ones are consumed; 4: the 192-key kernel where 0 is no longer it -- every part-boundary case below for each.)
+    k_attn_decode_wave (the default of the batched step) against k_attn_decode_stream (ze_tune knob 8 = 2): ragged
     contexts whose last 192-key part is anything from one key to full -- rounds past the end of a part re-read its last row
     and are masked -- logits within bf16 noise of the ring kernel's, reproducible, and a chain's logits the same bits alone,
     in a pair and among forty."""
@@ -341,6 +344,10 @@ def test_per_wave_attention_kernel_is_batch_invariant_and_agrees_with_the_ring_k
         e.fill_synthetic(seed=1, std=0.02, matrix_gain=4.0, bias_std=0.02, norm_jitter=0.1)
         lens = [5 + (37 * s) % 700 for s in range(n)]
         lens[3], lens[4], lens[5] = 191, 192, 193          # the part boundary itself (context = prompt + 1 at the first step)
+        lens[6], lens[8], lens[9] = 383, 384, 385          # ... of the 384-key parts
+        lens[10], lens[11], lens[12] = 255, 256, 257       # ... of the 256-key parts
+        lens[13], lens[14], lens[15] = 63, 64, 65          # one round, one round + one key
+        lens[16], lens[17] = 767, 769                      # two / three full 384-key parts
         ids = [prng.uniform_ints(70 + s, lens[s], 10, 1990).tolist() for s in range(n)]
         tok = [int(prng.uniform_ints(90 + s, 1, 10, 1990)[0]) for s in range(n)]
 
@@ -351,15 +358,15 @@ def test_per_wave_attention_kernel_is_batch_invariant_and_agrees_with_the_ring_k
                 e.prefill(s, ids[s], None, *e.rope_index(ids[s], []), want_logits=False)
             return [e.decode_batch(list(slots), [tok[s] + k for s in slots]).cpu().numpy() for k in (0, 1)]
 
-        ring, wave, again = run(list(range(n)), 2), run(list(range(n)), 0), run(list(range(n)), 0)
+        ring, wave, again = run(list(range(n)), 2), run(list(range(n)), wave_knob), run(list(range(n)), wave_knob)
         assert all(np.isfinite(a).all() for a in wave)
         assert all(np.array_equal(a, b) for a, b in zip(wave, again))
         err = max(float(np.abs(a - b).max()) for a, b in zip(ring, wave))
         assert err < 0.06, err
-        for solo in (7, 31, 0, 4):
-            alone = run([solo], 0)
+        for solo in (7, 31, 0, 4, 8, 9, 11, 14, 17):
+            alone = run([solo], wave_knob)
             assert all(np.array_equal(alone[k][0], wave[k][solo]) for k in (0, 1)), solo
-        pair = run([7, 31], 0)
+        pair = run([7, 31], wave_knob)
         assert all(np.array_equal(pair[k][0], wave[k][7]) and np.array_equal(pair[k][1], wave[k][31]) for k in (0, 1))
     finally:
         e.lib.ze_tune(8, 0)

@@ -468,6 +468,244 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AW_VST
                              out + (size_t)bz * out_row_stride, 0, 0, nparts);
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Round 4: the same per-wave streams over LONGER parts (ROUNDS x 64 keys, ROUNDS = 6: 384 keys), three rounds in flight
+// throughout.  A 192-key part requests everything at t = 0 and then only drains: chain-state look-up, ramp, cross-wave merge,
+// publish, ticket -- about 6 of a workgroup's 22 us -- are paid per 192 keys, and the queue is empty while they run.  Here
+// round u + 3 is requested as soon as round u has been consumed (its K registers and its V stage are free: the K loads re-use
+// kreg[u % 3], the V pieces stage u % 3 behind an lgkmcnt(0) that retires the transposed reads), so a workgroup keeps two to
+// three rounds = 32-48 KB in flight until its last round and pays the fixed costs once per 384 keys: half the partials,
+// tickets and merges.  A part's LIVE rounds NR = ceil(keys / 64) select one of ROUNDS straight-line bodies (a short last part
+// requests and computes nothing it does not have -- the 192-key kernel always ran three rounds, masked), each with literal
+// wait counts: retirement is in issue order, and at the wait for round u exactly the min(2, NR - 1 - u) younger rounds (8
+// operations each: 4 K loads + 4 V pieces) may stay outstanding.  The bodies only meet after their last load has been consumed
+// (ordinary values from there on: no register holding an in-flight load crosses a control-flow merge -- see the note on the
+// 192-key kernel).  Parts stay a function of the chain's own length alone (batch invariance); the per-key arithmetic is that
+// of the 192-key kernel, the grouping of the partial sums differs (384-key parts), so the two agree within rounding.
+template <int NR>
+__device__ __forceinline__ void aw_run_part(const bf16_t* __restrict__ qsrc, const bf16_t* __restrict__ kb,
+                                            const bf16_t* __restrict__ vb, long long pfx_delta, int pfx_rows, int t0, int t1,
+                                            int wid, int lane, unsigned ring_lds, const uint8_t* ring, float scale_log2e,
+                                            ad_f32x4 (&oacc)[8], float& m_run, float& l_run) {
+    constexpr int D = 128;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int r4 = lane >> 4, pos = lane & 15;
+    aw_u32x4 qf4[4], kreg[3][4];
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:64\n\t"
+        "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:192"
+        : "=&v"(qf4[0]), "=&v"(qf4[1]), "=&v"(qf4[2]), "=&v"(qf4[3])
+        : "v"(qsrc)
+        : "memory");
+    auto issue_v = [&](int u) {  // the V tile of round u into stage u % 3: four 1-KB pieces (no register results)
+        const int tok0 = t0 + u * AW_TOK + wid * 16;
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            const int row = 4 * pp + r4;
+            const int ch = pos ^ ((r4 << 2) | (pp & 3));
+            const int tok = min(tok0 + row, t1 - 1);
+            const bf16_t* src = vb + (tok < pfx_rows ? pfx_delta : 0ll) + (size_t)tok * D + ch * 8;
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(src), "s"(ring_lds + (unsigned)(u % 3) * AW_VSTAGE + (unsigned)pp * 1024u)
+                : "memory");
+        }
+    };
+#define AW_ISSUE_K(U, KR)                                                                                                   \
+    do {                                                                                                                    \
+        const int ktok_ = min(t0 + (U) * AW_TOK + wid * 16 + fr, t1 - 1);                                                   \
+        const bf16_t* ksrc_ = kb + (ktok_ < pfx_rows ? pfx_delta : 0ll) + (size_t)ktok_ * D + fq * 8;                       \
+        asm volatile(                                                                                                       \
+            "global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:64\n\t"                              \
+            "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:192"                      \
+            : "=&v"((KR)[0]), "=&v"((KR)[1]), "=&v"((KR)[2]), "=&v"((KR)[3])                                                \
+            : "v"(ksrc_)                                                                                                    \
+            : "memory");                                                                                                    \
+    } while (0)
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+        if (u < NR) {
+            AW_ISSUE_K(u, kreg[u]);
+            issue_v(u);
+        }
+    const int tq = fr >> 2, tp = fr & 3;
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        const int younger = (NR - 1 - u) < 2 ? (NR - 1 - u) : 2;  // rounds requested behind round u at this point
+        ad_f32x4 sacc;
+        if (younger == 2) sacc = aw_wait_qk<16>(kreg[u % 3], qf4);
+        else if (younger == 1) sacc = aw_wait_qk<8>(kreg[u % 3], qf4);
+        else sacc = aw_wait_qk<0>(kreg[u % 3], qf4);
+        const int kbase = t0 + u * AW_TOK + wid * 16 + fq * 4;
+        float p[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const float sv = (kbase + rr < t1) ? sacc[rr] * scale_log2e : -INFINITY;
+            p[rr] = sv;
+            mx = fmaxf(mx, sv);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = exp2f(m_run - m_use);  // m_run = -inf -> 0
+        float rs = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            p[rr] = __builtin_amdgcn_exp2f(p[rr] - m_use);  // arguments <= 0
+            rs += p[rr];
+        }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+        const uint2 pq = make_uint2(ad_pack_bf16(p[0], p[1]), ad_pack_bf16(p[2], p[3]));
+        const ad_v4s pb = *reinterpret_cast<const ad_v4s*>(&pq);
+        const uint8_t* sV = ring + (u % 3) * AW_VSTAGE;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const ad_v4s va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) ad_v4s*)(sV + ad_off(fq * 4 + tq, j * 2 + (tp >> 1)) + 8 * (tp & 1)));
+            oacc[j][0] *= alpha;
+            oacc[j][1] *= alpha;
+            oacc[j][2] *= alpha;
+            oacc[j][3] *= alpha;
+            oacc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, pb, oacc[j], 0, 0, 0);
+        }
+        if (u + 3 < NR) {  // round u is consumed: its K registers and its V stage take round u + 3
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            AW_ISSUE_K(u + 3, kreg[u % 3]);
+            issue_v(u + 3);
+        }
+    }
+#undef AW_ISSUE_K
+}
+
+template <int MB, int ROUNDS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k_attn_decode_wave_long(
+    const bf16_t* __restrict__ q, int q_row_stride, const bf16_t* __restrict__ kcache, const bf16_t* __restrict__ vcache,
+    size_t cache_seq_stride, const ze_seq_dev* __restrict__ st_base, const int* __restrict__ seq_ids, int heads, int kv_heads,
+    int max_ctx, float scale_log2e, float* __restrict__ ws, int max_parts, unsigned* __restrict__ tickets,
+    bf16_t* __restrict__ out, int out_row_stride, int x_rot, const int* __restrict__ prefix) {
+    constexpr int D = 128, PART = AW_TOK * ROUNDS;
+    static_assert(ROUNDS >= 3 && ROUNDS <= 8, "part length");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 4 waves x 3 V stages of 4 KB
+    __shared__ float s_ml[4][32];                                   // the waves' (m, l) per head column
+    const int bz = blockIdx.y;
+    const int xr = (int)((blockIdx.x + (unsigned)(x_rot & 15) * ((unsigned)bz >> (x_rot >> 4))) % gridDim.x);  // (k_attn_decode_wave)
+    const int kvh = xr % kv_heads, part = xr / kv_heads;
+    const int seq = seq_ids[bz];
+    const int ctx = st_base[seq].ctx + 1;
+    const int nparts = (ctx + PART - 1) / PART;
+    if (part >= nparts) return;  // workgroup-uniform: no part, no ticket
+    const int G = heads / kv_heads;
+    const int t0 = part * PART, t1 = min(ctx, t0 + PART);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const bf16_t* kb = kcache + (size_t)seq * cache_seq_stride + (size_t)kvh * max_ctx * D;
+    const bf16_t* vb = vcache + (size_t)seq * cache_seq_stride + (size_t)kvh * max_ctx * D;
+    const int hint = prefix ? prefix[seq] : 0;
+    const int pfx_rows = hint & 0xffff;
+    const long long pfx_delta = ((long long)(hint >> 16) - (long long)seq) * (long long)cache_seq_stride;  // in elements
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem) +
+                              (unsigned)wid * (3 * AW_VSTAGE);
+    const uint8_t* ring = smem + wid * (3 * AW_VSTAGE);
+    const bf16_t* qsrc = q + (size_t)bz * q_row_stride + (kvh * G + min(fr, G - 1)) * D + fq * 8;
+
+    ad_f32x4 oacc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) oacc[j] = ad_f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const int nr = __builtin_amdgcn_readfirstlane((t1 - t0 + AW_TOK - 1) / AW_TOK);  // live rounds of this part: 1 .. ROUNDS
+#define AW_CASE(N)                                                                                                          \
+    case N:                                                                                                                 \
+        if constexpr (N <= ROUNDS)                                                                                          \
+            aw_run_part<N>(qsrc, kb, vb, pfx_delta, pfx_rows, t0, t1, wid, lane, ring_lds, ring, scale_log2e, oacc, m_run, l_run); \
+        break
+    switch (nr) {
+        AW_CASE(1);
+        AW_CASE(2);
+        AW_CASE(3);
+        AW_CASE(4);
+        AW_CASE(5);
+        AW_CASE(6);
+        AW_CASE(7);
+        AW_CASE(8);
+        default: break;
+    }
+#undef AW_CASE
+    // ---- the four waves' results meet in LDS (their stages are idle now), merged in wave order (k_attn_decode_wave)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+        ad_f32x4* mine = reinterpret_cast<ad_f32x4*>(smem + wid * (3 * AW_VSTAGE));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mine[j * 64 + lane] = oacc[j];
+        if (fq == 0) {
+            s_ml[wid][fr] = m_run;
+            s_ml[wid][16 + fr] = l_run;
+        }
+    }
+    __syncthreads();
+    float mw[4], lw[4];
+    float m_all = -INFINITY;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        mw[x] = s_ml[x][fr];
+        lw[x] = s_ml[x][16 + fr];
+        m_all = fmaxf(m_all, mw[x]);
+    }
+    float l_all = 0.f;
+    ad_f32x4 om[2];
+    om[0] = om[1] = ad_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const float w = (mw[x] == -INFINITY) ? 0.f : exp2f(mw[x] - m_all);
+        l_all += w * lw[x];
+        const ad_f32x4* theirs = reinterpret_cast<const ad_f32x4*>(smem + x * (3 * AW_VSTAGE));
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const ad_f32x4 t = theirs[(2 * wid + jj) * 64 + lane];
+            om[jj][0] += w * t[0];
+            om[jj][1] += w * t[1];
+            om[jj][2] += w * t[2];
+            om[jj][3] += w * t[3];
+        }
+    }
+    __syncthreads();  // the tail reuses the LDS
+
+    float* wsb = ws + (size_t)bz * max_parts * heads * AD_STRIDE;
+    if (fr < G) {
+        const uint32_t dst = (uint32_t)((part * heads + kvh * G + fr) * AD_STRIDE * 4);
+        if (wid == 0 && fq == 0) ad_store16<true>(wsb, dst, m_all, l_all, 0.f, 0.f);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+            ad_store16<true>(wsb, dst + (uint32_t)((4 + (2 * wid + jj) * 16 + fq * 4) * 4), om[jj][0], om[jj][1], om[jj][2], om[jj][3]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned* flag = reinterpret_cast<unsigned*>(smem + 16 * 1024);
+    if (threadIdx.x == 0) {
+        unsigned* t = tickets + (size_t)bz * kv_heads + kvh;
+        const unsigned old = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned last = old == (unsigned)nparts - 1u;
+        if (last) __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = last;
+    }
+    __syncthreads();
+    if (*flag == 0u) return;
+    __syncthreads();
+    float* sW = reinterpret_cast<float*>(smem);
+    if (out_row_stride < 0)
+        attn_merge_group<MB>(sW, sW + AD_GMAX * 64, wsb, ctx, kvh, heads, kv_heads, max_parts, out, -out_row_stride, bz, nparts);
+    else
+        attn_merge_group<MB>(sW, sW + AD_GMAX * 64, wsb, ctx, kvh, heads, kv_heads, max_parts,
+                             out + (size_t)bz * out_row_stride, 0, 0, nparts);
+}
+
 extern int ze_gemv_knobs[16];
 
 void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_t* kcache, const bf16_t* vcache,
@@ -490,6 +728,24 @@ void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_
         // (knob 8 = 3, for A/B runs: every part of max_ctx in the grid, no rotation)
         const bool plain = ze_gemv_knobs[8] == 3;
         const int gparts = plain ? wparts : std::min(wparts, std::max(1, per_wave));
+        // knob 8 = 5 .. 9: the pipelined long-part form (k_attn_decode_wave_long) with 6 / 4 / 3 / 5 / 8 rounds per part
+        if (ze_gemv_knobs[8] >= 5 && ze_gemv_knobs[8] <= 9) {
+            const int kb_ = ze_gemv_knobs[8];
+            const int rounds = kb_ == 5 ? 6 : kb_ == 6 ? 4 : kb_ == 7 ? 3 : kb_ == 8 ? 5 : 8;
+            const int lparts = (max_ctx + rounds * AW_TOK - 1) / (rounds * AW_TOK);
+            const int lg = std::min(lparts, std::max(1, (per_wave * AW_PART + rounds * AW_TOK - 1) / (rounds * AW_TOK)));
+#define ZE_AWL(R)                                                                                                              \
+    k_attn_decode_wave_long<8, R><<<dim3(kv_heads * lg, n), 256, 4 * 3 * AW_VSTAGE, s>>>(                                      \
+        q, q_row_stride, kcache, vcache, cache_seq_stride, st, seq_ids, heads, kv_heads, max_ctx, sl, ws_partial, wparts, tickets, out, \
+        out_row_stride, 3 | (2 << 4), prefix)
+            if (rounds == 6) ZE_AWL(6);
+            else if (rounds == 4) ZE_AWL(4);
+            else if (rounds == 3) ZE_AWL(3);
+            else if (rounds == 5) ZE_AWL(5);
+            else ZE_AWL(8);
+#undef ZE_AWL
+            return;
+        }
         k_attn_decode_wave<8><<<dim3(kv_heads * gparts, n), 256, 4 * AW_VSTAGES * AW_VSTAGE, s>>>(
             q, q_row_stride, kcache, vcache, cache_seq_stride, st, seq_ids, heads, kv_heads, max_ctx, sl, ws_partial, wparts, tickets,
             out, out_row_stride, plain ? 0 : (3 | (2 << 4)), prefix);
