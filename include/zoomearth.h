@@ -359,6 +359,10 @@ int ze_op_embed_scatter(ze_engine* e, const int32_t* input_ids, int len, const v
 int ze_op_mrope_kv(ze_engine* e, int seq, int layer, void* qkv_bf16, int T, const int32_t* position_ids, int past, void* stream);
 int ze_op_rope_kv_decode(ze_engine* e, const int32_t* seqs, int n, int layer, void* qkv_bf16, void* stream);
 int ze_op_kv_read(ze_engine* e, int seq, int layer, int start, int n, void* out_k, void* out_v, void* stream);
+/* The attention of one batched decode step, alone (K16 at decode: HF:modeling_qwen2_5_vl.py:606-639 on the rows of the KV cache):
+ * qkv_bf16 [n, (heads + 2 kv_heads) x 128] = the chains' projections after ze_op_rope_kv_decode (their k / v are row ctx of the
+ * cache); out_bf16 [n, heads x 128] = softmax(q K^T / sqrt(128)) V over rows 0 .. ctx, per head, with the step's own kernel. */
+int ze_op_attn_decode(ze_engine* e, const int32_t* seqs, int n, int layer, const void* qkv_bf16, void* out_bf16, void* stream);
 
 /* ------------------------------------------------------------------ measurement */
 /* Runs the decode-path weight-streaming kernel `which` (0 qkv, 1 o_proj, 2 gate_up, 3 down, 4 lm_head) `iters`

@@ -159,3 +159,60 @@ def test_rope_and_kv_append_of_a_decode_step(tiny_engine):
         kc, vc = [x.float().cpu().numpy() for x in e.op_kv_read(s, 1, ctx[s], 1)]
         assert np.array_equal(kc, _text_rope_ref(cfg, k, pos3).transpose(1, 0, 2)), s
         assert np.array_equal(vc, v.transpose(1, 0, 2)), s
+
+
+@pytest.mark.parametrize("knob", [0, 4])
+def test_decode_attention_alone_against_float64_at_every_part_boundary(knob):
+    """K16 at decode (HF:modeling_qwen2_5_vl.py:606-639 over the cached rows), through `ze_op_attn_decode`: the batched step's
+    attention kernel on its own -- knob 0 the shipped k_attn_decode_wave_long (384-key parts, rounds requested as earlier ones are
+    consumed), knob 4 the 192-key k_attn_decode_wave -- on DENSE cached rows (a prefilled chain's real K / V) and random queries,
+    16 q heads on 2 kv heads as in the 3B model, against float64 softmax(q K^T / sqrt(128)) V over rows 0 .. ctx.  Contexts sit on
+    and either side of every boundary of both kernels' parts and rounds (64, 192, 256, 384, 768).  The probe that found two
+    mis-scheduled instantiations of the pipelined kernel (tools/probes/attn_wave_probe.hip) showed errors of 2-5 % of max |V| on
+    such rows where the right kernels show 0.05 %: the bound here is 2^-7 max |V|.  A chain's row is the same bits alone."""
+    from zoomearth_amd.config import ModelConfig, TextConfig, VisionConfig
+    from zoomearth_amd.engine import Engine
+    cfg = ModelConfig(vision=VisionConfig(depth=1, hidden_size=160, num_heads=2, intermediate_size=220, out_hidden_size=2048,
+                                          fullatt_block_indexes=(0,)),
+                      text=TextConfig(hidden_size=2048, num_hidden_layers=1, num_attention_heads=16, num_key_value_heads=2,
+                                      intermediate_size=1024, vocab_size=2048, tie_word_embeddings=True),
+                      image_token_id=2005, vision_start_token_id=2002, vision_end_token_id=2003, eos_token_ids=(2045, 2043),
+                      pad_token_id=2043, name="attn-op")
+    lens = [5, 62, 63, 64, 190, 191, 192, 254, 255, 256, 382, 383, 384, 500, 766, 767, 768, 1000]
+    n = len(lens)
+    e = Engine(cfg, device=0, max_seqs=n, max_ctx=1024, max_patches=256, max_tile_side=256)
+    try:
+        e.fill_synthetic(seed=3, std=0.02, matrix_gain=4.0, bias_std=0.5, norm_jitter=0.1)
+        for s_, L in enumerate(lens):
+            ids = prng.uniform_ints(300 + s_, L, 10, 1990).tolist()
+            e.seq_reset(s_)
+            e.prefill(s_, ids, None, *e.rope_index(ids, []), want_logits=False)
+        t = cfg.text
+        nq, nkv = t.num_attention_heads * 128, t.num_key_value_heads * 128
+        qkv_host = rnd(900, (n, nq + 2 * nkv), 1.0)
+        e.lib.ze_tune(8, knob)
+        seqs = list(range(n))
+        qkv = e.op_rope_kv_decode(seqs, 0, to_dev_bf16(qkv_host))     # rotates q / k in place, appends k / v at row ctx
+        out = e.op_attn_decode(seqs, 0, qkv)
+        got = out.float().cpu().numpy().reshape(n, t.num_attention_heads, 128)
+        q = qkv.float().cpu().numpy()[:, :nq].reshape(n, t.num_attention_heads, 128).astype(np.float64)
+        g = t.num_attention_heads // t.num_key_value_heads
+        worst = 0.0
+        for b, L in enumerate(lens):
+            k, v = e.op_kv_read(b, 0, 0, L + 1)
+            k, v = k.float().cpu().numpy().astype(np.float64), v.float().cpu().numpy().astype(np.float64)
+            for h in range(t.num_attention_heads):
+                sc = k[h // g] @ q[b, h] / np.sqrt(128.0)
+                p = np.exp(sc - sc.max())
+                want = (p / p.sum()) @ v[h // g]
+                err = float(np.abs(got[b, h] - want).max())
+                bound = 2.0 ** -7 * float(np.abs(v[h // g]).max())
+                worst = max(worst, err / bound)
+                assert err <= bound, (knob, L, h, err, bound)
+        print(f"knob {knob}: worst error / bound {worst:.3f}")
+        for b in (0, 6, 12, 17):
+            alone = e.op_attn_decode([b], 0, qkv[b:b + 1].contiguous())
+            assert torch.equal(alone[0], out[b]), (knob, lens[b])
+    finally:
+        e.lib.ze_tune(8, 0)
+        e.close()

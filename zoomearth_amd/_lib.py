@@ -127,6 +127,7 @@ _SIGS = {
     "ze_op_embed_scatter": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, _P, C.c_int, _P, _P]),
     "ze_op_mrope_kv": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int32), C.c_int, _P]),
     "ze_op_rope_kv_decode": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.c_int, _P, _P]),
+    "ze_op_attn_decode": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.c_int, _P, _P, _P]),
     "ze_op_kv_read": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "ze_profile_decode_kernel": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), _P]),
     "ze_profile_batch_kernel": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), _P]),

@@ -244,7 +244,15 @@ __device__ __forceinline__ void ab_wait_vm() {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int aw_u32x4;
 
-// S^T tile of one round: wait until all but the N youngest memory operations of the wave have retired, then K Q^T
+// S^T tile of one round: wait until all but the N youngest memory operations of the wave have retired, then K Q^T.
+// EVERY use is fenced by __builtin_amdgcn_sched_barrier(0) on both sides (round 4).  hipcc cannot see into the statement -- four
+// 8-pass MFMAs on one accumulator -- and, left free, it interleaves the P V work of the previous round (ds_read_b64_tr_b16 into
+// registers the statement's MFMAs read, its own MFMAs) with it.  In two instantiations of k_attn_decode_wave_long (192- and 256-key
+// parts, 119 / 128 VGPRs: tight re-use) that produced wrong rows -- the second register of one V^T fragment came back empty in
+// round 1, deterministically, whatever nops were added -- while the assembly satisfied every hazard rule I could check by hand
+// and the in-flight-register walker (tools/check_attn_asm.py); with the fences all five instantiations tried agree with float64
+// to 5e-4 on dense random rows (tools/probes/attn_wave_probe.hip, kept as a GPU test) and the 192-key form of the pipelined
+// kernel is bit-identical to k_attn_decode_wave.  Cost of the fences: none measurable.
 template <int N>
 __device__ __forceinline__ ad_f32x4 aw_wait_qk(const aw_u32x4 (&k4)[4], const aw_u32x4 (&q4)[4]) {
     ad_f32x4 sacc;
@@ -355,6 +363,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AW_VST
         if (u == 0) sacc = aw_wait_qk<(AW_VSTAGES == 2 ? 12 : 16)>(kreg[0], qf4);
         else if (u == 1) sacc = aw_wait_qk<8>(kreg[1], qf4);
         else sacc = aw_wait_qk<0>(kreg[2], qf4);
+        __builtin_amdgcn_sched_barrier(0);  // (see aw_wait_qk: nothing of the compiler's crosses the statement)
         const int kbase = t0 + u * AW_TOK + wid * 16 + fq * 4;
         float p[4];
         float mx = -INFINITY;
@@ -393,6 +402,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AW_VST
             oacc[j][3] *= alpha;
             oacc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, pb, oacc[j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (AW_VSTAGES == 2 && u == 0) {  // stage 0 has been read (the transposed reads have returned): it takes round 2's tile
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             issue_v(2);
@@ -538,6 +548,7 @@ __device__ __forceinline__ void aw_run_part(const bf16_t* __restrict__ qsrc, con
         if (younger == 2) sacc = aw_wait_qk<16>(kreg[u % 3], qf4);
         else if (younger == 1) sacc = aw_wait_qk<8>(kreg[u % 3], qf4);
         else sacc = aw_wait_qk<0>(kreg[u % 3], qf4);
+        __builtin_amdgcn_sched_barrier(0);
         const int kbase = t0 + u * AW_TOK + wid * 16 + fq * 4;
         float p[4];
         float mx = -INFINITY;
@@ -575,6 +586,7 @@ __device__ __forceinline__ void aw_run_part(const bf16_t* __restrict__ qsrc, con
             oacc[j][3] *= alpha;
             oacc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, pb, oacc[j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (u + 3 < NR) {  // round u is consumed: its K registers and its V stage take round u + 3
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             AW_ISSUE_K(u + 3, kreg[u % 3]);
@@ -728,22 +740,16 @@ void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_
         // (knob 8 = 3, for A/B runs: every part of max_ctx in the grid, no rotation)
         const bool plain = ze_gemv_knobs[8] == 3;
         const int gparts = plain ? wparts : std::min(wparts, std::max(1, per_wave));
-        // knob 8 = 5 .. 9: the pipelined long-part form (k_attn_decode_wave_long) with 6 / 4 / 3 / 5 / 8 rounds per part
-        if (ze_gemv_knobs[8] >= 5 && ze_gemv_knobs[8] <= 9) {
-            const int kb_ = ze_gemv_knobs[8];
-            const int rounds = kb_ == 5 ? 6 : kb_ == 6 ? 4 : kb_ == 7 ? 3 : kb_ == 8 ? 5 : 8;
+        // Round 4: 384-key parts on the pipelined form (k_attn_decode_wave_long<8, 6>: 4.4 -> 4.7-4.9 TB/s on independent chains at
+        // 410-768 of them, 5.5 -> 6.1-6.4 with the stream's shared prefixes; 320-key parts 4.70 / 5.92 at 410, 512-key 4.54 / 5.41,
+        // 256-key 4.51 / 5.49).  knob 8 = 4: the 192-key kernel (A/B runs and the agreement test); 3: every part of max_ctx in the grid, no rotation
+        if (ze_gemv_knobs[8] != 4) {
+            constexpr int rounds = 6;
             const int lparts = (max_ctx + rounds * AW_TOK - 1) / (rounds * AW_TOK);
-            const int lg = std::min(lparts, std::max(1, (per_wave * AW_PART + rounds * AW_TOK - 1) / (rounds * AW_TOK)));
-#define ZE_AWL(R)                                                                                                              \
-    k_attn_decode_wave_long<8, R><<<dim3(kv_heads * lg, n), 256, 4 * 3 * AW_VSTAGE, s>>>(                                      \
-        q, q_row_stride, kcache, vcache, cache_seq_stride, st, seq_ids, heads, kv_heads, max_ctx, sl, ws_partial, wparts, tickets, out, \
-        out_row_stride, 3 | (2 << 4), prefix)
-            if (rounds == 6) ZE_AWL(6);
-            else if (rounds == 4) ZE_AWL(4);
-            else if (rounds == 3) ZE_AWL(3);
-            else if (rounds == 5) ZE_AWL(5);
-            else ZE_AWL(8);
-#undef ZE_AWL
+            const int lg = plain ? lparts : std::min(lparts, std::max(1, (per_wave * AW_PART + rounds * AW_TOK - 1) / (rounds * AW_TOK)));
+            k_attn_decode_wave_long<8, rounds><<<dim3(kv_heads * lg, n), 256, 4 * 3 * AW_VSTAGE, s>>>(
+                q, q_row_stride, kcache, vcache, cache_seq_stride, st, seq_ids, heads, kv_heads, max_ctx, sl, ws_partial, wparts, tickets, out,
+                out_row_stride, plain ? 0 : (3 | (2 << 4)), prefix);
             return;
         }
         k_attn_decode_wave<8><<<dim3(kv_heads * gparts, n), 256, 4 * AW_VSTAGES * AW_VSTAGE, s>>>(

@@ -1195,13 +1195,17 @@ static int upload_batch(ze_engine* e, const int32_t* seqs, int n, hipStream_t s)
 // decode attention of the batched step: the per-wave streaming kernel k_attn_decode_wave (ze_attn_batch.hip); knob 8 = 2:
 // its predecessor k_attn_decode_stream (a workgroup-wide LDS-DMA ring); knob 8 = 1: the 64-token-slice kernel of the
 // single-chain step with a chain dimension (the round-1 form) -- both kept for A/B measurements
-static void launch_batch_attention(ze_engine* e, int li, int n, bool frag_out, hipStream_t s) {
+// (q_rows / out_rows: the step's own buffers, or the caller's -- ze_op_attn_decode)
+static void launch_batch_attention(ze_engine* e, int li, int n, bool frag_out, hipStream_t s, const bf16_t* q_rows = nullptr,
+                                   bf16_t* out_rows = nullptr) {
     const ze_config& c = e->cfg;
     const int hd = e->head_dim, nq = c.heads * hd, nqkv = nq + 2 * c.kv_heads * hd;
     const size_t seq_stride = (size_t)c.kv_heads * c.max_ctx * hd;
     const float scale = 1.0f / sqrtf((float)hd);
+    const bf16_t* qb = q_rows ? q_rows : e->bqkv;
+    bf16_t* ob = out_rows ? out_rows : e->bo;
     if (ze_gemv_knobs[8] == 1)
-        ze_launch_attn_decode(e->bqkv, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, e->bo, frag_out ? -(nq / 32) : nq, e->st_dev,
+        ze_launch_attn_decode(qb, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, ob, frag_out ? -(nq / 32) : nq, e->st_dev,
                               e->bseq, n, c.heads, c.kv_heads, hd, c.max_ctx, scale, e->bpartial, e->max_splits, e->atickets, s);
     else {
         // tokens per part (a multiple of 32; knob 11 for measurements): a function of nothing but the build, so a chain's
@@ -1213,7 +1217,7 @@ static void launch_batch_attention(ze_engine* e, int li, int n, bool frag_out, h
                               hd == 128 && c.heads / c.kv_heads <= 16;  // (128-wide heads, the q heads of a kv head as MFMA columns)
         const int chunk = ze_gemv_knobs[11] >= 64 ? ze_gemv_knobs[11] / 32 * 32 : 0;  // 0: a sixth of the chain's context
         const int max_parts = chunk ? (c.max_ctx + chunk - 1) / chunk : 8;           // (at most 8 parts: 128-token floor)
-        ze_launch_attn_decode_stream(e->bqkv, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, e->bo, frag_out ? -(nq / 32) : nq,
+        ze_launch_attn_decode_stream(qb, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, ob, frag_out ? -(nq / 32) : nq,
                                      e->st_dev, e->bseq, n, c.heads, c.kv_heads, c.max_ctx, scale, e->bpartial, max_parts,
                                      e->atickets, s, chunk, per_wave ? (e->live_parts > 0 ? e->live_parts : wparts) : 0, e->pfx_dev);
     }
@@ -1802,6 +1806,26 @@ extern "C" int ze_op_rope_kv_decode(ze_engine* e, const int32_t* seqs, int n, in
     ze_launch_set_ints(e->bseq, seqs, n, s);
     ze_launch_rope_kv_batch((bf16_t*)qkv_bf16, n, c.heads, c.kv_heads, e->head_dim, e->cosT, e->sinT, e->st_dev, e->bseq, e->kc(layer, 0),
                             e->vc(layer, 0), (size_t)c.kv_heads * c.max_ctx * e->head_dim, c.max_ctx, s);
+    ZE_KCHECK();
+    return ZE_OK;
+}
+// The attention of ONE batched decode step, alone: row b of qkv_bf16 [n, (heads + 2 kv_heads) x 128] is chain seqs[b]'s
+// projection AFTER ze_op_rope_kv_decode (which rotated q / k and appended k, v at row ctx of the cache); the kernel of the step
+// (k_attn_decode_wave_long in the row-streaming family and from 17 chains on, the fragment family's choice below) attends the
+// q heads over rows 0 .. ctx of `layer` and writes out_bf16 [n, heads x 128].  Chain state is not advanced.
+extern "C" int ze_op_attn_decode(ze_engine* e, const int32_t* seqs, int n, int layer, const void* qkv_bf16, void* out_bf16, void* stream) {
+    if (!e || !seqs || !qkv_bf16 || !out_bf16 || n <= 0 || n > e->cfg.max_seqs || layer < 0 || layer >= e->cfg.layers)
+        return ze_fail(e, ZE_ERR_INVALID, "bad attn_decode arguments");
+    for (int i = 0; i < n; ++i) {
+        ZE_TRY(check_seq(e, seqs[i]));
+        if (e->ctx_host[seqs[i]] + 1 > e->cfg.max_ctx) return ze_fail(e, ZE_ERR_NOMEM, "sequence exceeds max_ctx");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    ze_launch_set_ints(e->bseq, seqs, n, s);
+    sync_prefix(e, seqs, n, s);
+    set_live_parts(e, seqs, n, 1);
+    launch_batch_attention(e, layer, n, false, s, (const bf16_t*)qkv_bf16, (bf16_t*)out_bf16);
     ZE_KCHECK();
     return ZE_OK;
 }

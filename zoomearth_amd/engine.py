@@ -494,6 +494,15 @@ class Engine:
         self._check(self.lib.ze_op_rope_kv_decode(self.h, sp, len(sq), layer, _ptr(qkv), self._stream()))
         return qkv
 
+    def op_attn_decode(self, seqs, layer: int, qkv: torch.Tensor) -> torch.Tensor:
+        """the attention of one batched decode step, alone: qkv as op_rope_kv_decode left it -> [n, heads x 128]"""
+        sq, sp = _i32(seqs)
+        t = self.config.text
+        assert qkv.shape[0] == len(sq) and qkv.dtype == torch.bfloat16 and qkv.is_contiguous()
+        out = torch.empty((len(sq), t.hidden_size), dtype=torch.bfloat16, device=self.device)
+        self._check(self.lib.ze_op_attn_decode(self.h, sp, len(sq), layer, _ptr(qkv), _ptr(out), self._stream()))
+        return out
+
     def op_kv_read(self, seq: int, layer: int, start: int, n: int):
         t = self.config.text
         shape = (t.num_key_value_heads, n, t.hidden_size // t.num_attention_heads)
