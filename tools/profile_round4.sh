@@ -36,7 +36,7 @@ for mode in wide410 wide410_shared wide580 wide580_shared batch64 configs1; do
   pmc WRITE_SIZE write_size $mode
 done
 # the default line's workload (BASELINE configs[3], the question stream), configs[1] and configs[2]
-stats stream --steps 8 --warmup 2 --no-cpu-baseline --no-batch64 --no-configs1
+stats stream --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-batch64 --no-configs1   # (the driver's command, minus the annexes)
 if [ "${2:-}" != "fast" ]; then
   stats configs1 --batch 1 --steps 3 --warmup 1 --no-cpu-baseline
   stats batch64 --batch 64 --steps 1 --warmup 1 --no-cpu-baseline
