@@ -687,6 +687,8 @@ def main():
         torch.cuda.synchronize()
         e2.weights_invalidate()
         engines.append(e2)
+    if len(engines) > 1:
+        e.lib.ze_tune(4, 1)   # engines sharing the GPU: tile-granular prefill GEMM launches (what model.clone_lane() sets)
 
     def barrier():
         torch.cuda.synchronize()
@@ -1080,6 +1082,8 @@ def main():
             line["decode_ms_per_step"] = round(phases["decode"] / steps_run, 3)
             line["mean_chains_per_step"] = round(st.get("chain_steps", 0) / steps_run, 1)
             line["scheduler"] = st
+            if len(engines) > 1:
+                e.lib.ze_tune(4, 0)   # the annexes below run ONE engine alone: persistent launches again
             if args.model == "3b" and not args.fp8:
                 live = int(min(SLOTS, max(1, round(line["mean_chains_per_step"]))))
                 mean_ctx = live_like_contexts(live)

@@ -378,7 +378,9 @@ int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters, float* av
 /* Measurement-only kernel-configuration override (A/B of kernels and launch shapes inside one process; value 0 is always
  * the shipped default, every alternative computes the same function -- bit for bit unless noted).  Knobs (0..15):
  *   0, 1  variants of the single-chain down / gate-up GEMVs          2   grid cap of the GEMV family
- *   3, 4  unused (the one-launch-per-layer kernels left in round 4)  5   1: no fragment / skinny kernels in the batched step
+ *   3     first row count of the 320 x 192 decode tiles (measurements) 5   1: no fragment / skinny kernels in the batched step
+ *   4     1: the eight-phase GEMM launches one tile per workgroup instead of persistent workgroups -- for SEVERAL ENGINES ON
+ *         ONE GPU (lanes): the other engine's kernels get CUs at tile boundaries (set by clone_lane; same bits either way)
  *   6, 7  GEMM policy (register-staged vs LDS-DMA ring; forced tile) 8   batched decode attention: 2 = ring kernel,
  *                                                                        1 = 64-key slice kernel (agree within rounding)
  *   9     1: skinny instead of one-shot o projection                 10  1: bf16 fragments on a quantised engine

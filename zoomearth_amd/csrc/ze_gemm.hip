@@ -972,7 +972,12 @@ static void launch_p8(int epi, const bf16_t* A, int lda, const bf16_t* W, int ld
         cus = std::max(8, cus / 8 * 8);  // (a multiple of 8: a persistent workgroup's tiles keep its XCD label)
     }
     const int tiles = ze_cdiv(M, 256) * ze_cdiv(N, 256);
-    const int grid = ze_gemv_knobs[7] == 9 ? tiles : std::min(tiles, cus);  // (knob 7 = 9: one tile per workgroup, for A/B runs)
+    // Persistent workgroups (a tile's first half-tiles requested behind the previous tile's epilogue) -- unless several engines
+    // share the GPU (lanes: knob 4 = 1, set by clone_lane / bench.py): a persistent launch holds every CU's LDS until its LAST tile
+    // is done, and the other lane's decode kernels wait for all of it (the o projection's 200 workgroups averaged 127 us in the
+    // two-lane stream against 16 alone); one tile per workgroup lets them in at tile boundaries: stream 80.5 -> 81.6 questions/s
+    // same box, twice.  (knob 7 = 9: the same for A/B runs)
+    const int grid = (ze_gemv_knobs[7] == 9 || ze_gemv_knobs[4] == 1) ? tiles : std::min(tiles, cus);
     // the wide-store epilogue (p8_finish_wide: 16-byte row pieces through 4 KB of LDS per wave) wherever rows are 16-byte
     // aligned; knob 7 = 10: the plain two-byte epilogue, for A/B runs and the bit-equality test
     const bool sw = epi == ZE_EPI_SWIGLU;
