@@ -349,6 +349,12 @@ def test_gemm_eight_phase_kernel(tiny_engine, m, n, k, bias, act):
     assert torch.equal(got_t, ref)
     for _ in range(8):
         assert torch.equal(tiny_engine.op_linear(da, dw, db, 9 if act == 4 else 8), got_t)
+    try:   # one tile per workgroup instead of persistent workgroups (knob 4: what lanes sharing a GPU run): the same bits
+        tiny_engine.lib.ze_tune(4, 1)
+        for _ in range(3):
+            assert torch.equal(tiny_engine.op_linear(da, dw, db, 9 if act == 4 else 8), got_t)
+    finally:
+        tiny_engine.lib.ze_tune(4, 0)
     if act == 0:
         want = a.astype(np.float64) @ w.astype(np.float64).T + (b.astype(np.float64) if bias else 0.0)
         close_bf16(got_t.float().cpu().numpy(), want, scale=0.05 * np.sqrt(k) * 0.05)
