@@ -54,6 +54,13 @@ def test_bench_line_contract():
     assert 0 < rp["question"]["frac"] < 1 and rp["question"]["measured_ms"] > rp["question"]["roofline_ms"] > 0
     assert abs(rp["question"]["measured_ms"] - 1000.0 / d["value"]) < 0.02 * rp["question"]["measured_ms"]
     assert abs(rp["isolated_ms_per_question"] - sum(rp[k]["ms_per_question"] for k in ("vit", "prefill", "decode"))) < 0.01
+    # the decode phase is the histogram-weighted sum of the step timed alone in every live-chain bucket the stream visited
+    hist = rp["decode"]["steps_by_live_chains"]
+    assert hist and sum(b["steps"] for b in hist) == d["scheduler"]["steps"]
+    assert all(b["step_us"] > 0 and b["timed_at"] >= 65 for b in hist)
+    want_ms = sum(b["steps"] * b["step_us"] for b in hist) / 1000.0 / d["per_rank"]["questions"][0]
+    assert abs(want_ms - rp["decode"]["ms_per_question"]) < 0.01 * want_ms + 0.002
+    assert sum(v for k, v in d["scheduler"].items() if k.startswith("steps_le_") or k == "steps_gt_768") == d["scheduler"]["steps"]
     assert d["per_rank"]["filled_own_weights"] == [True]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "threads", "kind", "sample"):

@@ -14,6 +14,8 @@
 // workgroup of the (chain, kv head) with the fence-free sc1 hand-off of the single-chain kernel.
 // The part geometry is a function of the chain's own context length alone, so a chain's result does not depend on
 // which chains share the launch.
+#include <cstdlib>
+
 #include "ze_kernels.h"
 #include "ze_attn_decode.h"
 
@@ -720,6 +722,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k
 
 extern int ze_gemv_knobs[16];
 
+// (measurements: ZE_XROT = step | shift << 4 overrides the grid rotation of the pipelined kernel)
+static int xrot_env() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ZE_XROT");
+        v = e ? atoi(e) : (3 | (2 << 4));
+    }
+    return v;
+}
+
 void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_t* kcache, const bf16_t* vcache,
                                   size_t cache_seq_stride, bf16_t* out, int out_row_stride, const ze_seq_dev* st,
                                   const int* seq_ids, int n, int heads, int kv_heads, int max_ctx, float scale,
@@ -749,7 +761,7 @@ void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_
             const int lg = plain ? lparts : std::min(lparts, std::max(1, (per_wave * AW_PART + rounds * AW_TOK - 1) / (rounds * AW_TOK)));
             k_attn_decode_wave_long<8, rounds><<<dim3(kv_heads * lg, n), 256, 4 * 3 * AW_VSTAGE, s>>>(
                 q, q_row_stride, kcache, vcache, cache_seq_stride, st, seq_ids, heads, kv_heads, max_ctx, sl, ws_partial, wparts, tickets, out,
-                out_row_stride, plain ? 0 : (3 | (2 << 4)), prefix);
+                out_row_stride, plain ? 0 : xrot_env(), prefix);
             return;
         }
         k_attn_decode_wave<8><<<dim3(kv_heads * gparts, n), 256, 4 * AW_VSTAGES * AW_VSTAGE, s>>>(
