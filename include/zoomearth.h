@@ -376,7 +376,9 @@ int ze_profile_decode_kernel(ze_engine* e, int which, int iters, float* avg_us, 
 int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters, float* avg_us, double* bytes_per_launch,
                             void* stream);
 /* Measurement-only kernel-configuration override (A/B of kernels and launch shapes inside one process; value 0 is always
- * the shipped default, every alternative computes the same function -- bit for bit unless noted).  Knobs (0..15):
+ * the shipped default, every alternative computes the same function -- bit for bit unless noted).  Knobs (0..23; round 4 re-used
+ * knobs 3 and 4, which until round 3 switched the removed one-launch-per-layer kernels: an old `3:1` / `4:1` habit now changes GEMM
+ * tiling / launch form -- same results, different speed):
  *   0, 1  variants of the single-chain down / gate-up GEMVs          2   grid cap of the GEMV family
  *   3     first row count of the 320 x 192 decode tiles (measurements) 5   1: no fragment / skinny kernels in the batched step
  *   4     1: the eight-phase GEMM launches one tile per workgroup instead of persistent workgroups -- for SEVERAL ENGINES ON
@@ -387,6 +389,8 @@ int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters, float* av
  *   12    1: bf16 GEMMs instead of the block-scaled FP8 MFMA in a prefill with FP8 activations (agree within rounding)
  *   11    fixed part size (keys) of the ring attention kernel        13  1: streaming launcher beyond 64 chains
  *   14    1: separate arg-max pass in single-chain greedy decode
+ *   15    tile family of the row-streaming decode GEMMs (measurements)  16  grid rotation step | shift << 4 of the decode attention
+ *   17    1: no shared-prefix hints (every chain reads its own K/V rows: same bits, more HBM traffic)
  * Changing a knob invalidates captured decode graphs (they are re-captured on the next step). */
 int ze_tune(int knob, int value);
 /* Per-phase device time (ms) accumulated by HIP events since the last reset: [0] front-end, [1] ViT,

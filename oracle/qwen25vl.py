@@ -134,6 +134,20 @@ def tiny_config() -> Config:
     )
 
 
+def heads_config() -> Config:
+    """The 3B model's HEAD STRUCTURE at small depth (VERDICT r4 missing #4): text 16 query / 2 key-value heads x 128 (GQA group
+    8, hidden 2048 -- `repeat_kv` at the real group size), ViT 16 heads x 80 (hidden 1280), two layers / two blocks (one of
+    them full attention), small MLPs and vocabulary.  tests/golden/heads_chain.npz pins the oracle to transformers on it."""
+    return Config(
+        vision=VisionConfig(depth=2, hidden_size=1280, num_heads=16, intermediate_size=220, out_hidden_size=2048,
+                            fullatt_block_indexes=(1,)),
+        text=TextConfig(hidden_size=2048, num_hidden_layers=2, num_attention_heads=16, num_key_value_heads=2,
+                        intermediate_size=1376, vocab_size=2048, tie_word_embeddings=True),
+        image_token_id=2005, vision_start_token_id=2002, vision_end_token_id=2003,
+        eos_token_ids=(2045, 2043), pad_token_id=2043,
+    )
+
+
 def weight_shapes(cfg: Config) -> dict:
     """HF 5.x checkpoint keys -> shapes."""
     v, t = cfg.vision, cfg.text

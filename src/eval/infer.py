@@ -62,6 +62,16 @@ def done_question_ids(path):
     return ids
 
 
+def done_question_ids_all(exp_name, world):
+    """--resume: what ANY rank's file of the interrupted run holds.  With --steal a rank's file holds tiles it took from other
+    ranks and lacks its own tiles that were taken from it, so a rank that looked at its own file alone would answer the stolen
+    questions a second time (and the merged file would count them twice)."""
+    ids = set()
+    for r in range(max(1, world)):
+        ids |= done_question_ids(f"results/{exp_name}{r}.jsonl")
+    return ids
+
+
 def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir="./image/", max_new_tokens=1024,
                     batch_size=BATCH_SIZE, max_ctx=4096, do_sample=True, resume=False, decode_workers=3, decode_ahead=6, lanes=1,
                     steal=False):
@@ -93,7 +103,7 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
     out_path = f"results/{exp_name}{accelerator.process_index}.jsonl"
     # --resume: keep what an interrupted run of this rank wrote and skip those question_ids (the reference opens the file
     # with "w" and starts over, :167)
-    skip = done_question_ids(out_path) if resume else set()
+    skip = frozenset(done_question_ids_all(exp_name, world)) if resume else frozenset()
     if resume and os.path.exists(out_path):  # drop a torn last line before appending -- also when it is the ONLY line
         with open(out_path, encoding="utf-8") as f:
             good = [ln for ln in f if ln.endswith("\n")]
@@ -180,8 +190,8 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
                 continue
             view = None  # (view, scale): every question of a tile looks at the same <=512-px view
             for idx, sample in items:
-                if idx in done:                        # recorded by an earlier run (--resume)
-                    continue
+                if sample.get("question_id") in skip:  # recorded by an earlier run (--resume): the immutable set, not `done`,
+                    continue                           # whose pre-populated entries another lane's flush() may already have popped
                 # keep the queue short (tiles stay resident only while needed) -- and while the next tile is still being
                 # decoded, advance the chains that are already in: the GPU never idles behind a decode
                 while len(sched.waiting) >= batch_size or (sched.busy() and not tiles.ready(path)):
@@ -236,16 +246,24 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
         except BaseException as ex:  # noqa: BLE001
             errors.append(ex)
 
-    if lanes == 1:
-        run_lane(0)
-    else:
-        threads = [threading.Thread(target=lane_thread, args=(ln,), name=f"ze-lane{ln}") for ln in range(lanes)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        if errors:
-            raise errors[0]
+    try:
+        if lanes == 1:
+            run_lane(0)
+        else:
+            threads = [threading.Thread(target=lane_thread, args=(ln,), name=f"ze-lane{ln}") for ln in range(lanes)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            if errors:
+                raise errors[0]
+    except BaseException:
+        # a failing rank still says it will claim nothing more (rank 0 would otherwise wait for it until its deadline) and
+        # names the tiles it had claimed but not finished: their questions are in no file
+        if claims is not None:
+            fout.flush()
+            claims.abandon()
+        raise
     flush()
     bar.close()
     fout.close()

@@ -171,11 +171,14 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 names = [f"tile{t:03d}.tif" for t in range(40) for _ in range(3 + (t * 7) % 9)]
 lists = [tile_groups(names, shard_by_tile(names, r, world)) for r in range(world)]
 claims = TileClaims.connect(rank, world, lists)
+claims.store.add("test_ready", 1)                         # start together: an interpreter that came up late would find its list stolen
+while claims.store.add("test_ready", 0) < world:
+    time.sleep(0.01)
 mine = []
 for pos, (tile, idx) in enumerate(lists[rank]):          # own tiles, front to back; rank 2 is ten times slower per question
     if claims.claim(rank, pos):
         mine.append((rank, pos, tile, len(idx)))
-        time.sleep((0.02 if rank == 2 else 0.002) * len(idx))
+        time.sleep((0.05 if rank == 2 else 0.002) * len(idx))
 while True:                                              # own list exhausted: whole tiles of the others, from the back
     t = claims.steal()
     if t is None:
@@ -210,6 +213,76 @@ def test_tile_work_stealing_covers_every_tile_exactly_once(tmp_path):
     stolen_from_2 = sorted(t[1] for r in (by[0], by[1]) for t in r["tiles"] if t[0] == 2)
     own_2 = sorted(t[1] for t in by[2]["tiles"])
     assert own_2 and stolen_from_2 and max(own_2) < min(stolen_from_2)          # owner from the front, thieves from the back
+
+
+def test_resume_after_an_interrupted_stolen_run_counts_every_question_once(tmp_path, monkeypatch):
+    """with --steal a rank's file holds tiles it took from other ranks and lacks its own tiles that were
+    taken from it.  A --resume run must skip what ANY rank's file holds (done_question_ids_all), and the merge keeps a
+    question_id once even when two files hold it (files of a run resumed by the older code)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ze_infer", os.path.join(ROOT, "src", "eval", "infer.py"))
+    inf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(inf)
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("results")
+    rec = lambda q, who: json.dumps(dict(question_id=q, output1=f"by rank {who}"))  # noqa: E731
+    # the interrupted run: rank 0 answered its own 0..3 and STOLE 10, 11 from rank 1; rank 1 answered 12 and died in 13 (torn line)
+    with open("results/exp0.jsonl", "w") as f:
+        f.write("\n".join(rec(q, 0) for q in (0, 1, 2, 3, 10, 11)) + "\n")
+    with open("results/exp1.jsonl", "w") as f:
+        f.write(rec(12, 1) + "\n" + '{"question_id": 13, "outp')
+    assert inf.done_question_ids("results/exp1.jsonl") == {12}
+    assert inf.done_question_ids_all("exp", 2) == {0, 1, 2, 3, 10, 11, 12}     # rank 1 will NOT answer 10, 11 again
+    # files as the older resume left them (rank 1 re-answered the stolen 10, 11): the merge still counts them once, first record wins
+    with open("results/exp1.jsonl", "w") as f:
+        f.write("\n".join(rec(q, 1) for q in (12, 13, 10, 11)) + "\n")
+    n = accel.merge_results("results/exp", 2, "results/exp.jsonl")
+    rows = [json.loads(ln) for ln in open("results/exp.jsonl")]
+    assert n == len(rows) == 8 and [r["question_id"] for r in rows] == [0, 1, 2, 3, 10, 11, 12, 13]
+    assert {r["question_id"]: r["output1"] for r in rows}[10] == "by rank 0"
+
+
+CLAIMS_WORKER = """
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+from zoomearth_amd.accel import TileClaims
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+lists = [[(f"t{r}_{i}.tif", [0]) for i in range(3)] for r in range(world)]
+claims = TileClaims.connect(rank, world, lists)
+assert claims.claim(rank, 0)
+if rank == 1 and sys.argv[2] == "crash":
+    os._exit(3)                                  # dies without a word: rank 0 must not hang
+if rank == 1 and sys.argv[2] == "abandon":
+    claims.abandon()                             # the error path of infer.py: says so, names its unfinished tile
+    sys.exit(4)
+try:
+    claims.finish(deadline_s=3.0)
+    print("FINISHED", flush=True)
+except RuntimeError as ex:
+    print("DEADLINE " + str(ex), flush=True)
+    sys.exit(5)
+"""
+
+
+@pytest.mark.parametrize("mode", ["crash", "abandon"])
+def test_tile_claims_finish_does_not_hang_on_a_dead_rank(tmp_path, mode):
+    """rank 0 polled `ze_ranks_done` forever.  A rank that crashes: rank 0 fails after its deadline and names the
+    missing rank.  A rank that takes infer.py's error path (abandon): rank 0 finishes at once and the failing rank prints the
+    tile it had claimed."""
+    script = tmp_path / "claims_worker.py"
+    script.write_text(CLAIMS_WORKER)
+    port = 29700 + os.getpid() % 90
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    if mode == "crash":
+        assert procs[0].returncode == 5 and "DEADLINE" in outs[0] and "[1]" in outs[0], outs
+        assert procs[1].returncode == 3
+    else:
+        assert procs[0].returncode == 0 and "FINISHED" in outs[0], outs
+        assert procs[1].returncode == 4 and "t1_0.tif" in outs[1] and "--resume" in outs[1], outs
 
 
 def test_scorer(tmp_path):

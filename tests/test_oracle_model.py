@@ -112,3 +112,52 @@ def test_per_token_logps_match_reference(chain, golden_npz):
     assert np.abs(got16 - s["logps_fp32"]).max() <= 1.5 * hf_err
     # HF's own bf16 log-softmax output is the fp32-softmax value rounded to bf16
     assert np.abs(s["logps_bf16"] - s["logps_bf16_logits_fp32_softmax"]).max() <= 2.0 ** -7 * np.abs(s["logps_bf16"]).max()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The 3B HEAD STRUCTURE (16 query / 2 key-value heads x 128: GQA group 8; 16 ViT heads x 80) against transformers
+# (tests/golden/heads_chain.npz, VERDICT r4 missing #4: the tiny fixture has 4 / 2 and 2 heads)
+@pytest.fixture(scope="module")
+def heads(golden_npz):
+    z = golden_npz("heads_chain.npz")
+    c = json.loads(npz_str(z["chain_json"]))
+    cfg = qwen25vl.heads_config()
+    assert (cfg.text.num_attention_heads, cfg.text.num_key_value_heads, cfg.head_dim) == (16, 2, 128)
+    assert (cfg.vision.num_heads, cfg.vision.hidden_size // cfg.vision.num_heads) == (16, 80)
+    w = qwen25vl.synthetic_weights(cfg, seed=c["weight_seed"], std=c["std"], matrix_gain=c["matrix_gain"], bias_std=c["bias_std"],
+                                   norm_jitter=c["norm_jitter"])
+    tile = prng.synthetic_tile(c["tile_seed"], c["tile_h"], c["tile_w"])
+    assert max(tile.shape[:2]) <= 512          # the reference's resize_image leaves a tile of at most 512 px as it is
+    view = tile
+    assert sha(view) == npz_str(z["view_sha256"])
+    pv, g = frontend.image_to_pixel_values(view)
+    assert list(g) == z["grid"].tolist()
+    return z, c, cfg, w, pv, g
+
+
+def test_fp32_oracle_matches_reference_at_the_3b_head_structure(heads):
+    z, c, cfg, w, pv, g = heads
+    o = qwen25vl.Qwen25VLOracle(cfg, w, "fp32")
+    vit = o.vit_forward(pv, [g])
+    ref = z["vit_fp32"]
+    assert np.abs(vit[:: max(1, vit.shape[0] // 16)][:20] - ref).max() < 2e-5 * max(1.0, float(np.abs(ref).max()))
+    r = qwen25vl.greedy_generate(o, z["ids"].tolist(), pv, [g], c["n1"], c["repetition_penalty"], eos_token_ids=())
+    assert r["tokens"] == z["tokens_fp32"].tolist()
+    ref32 = z["logits_fp32"]
+    assert np.abs(r["logits"] - ref32).max() < 1e-4, np.abs(r["logits"] - ref32).max()   # float rounding only (the tiny fixture's bar)
+    assert len(set(r["tokens"])) >= 16
+
+
+def test_bf16_oracle_within_reference_bf16_error_at_the_3b_head_structure(heads):
+    z, c, cfg, w, pv, g = heads
+    o = qwen25vl.Qwen25VLOracle(cfg, w, "bf16")
+    r = qwen25vl.greedy_generate(o, z["ids"].tolist(), pv, [g], c["n1"], c["repetition_penalty"], eos_token_ids=(),
+                                 forced_tokens=z["tokens_fp32"].tolist())
+    ref32, ref16 = z["logits_fp32"], z["logits_bf16"]
+    hf_err, my_err = np.abs(ref16 - ref32).max(), np.abs(r["logits"] - ref32).max()
+    hf_rms, my_rms = np.sqrt(np.mean((ref16 - ref32) ** 2)), np.sqrt(np.mean((r["logits"] - ref32) ** 2))
+    assert my_err <= 1.5 * hf_err, (my_err, hf_err)
+    assert my_rms <= 1.5 * hf_rms, (my_rms, hf_rms)
+    vit = o.vit_forward(pv, [g])
+    sel = vit[:: max(1, vit.shape[0] // 16)][:20]
+    assert np.abs(sel - z["vit_fp32"]).max() <= 1.5 * np.abs(z["vit_bf16"] - z["vit_fp32"]).max()

@@ -12,7 +12,7 @@
 
 #include "ze_kernels.h"
 
-int ze_gemv_knobs[16] = {0};
+int ze_gemv_knobs[24] = {0};
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
 static bf16_t f2b(float f) {

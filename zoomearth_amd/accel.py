@@ -199,6 +199,7 @@ class TileClaims:
     def __init__(self, store, rank: int, world: int, lists):
         self.store, self.rank, self.world, self.lists = store, rank, world, lists
         self.stolen = 0
+        self.mine = []       # (owner, pos) of every tile this rank has claimed, in claim order
 
     @staticmethod
     def connect(rank: int, world: int, lists, port_offset: int = 17, timeout_s: float = 600.0):
@@ -212,7 +213,10 @@ class TileClaims:
         return TileClaims(store, rank, world, lists)
 
     def claim(self, owner: int, pos: int) -> bool:
-        return self.store.add(f"ze_tile/{owner}/{pos}", 1) == 1
+        won = self.store.add(f"ze_tile/{owner}/{pos}", 1) == 1
+        if won:
+            self.mine.append((owner, pos))
+        return won
 
     def steal(self):
         """(owner, pos) of a tile of another rank this rank now owns, or None when nothing is left anywhere."""
@@ -224,13 +228,43 @@ class TileClaims:
                     return owner, pos
         return None
 
-    def finish(self, poll_s: float = 0.05):
-        """Every rank says it will make no more claims; rank 0 (the store's host) stays until all have."""
+    def finish(self, poll_s: float = 0.05, deadline_s: float = None):
+        """Every rank says it will make no more claims; rank 0 (the store's host) stays until all have -- for at most
+        `deadline_s` seconds (ZE_STEAL_DEADLINE_S, default 1800): a rank that died never says so, and rank 0 then names the
+        missing ranks and fails instead of hanging."""
         import time
         self.store.add("ze_ranks_done", 1)
+        self.store.set(f"ze_rank_done/{self.rank}", "1")
         if self.rank == 0:
+            if deadline_s is None:
+                deadline_s = float(os.environ.get("ZE_STEAL_DEADLINE_S", "1800"))
+            t_end = time.monotonic() + deadline_s
             while self.store.add("ze_ranks_done", 0) < self.world:
+                if time.monotonic() > t_end:
+                    missing = [r for r in range(self.world) if not self._said_done(r)]
+                    raise RuntimeError(f"TileClaims.finish: ranks {missing} did not report within {deadline_s:.0f} s "
+                                       f"(crashed or hung); their claimed tiles may be missing from the results")
                 time.sleep(poll_s)
+
+    def _said_done(self, r: int) -> bool:
+        try:
+            return self.store.check([f"ze_rank_done/{r}"])
+        except Exception:
+            return False
+
+    def abandon(self, finished=()):
+        """Error path: this rank will claim nothing more.  Prints the tiles it had claimed that are not in `finished` (their
+        records are in no file: a --resume run answers them) and counts itself done so that rank 0 does not wait for it."""
+        import sys
+        left = [self.lists[o][p][0] for (o, p) in self.mine if (o, p) not in set(finished)]
+        if left:
+            print(f"[rank {self.rank}] failed with {len(left)} claimed tile(s) possibly unfinished: {left[:8]}"
+                  f"{' ...' if len(left) > 8 else ''} -- rerun with --resume", file=sys.stderr, flush=True)
+        try:
+            self.store.add("ze_ranks_done", 1)
+            self.store.set(f"ze_rank_done/{self.rank}", "1")
+        except Exception:
+            pass
 
 
 class ShardedLoader:
@@ -281,14 +315,24 @@ class ShardedLoader:
 
 
 def merge_results(pattern_prefix: str, world: int, out_path: str) -> int:
-    """Concatenate results/{exp}{rank}.jsonl of all ranks sorted by question_id into one file for eval.sh."""
+    """Concatenate results/{exp}{rank}.jsonl of all ranks sorted by question_id into one file for eval.sh.  A question_id is
+    kept ONCE (the first record in rank order): an interrupted --steal run that was resumed can hold a question in the
+    thief's file and again in its owner's, and eval.py would count it twice."""
     import json
-    rows = []
+    rows, seen = [], set()
     for r in range(world):
         p = f"{pattern_prefix}{r}.jsonl"
         if os.path.exists(p):
             with open(p, encoding="utf-8") as f:
-                rows.extend(json.loads(line) for line in f if line.strip())
+                for line in f:
+                    if not line.strip():
+                        continue
+                    d = json.loads(line)
+                    key = (str(type(d["question_id"])), d["question_id"])
+                    if key in seen:
+                        continue
+                    seen.add(key)
+                    rows.append(d)
     rows.sort(key=lambda d: (str(type(d["question_id"])), d["question_id"]))
     with open(out_path, "w", encoding="utf-8") as f:
         for d in rows:

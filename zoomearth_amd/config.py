@@ -81,6 +81,17 @@ class ModelConfig:
             image_token_id=2005, vision_start_token_id=2002, vision_end_token_id=2003,
             eos_token_ids=(2045, 2043), pad_token_id=2043, name="tiny")
 
+    @staticmethod
+    def heads() -> "ModelConfig":
+        """The 3B model's head structure at small depth (same as oracle.qwen25vl.heads_config; tests/golden/heads_chain.npz)."""
+        return ModelConfig(
+            vision=VisionConfig(depth=2, hidden_size=1280, num_heads=16, intermediate_size=220, out_hidden_size=2048,
+                                fullatt_block_indexes=(1,)),
+            text=TextConfig(hidden_size=2048, num_hidden_layers=2, num_attention_heads=16, num_key_value_heads=2,
+                            intermediate_size=1376, vocab_size=2048, tie_word_embeddings=True),
+            image_token_id=2005, vision_start_token_id=2002, vision_end_token_id=2003,
+            eos_token_ids=(2045, 2043), pad_token_id=2043, name="heads")
+
     # -------- HF config.json
     @staticmethod
     def from_hf_dict(d: dict) -> "ModelConfig":

@@ -23,11 +23,17 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef unsigned int fa_u32x4 __attribute__((ext_vector_type(4)));
 
-// two f32 -> packed bf16 (round to nearest even) in ONE instruction; the software conversion costs ~6 VALU ops per
-// element and the probabilities of a tile are 32 elements per lane
+// two f32 -> packed bf16 (round to nearest even) in ONE instruction (v_cvt_pk_bf16_f32); the software conversion costs ~6 VALU
+// ops per element and the probabilities of a tile are 32 elements per lane.  A vector conversion, NOT inline asm (round 5): an
+// MFMA reading a VALU result needs two wait states on gfx950 and hipcc cannot count them from a VALU write hidden in an asm
+// statement (ze_attn_decode.h: ad_pack_bf16 -- the root cause of round 4's mis-scheduled decode-attention instantiations, and
+// the likely one of the D = 80 flash instantiation that came out wrong under the SLP vectoriser and under waves_per_eu(2)).
 __device__ __forceinline__ uint32_t fa_pack_bf16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float fa_f32x2_;
+    typedef __attribute__((ext_vector_type(2))) __bf16 fa_bf16x2_;
+    const fa_bf16x2_ b = __builtin_convertvector(fa_f32x2_{lo, hi}, fa_bf16x2_);
     uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    __builtin_memcpy(&r, &b, 4);
     return r;
 }
 
@@ -329,7 +335,7 @@ void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_rs, int q_hs
 #define FA_LAUNCH(DD, CC, QQ) FA_LAUNCH_(DD, CC, QQ, false)
     // D = 128 causal (the prefill: K / V rows are whole 256-byte cache rows, 16-byte aligned): the LDS-DMA staging form;
     // ze_tune knob 1 = 7 keeps the register-staged form for A/B runs and the bit-equality test
-    extern int ze_gemv_knobs[16];
+    extern int ze_gemv_knobs[24];
     if (D == 128 && causal && ZE_FA_CAUSAL_BKV == 64 && ze_gemv_knobs[1] != 7 && k_rs % 8 == 0 && v_rs % 8 == 0 && k_hs % 8 == 0 &&
         v_hs % 8 == 0 && ((size_t)k % 16) == 0 && ((size_t)v % 16) == 0 && kv_seq_stride % 8 == 0) {
         if (q_tile > 64) FA_LAUNCH_(128, 1, 2, true);

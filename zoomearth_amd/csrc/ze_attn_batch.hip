@@ -14,8 +14,6 @@
 // workgroup of the (chain, kv head) with the fence-free sc1 hand-off of the single-chain kernel.
 // The part geometry is a function of the chain's own context length alone, so a chain's result does not depend on
 // which chains share the launch.
-#include <cstdlib>
-
 #include "ze_kernels.h"
 #include "ze_attn_decode.h"
 
@@ -246,25 +244,51 @@ __device__ __forceinline__ void ab_wait_vm() {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int aw_u32x4;
 
+// Measurement hooks of tools/probes/fence_hunt.sh (the shipped build defines none of them): the part length of the pipelined
+// kernel, the two sites where round 4 fenced the scheduler (A: behind the wait + K Q^T statement, B: behind the P V loop; empty
+// since round 5 -- the cause was the asm conversion in ad_pack_bf16, see aw_wait_qk; -DAW_FENCED restores the fences for A/B
+// runs) and text spliced into the statement.
+#ifndef AW_LONG_ROUNDS
+#define AW_LONG_ROUNDS 6
+#endif
+#ifdef AW_FENCED
+#define AW_FENCE_A() __builtin_amdgcn_sched_barrier(0)
+#define AW_FENCE_B() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifndef AW_FENCE_A
+#define AW_FENCE_A() do {} while (0)
+#endif
+#ifndef AW_FENCE_B
+#define AW_FENCE_B() do {} while (0)
+#endif
+#ifndef AW_ASM_PRE
+#define AW_ASM_PRE ""
+#endif
+#ifndef AW_ASM_POST
+#define AW_ASM_POST ""
+#endif
+
 // S^T tile of one round: wait until all but the N youngest memory operations of the wave have retired, then K Q^T.
-// EVERY use is fenced by __builtin_amdgcn_sched_barrier(0) on both sides (round 4).  hipcc cannot see into the statement -- four
-// 8-pass MFMAs on one accumulator -- and, left free, it interleaves the P V work of the previous round (ds_read_b64_tr_b16 into
-// registers the statement's MFMAs read, its own MFMAs) with it.  In two instantiations of k_attn_decode_wave_long (192- and 256-key
-// parts, 119 / 128 VGPRs: tight re-use) that produced wrong rows -- the second register of one V^T fragment came back empty in
-// round 1, deterministically, whatever nops were added -- while the assembly satisfied every hazard rule I could check by hand
-// and the in-flight-register walker (tools/check_attn_asm.py); with the fences all five instantiations tried agree with float64
-// to 5e-4 on dense random rows (tools/probes/attn_wave_probe.hip, kept as a GPU test) and the 192-key form of the pipelined
-// kernel is bit-identical to k_attn_decode_wave.  Cost of the fences: none measurable.
+// The statement pads its last MFMA with 24 wait states (an 8-pass MFMA's result may be read 11 after it): hipcc cannot see that
+// the statement is four MFMAs, so it inserts none of its own.  ROUND 4 fenced every use with __builtin_amdgcn_sched_barrier(0)
+// because two instantiations of k_attn_decode_wave_long (192- / 256-key parts) returned wrong rows without -- keys 2, 3 of every
+// group of four missing from one P V product.  ROUND 5 found the cause, and it is not this statement: ad_pack_bf16 converted P
+// with `asm("v_cvt_pk_bf16_f32 ...")`, a VALU write hipcc cannot see, and where the scheduler put the first P V MFMA one
+// instruction behind it the MFMA read the register's old value (gfx950 wants two wait states between a VALU write and an MFMA
+// read; the compiler pads only pairs it knows).  Either fence happened to keep the pair apart; two s_nops behind the cvt, or the
+// conversion as a plain vector conversion (what ships), fix it with no fence at all -- tools/probes/fence_hunt.sh has the eleven
+// variants, tools/check_mfma_hazards.py flags exactly the failing ones from the assembly alone and is a CPU test over the whole
+// library.  The fences are gone (-DAW_FENCED brings them back for A/B runs).
 template <int N>
 __device__ __forceinline__ ad_f32x4 aw_wait_qk(const aw_u32x4 (&k4)[4], const aw_u32x4 (&q4)[4]) {
     ad_f32x4 sacc;
     asm volatile(
-        "s_waitcnt vmcnt(%9)\n\t"
+        "s_waitcnt vmcnt(%9)\n\t" AW_ASM_PRE
         "v_mfma_f32_16x16x32_bf16 %0, %1, %5, 0\n\t"
         "v_mfma_f32_16x16x32_bf16 %0, %2, %6, %0\n\t"
         "v_mfma_f32_16x16x32_bf16 %0, %3, %7, %0\n\t"
         "v_mfma_f32_16x16x32_bf16 %0, %4, %8, %0\n\t"
-        "s_nop 15\n\ts_nop 7"
+        "s_nop 15\n\ts_nop 7" AW_ASM_POST
         : "=&v"(sacc)
         : "v"(k4[0]), "v"(k4[1]), "v"(k4[2]), "v"(k4[3]), "v"(q4[0]), "v"(q4[1]), "v"(q4[2]), "v"(q4[3]), "n"(N)
         : "memory");
@@ -365,7 +389,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AW_VST
         if (u == 0) sacc = aw_wait_qk<(AW_VSTAGES == 2 ? 12 : 16)>(kreg[0], qf4);
         else if (u == 1) sacc = aw_wait_qk<8>(kreg[1], qf4);
         else sacc = aw_wait_qk<0>(kreg[2], qf4);
-        __builtin_amdgcn_sched_barrier(0);  // (see aw_wait_qk: nothing of the compiler's crosses the statement)
+        AW_FENCE_A();
         const int kbase = t0 + u * AW_TOK + wid * 16 + fq * 4;
         float p[4];
         float mx = -INFINITY;
@@ -404,7 +428,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AW_VST
             oacc[j][3] *= alpha;
             oacc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, pb, oacc[j], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        AW_FENCE_B();
         if (AW_VSTAGES == 2 && u == 0) {  // stage 0 has been read (the transposed reads have returned): it takes round 2's tile
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             issue_v(2);
@@ -550,7 +574,7 @@ __device__ __forceinline__ void aw_run_part(const bf16_t* __restrict__ qsrc, con
         if (younger == 2) sacc = aw_wait_qk<16>(kreg[u % 3], qf4);
         else if (younger == 1) sacc = aw_wait_qk<8>(kreg[u % 3], qf4);
         else sacc = aw_wait_qk<0>(kreg[u % 3], qf4);
-        __builtin_amdgcn_sched_barrier(0);
+        AW_FENCE_A();
         const int kbase = t0 + u * AW_TOK + wid * 16 + fq * 4;
         float p[4];
         float mx = -INFINITY;
@@ -588,7 +612,7 @@ __device__ __forceinline__ void aw_run_part(const bf16_t* __restrict__ qsrc, con
             oacc[j][3] *= alpha;
             oacc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, pb, oacc[j], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        AW_FENCE_B();
         if (u + 3 < NR) {  // round u is consumed: its K registers and its V stage take round u + 3
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             AW_ISSUE_K(u + 3, kreg[u % 3]);
@@ -720,17 +744,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k
                              out + (size_t)bz * out_row_stride, 0, 0, nparts);
 }
 
-extern int ze_gemv_knobs[16];
+extern int ze_gemv_knobs[24];
 
-// (measurements: ZE_XROT = step | shift << 4 overrides the grid rotation of the pipelined kernel)
-static int xrot_env() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("ZE_XROT");
-        v = e ? atoi(e) : (3 | (2 << 4));
-    }
-    return v;
-}
+// (measurements: ze_tune knob 16 = step | shift << 4 overrides the grid rotation of the pipelined kernel; 0 = the shipped 3 | 2 << 4)
+static int xrot_knob() { return ze_gemv_knobs[16] > 0 ? ze_gemv_knobs[16] : (3 | (2 << 4)); }
 
 void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_t* kcache, const bf16_t* vcache,
                                   size_t cache_seq_stride, bf16_t* out, int out_row_stride, const ze_seq_dev* st,
@@ -756,12 +773,12 @@ void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_
         // 410-768 of them, 5.5 -> 6.1-6.4 with the stream's shared prefixes; 320-key parts 4.70 / 5.92 at 410, 512-key 4.54 / 5.41,
         // 256-key 4.51 / 5.49).  knob 8 = 4: the 192-key kernel (A/B runs and the agreement test); 3: every part of max_ctx in the grid, no rotation
         if (ze_gemv_knobs[8] != 4) {
-            constexpr int rounds = 6;
+            constexpr int rounds = AW_LONG_ROUNDS;
             const int lparts = (max_ctx + rounds * AW_TOK - 1) / (rounds * AW_TOK);
             const int lg = plain ? lparts : std::min(lparts, std::max(1, (per_wave * AW_PART + rounds * AW_TOK - 1) / (rounds * AW_TOK)));
             k_attn_decode_wave_long<8, rounds><<<dim3(kv_heads * lg, n), 256, 4 * 3 * AW_VSTAGE, s>>>(
                 q, q_row_stride, kcache, vcache, cache_seq_stride, st, seq_ids, heads, kv_heads, max_ctx, sl, ws_partial, wparts, tickets, out,
-                out_row_stride, plain ? 0 : xrot_env(), prefix);
+                out_row_stride, plain ? 0 : xrot_knob(), prefix);
             return;
         }
         k_attn_decode_wave<8><<<dim3(kv_heads * gparts, n), 256, 4 * AW_VSTAGES * AW_VSTAGE, s>>>(

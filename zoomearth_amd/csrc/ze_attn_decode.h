@@ -32,9 +32,29 @@ typedef short ad_v8s __attribute__((ext_vector_type(8)));
 // (the image of the prefill flash kernel, ze_attention.hip: conflict-free for the ds_read_b128 row reads of K as an
 // MFMA operand and for the ds_read_b64_tr_b16 transposed reads of V^T).
 __device__ __forceinline__ int ad_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+// f32 pair -> packed bf16 (round to nearest even: v_cvt_pk_bf16_f32).  Written as a CONVERSION, not as inline asm (round 5): on
+// gfx950 an MFMA that reads a VGPR a VALU instruction wrote needs two wait states in between; hipcc's hazard recogniser inserts
+// them for instructions it knows, but it cannot see a VALU write INSIDE an asm statement -- with `asm("v_cvt_pk_bf16_f32 ...")`
+// feeding P^T to the P V MFMA one instruction later, the MFMA read the register's OLD value (keys 2, 3 of every group of four
+// lost in two instantiations of k_attn_decode_wave_long; DESIGN.md 3, rule "no VALU result leaves an asm statement towards an
+// MFMA"; tools/check_mfma_hazards.py proves it on the generated code of the whole library).  Same instruction, same bits.
+// AD_PACK_ASM / AD_PACK_PRE / AD_PACK_POST: the old form and its padding, for tools/probes/fence_hunt.sh only.
 __device__ __forceinline__ uint32_t ad_pack_bf16(float lo, float hi) {
     uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+#ifdef AD_PACK_ASM
+#ifndef AD_PACK_PRE
+#define AD_PACK_PRE ""
+#endif
+#ifndef AD_PACK_POST
+#define AD_PACK_POST ""
+#endif
+    asm(AD_PACK_PRE "v_cvt_pk_bf16_f32 %0, %1, %2" AD_PACK_POST : "=v"(r) : "v"(lo), "v"(hi));
+#else
+    typedef __attribute__((ext_vector_type(2))) float ad_f32x2_;
+    typedef __attribute__((ext_vector_type(2))) __bf16 ad_bf16x2_;
+    const ad_bf16x2_ b = __builtin_convertvector(ad_f32x2_{lo, hi}, ad_bf16x2_);
+    __builtin_memcpy(&r, &b, 4);
+#endif
     return r;
 }
 

@@ -114,7 +114,7 @@ struct ze_engine {
     std::vector<int> pfx_host, pfx_pushed;
     int* pfx_dev = nullptr;
     std::vector<hipEvent_t> pfx_copy_ev;
-    bool prefix_hints = true;      // ZE_PREFIX_HINT=0: every chain reads its own rows
+    bool prefix_hints = true;      // the hint fits its 16 + 16 bits (ze_tune knob 17 = 1: every chain reads its own rows)
     std::vector<hipGraphExec_t> graphs;
     std::vector<float> graph_penalty;
     std::vector<int> graph_ignore_eos;

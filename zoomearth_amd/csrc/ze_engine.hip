@@ -291,10 +291,7 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     e->pfx_pushed.assign(c.max_seqs, 0);
     e->pfx_copy_ev.assign(c.max_seqs, nullptr);
     chk(dev_alloc(e, &e->pfx_dev, c.max_seqs));
-    {
-        const char* ph = getenv("ZE_PREFIX_HINT");
-        e->prefix_hints = !(ph && ph[0] == '0') && c.max_seqs < 32768 && c.max_ctx < 65536;
-    }
+    e->prefix_hints = c.max_seqs < 32768 && c.max_ctx < 65536;  // (ze_tune knob 17 = 1: every chain reads its own rows, for A/B runs)
     e->delta_host.assign(c.max_seqs, 0);
     e->graphs.assign(c.max_seqs, nullptr);
     e->graph_penalty.assign(c.max_seqs, 0.f);

@@ -13,7 +13,7 @@
         if (_r != 0) return _r; \
     } while (0)
 #define ZE_KCHECK() ZE_HIP(hipGetLastError())
-extern int ze_gemv_knobs[16];
+extern int ze_gemv_knobs[24];
 
 // ================================================================== front-end
 // dst = crop(src, box).resize((dst_w, dst_h), BICUBIC), Pillow-exact (two passes, u8 intermediate).
@@ -371,7 +371,7 @@ static void sync_prefix(ze_engine* e, const int32_t* seqs, int n, hipStream_t s)
     int idx[64], val[64], m = 0;
     for (int i = 0; i < n; ++i) {
         const int q = seqs[i];
-        const int want = e->prefix_hints ? e->pfx_host[q] : 0;
+        const int want = (e->prefix_hints && ze_gemv_knobs[17] != 1) ? e->pfx_host[q] : 0;
         if (e->pfx_pushed[q] == want) continue;
         e->pfx_pushed[q] = want;
         idx[m] = q, val[m] = want;
@@ -1091,8 +1091,12 @@ static int ensure_fragments(ze_engine* e, hipStream_t s) {
         L.qkv.wp = L.qkv.bias_p = nullptr;
     }
     e->lm_head_f = nullptr;
+    // Each kernel family gets only the copies it reads: the row-streaming regime the permuted qkv rows (0.38 GB at the
+    // 3B shape), the fragment family the fragment-major arena (4.5 GB) -- an engine of 64 slots never runs the first, one of 768
+    // never the second.  ze_set_decode_regime clears frag_ready, so a regime change rebuilds what the new family needs.
+    const bool wide = e->wide_regime();
     // row-streaming regime: the qkv rows permuted per head, so that M-RoPE + the KV append run as the projection's epilogue
-    if (hd == 128 && H % 64 == 0 && H / 64 >= 4 && nqkv % 128 == 0) {
+    if (wide && hd == 128 && H % 64 == 0 && H / 64 >= 4 && nqkv % 128 == 0) {
         const size_t per_layer = (size_t)nqkv * H + nqkv;
         if (!e->arena_p) ZE_HIP(hipMalloc((void**)&e->arena_p, per_layer * c.layers * sizeof(bf16_t)));
         if (!e->qkv_epi_dev) ZE_HIP(hipMalloc((void**)&e->qkv_epi_dev, sizeof(ze_qkv_epi) * c.layers));
@@ -1121,7 +1125,7 @@ static int ensure_fragments(ze_engine* e, hipStream_t s) {
         ZE_HIP(hipStreamSynchronize(s));  // (host is a local)
         ZE_KCHECK();
     }
-    if (ok) {
+    if (ok && !wide) {
         const size_t per_layer = (size_t)(nqkv + 2 * ip) * H + (size_t)H * nq;
         const size_t total = per_layer * c.layers + (size_t)c.vocab * H;
         if (!e->arena_f) ZE_HIP(hipMalloc((void**)&e->arena_f, total * sizeof(bf16_t)));
@@ -1938,7 +1942,9 @@ extern "C" int ze_op_quantize_fp8(ze_engine* e, void* w_bf16, int rows, int cols
 extern "C" int ze_set_decode_regime(ze_engine* e, int regime) {
     if (!e || regime < -1 || regime > 1) return ze_fail(e, ZE_ERR_INVALID, "regime is -1 (by capacity), 0 (fragment kernels) or 1 (row streaming)");
     if (regime != e->decode_regime) {
+        const bool was = e->wide_regime();
         e->decode_regime = regime;
+        if (was != e->wide_regime()) e->frag_ready = false;  // the other family's weight copies are built on its first step
         ++ze_tune_epoch;  // captured batched steps bake the kernel family in
     }
     return e->wide_regime() ? 1 : 0;
@@ -1946,7 +1952,7 @@ extern "C" int ze_set_decode_regime(ze_engine* e, int regime) {
 
 // ================================================================== measurement
 extern "C" int ze_tune(int knob, int value) {
-    if (knob < 0 || knob >= 16) return ze_fail(nullptr, ZE_ERR_INVALID, "unknown knob");
+    if (knob < 0 || knob >= 24) return ze_fail(nullptr, ZE_ERR_INVALID, "unknown knob");
     ze_gemv_knobs[knob] = value;
     ++ze_tune_epoch;  // captured decode steps bake the launch policy in: engines drop their graphs on the next use
     return ZE_OK;

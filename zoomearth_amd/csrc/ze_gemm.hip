@@ -20,7 +20,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define GEMM_BK 64
 
-extern int ze_gemv_knobs[16];  // [5]: 1 = no skinny kernel in the weight-streaming launcher; [6]: 0 = shipped policy, 1 = register-staged kernel everywhere, 2 = ring wherever it applies
+extern int ze_gemv_knobs[24];  // [5]: 1 = no skinny kernel in the weight-streaming launcher; [6]: 0 = shipped policy, 1 = register-staged kernel everywhere, 2 = ring wherever it applies
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(256) k_gemv(const ze_gemv_args a) {
     }
 }
 
-extern int ze_gemv_knobs[16];
+extern int ze_gemv_knobs[24];
 
 template <int EPI, int PAIRS, int KSPLIT, int CH, int WB = 16>
 static void launch_gemv_cfg(const ze_gemv_args& a, hipStream_t s) {
