@@ -391,6 +391,8 @@ int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters, float* av
  *   14    1: separate arg-max pass in single-chain greedy decode
  *   15    tile family of the row-streaming decode GEMMs (measurements)  16  grid rotation step | shift << 4 of the decode attention
  *   17    1: no shared-prefix hints (every chain reads its own K/V rows: same bits, more HBM traffic)
+ *   18    1: round 4's K loop on the 513 .. 768-row decode tiles (K-steps of 32 in four stages; default: 64 in two; same bits)
+ *   19    4: the tall qkv / o decode tiles on a plain four-stage ring, one barrier per K-step (default: six stages in groups of two)
  * Changing a knob invalidates captured decode graphs (they are re-captured on the next step). */
 int ze_tune(int knob, int value);
 /* Per-phase device time (ms) accumulated by HIP events since the last reset: [0] front-end, [1] ViT,

@@ -507,7 +507,7 @@ __device__ __forceinline__ void ring_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int STAGES, int EPI, int WM = 2, int WN = 2, bool SPREAD = false, bool WIDE_EPI = false, int BK = GEMM_BK>
+template <int BM, int BN, int STAGES, int EPI, int WM = 2, int WN = 2, bool SPREAD = false, bool WIDE_EPI = false, int BK = GEMM_BK, int KPB = 1>
 __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
                                                    int ldw, const bf16_t* __restrict__ bias,
                                                    const bf16_t* __restrict__ R, int ldr, bf16_t* __restrict__ C,
@@ -524,8 +524,12 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
     // (BK = 32 only: REM waves carry one piece more -- 320 x 128 is 28 pieces, 384 x 192 is 36, on eight waves -- and count it
     //  in their own waits; wid is wave-uniform, so the branch costs a scalar compare)
     constexpr int REM = (BM + BN) * BK * 2 / 1024 % (WM * WN);
-    static_assert((REM == 0 || BK == 32) && BM % 16 == 0 && BN % 16 == 0, "a stage's pieces divide evenly among the waves");
-    static_assert(STAGES >= 2 && STAGES <= 8 && (STAGES > 4 ? 6 : 2) * (LPW + (REM ? 1 : 0)) < 64, "ring depth (vmcnt is a 6-bit counter)");
+    // (BK = 64, round 5: the tall decode tiles -- 80 / 96 / 112 / 128 rows x 64 columns on BM / 16 x 2 waves, one 16 x 32 output tile
+    //  each -- have (BM + 64) / 8 pieces on 10 .. 16 waves: the combined piece list [A rows | W rows] is dealt the same way)
+    static_assert((REM == 0 || BK == 32 || !SPREAD) && BM % 16 == 0 && BN % 16 == 0, "a stage's pieces divide evenly among the waves");
+    constexpr bool UNEVEN64 = BK == 64 && ((BM / 8) % (WM * WN) != 0 || (BN / 8) % (WM * WN) != 0);
+    static_assert(!UNEVEN64 || !SPREAD, "the spread refill walks the A and W pieces separately");
+    static_assert(STAGES >= 2 && STAGES <= 8 && (STAGES > 4 ? STAGES - 2 : 2) * (LPW + (REM ? 1 : 0)) < 64, "ring depth (vmcnt is a 6-bit counter)");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
@@ -570,28 +574,113 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
                 ring_issue32_one<BM>(A, lda, bm0, M - 1, W, ldw, bn0, N - 1, k0, img, wid + g * (NT / 64), lane);
             if (REM > 0 && wid < REM)
                 ring_issue32_one<BM>(A, lda, bm0, M - 1, W, ldw, bn0, N - 1, k0, img, wid + LPW * (NT / 64), lane);
+        } else if constexpr (UNEVEN64) {
+            // piece p = rows 8 p .. 8 p + 7 of the image [A rows | W rows] (BM is a multiple of 8: a piece never straddles)
+            auto one = [&](int pc) {
+                if (pc < BM / 8) ring_issue_one(A, lda, bm0, M - 1, k0, img, pc, lane);
+                else ring_issue_one(W, ldw, bn0, N - 1, k0, img + BM * 128, pc - BM / 8, lane);
+            };
+#pragma unroll
+            for (int g = 0; g < LPW; ++g) one(wid + g * (NT / 64));
+            if (REM > 0 && wid < REM) one(wid + LPW * (NT / 64));
         } else {
             ring_issue<BM, NT>(A, lda, bm0, M - 1, k0, img, wid, lane);
             ring_issue<BN, NT>(W, ldw, bn0, N - 1, k0, img + BM * 128, wid, lane);
         }
     };
+    const int fr = lane & 15, fq = lane >> 4;
+    // KPB > 1 (round 5; BK = 64, no spread refill, nk a multiple of KPB -- the launcher checks): KPB K-steps per barrier.  The narrow
+    // projections of a decode step (qkv, o: 16 x 32 outputs per wave) spend a K-step on its fixed chain -- counted wait, barrier,
+    // DMA issue, fragment-read latency -- not on its four MFMAs: 32 K-steps took 14 us of a 16-us launch whatever the tile and
+    // whatever the ring depth (4 / 6 / 8 stages: 16.2 / 18.9 / 18.2 us).  Here the ring moves in GROUPS of KPB stages: one wait, one
+    // barrier and one batch of refill DMAs per group, then the group's 2 x KPB fragment reads and MFMA rows back to back.  Same
+    // MFMAs in the same K order per output element: the same bits.
+    // (Round 5, tried and dropped: a two-phase loop -- waves 0-3 read step k's fragments and request refills while their SIMD partners,
+    // waves 4-7, run the MFMAs of step k - 1, then the roles swap; bit-identical; gate/up on 320 x 192 tiles 62.2 against 63.4 us, on
+    // 384 x 192 tiles 71.3 against 77.9 -- the launch is bound by its LDS-DMA intake, see ze_launch_gemm_wide.  git history has it.)
+    if constexpr (KPB > 1) {
+        static_assert(BK == 64 && !SPREAD && STAGES % KPB == 0 && STAGES / KPB >= 2 && STAGES / KPB <= 4, "groups of K-steps");
+        constexpr int G = STAGES / KPB;                          // groups the ring holds
+        constexpr int GP = KPB * LPW, GPR = KPB * (LPW + 1);     // pieces of a group per wave (waves with the extra piece: GPR)
+        static_assert((G - 2) * GPR < 64, "vmcnt is a 6-bit counter");
+        const int ng = nk / KPB;
+        auto issue_group = [&](int g) {
+#pragma unroll
+            for (int u = 0; u < KPB; ++u) issue(g * KPB + u);
+        };
+#pragma unroll
+        for (int g = 0; g < G - 1; ++g)
+            if (g < ng) issue_group(g);
+        for (int g = 0; g < ng; ++g) {
+            const int ahead = min(G - 2, ng - 1 - g);  // groups still allowed in flight behind group g
+            if (REM > 0 && wid < REM) {
+                if (ahead >= 2) ring_wait<(G > 3 ? 2 : 0) * GPR>();
+                else if (ahead == 1) ring_wait<(G > 2 ? 1 : 0) * GPR>();
+                else ring_wait<0>();
+            } else {
+                if (ahead >= 2) ring_wait<(G > 3 ? 2 : 0) * GP>();
+                else if (ahead == 1) ring_wait<(G > 2 ? 1 : 0) * GP>();
+                else ring_wait<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            if (g + G - 1 < ng) issue_group(g + G - 1);
+#pragma unroll
+            for (int u = 0; u < KPB; ++u) {
+                const uint8_t* imgA = smem + ((g * KPB + u) % STAGES) * STAGE_BYTES;
+                const uint8_t* imgB = imgA + BM * 128;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int chunk = kk * 4 + fq;
+                    bf16x8 fa[TM], fb[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int row = wm0 + i * 16 + fr;
+                        fa[i] = *reinterpret_cast<const bf16x8*>(imgA + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int row = wn0 + j * 16 + fr;
+                        fb[j] = *reinterpret_cast<const bf16x8*>(imgB + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        gemm_finish<BM, BN, EPI, WM, WN, WIDE_EPI>(acc, smem, bias, R, ldr, C, ldc, c_rows, M, N, ksplit, ks, bid, nwg, bm0, bn0, slab, tickets);
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < nk) issue(s);
 
-    const int fr = lane & 15, fq = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         // stages still allowed in flight behind stage kt: min(STAGES - 2, nk - 1 - kt)
         const int ahead = min(STAGES - 2, nk - 1 - kt);
         if constexpr (STAGES > 4) {
-            switch (ahead) {
-                case 6: ring_wait<6 * LPW>(); break;
-                case 5: ring_wait<5 * LPW>(); break;
-                case 4: ring_wait<4 * LPW>(); break;
-                case 3: ring_wait<3 * LPW>(); break;
-                case 2: ring_wait<2 * LPW>(); break;
-                case 1: ring_wait<LPW>(); break;
-                default: ring_wait<0>(); break;
+            if (REM > 0 && wid < REM) {  // (the waves that carry one piece more per stage count it in their own waits)
+                switch (ahead) {
+                    case 6: ring_wait<6 * (LPW + 1)>(); break;
+                    case 5: ring_wait<5 * (LPW + 1)>(); break;
+                    case 4: ring_wait<4 * (LPW + 1)>(); break;
+                    case 3: ring_wait<3 * (LPW + 1)>(); break;
+                    case 2: ring_wait<2 * (LPW + 1)>(); break;
+                    case 1: ring_wait<LPW + 1>(); break;
+                    default: ring_wait<0>(); break;
+                }
+            } else {
+                switch (ahead) {
+                    case 6: ring_wait<6 * LPW>(); break;
+                    case 5: ring_wait<5 * LPW>(); break;
+                    case 4: ring_wait<4 * LPW>(); break;
+                    case 3: ring_wait<3 * LPW>(); break;
+                    case 2: ring_wait<2 * LPW>(); break;
+                    case 1: ring_wait<LPW>(); break;
+                    default: ring_wait<0>(); break;
+                }
             }
         } else if (REM > 0 && wid < REM) {
             if (ahead >= 2) ring_wait<2 * (LPW + 1)>();
@@ -615,15 +704,31 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_ring(const bf16_t* __rest
             const uint8_t* imgB = imgA + BM * 64;
             const int sw = (-(fr >> 2)) & 3;  // (tile and wave origins are multiples of 16 rows: the swizzle term is the lane's)
             bf16x8 fa[TM], fb[TN];
+            // (ablation builds of tools/probes/ring_ablate.sh, never shipped: ZE_RING_ABLATE = 1 no MFMAs, 2 no fragment reads either)
+#if !defined(ZE_RING_ABLATE) || ZE_RING_ABLATE < 2
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(imgA + (wm0 + i * 16 + fr) * 64 + ((fq ^ sw) << 4));
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(imgB + (wn0 + j * 16 + fr) * 64 + ((fq ^ sw) << 4));
+#else
+            (void)imgA; (void)imgB; (void)sw;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = bf16x8{};
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = bf16x8{};
+#endif
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
+#if !defined(ZE_RING_ABLATE)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+#elif ZE_RING_ABLATE == 1
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {  // keep the fragment reads alive without the matrix pipe
+                    acc[i][j][0] += __uint_as_float((unsigned)fa[i][0] ^ (unsigned)fb[j][0]);
+                }
+#endif
                 if (SPREAD && more) {
 #pragma unroll
                     for (int pc = 0; pc < LPW; ++pc)
@@ -1637,7 +1742,7 @@ __global__ void __launch_bounds__(256) k_gemm_skinny(const bf16_t* __restrict__ 
 // The split-K workspace (fp32 slabs + per-tile tickets) belongs to the calling engine and travels with every call
 // (ze_gemm_ws); the launch macros below name its two pointers g_slab / g_tickets.
 // one ring instantiation, every epilogue
-template <int BM, int BN, int ST, int WM, int WN, bool SPR, bool WIDE = false, bool QKV = false, int BK = GEMM_BK>
+template <int BM, int BN, int ST, int WM, int WN, bool SPR, bool WIDE = false, bool QKV = false, int BK = GEMM_BK, int KPB = 1>
 static void launch_ring_variant(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,
                                 const bf16_t* R, int ldr, bf16_t* C, int ldc, const int* c_rows, int M, int N, int K,
                                 hipStream_t s, int ksplit = 1, const ze_gemm_ws& ws = ze_gemm_ws()) {
@@ -1649,11 +1754,11 @@ static void launch_ring_variant(int epi, const bf16_t* A, int lda, const bf16_t*
     do {                                                                                                            \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<BM, BN, ST, E, WM, WN, SPR, WIDE, BK>),  \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<BM, BN, ST, E, WM, WN, SPR, WIDE, BK, KPB>),  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL((k_gemm_ring<BM, BN, ST, E, WM, WN, SPR, WIDE, BK>), dim3(grid), dim3(64 * WM * WN), lds, s, A, \
+        hipLaunchKernelGGL((k_gemm_ring<BM, BN, ST, E, WM, WN, SPR, WIDE, BK, KPB>), dim3(grid), dim3(64 * WM * WN), lds, s, A, \
                            lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, ksplit, g_slab, g_tickets);          \
     } while (0)
     if constexpr (QKV) {   // (the decode step's qkv projection with rope + KV append)
@@ -1678,7 +1783,7 @@ static void launch_ring_variant(int epi, const bf16_t* A, int lda, const bf16_t*
                                  (ldc % 8) == 0 && ((size_t)C % 16) == 0 && ((sw ? N / 2 : N) % 8) == 0 && (!sw || BN % 32 == 0) &&
                                  (epi != ZE_EPI_RESIDUAL || ((ldr % 8) == 0 && ((size_t)R % 16) == 0)) && epi != ZE_EPI_QKV_ROPE;
             if (wide_ok) {
-                launch_ring_variant<BM, BN, ST, WM, WN, SPR, true, false, BK>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, ksplit, ws);
+                launch_ring_variant<BM, BN, ST, WM, WN, SPR, true, false, BK, KPB>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, ksplit, ws);
                 return;
             }
         }
@@ -2045,6 +2150,10 @@ __global__ void __launch_bounds__(64 * WM * WN) k_splitk_reduce(const float* __r
     }
 }
 
+// (Round 5, tried and dropped: a reducer that owns whole rows -- four rows x all N columns per workgroup, coalesced slab reads, the rows
+// through LDS into k_rmsnorm_row's element order -- and also writes the next layer's normalised input.  Bit-identical to the two
+// launches, but M / 4 workgroups are too few to keep the slab reads going: 52.6 us against 48.1 + 3.7 for the pair at 576 rows, 30.7
+// against 21.1 + 3.5 at 128, and the question stream did not move.  DESIGN.md 7f.)
 // the slice count of the weight-streaming split (launch_cfg, stream mode, 64-column tiles): a function of (N, K) alone
 static int stream_ksplit(int N, int K) {
     int ksplit = 1;
@@ -2090,6 +2199,42 @@ void ze_launch_permute_qkv(const bf16_t* W, int ldw, const bf16_t* bias, int n_h
     k_permute_qkv<<<n_heads_total * 128, 256, 0, s>>>(W, ldw, bias, K, Wp, bias_p);
 }
 
+// Tall tiles for the narrow projections of a decode step (qkv, o: N <= 4096, K = hidden) at 385 .. 768 rows (round 5).  These
+// launches are bound by what a CU takes in from L2 (10.5 MB of weights; every workgroup stages its rows of A and of W
+// over the whole K): 64 x 64 tiles are the cheapest tile per output (512 KB staged per 4096 outputs) -- but 7 .. 12 row tiles x 40
+// column tiles are 280 .. 480 workgroups, so 24 .. 224 CUs take in TWO tiles (1 MB) while the rest wait.  A tile of BM x 64 with
+// BM = 80 / 96 / 112 / 128 -- BM / 16 x 2 waves, every wave the same 16 x 32 outputs as on the 64 x 64 tile -- makes the grid ONE
+// round of at most 256 workgroups of (BM + 64) x 4 KB each: 576 KB on the busiest CU instead of 1 MB at 399 rows, 640 KB at 576.
+// K in sequence per output element on every tile: the same bits (test_linear_wide_decode).  false = 64-row tiles already fit one round
+// (or the shape is not a narrow projection): the caller's old rule applies.  knob 13 = 4: off.
+template <bool QKV>
+static bool launch_tall(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R, int ldr, bf16_t* C,
+                        int ldc, int M, int N, int K, hipStream_t s) {
+    const int nct = ze_cdiv(N, 64);
+    if (ze_gemv_knobs[13] == 4 || K % GEMM_BK != 0 || K / GEMM_BK < 4 || M <= 64 || M > 768) return false;
+    if (!QKV && epi != ZE_EPI_NONE && epi != ZE_EPI_RESIDUAL) return false;
+    // one workgroup per CU.  Default: six stages in three groups of two K-steps (one barrier per 128 of K; two groups in flight: 16.0 /
+    // 11.5 us for qkv / o at 399 rows against 16.4 / 12.1 on the plain four-stage ring, knob 19 = 4; eight stages in four groups of two:
+    // level; in two groups of four: 17.8 / 13.6; a plain ring of six or eight stages: 18.9 / 18.2 -- what bounds these launches is what
+    // a CU takes in per microsecond, not the depth of its ring)
+#define ZE_TALL_G(BM_, ST_, KPB_) launch_ring_variant<(BM_), 64, ST_, (BM_) / 16, 2, false, false, QKV, GEMM_BK, KPB_>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s)
+#define ZE_TALL_ST(BM_)                                                        \
+    do {                                                                       \
+        const int nk_ = K / GEMM_BK;                                           \
+        if (ze_gemv_knobs[19] == 4 || nk_ % 2) ZE_TALL_G(BM_, 4, 1);           \
+        else ZE_TALL_G(BM_, 6, 2);                                             \
+    } while (0)
+    if (ze_cdiv(M, 64) * nct <= 256) ZE_TALL_ST(64);
+    else if (ze_cdiv(M, 80) * nct <= 256) ZE_TALL_ST(80);
+    else if (ze_cdiv(M, 96) * nct <= 256) ZE_TALL_ST(96);
+    else if (ze_cdiv(M, 112) * nct <= 256) ZE_TALL_ST(112);
+    else if (ze_cdiv(M, 128) * nct <= 256) ZE_TALL_ST(128);
+    else return false;
+#undef ZE_TALL_ST
+#undef ZE_TALL_G
+    return true;
+}
+
 // The tile follows ze_launch_gemm's choice for these shapes (64 x 64 up to one round of workgroups, 64 x 128 beyond): K in
 // sequence on both, so a chain's bits do not depend on the row count -- and equal the unfused pair of launches.
 void ze_launch_gemm_qkv_rope(const bf16_t* A, int lda, const bf16_t* Wp, int ldw, const bf16_t* bias_p, const ze_qkv_epi* dev_args,
@@ -2097,6 +2242,7 @@ void ze_launch_gemm_qkv_rope(const bf16_t* A, int lda, const bf16_t* Wp, int ldw
     if (M <= 0 || N <= 0) return;
     const long b64 = (long)ze_cdiv(M, 64) * ze_cdiv(N, 64);
     const bf16_t* R = reinterpret_cast<const bf16_t*>(dev_args);
+    if (launch_tall<true>(ZE_EPI_QKV_ROPE, A, lda, Wp, ldw, bias_p, R, 0, C, ldc, M, N, K, s)) return;
     // (two 64-KB workgroups share a CU: up to 512 tiles stay on 64 x 64 -- 16.4 against 20.8 us at 410 rows, 19.9 / 21.0 at 580, 20.9 /
     //  22.7 at 768; knob 13 = 3: 64 x 128 from 257 tiles on, the rule before)
     if (b64 <= (ze_gemv_knobs[13] == 3 ? 256 : 512))
@@ -2154,10 +2300,18 @@ void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int
             // 513 .. 640 / 641 .. 768 rows: 320 x 128 / 384 x 128 tiles with K-steps of 32 (four stages): two row tiles x 16
             // column tiles x 8 slices = 256 workgroups, one round, where five or six row tiles of 128 x 256 are 320 / 384
             // workgroups -- a second round for a quarter / half of the chip.  knob 15 = 7: off
-            if (M > 512 && M <= 640 && ze_gemv_knobs[15] != 7 &&
-                launch_splitk_two<320, 128, 4, true, 4, 2, 32>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
-            if (M > 640 && M <= 768 && ze_gemv_knobs[15] != 7 &&
-                launch_splitk_two<384, 128, 4, true, 4, 2, 32>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
+            // (knob 18, as for gate/up: 0 K-steps of 64 in two stages -- 56.3 -> 53.3 us at 704 rows, level at 576 --, 1 round 4's form)
+            if (M > 512 && M <= 640 && ze_gemv_knobs[15] != 7) {
+                const int f = ze_gemv_knobs[18];
+                if (f == 1 ? launch_splitk_two<320, 128, 4, true, 4, 2, 32>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)
+                           : launch_splitk_two<320, 128, 2, false, 4, 2>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
+            }
+            if (M > 640 && M <= 768 && ze_gemv_knobs[15] != 7) {
+                const int f = ze_gemv_knobs[18];
+                if (f == 1 ? launch_splitk_two<384, 128, 4, true, 4, 2, 32>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)
+                           : launch_splitk_two<384, 128, 2, false, 4, 2>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
+            }
+            // (round 5: 128 x 256 without the spread refill 35.7 against 35.1 us at 399 rows, in two stages 43.8)
             if (M > 256 && launch_splitk_two<128, 256, 3, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
             if (M > 128 && M <= 256 && launch_splitk_two<128, 128, 4, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
             if (M > 64 && M <= 128 && launch_splitk_two<64, 128, 4, false>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
@@ -2186,12 +2340,31 @@ void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int
         // the ring with K-steps of 32 -- four 32-KB stages, two row tiles x 115 column tiles = 230 workgroups in ONE round, 512
         // staged rows per 320 x 192 outputs -- instead of a 512-row and a 128-row weight-streaming pass.  knob 15 = 7: off
         if (epi == ZE_EPI_SWIGLU && M > ze_ring32_from && M <= 640 && v != 7 && v != 4) {
-            launch_ring_variant<320, 192, 4, 4, 2, true, true, false, 32>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s);
+            // (round 5: the two-phase loop -- the waves of a SIMD in opposite phases; knob 18 = 1: the plain loop with the spread refill)
+            // Round 5.  The launch is bound by what its workgroups take in through LDS-DMA -- with the MFMAs AND the fragment reads compiled
+            // out (tools/probes/ring_ablate.sh) it still takes 57.6 of 63.1 us at 576 rows: 230 workgroups x 2 MB = 460 MB at 8 TB/s, the
+            // rate every GEMM of this library stages at -- so neither a two-phase K loop (the waves of a SIMD in opposite phases: -1 us),
+            // nor fragments read a step ahead (0), nor deeper rings changed it.  What did: K-steps of 64 in TWO stages (a DMA piece is
+            // eight whole 128-byte rows instead of sixteen half lines): 63.7 -> 59.4 us at 576 rows, 77.5 -> 69.1 at 768.  Same MFMAs in
+            // the same K order on every form: the same bits.  knob 18: 0 this default, 1 round 4's form (K-steps of 32, four stages,
+            // spread refill).
+            const int f = ze_gemv_knobs[18];
+            if (f == 1) launch_ring_variant<320, 192, 4, 4, 2, true, true, false, 32>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s);
+            else launch_ring_variant<320, 192, 2, 4, 2, false, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s);
             return;
         }
         // 641 .. 768 rows: 384 x 192 tiles the same way (four 36-KB stages, 96 x 96 outputs per wave)
         if (epi == ZE_EPI_SWIGLU && M > 640 && M <= 768 && v != 7 && v != 4) {
-            launch_ring_variant<384, 192, 4, 4, 2, true, true, false, 32>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s);
+            const int f = ze_gemv_knobs[18];
+            if (f == 1) launch_ring_variant<384, 192, 4, 4, 2, true, true, false, 32>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s);
+            else launch_ring_variant<384, 192, 2, 4, 2, false, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s);
+            return;
+        }
+        // 385 .. 512 rows (round 5): 256 x 192 tiles on K-steps of 64 in two stages WITHOUT the spread refill -- two row tiles x 115
+        // column tiles = 230 workgroups staging 1.8 MB each, against 2.4 MB for the 512 x 96 weight-streaming tile (round 4 had tried
+        // this tile with the spread refill: 61.9 against 57.4 us at 440 rows).  knob 15 = 8: the weight-streaming tile
+        if (epi == ZE_EPI_SWIGLU && M > 384 && M <= 512 && v != 8 && v != 4 && v != 7) {
+            launch_ring_variant<256, 192, 2, 4, 2, false, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s);
             return;
         }
         const int blk = (epi == ZE_EPI_SWIGLU && K / GEMM_BK == 32 && v != 5) ? 512 : 256;
@@ -2205,6 +2378,7 @@ void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int
             // output element: the same bits.  knob 15 = 4: the weight-streaming tile there too
             if (mb > 256 && mb <= 384 && epi == ZE_EPI_SWIGLU && v != 4 && r0 == 0 && M <= 384) {
                 // (the refill DMAs spread between the rows of MFMAs: 40.6 against 41.6 us at 344 rows)
+                // (round 5: without the spread refill 41.4 us, in two stages 46.9, against 40.3 as is at 344 rows)
                 launch_ring_variant<192, 192, 3, 4, 2, true, true>(epi, Ab, lda, W, ldw, bias, R, ldr, Cb, ldc, nullptr, mb, N, K, s);
                 continue;
             }
@@ -2218,6 +2392,7 @@ void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int
             if (!done && r0 > 0) done = true, ze_launch_gemm(epi, Ab, lda, W, ldw, bias, R, ldr, Cb, ldc, nullptr, mb, N, K, s);
         }
     }
+    if (!done && N <= 4096 && launch_tall<false>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, s)) return;
     if (!done) ze_launch_gemm(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s);
 }
 
