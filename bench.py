@@ -43,10 +43,10 @@ L_TEXT_A, L_TEXT_B, N1, N2, PENALTY = 21, 455, 192, 96, 1.05  # 21 + 455 = 476 t
 HBM_PEAK_GBS = 8000.0
 BATCH_KERNELS = {0: "qkv", 1: "o_proj", 2: "gate_up", 3: "down", 4: "lm_head", 5: "attention", 6: "rmsnorm", 7: "rope_kv"}
 BATCH_KERNEL_NAMES_WIDE = {
-    0: "k_gemm_ring<64,64,QKV_ROPE> (row-streaming decode qkv projection + M-RoPE + KV append in one launch, rows = chains)",
-    1: "k_gemm_ring (row-streaming decode o projection + residual)",
-    2: "k_gemm_ring<192,192,SWIGLU> at 257-384 chains, k_gemm_wstream<BM,96,SWIGLU> otherwise (row-streaming decode gate/up projection)",
-    3: "k_gemm_ring split-K x 8 + k_splitk_reduce (row-streaming decode down projection; 192 x 128 tiles at 257-384 chains)",
+    0: "k_gemm_ring<64..128,64,QKV_ROPE> (row-streaming decode qkv projection + M-RoPE + KV append in one launch, rows = chains; the row tile follows the row count: one round of workgroups)",
+    1: "k_gemm_ring<64..128,64,RESIDUAL> (row-streaming decode o projection + residual)",
+    2: "k_gemm_ring<192,192 / 256,192 / 320,192 / 384,192,SWIGLU> by row count above 256 chains, k_gemm_wstream<BM,96,SWIGLU> below (row-streaming decode gate/up projection)",
+    3: "k_gemm_ring split-K x 8 + k_splitk_reduce (row-streaming decode down projection; 192 x 128 / 128 x 256 / 320 x 128 / 384 x 128 tiles by row count)",
     4: "k_gemm_wstream / k_gemm_ring<256,256,F32> (row-streaming decode lm_head)",
     5: "k_attn_decode_wave_long<8, 6> (batched decode attention: 384-key parts, every wave streams 16 keys of each 64-key round -- K rows straight into MFMA registers, V rows through its own LDS stages -- three rounds in flight until the part ends)",
 }
@@ -229,6 +229,47 @@ def question_table(n_questions: int, seed: int = 0):
     return [t for t, c in enumerate(counts) for _ in range(c)]
 
 
+class TileFeeder:
+    """Tile uploads INSIDE the timed region (VERDICT r4 #3 / SURVEY 8d: the metric starts at "tile decoded in host RAM"): a lane's
+    tiles go pinned host memory -> HBM (ze_tile_upload) on a stream of the feeder's own, `depth` tiles ahead of their first
+    question, so the 75-MB copies run beside the lane's compute; tile(t)() makes the caller's stream wait for tile t's copy and
+    hands the DeviceImage over (the same object for every question of the tile).  What image.TilePrefetcher does for
+    src/eval/infer.py behind a file decode; here the "decoded" tiles are the synthetic pool."""
+
+    def __init__(self, engine, host_pool, order, depth: int = 3):
+        import torch
+        self.e, self.pool, self.order, self.depth = engine, host_pool, list(order), depth
+        self.pos = {t: i for i, t in enumerate(self.order)}
+        self.stream = torch.cuda.Stream(device=engine.device)
+        self.img, self.ev, self.timed, self.next = {}, {}, [], 0
+
+    def _kick(self, upto: int) -> None:
+        import torch
+        from zoomearth_amd.image import DeviceImage
+        while self.next < len(self.order) and self.next <= upto:
+            t = self.order[self.next]
+            with torch.cuda.stream(self.stream):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                d = self.e.tile_upload(self.pool[t % len(self.pool)] if isinstance(t, int) else self.pool[t[1] % len(self.pool)])
+                b.record()
+            self.img[t], self.ev[t] = DeviceImage(d, self.e), b
+            self.timed.append((a, b))
+            self.next += 1
+
+    def tile(self, t):
+        def get():
+            import torch
+            self._kick(self.pos[t] + self.depth)
+            torch.cuda.current_stream(self.e.device).wait_event(self.ev[t])
+            return self.img[t]
+        return get
+
+    def upload_ms(self):
+        """(total device ms of the copies, number of tiles) -- after the run"""
+        return sum(a.elapsed_time(b) for a, b in self.timed), len(self.timed)
+
+
 def run_stream(engine, table, q0: int, slots: int, stats=None, use_graph=None):
     """The questions `table` = [(question number offset, tile DeviceImage, view key)] through the continuous-batching
     scheduler and the host code of src/eval/infer.py (hostloop: views, crops, prompts); the "parsed" box is scripted,
@@ -246,6 +287,12 @@ def run_stream(engine, table, q0: int, slots: int, stats=None, use_graph=None):
     views = {}
     for b, tile, vkey in table:
         q = q0 + b
+        # (as src/eval/infer.py: the queue stays short -- tiles are uploaded shortly before their first question, while the chains
+        #  already in advance -- instead of every question of the run being submitted before the first step)
+        while len(sched.waiting) >= slots:
+            sched.step()
+        if callable(tile):
+            tile = tile()          # TileFeeder: the upload was requested tiles ahead on a stream of its own
         if vkey not in views:
             views[vkey] = H.resize_image(tile)
         n1, n2 = ragged_lengths(q)
@@ -267,7 +314,7 @@ def run_stream(engine, table, q0: int, slots: int, stats=None, use_graph=None):
     return done
 
 
-def run_stream_lanes(engines, table, q0: int, slots: int, stats=None, use_graph=None):
+def run_stream_lanes(engines, table, q0: int, slots: int, stats=None, use_graph=None, host_pool=None):
     """The same stream on several LANES of one GPU: every lane is an engine of its own (weights, KV cache, workspaces) with
     its own scheduler, host thread and HIP stream; tiles are dealt to the lanes whole (a tile's questions share its view and
     its prompt prefix).  While one lane is in a prefill / ViT round (matrix-bound) the other one decodes (bandwidth- and
@@ -276,24 +323,43 @@ def run_stream_lanes(engines, table, q0: int, slots: int, stats=None, use_graph=
 
     import torch
     from zoomearth_amd.image import DeviceImage
-    if len(engines) == 1:
-        return run_stream(engines[0], table, q0, slots, stats, use_graph)
     lane_of, parts = {}, [[] for _ in engines]
     for b, tile, vkey in table:
         ln = lane_of.setdefault(vkey, len(lane_of) % len(engines))
         parts[ln].append((b, tile, vkey))
     outs, errs, sts = [None] * len(engines), [], [dict() for _ in engines]
+    feeders = [None] * len(engines)
 
-    def work(ln):
-        try:
-            e = engines[ln]
-            mine, own = [], {}
+    def lane_table(ln):
+        """host_pool given: `tile` entries are tile ids, uploaded by the lane's TileFeeder as the stream reaches them."""
+        e = engines[ln]
+        if host_pool is None:
+            own, mine = {}, []
             for b, tile, vkey in parts[ln]:  # the lane's engine runs the tile's front-end launches
                 if vkey not in own:
                     own[vkey] = tile if tile.engine is e else DeviceImage(tile.base, e)
                 mine.append((b, own[vkey], vkey))
+            return mine
+        order = []
+        for _, tile, _ in parts[ln]:
+            if not order or order[-1] != tile:
+                if tile not in order:
+                    order.append(tile)
+        feeders[ln] = TileFeeder(e, host_pool, order)
+        return [(b, feeders[ln].tile(tile), vkey) for b, tile, vkey in parts[ln]]
+
+    if len(engines) == 1:
+        done = run_stream(engines[0], lane_table(0), q0, slots, stats, use_graph)
+        if stats is not None and feeders[0] is not None:
+            torch.cuda.synchronize()
+            stats["tile_upload_ms_total"], stats["tiles_uploaded"] = feeders[0].upload_ms()
+        return done
+
+    def work(ln):
+        try:
+            e = engines[ln]
             with torch.cuda.stream(torch.cuda.Stream(device=e.device)):
-                outs[ln] = run_stream(e, mine, q0, slots, sts[ln], use_graph)
+                outs[ln] = run_stream(e, lane_table(ln), q0, slots, sts[ln], use_graph)
                 torch.cuda.current_stream().synchronize()
         except BaseException as ex:  # noqa: BLE001
             errs.append(ex)
@@ -315,6 +381,10 @@ def run_stream_lanes(engines, table, q0: int, slots: int, stats=None, use_graph=
                     stats[k] = stats.get(k, 0) + v
         stats["lens"] = [done[q0 + b] for b, _, _ in table]
         stats["lanes"] = len(engines)
+        if any(f is not None for f in feeders):
+            torch.cuda.synchronize()
+            ups = [f.upload_ms() for f in feeders if f is not None]
+            stats["tile_upload_ms_total"], stats["tiles_uploaded"] = sum(u[0] for u in ups), sum(u[1] for u in ups)
     return done
 
 
@@ -724,21 +794,30 @@ def main():
         mine = shard_by_tile([f"tile{t:05d}.tif" for t in tile_of], rank, world)
         warm_tile_of = question_table(args.warmup * Q_STEP, seed=2)
         my_tiles = sorted({tile_of[i] for i in mine})
-        dev = {t: DeviceImage(upload(t), e) for t in my_tiles}
-        warm_dev = {t: dev[my_tiles[t % len(my_tiles)]] for t in set(warm_tile_of)} if my_tiles else {}
-        table = [(i, dev[tile_of[i]], tile_of[i]) for i in mine]
-        warm_table = [(i, warm_dev[t], ("w", t)) for i, t in enumerate(warm_tile_of)]
+        # Round 5: the tiles are NOT resident when the timed region starts.  Every lane uploads its tiles itself, pinned host pool ->
+        # HBM on a stream of its own, three tiles ahead of their first question (TileFeeder): `value` includes the uploads, as
+        # SURVEY 8d's metric does ("tile decoded in host RAM -> answer token ids").  ZE_BENCH_RESIDENT_TILES=1: round 4's form.
+        resident = os.environ.get("ZE_BENCH_RESIDENT_TILES") == "1"
+        if resident:
+            dev = {t: DeviceImage(upload(t), e) for t in my_tiles}
+            table = [(i, dev[tile_of[i]], tile_of[i]) for i in mine]
+        else:
+            table = [(i, tile_of[i], tile_of[i]) for i in mine]
+        warm_table = [(i, ("w", t), ("w", t)) for i, t in enumerate(warm_tile_of)]
         if warm_table:
-            run_stream_lanes(engines, warm_table, 9_000_000 + rank * 100_000, SLOTS, use_graph=sched_graph)
+            run_stream_lanes(engines, warm_table, 9_000_000 + rank * 100_000, SLOTS, use_graph=sched_graph, host_pool=host_pool)
         for en in engines:
             en.phase_timers(enable=True, reset=True)
         barrier()
         t0 = time.perf_counter()
-        run_stream_lanes(engines, table, 1_000_000, SLOTS, bstats, use_graph=sched_graph)
+        run_stream_lanes(engines, table, 1_000_000, SLOTS, bstats, use_graph=sched_graph, host_pool=None if resident else host_pool)
         torch.cuda.synchronize()
         my_dt = time.perf_counter() - t0
         barrier()
         dt = time.perf_counter() - t0
+        if not resident:  # (the annexes below look at one resident tile)
+            upload_stats["n"], upload_stats["s"] = int(bstats.pop("tiles_uploaded", 0)), bstats.pop("tile_upload_ms_total", 0.0) / 1000.0
+            dev = {t: DeviceImage(e.tile_upload(host_pool[t % n_pool]), e) for t in my_tiles[:6]}
         n_questions = n_total
         lens_all = bstats.pop("lens")
         lens = (int(np.mean([l[0] for l in lens_all])), int(np.mean([l[2] for l in lens_all])),
@@ -808,7 +887,10 @@ def main():
         layer_us = sum(per_step.values())
         traffic, traffic_src = committed_traffic("stream" if wide else "batch64", BATCH_KERNELS[dom], r["bytes"])
         obj = {"bound": "hbm", "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "avg_us": r["us"],
+               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+               # what crosses the HBM interface (the PMC traffic, Infinity-Cache hits included) per second against the peak: below
+               # `frac` where chains share rows, above it where a kernel re-reads
+               "hbm_interface_frac": (traffic / (r["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None, "avg_us": r["us"],
                "bytes_per_launch": r["bytes"], "chains": n, "layer_us": round(layer_us, 1),
                "step_kernels": {k: {"us": v["us"], "GBps": v["GBps"]} for k, v in rows.items()}}
         if shared and BATCH_KERNELS[dom] == "attention" and hasattr(e, "seq_set_prefix_hint"):
@@ -827,7 +909,9 @@ def main():
                 t2, t2_src = committed_traffic("stream_shared", "attention", by2)
                 obj["independent_chains"] = {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "avg_us": r["us"], "traffic": traffic,
                                              "traffic_source": traffic_src}
+                obj["independent_chains"]["hbm_interface_frac"] = obj.get("hbm_interface_frac")
                 obj.update(achieved=ach2, frac=ach2 / HBM_PEAK_GBS, avg_us=round(u2, 2), traffic=t2, traffic_source=t2_src,
+                           hbm_interface_frac=(t2 / (u2 * 1e-6) / 1e9 / HBM_PEAK_GBS) if t2 else None,
                            layer_us=round(layer_us - r["us"] + u2, 1),
                            sharing=(f"{hinted} of the {n} chains read their first {prows} rows (system turn + the view's image tokens) from the "
                                     f"cache of the first chain of their tile ({group} chains per tile, as the stream's 10.5), "
@@ -980,6 +1064,46 @@ def main():
         except Exception:
             return None, None
 
+    def top_kernel_by_gpu_time():
+        """the line's `roofline` names the dominant kernel of the DECODE STEP; the stream's largest consumer of GPU time
+        is another one.  Its name and share come from the latest committed rocprofv3 --kernel-trace --stats summary of this very
+        command (profiles/rNN_stream_kernel_stats.csv: a profiler cannot run inside this process); its own roofline fraction is
+        measured here, alone on the GPU, at the shape the stream runs it."""
+        import csv
+        import glob
+        import re as _re
+        best = None
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_stream_kernel_stats.csv"))):
+            m = _re.match(r"r(\d+)_stream_kernel_stats", os.path.basename(f))
+            if m and (best is None or int(m.group(1)) >= best[0]):
+                best = (int(m.group(1)), f)
+        if best is None:
+            return None
+        rows = [r for r in csv.DictReader(open(best[1])) if r.get("source") == "kernel_stats" and r.get("pct_time")]
+        if not rows:
+            return None
+        top = max(rows, key=lambda r: float(r["pct_time"]))
+        obj = {"kernel": top["kernel"].split("(")[0], "share_of_gpu_time": round(float(top["pct_time"]) / 100.0, 4),
+               "mean_us_in_stream": round(float(top["mean"]) / 1000.0, 1), "share_source": "profiles/" + os.path.basename(best[1])}
+        if "k_gemm_p8<3" in top["kernel"]:  # the prefill / ViT gate-up (SwiGLU epilogue) on the eight-phase 256 x 256 tiles
+            m_rows, n_cols, k_dim = 16 * (L_TEXT_A + 2 + 324 + L_TEXT_B), 2 * cfg.text.intermediate_size, cfg.text.hidden_size
+            a = (torch.randn(m_rows, k_dim, device="cuda") * 0.5).to(torch.bfloat16)
+            w = (torch.randn(n_cols, k_dim, device="cuda") * 0.05).to(torch.bfloat16)
+            for _ in range(2):
+                e.op_linear(a, w, act=4)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(6):
+                e.op_linear(a, w, act=4)
+            ev1.record()
+            torch.cuda.synchronize()
+            us = ev0.elapsed_time(ev1) * 1000.0 / 6
+            tf = 2.0 * m_rows * n_cols * k_dim / (us * 1e-6) / 1e12
+            obj.update(bound="mfma", isolated_us=round(us, 1), achieved_TFLOPs=round(tf, 1), peak_TFLOPs=2500.0, frac=tf / 2500.0,
+                       shape=f"the 16-chain prefill pass: {m_rows} rows x {n_cols} (gate/up interleaved) x {k_dim}, SwiGLU epilogue, random operands")
+            del a, w
+        return obj
+
     def configs1_object(steps, warmup):
         """BASELINE configs[1]: one chain, batch 1 -- `steps` questions through the single-chain path (GEMV decode under a
         captured hipGraph), with the roofline of ITS dominant kernel and the per-phase fractions"""
@@ -1071,9 +1195,13 @@ def main():
                          "filled_own_weights": [bool(r[2]) for r in per_rank], "dist_backend": backend if use_dist else None,
                          "imbalance": round(max(r[1] for r in per_rank) / max(1e-9, float(np.mean([r[1] for r in per_rank]))), 4)},
             "tile_upload_ms": round(1000.0 * upload_stats["s"] / n_up, 3),
-            "tile_upload_note": (f"one {args.tile}x{args.tile}x3 u8 tile, pinned host memory -> HBM (ze_tile_upload), per TILE, "
-                                 f"{upload_stats['n']} tiles uploaded on this rank outside the timed region (tiles are resident when "
-                                 "it starts)"),
+            "tile_upload_note": ((f"one {args.tile}x{args.tile}x3 u8 tile, pinned host memory -> HBM (ze_tile_upload), device time per TILE; "
+                                  f"{upload_stats['n']} tiles uploaded on this rank INSIDE the timed region, each by its lane three tiles ahead "
+                                  "of its first question on a stream of its own (TileFeeder): `value` includes them")
+                                 if stream and os.environ.get("ZE_BENCH_RESIDENT_TILES") != "1" else
+                                 (f"one {args.tile}x{args.tile}x3 u8 tile, pinned host memory -> HBM (ze_tile_upload), per TILE, "
+                                  f"{upload_stats['n']} tiles uploaded on this rank outside the timed region (tiles are resident when "
+                                  "it starts)")),
             "phase_ms_per_question": {k: round(v / max(1, len(mine)), 3) for k, v in phases.items()},
         }
         if stream:
@@ -1094,6 +1222,10 @@ def main():
                     line["roofline_phases"] = stream_rooflines(st, line["roofline"], live, max(1, len(mine)), my_dt)
                 except Exception as ex:  # the line must not die on its annex
                     line["roofline_phases"] = {"error": f"{type(ex).__name__}: {ex}"}
+                try:
+                    line["roofline"]["top_kernel_by_gpu_time"] = top_kernel_by_gpu_time()
+                except Exception as ex:
+                    line["roofline"]["top_kernel_by_gpu_time"] = {"error": f"{type(ex).__name__}: {ex}"}
         if args.model == "3b" and not args.fp8 and not stream:
             if B == 1:
                 pm = line["phase_ms_per_question"]

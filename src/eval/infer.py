@@ -150,6 +150,9 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
         lists = [tile_groups(names_all, shard_by_tile(names_all, r, world)) for r in range(world)]
         assert [n for n, _ in lists[accelerator.process_index]] == [n for n, _ in groups], "the loader's order is the LPT list's"
         claims = TileClaims.connect(accelerator.process_index, world, lists)
+    # test hook: ZE_TEST_SLOW_RANK="<rank>:<seconds>" makes that rank pause before every tile of its own list (tests/test_gpu_infer_e2e.py)
+    slow = os.environ.get("ZE_TEST_SLOW_RANK", "")
+    slow_s = float(slow.split(":")[1]) if slow and int(slow.split(":")[0]) == accelerator.process_index else 0.0
     bar = tqdm(total=len(samples), desc="Evaluating")
 
     def flush():  # records leave in the rank's dataset order, whatever order (and on whatever lane) the chains finish
@@ -183,6 +186,9 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
 
         for g, name, items in todo:
             path = tile_path(name)
+            if claims is not None and slow_s > 0:
+                import time
+                time.sleep(slow_s)                     # (test hook ZE_TEST_SLOW_RANK: a straggler for the stealing tests)
             if claims is not None and not claims.claim(accelerator.process_index, g):
                 tiles.skip(path)                       # another rank took this tile off the back of the list: its file has it
                 for idx, sample in items:
@@ -283,6 +289,8 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
             stats[k] = stats.get(k, 0) + v
     stats["lanes"] = lanes
     stats["stolen_tiles"] = claims.stolen if claims is not None else 0
+    if claims is not None:
+        print(f"[rank {accelerator.process_index}] tiles run: {len(claims.mine)} ({claims.stolen} of them taken from other ranks' lists)", flush=True)
     return stats
 
 

@@ -66,7 +66,12 @@ def workdir_wide(tmp_path_factory):
     return build_workdir(tmp_path_factory.mktemp("lrsgro_wide"), 90)
 
 
-def build_workdir(d, n_questions):
+@pytest.fixture(scope="module")
+def workdir_tiles(tmp_path_factory):
+    return build_workdir(tmp_path_factory.mktemp("lrsgro_tiles"), 48, n_tiles=16)
+
+
+def build_workdir(d, n_questions, n_tiles=3):
     from datasets import Dataset
     from PIL import Image
     ck = d / "ckpt"
@@ -86,11 +91,14 @@ def build_workdir(d, n_questions):
     write_tokenizer(str(ck))
     os.makedirs(d / "image")
     sizes = [(700, 640), (900, 520), (300, 280)]  # the last one is smaller than the 512-px view: no downscale
-    for t, (w, h) in enumerate(sizes):
+    for t in range(n_tiles):
+        w, h = sizes[t % 3]
         Image.fromarray(prng.synthetic_tile(300 + t, h, w)).save(d / "image" / f"tile{t}.png")
     rows = []
     for q in range(n_questions):
         t = (0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 0)[q % 11]  # grouped by tile, with one straggler at the end
+        if n_tiles != 3:
+            t = q * n_tiles // n_questions             # (many tiles: the same number of questions each, in tile order)
         rows.append({"question": " ".join(word(int(v)) for v in prng.uniform_ints(500 + q, 4 + q % 3, 0, 1999)),
                      "image_name": f"some/dir/tile{t}.png", "question_id": 1000 + q, "ground_truth": word(3 * q),
                      "category": "cat%d" % (q % 2), "type": ("count", "object", "relation")[q % 3],
@@ -277,3 +285,43 @@ def test_infer_with_more_than_64_chains(workdir_wide):
     same = sum(1 for x, y in zip(a, n) if x == y)
     print(f"96 chains vs 8 chains: {same} of {len(a)} records identical")
     assert same >= len(a) // 2
+
+
+def test_four_concurrent_ranks_with_a_straggler_steal_whole_tiles(workdir_tiles):
+    """more than two ranks had never run anywhere.  Four ranks AT ONCE through the entry point (gloo on this box's one
+    GPU), 48 questions about 16 tiles, weights by broadcast, tile-level work stealing on -- and rank 3 a straggler (it pauses
+    before every tile of its list: ZE_TEST_SLOW_RANK).  Every question is answered exactly once, a tile never splits, the fast
+    ranks take tiles off the straggler's list, and the merged file equals the single-rank run."""
+    import socket
+    d, rows = workdir_tiles
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in range(4):
+        cmd = [sys.executable, "src/infer.py", "--model_name", "ckpt", "--exp_name", "st4_", "--max_new_tokens", "10", "--max_ctx", "2048",
+               "--batch_size", "4", "--steal"]
+        env = dict(os.environ, PYTHONPATH=ROOT, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="4", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), ZE_DIST_BACKEND="gloo", ZE_TEST_SLOW_RANK="3:4.0")
+        procs.append(subprocess.Popen(cmd, cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=1200) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-2000:] + se[-4000:]
+    assert "weights broadcast to 4 ranks" in outs[0][0]
+    stolen = []
+    for so, _ in outs:
+        ln = next(x for x in so.splitlines() if "tiles run:" in x)
+        stolen.append(int(ln.split("(")[1].split()[0]))
+    assert stolen[3] == 0 and sum(stolen[:3]) >= 1, stolen          # the straggler is relieved, and never steals itself
+    from zoomearth_amd.accel import merge_results
+    n = merge_results(str(d / "results" / "st4_"), 4, str(d / "results" / "st4_merged.jsonl"))
+    parts = [load(d / "results" / f"st4_{r}.jsonl") for r in range(4)]
+    assert n == len(rows) == sum(len(p) for p in parts)
+    ids = [r["question_id"] for p in parts for r in p]
+    assert len(ids) == len(set(ids))                                    # every question exactly once
+    tiles = [{r["image"] for r in p} for p in parts]
+    assert all(not (tiles[a] & tiles[b]) for a in range(4) for b in range(a + 1, 4))   # a tile never splits
+    run([sys.executable, "src/infer.py", "--model_name", "ckpt", "--exp_name", "st4one_", "--max_new_tokens", "10", "--max_ctx", "2048",
+         "--batch_size", "4"], d)
+    merged, single = load(d / "results" / "st4_merged.jsonl"), load(d / "results" / "st4one_0.jsonl")
+    assert merged == sorted(single, key=lambda r: r["question_id"])

@@ -150,13 +150,17 @@ dist.destroy_process_group()
 """
 
 
-def test_two_process_gloo_sharding_and_broadcast(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_two_process_gloo_sharding_and_broadcast(tmp_path, world):
+    """(world = 8, round 5: the eight-rank shape -- seven receivers of the plain broadcast, the scatter + all-gather form with seven
+    real peers, the tile sharding over eight ranks -- had never executed; here on CPU over gloo.)"""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    port = 29600 + os.getpid() % 200
+    port = 29600 + os.getpid() % 200 + (world == 8) * 211
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs

@@ -897,7 +897,7 @@ template <int EPI, bool WIDE = false>
 __global__ void __launch_bounds__(512) k_gemm_p8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
                                                  const bf16_t* __restrict__ bias, const bf16_t* __restrict__ R, int ldr,
                                                  bf16_t* __restrict__ C, int ldc, const int* __restrict__ c_rows, int M, int N,
-                                                 int K) {
+                                                 int K, int blk) {
     constexpr int BM = 256, BN = 256, HALF = 128 * 128, BUF = 4 * HALF;  // buffer = [A-half 0][A-half 1][W-half 0][W-half 1]
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
@@ -914,10 +914,35 @@ __global__ void __launch_bounds__(512) k_gemm_p8(const bf16_t* __restrict__ A, i
     // that order: gridDim.x is a multiple of 8, so a workgroup's tiles keep its XCD label), and the first seven half-tiles of
     // its NEXT tile are requested before the epilogue of the current one -- the ~2 us a tile's prologue waits for its first
     // K-tile pass behind the stores (K = 2048: 32 K-tiles of ~1.9 us per tile; K = 1280, the ViT: 20).
+    // BLOCKED WALK (round 5).  The remap gives an XCD a contiguous range of the launch order, and that order ran DOWN A COLUMN of
+    // tiles: the 32 workgroups an XCD runs at a time then share ONE W tile and touch 32 different A tiles -- and for every one of its
+    // columns the XCD pulls ALL of A through the fabric again (its L2 holds 4 MB; the 16-chain prefill's gate/up: 10.75 columns x 52 MB
+    // per XCD = 4.5 GB per launch from the Infinity Cache, which serves ~7 TB/s against ~20 for L2 hits: tools/probes/ingest_probe.hip;
+    // the down projection: every XCD reads the whole 288-MB A -- from HBM, it does not fit the Infinity Cache).  With blk = R << 8 | C
+    // the order runs through blocks of R row tiles x C column tiles (panels of C columns, row blocks of R inside a panel, down a column
+    // inside a block): 32 concurrent tiles = an 8 x 4 block share 8 A tiles and 4 W tiles, and an A tile crosses the fabric once per
+    // FOUR columns.  Which workgroup computes which tile never changes a tile's arithmetic: same bits.  blk = 0: the column walk.
     int bm0 = 0, bn0 = 0, bid = 0;
     auto place = [&](int tile) {
         const int q = nwg / 8, r = nwg % 8, xcd = tile % 8, idx = tile / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        if (blk > 0) {
+            // (major = the dimension the old walk ran along: rows when col_major)
+            const int nmaj = col_major ? nby : nbx, nmin = col_major ? nbx : nby;
+            const int RB = blk >> 8, CB = blk & 255;                      // block = RB tiles along major x CB along minor
+            const int per_full = nmaj * CB, full = nmin / CB;
+            int panel, o, cw;
+            if (bid < full * per_full) { panel = bid / per_full; o = bid % per_full; cw = CB; }
+            else { panel = full; o = bid - full * per_full; cw = nmin - full * CB; }
+            const int per_rb = RB * cw, fb = nmaj / RB;
+            int rb, oo, rw;
+            if (o < fb * per_rb) { rb = o / per_rb; oo = o % per_rb; rw = RB; }
+            else { rb = fb; oo = o - fb * per_rb; rw = nmaj - fb * RB; }
+            const int tmaj = rb * RB + oo % rw, tmin = panel * CB + oo / rw;
+            bm0 = (col_major ? tmaj : tmin) * BM;
+            bn0 = (col_major ? tmin : tmaj) * BN;
+            return;
+        }
         bm0 = (col_major ? bid % nby : bid / nbx) * BM;
         bn0 = (col_major ? bid / nby : bid % nbx) * BN;
     };
@@ -1089,6 +1114,9 @@ static void launch_p8(int epi, const bf16_t* A, int lda, const bf16_t* W, int ld
     const bool wide = ze_gemv_knobs[7] != 10 && (ldc % 8) == 0 && ((size_t)C % 16) == 0 && ((sw ? N / 2 : N) % 8) == 0 &&
                       (epi != ZE_EPI_RESIDUAL || ((ldr % 8) == 0 && ((size_t)R % 16) == 0));
     const size_t lds = wide ? (128 + 32) * 1024 : 128 * 1024;
+    // the blocked walk of the tile grid (k_gemm_p8: `place`): 8 x 4 blocks; knob 21 = 1: the column walk of rounds 3-4, any other
+    // value v > 1: blocks of (v >> 8) x (v & 255)
+    const int blk = ze_gemv_knobs[21] == 1 ? 0 : (ze_gemv_knobs[21] > 1 ? ze_gemv_knobs[21] : ((8 << 8) | 4));
 #define ZE_P8_LAUNCH(E, WD)                                                                                                    \
     do {                                                                                                                       \
         static bool attr_set = false;                                                                                          \
@@ -1096,7 +1124,7 @@ static void launch_p8(int epi, const bf16_t* A, int lda, const bf16_t* W, int ld
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_p8<E, WD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr_set = true;                                                                                                   \
         }                                                                                                                      \
-        hipLaunchKernelGGL((k_gemm_p8<E, WD>), dim3(grid), dim3(512), lds, s, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K); \
+        hipLaunchKernelGGL((k_gemm_p8<E, WD>), dim3(grid), dim3(512), lds, s, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, blk); \
     } while (0)
     if (wide) {
         switch (epi) {
