@@ -39,7 +39,7 @@ if ROUND >= 4:  # round 4: the stream's rows at the line's own mean chain count 
     SECTION.update(wide410="stream", wide410_shared="stream_shared", wide580="stream580", wide580_shared="stream580_shared")
 
 if ROUND >= 5:  # round 5: tall one-round tiles for qkv / o, K-steps of 64 in two stages for the 256- / 320-row gate/up and down tiles
-    KEYS["wide410"].update(gate_up="k_gemm_ring<256, 192, 2, 3", qkv="k_gemm_ring<64, 64, 6, 5", o_proj="k_gemm_ring<64, 64, 6, 2, 4, 2, false, true")
+    KEYS["wide410"].update(gate_up="k_gemm_ring<256, 192, 2, 3", qkv="k_gemm_ring<80, 64, 6, 5", o_proj="k_gemm_ring<64, 64, 6, 2, 4, 2, false, true")
     KEYS["wide580"].update(gate_up="k_gemm_ring<320, 192, 2, 3", down=("k_gemm_ring<320, 128, 2, 0", "k_splitk_reduce<320, 128"),
                            qkv="k_gemm_ring<112, 64, 6, 5", o_proj="k_gemm_ring<80, 64, 6, 2")
 
