@@ -102,6 +102,31 @@ def test_3b_layer_shape_vit_prefill_decode_vs_oracle():
             else:
                 undecidable += 1
         print(f"3B greedy tokens: {len(got) - undecidable} of {len(got)} steps decidable and equal")
+        # free-running greedy (SURVEY 8 c.2 protocol item iii): engine and fp32 oracle each follow their OWN tokens
+        # (repetition penalty 1.3: diverse output); reported: the first step where they part and the oracle's top-1 / top-2 margin
+        # there -- on random weights a margin below the bf16 noise is expected within a few dozen steps (the reference's own bf16 run
+        # parts from its fp32 run after 15-43 steps in SURVEY's probe); asserted: every step BEFORE the first sub-margin step agrees
+        n_free, pen = 24, 1.3
+        restore(o32, snap32)
+        seen, lg, ref_toks, margins = list(ids), ref32[0], [], []
+        for _ in range(n_free):
+            sc = Q.apply_repetition_penalty(lg, seen, pen)
+            top2 = np.partition(sc, -2)[-2:]
+            margins.append(float(top2[1] - top2[0]))
+            tok = int(np.argmax(sc))
+            ref_toks.append(tok)
+            seen.append(tok)
+            lg = o32.decode_step(tok)
+        e.seq_reset(0)
+        e.prefill(0, ids, emb, pos, delta)
+        e.mark_seen(0, ids)
+        got_toks = e.generate(0, n_free, repetition_penalty=pen, ignore_eos=True)
+        first = next((i for i, (a, b) in enumerate(zip(got_toks, ref_toks)) if a != b), None)
+        first_sub = next((i for i, m in enumerate(margins) if m <= 2.0 * 2.0 * yard), n_free)
+        print(f"3B free-running greedy, {n_free} tokens, penalty {pen}: " +
+              (f"identical to the fp32 oracle's ({len(set(ref_toks))} distinct tokens)" if first is None else
+               f"first divergence at step {first}, oracle margin there {margins[first]:.4f} (bf16 yardstick {yard:.4f}; first sub-margin step {first_sub})"))
+        assert first is None or first >= first_sub, (first, first_sub, margins[:first + 1])
 
         # ---- the same chain through the batched decode step at 1, 33 and 64 chains.  Chain c = the prompt (every
         # eighth chain a shorter prefix of it: ragged contexts), then two teacher-forced steps with its own tokens.
