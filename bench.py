@@ -281,7 +281,7 @@ def run_stream(engine, table, q0: int, slots: int, stats=None, use_graph=None):
     model = Model64(engine)
     proc = SynthProcessor(engine.config, engine)
     sched = ChainScheduler(model, proc, do_sample=False, repetition_penalty=PENALTY, ignore_eos=True, burst=int(os.environ.get("ZE_BURST", "8")),
-                           use_graph=use_graph, min_admit=int(os.environ.get("ZE_MIN_ADMIT", str(max(1, 3 * slots // 4 if slots > 64 else slots // 2)))),
+                           use_graph=use_graph, min_admit=int(os.environ.get("ZE_MIN_ADMIT", str(max(1, 3 * slots // 4 if slots > 64 else slots // 2)))), hold_below=int(os.environ.get("ZE_HOLD", "0")),
                            max_wait_bursts=int(os.environ.get("ZE_MAX_WAIT", "8" if slots > 64 else "12")), max_batch=slots)
     done = {}
     views = {}
@@ -358,9 +358,21 @@ def run_stream_lanes(engines, table, q0: int, slots: int, stats=None, use_graph=
     def work(ln):
         try:
             e = engines[ln]
+            prof = None
+            if ln == 0 and os.environ.get("ZE_BENCH_HOSTPROF") == "1":  # measurement only: cProfile of lane 0's host thread -> stderr
+                import cProfile
+                prof = cProfile.Profile()
+                prof.enable()
             with torch.cuda.stream(torch.cuda.Stream(device=e.device)):
                 outs[ln] = run_stream(e, lane_table(ln), q0, slots, sts[ln], use_graph)
                 torch.cuda.current_stream().synchronize()
+            if prof is not None:
+                import io
+                import pstats
+                prof.disable()
+                buf = io.StringIO()
+                pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(45)
+                print(buf.getvalue(), file=sys.stderr)
         except BaseException as ex:  # noqa: BLE001
             errs.append(ex)
 

@@ -265,6 +265,9 @@ int ze_decode_burst(ze_engine* e, const int32_t* seqs, int n, int steps, const z
 int ze_decode_burst_begin(ze_engine* e, const int32_t* seqs, int n, int steps, const ze_gen_params* p, void* stream);
 int ze_decode_burst_end(ze_engine* e, const int32_t* seqs, int n, int32_t* n_generated, int32_t* finished, void* stream);
 int ze_chain_tokens(ze_engine* e, int seq, int32_t* out_tokens, int capacity, int* n_out, void* stream);
+/* ze_chain_tokens for the n chains a burst retires, in one gather launch + one device -> host copy + one wait.
+ * out_tokens: host int32 [n, capacity] (row i: the ids of seqs[i], trimmed after the first EOS), n_out [n]. */
+int ze_chain_tokens_batch(ze_engine* e, const int32_t* seqs, int n, int32_t* out_tokens, int capacity, int32_t* n_out, void* stream);
 /* Rollout scoring (replaces _get_per_token_logps, src/train/RL/src/open-r1-multimodal/src/open_r1/trainer/
  * grpo_trainer.py:494-504, as the trainer calls it under torch.no_grad for the old policy and the reference model,
  * :660-683): ze_prefill of the sequence, plus, for EVERY position t < len - 1,
@@ -276,6 +279,8 @@ int ze_score(ze_engine* e, int seq, const int32_t* input_ids, int len, const voi
              const int32_t* position_ids, int rope_delta, float* out_logps, void* stream);
 /* Marks every id in `ids` (host int32) as seen for the repetition penalty of `seq` (the prompt). */
 int ze_seq_mark_seen(ze_engine* e, int seq, const int32_t* ids, int n, void* stream);
+/* ze_seq_mark_seen for the n chains of a prefill pass at once: ids = the chains' prompts back to back, counts[i] ids for seqs[i]. */
+int ze_seq_mark_seen_batch(ze_engine* e, const int32_t* seqs, const int32_t* counts, int n, const int32_t* ids, void* stream);
 /* Applies penalty + argmax to f32 logits [vocab] (device) with the seen-set of `seq`; *out_token host. */
 int ze_op_sample_greedy(ze_engine* e, int seq, const float* logits, float repetition_penalty, int32_t* out_token,
                         void* stream);

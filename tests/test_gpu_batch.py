@@ -558,3 +558,60 @@ def test_attention_grid_rotation_and_extent_do_not_change_a_bit(max_ctx):
             assert np.array_equal(a, b)
     finally:
         e.close()
+
+
+def test_batched_mark_seen_and_chain_tokens_equal_the_single_chain_calls(eng):
+    """ze_seq_mark_seen_batch / ze_chain_tokens_batch (what the scheduler calls once per prefill pass / per burst) against the
+    single-chain calls: the same tokens under a repetition penalty (the penalty reads the seen set the batched call wrote),
+    ragged lengths, an EOS-trimmed chain among them, and the calls' error behaviour."""
+    e = eng
+    prompts = [text_ids(71, 40), text_ids(72, 9), text_ids(73, 77)]
+    lens = [9, 14, 5]
+
+    def run(batched):
+        p = e.gen_params(repetition_penalty=1.3, ignore_eos=True)
+        for i, ids in enumerate(prompts):
+            prefill_text(e, i, ids)
+        if batched:
+            e.mark_seen_batch([2, 0, 1], [prompts[2], prompts[0], prompts[1]])
+        else:
+            for i, ids in enumerate(prompts):
+                e.mark_seen(i, ids)
+        for i in range(3):
+            e.chain_begin(i, p)
+        e.decode_burst([0, 1, 2], 4, p)
+        e.decode_burst([0, 1], 4, p)
+        e.decode_burst([1], 5, p)
+        if batched:
+            return e.chain_tokens_batch([1, 2, 0], 14)
+        return [e.chain_tokens(s, 14) for s in (1, 2, 0)]
+
+    single, batch = run(False), run(True)
+    assert [len(t) for t in single] == [lens[1], lens[2], lens[0]]
+    assert batch == single
+    # a capacity below what a chain generated clips, as the single-chain call does
+    assert e.chain_tokens_batch([1, 0], 6) == [single[0][:6], single[2][:6]]
+    assert e.chain_tokens_batch([], 6) == []
+    with pytest.raises(Exception):
+        e.chain_tokens_batch([0, 99999], 4)
+    with pytest.raises(Exception):
+        e.mark_seen_batch([0], [[10, 2 ** 30]])
+    # EOS: a finished chain's row ends at its EOS (a second engine whose EOS id is chain 1's 4th token)
+    from zoomearth_amd.config import ModelConfig
+    from zoomearth_amd.engine import Engine
+    cfg = ModelConfig.tiny()
+    cfg.eos_token_ids = (single[0][3],)
+    e2 = Engine(cfg, max_seqs=3, max_ctx=512, max_patches=1024, max_tile_side=1024)
+    try:
+        e2.fill_synthetic(**CHAIN_W)
+        p = e2.gen_params(repetition_penalty=1.3, ignore_eos=False)
+        for i, ids in enumerate(prompts):
+            prefill_text(e2, i, ids)
+        e2.mark_seen_batch([0, 1, 2], prompts)
+        for i in range(3):
+            e2.chain_begin(i, p)
+        e2.decode_burst([0, 1, 2], 8, p)
+        one = [e2.chain_tokens(s, 14) for s in range(3)]
+        assert one[1] == single[0][:4] and e2.chain_tokens_batch([0, 1, 2], 14) == one
+    finally:
+        e2.close()

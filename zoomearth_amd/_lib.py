@@ -110,6 +110,8 @@ _SIGS = {
     "ze_decode_burst_end": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
     "ze_chain_tokens": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int), _P]),
     "ze_seq_mark_seen": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.c_int, _P]),
+    "ze_seq_mark_seen_batch": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), _P]),
+    "ze_chain_tokens_batch": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), _P]),
     "ze_op_sample_greedy": (C.c_int, [_P, C.c_int, _P, C.c_float, C.POINTER(C.c_int32), _P]),
     "ze_op_sample_temperature": (C.c_int, [_P, C.c_int, _P, C.c_float, C.c_float, C.c_uint64, C.c_int,
                                            C.POINTER(C.c_int32), _P]),

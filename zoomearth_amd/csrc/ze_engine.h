@@ -148,6 +148,12 @@ struct ze_engine {
     int prefill_rows = 0;
     int* t_host_ints = nullptr;  // pinned
     size_t t_host_ints_cap = 0;
+    // batched host <-> device id transfers of the scheduler (ze_seq_mark_seen_batch: host -> device on the admission stream;
+    // ze_chain_tokens_batch: device -> host on the decode stream): one pinned + one device buffer per direction, max_seqs x
+    // max_ctx ints, allocated at first use
+    int *xs_host = nullptr, *xs_dev = nullptr, *xt_host = nullptr, *xt_dev = nullptr;
+    size_t xs_cap = 0, xt_cap = 0;
+    hipEvent_t xs_staged = nullptr;
 
     // decode workspace
     bf16_t *dh = nullptr, *dq = nullptr, *dattn = nullptr, *dact = nullptr;

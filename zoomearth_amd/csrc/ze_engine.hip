@@ -443,7 +443,10 @@ extern "C" int ze_engine_destroy(ze_engine* e) {
     if (e->fe_done) hipEventDestroy(e->fe_done);
     if (e->v_staged) hipEventDestroy(e->v_staged);
     if (e->t_staged) hipEventDestroy(e->t_staged);
-    void* host[] = {e->fe_coef_host, e->v_host_ints, e->v_host_f32, e->t_host_ints, e->d_host_ints, e->bstate_host};
+    if (e->xs_staged) hipEventDestroy(e->xs_staged);
+    if (e->xs_dev) hipFree(e->xs_dev);
+    if (e->xt_dev) hipFree(e->xt_dev);
+    void* host[] = {e->fe_coef_host, e->v_host_ints, e->v_host_f32, e->t_host_ints, e->d_host_ints, e->bstate_host, e->xs_host, e->xt_host};
     for (void* p : host)
         if (p) hipHostFree(p);
     delete e;

@@ -246,3 +246,6 @@ void ze_launch_sample_batch(const float* logits, int vocab, uint8_t* seen_base, 
                             int advance_ctx, int sample, int32_t* out_tokens_base, int max_gen, float* ws,
                             float* ws_sum, const ze_sample_opts& so, hipStream_t s);
 void ze_launch_mark_seen(uint8_t* seen, const int* ids, int n, hipStream_t s);
+void ze_launch_mark_seen_batch(uint8_t* seen, int vocab, const int* hdr, const int* ids, int n, int max_count, hipStream_t s);
+void ze_launch_gather_chain_tokens(const ze_seq_dev* st, const int* out_tokens, int max_ctx, const int* slots, int n, int cap, int* out,
+                                   hipStream_t s);

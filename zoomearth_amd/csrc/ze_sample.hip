@@ -157,6 +157,34 @@ void ze_launch_mark_seen(uint8_t* seen, const int* ids, int n, hipStream_t s) {
     if (n > 0) k_mark_seen<<<ze_cdiv(n, 256), 256, 0, s>>>(seen, ids, n);
 }
 
+// the prompts of several chains in one launch: hdr = [offs (n + 1) | chain slots (n)], ids follow; grid.y = chain
+__global__ void k_mark_seen_batch(uint8_t* __restrict__ seen, size_t vocab, const int* __restrict__ hdr, const int* __restrict__ ids, int n) {
+    const int c = blockIdx.y, o0 = hdr[c], cnt = hdr[c + 1] - o0;
+    uint8_t* sn = seen + (size_t)hdr[n + 1 + c] * vocab;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256) sn[ids[o0 + i]] = 1;
+}
+void ze_launch_mark_seen_batch(uint8_t* seen, int vocab, const int* hdr, const int* ids, int n, int max_count, hipStream_t s) {
+    if (n > 0 && max_count > 0) k_mark_seen_batch<<<dim3(std::min(ze_cdiv(max_count, 256), 16), n), 256, 0, s>>>(seen, (size_t)vocab, hdr, ids, n);
+}
+
+// the generated ids of several chains, gathered for ONE device -> host copy: out = [n_gen, finished per chain (2n) | n rows of cap ids]
+__global__ void k_gather_chain_tokens(const ze_seq_dev* __restrict__ st, const int* __restrict__ out_tokens, int max_ctx,
+                                      const int* __restrict__ slots, int n, int cap, int* __restrict__ out) {
+    const int c = blockIdx.y, seq = slots[c];
+    const int ng = min(min(st[seq].n_gen, cap), max_ctx);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[2 * c] = ng;
+        out[2 * c + 1] = st[seq].finished;
+    }
+    const int* src = out_tokens + (size_t)seq * max_ctx;
+    int* dst = out + 2 * n + (size_t)c * cap;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ng; i += gridDim.x * 256) dst[i] = src[i];
+}
+void ze_launch_gather_chain_tokens(const ze_seq_dev* st, const int* out_tokens, int max_ctx, const int* slots, int n, int cap, int* out,
+                                   hipStream_t s) {
+    if (n > 0) k_gather_chain_tokens<<<dim3(std::max(1, std::min(ze_cdiv(cap, 256), 8)), n), 256, 0, s>>>(st, out_tokens, max_ctx, slots, n, cap, out);
+}
+
 // ------------------------------------------------------------------ batched sampling: grid.y = chain
 __global__ void __launch_bounds__(256) k_argmax_partial_batch(const float* __restrict__ logits, int vocab,
                                                               const uint8_t* __restrict__ seen_base,

@@ -257,6 +257,15 @@ class Engine:
         a, p = _i32(ids)
         self._check(self.lib.ze_seq_mark_seen(self.h, seq, p, len(a), self._stream()))
 
+    def mark_seen_batch(self, seqs, ids_list):
+        """mark_seen for the chains of a prefill pass at once (one copy, one launch)."""
+        if not len(seqs):
+            return
+        sq, sp = _i32(seqs)
+        cnt, cp = _i32([len(x) for x in ids_list])
+        flat, fp = _i32(np.concatenate([np.asarray(x, dtype=np.int32) for x in ids_list]) if len(ids_list) else [])
+        self._check(self.lib.ze_seq_mark_seen_batch(self.h, sp, cp, len(sq), fp, self._stream()))
+
     def prefill(self, seq: int, new_ids, image_embeds, position_ids, rope_delta: int, want_logits: bool = True):
         """Appends `new_ids` to chain `seq`. position_ids: int32 [3, len(new_ids)]."""
         ids, ip = _i32(new_ids)
@@ -404,6 +413,18 @@ class Engine:
         st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
         self._check(self.lib.ze_chain_tokens(self.h, seq, out, cap, C.byref(n), st))
         return [int(out[i]) for i in range(n.value)]
+
+    def chain_tokens_batch(self, seqs, capacity: int = 0, stream=None):
+        """chain_tokens for several chains in one device -> host copy and one wait; returns a list of id lists."""
+        if not len(seqs):
+            return []
+        cap = max(1, min(int(capacity) if capacity else self.max_ctx, self.max_ctx))
+        sq, sp = _i32(seqs)
+        out = np.empty((len(sq), cap), dtype=np.int32)
+        n = (C.c_int32 * len(sq))()
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
+        self._check(self.lib.ze_chain_tokens_batch(self.h, sp, len(sq), out.ctypes.data_as(C.POINTER(C.c_int32)), cap, n, st))
+        return [out[i, :n[i]].tolist() for i in range(len(sq))]
 
     def tile_upload(self, host_rgb) -> torch.Tensor:
         """Decoded RGB u8 [H, W, 3] host array / tensor (ideally pinned) -> device tensor (ze_tile_upload)."""

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import contextlib
 import os
+import time
 from collections import OrderedDict, deque
 from dataclasses import dataclass, field
 from typing import Any, Callable, List, Optional
@@ -55,7 +56,7 @@ class ChainScheduler:
     def __init__(self, model, processor, do_sample: bool = False, temperature=None, repetition_penalty=None, seed: int = 0,
                  burst: int = 8, max_batch: Optional[int] = None, ignore_eos: bool = False, use_graph: Optional[bool] = None,
                  feature_cache: int = 64, min_admit: int = 1, max_wait_bursts: int = 2, share_prefix: bool = True,
-                 min_shared: int = 64, reuse_generated: bool = True, overlap: Optional[bool] = None):
+                 min_shared: int = 64, reuse_generated: bool = True, overlap: Optional[bool] = None, hold_below: int = 0):
         self.model, self.processor, self.engine = model, processor, model.engine
         gc = model.generation_config
         pen = repetition_penalty if repetition_penalty is not None else (getattr(gc, "repetition_penalty", 1.0) or 1.0)
@@ -77,6 +78,10 @@ class ChainScheduler:
         self.min_admit = max(1, int(min_admit))
         self.max_wait_bursts = max(0, int(max_wait_bursts))
         self._waited = 0
+        # Hold: while an admission round still has prefill passes to run and fewer than `hold_below` chains are live, the live
+        # chains do not decode -- a step costs almost the same at 60 chains as at 400, so the early members of a round wait
+        # for the later ones instead of stepping alone beside the passes.  0: never hold (a server's latency setting).
+        self.hold_below = max(0, int(hold_below))
         # Shared prompt prefixes: the questions about one tile start with the same system turn and the same view's image
         # tokens (347 of the 802 tokens of a stage-1 prompt).  A fresh chain whose prompt starts like that of a chain that
         # already holds those K/V rows copies them (ze_seq_copy_prefix) and prefills only its own tail; when a round brings
@@ -138,23 +143,37 @@ class ChainScheduler:
 
     # ------------------------------------------------------------------ one scheduling round
     def step(self) -> None:
+        tp = time.perf_counter
+        t0 = tp()
         if self._side is not None:
             # what the caller put on ITS stream before submitting (the tile upload, the view's resize) is read by the
             # admission work on the side stream: order the two here, while the caller's stream holds nothing else
             self._side.wait_stream(torch.cuda.current_stream(self.engine.device))
-        handle = self._burst_begin() if (self.live and self.overlap) else None
+        hold = bool(self._groups or self._ready) and len(self.live) < self.hold_below
+        handle = self._burst_begin() if (self.live and self.overlap and not hold) else None
+        t1 = tp()
         with self._side_stream():
             if not self._groups:
                 self._admit()
+            t2 = tp()
             if self._groups:
                 self._run_group(self._groups.popleft())
                 if handle is not None:
                     self.stats["overlapped_passes"] += 1
+        t3 = tp()
         if handle is not None:
             self._burst_end(handle)
-        self._join_ready()
-        if handle is None and self.live:
+        t4 = tp()
+        self._join_ready(wait=hold and not self._groups)   # (held with nothing left to enqueue: wait for the oldest pass)
+        if handle is None and self.live and not hold:
             self._burst()
+        elif hold:
+            self.stats["held_steps"] = self.stats.get("held_steps", 0) + 1
+        t5 = tp()
+        st = self.stats   # host seconds of the scheduling round by part (burst_end = waiting for the GPU + retiring + the callbacks)
+        for k, v in (("host_s_burst_begin", t1 - t0), ("host_s_admit", t2 - t1), ("host_s_pass", t3 - t2), ("host_s_burst_end", t4 - t3),
+                     ("host_s_join", t5 - t4)):
+            st[k] = st.get(k, 0.0) + v
 
     def _side_stream(self):
         """Admission work (front-end, ViT, prefill, the callbacks' crops) runs on the side stream when overlapping."""
@@ -414,16 +433,19 @@ class ChainScheduler:
             self._fail_all([it["req"] for it in ok], ex)
             return
         self.stats["prefill_rows"] += sum(len(x) for x in ids_l)
-        for it in ok:
-            if not it["final"]:
-                continue                                       # pass A: the chain is completed by pass B
+        final = [it for it in ok if it["final"]]                # (pass A: the chain is completed by pass B)
+        if self.penalty != 1.0 and final:
+            if hasattr(e, "mark_seen_batch"):                  # the prompts of the pass in one copy + one launch
+                e.mark_seen_batch([it["req"].slot for it in final], [it["ids"] for it in final])
+            else:
+                for it in final:
+                    e.mark_seen(it["req"].slot, it["ids"])
+        for it in final:
             req, ids, keys = it["req"], it["ids"], it["keys"]
-            if self.penalty != 1.0:
-                e.mark_seen(req.slot, ids)
             req.n_prompt = len(ids)
             self._ready.append((req, tuple(ids), tuple(keys)))
 
-    def _join_ready(self) -> None:
+    def _join_ready(self, wait: bool = False) -> None:
         """The prefilled newcomers draw their first token (from the logits their pass left) and join the live set.  When
         overlapping, a pass that is still running does not hold the live chains up: they go into their next burst, the
         newcomers join behind a later one (with nothing live, the call waits for the oldest pass)."""
@@ -436,7 +458,7 @@ class ChainScheduler:
                 self._pass_done = [None] * len(self._ready)
             for i, ev in enumerate(self._pass_done):
                 if ev is not None and not ev.query():
-                    if i == 0 and not self.live:
+                    if i == 0 and (wait or not self.live):
                         ev.synchronize()                    # nothing to decode meanwhile
                         continue
                     keep_from = i
@@ -457,6 +479,10 @@ class ChainScheduler:
     def _tally_step_rows(self, ran: int, n: int) -> None:
         if ran <= 0:
             return
+        if os.environ.get("ZE_SCHED_TRACE"):   # measurement only: one line per burst (tools/sched_trace.py draws the occupancy)
+            import time
+            with open(os.environ["ZE_SCHED_TRACE"], "a") as f:
+                f.write(f"{id(self) % 100000} {time.perf_counter():.4f} {n} {ran} {len(self.waiting)} {len(self._groups)} {len(self._ready)}\n")
         b = next((x for x in self._ROW_BOUNDS if n <= x), None)
         k = f"steps_le_{b}" if b is not None else "steps_gt_768"
         self.stats[k] = self.stats.get(k, 0) + ran
@@ -472,11 +498,25 @@ class ChainScheduler:
         self.stats["steps"] += ran
         self.stats["chain_steps"] += ran * len(slots)
         self._tally_step_rows(ran, len(slots))
+        self._retire_finished(slots, n_gen, fin)
+
+    def _retire_finished(self, slots, n_gen, fin) -> None:
+        """The chains the burst finished leave the live set: their ids come over in ONE copy (chain_tokens_batch), then the
+        callbacks run."""
+        e = self.engine
+        out = []
         for slot, ng, f in zip(slots, n_gen, fin):
             l = self.live[slot]
             l.produced = ng
             if f or ng >= min(l.req.max_new_tokens, e.max_ctx - l.req.n_prompt + 1):
-                self._retire(slot)
+                out.append(slot)
+        toks = None
+        if len(out) > 1 and hasattr(e, "chain_tokens_batch"):
+            ds = getattr(self, "_decode_stream", None)
+            cap = max(self.live[s].req.max_new_tokens for s in out)
+            toks = e.chain_tokens_batch(out, cap, stream=ds) if ds is not None else e.chain_tokens_batch(out, cap)
+        for i, slot in enumerate(out):
+            self._retire(slot, None if toks is None else toks[i][:self.live[slot].req.max_new_tokens])
 
     def _burst_begin(self):
         e = self.engine
@@ -490,24 +530,25 @@ class ChainScheduler:
         e = self.engine
         slots, ran = handle
         self._decode_stream = torch.cuda.current_stream(e.device) if self._side is not None else None
+        t0 = time.perf_counter()
         n_gen, fin = e.decode_burst_end(slots)
+        self.stats["host_s_burst_wait"] = self.stats.get("host_s_burst_wait", 0.0) + time.perf_counter() - t0
         self.stats["bursts"] += 1
         self.stats["steps"] += ran
         self.stats["chain_steps"] += ran * len(slots)
         self._tally_step_rows(ran, len(slots))
         with self._side_stream():   # (the callbacks of finished chains crop / resize on the front-end's stream)
-            for slot, ng, f in zip(slots, n_gen, fin):
-                l = self.live[slot]
-                l.produced = ng
-                if f or ng >= min(l.req.max_new_tokens, e.max_ctx - l.req.n_prompt + 1):
-                    self._retire(slot)
+            self._retire_finished(slots, n_gen, fin)
 
-    def _retire(self, slot: int) -> None:
+    def _retire(self, slot: int, tokens=None) -> None:
         l = self.live.pop(slot)
         req = l.req
         ds = getattr(self, "_decode_stream", None)
-        req.tokens = (self.engine.chain_tokens(slot, req.max_new_tokens, stream=ds) if ds is not None
-                      else self.engine.chain_tokens(slot, req.max_new_tokens))
+        if tokens is not None:
+            req.tokens = tokens
+        else:
+            req.tokens = (self.engine.chain_tokens(slot, req.max_new_tokens, stream=ds) if ds is not None
+                          else self.engine.chain_tokens(slot, req.max_new_tokens))
         req.text = self.processor.tokenizer.decode(req.tokens, skip_special_tokens=True).strip()
         follow = None
         try:
