@@ -5,7 +5,8 @@ model_name="${model_name:-${1:-}}"
 exp_name="${exp_name:-${2:-zoomearth}}"
 NGPU="${NGPU:-1}"
 # ZE_THROUGHPUT=1: the fastest setting measured through this entry point on TIFF tiles on disk (README: 89.9 questions/s on one
-# GPU) -- two engines per GPU with 512 chain slots each -- at the DEFAULT context budget of 4096 tokens per chain (2 x 77 GB of
+# GPU) -- two engines per GPU with 512 chain slots each, the live chains of a lane holding while an admission round that leaves
+# fewer than 384 of them live is still being prefilled (--hold) -- at the DEFAULT context budget of 4096 tokens per chain (2 x 77 GB of
 # KV cache of the 288 GB): the stage-2 prompt of the real dataset reaches ~3200 tokens at the default image budgets, so a
 # smaller --max_ctx would clip long chains (an error record instead of an answer) and change the accuracy.  bench.py's
 # synthetic stream (L2 + N2 <= 1416 tokens) runs 2 x 768 slots of 2048 tokens; pass EXTRA_ARGS="--batch_size 768 --max_ctx 2048"
@@ -14,7 +15,7 @@ NGPU="${NGPU:-1}"
 # size above 64, equal to the first family within bf16 rounding: DESIGN.md section 5).  EXTRA_ARGS are passed through (later
 # flags win).
 if [ "${ZE_THROUGHPUT:-0}" = "1" ]; then
-  EXTRA_ARGS="--batch_size 512 --lanes 2 ${EXTRA_ARGS:-}"
+  EXTRA_ARGS="--batch_size 512 --lanes 2 --hold 384 ${EXTRA_ARGS:-}"
 fi
 echo "Infering model: $model_name on LRS-GRO!"
 echo "Experiment name: $exp_name!"

@@ -505,3 +505,53 @@ def test_serve_dispatcher_admits_into_the_running_batch():
     assert len(out) == 7 and all(o["object"] == "chat.completion" for o in out.values())
     assert srv.scheduler.stats["admitted"] >= 7
     srv.close()
+
+
+class OverlapStub(StubEngine):
+    """The stub with the calls the overlapping scheduler uses: the two halves of a burst, and the batched forms of mark_seen /
+    chain_tokens (one call per prefill pass / per burst)."""
+
+    def decode_burst_begin(self, slots, steps, params):
+        self._pending = self.decode_burst(slots, steps, params)
+        return self._pending[0]
+
+    def decode_burst_end(self, slots):
+        return self._pending[1], self._pending[2]
+
+    def mark_seen_batch(self, slots, ids_list):
+        assert len(slots) == len(ids_list) and all(self.chains[s]["ids"] == [] or True for s in slots)
+        self.log.append(("seen", list(slots), [len(x) for x in ids_list]))
+
+    def chain_tokens_batch(self, slots, cap=0, stream=None):
+        self.log.append(("tokens", list(slots)))
+        return [self.chain_tokens(s, cap) for s in slots]
+
+
+@pytest.mark.parametrize("hold", [0, 8])
+def test_hold_keeps_the_early_members_of_an_admission_round_from_stepping_alone(hold):
+    """hold_below: while the round still has prefill passes to run and fewer than `hold_below` chains are live, nobody decodes
+    (a step costs almost the same at 2 chains as at 8).  Same answers either way; with the hold the first burst already has
+    eight chains, without it the first two chains step beside the second pass.  The scheduler makes ONE mark_seen call per
+    pass and ONE token fetch per burst that retires several chains."""
+    model = make_model(max_seqs=12, max_prefill_rows=6)
+    model.engine.__class__ = OverlapStub
+    model.generation_config.repetition_penalty = 1.1
+    sched = ChainScheduler(model, Proc(), burst=2, hold_below=hold, share_prefix=False)
+    assert sched.overlap
+    got = {}
+    for q in range(12):
+        sched.submit(Request(prompt=f"{11 + 2 * q} 50 51", images=[], max_new_tokens=5,
+                             on_done=lambda r, toks, text, q=q: got.__setitem__(q, toks)))
+    sched.run()
+    assert got == {q: expected(11 + 2 * q, 5) for q in range(12)}
+    log = model.engine.log
+    bursts = [x[1] for x in log if x[0] == "burst" and x[2] > 0]
+    passes = [x for x in log if x[0] == "prefill"]
+    assert len(passes) == 6 and all(len(p[1]) == 2 for p in passes)          # two 3-token prompts per 6-row pass
+    assert [x for x in log if x[0] == "seen"] == [("seen", p[1], [3, 3]) for p in passes]
+    if hold:
+        assert bursts[0] >= 8 and sched.stats["held_steps"] >= 3
+        assert any(x[0] == "tokens" and len(x[1]) >= 8 for x in log)          # the chains that began together retire together
+    else:
+        assert bursts[0] == 2 and "held_steps" not in sched.stats
+    assert not sched.live and sorted(sched.free) == list(range(12))
