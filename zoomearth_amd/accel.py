@@ -233,8 +233,10 @@ class TileClaims:
         `deadline_s` seconds (ZE_STEAL_DEADLINE_S, default 1800): a rank that died never says so, and rank 0 then names the
         missing ranks and fails instead of hanging."""
         import time
-        self.store.add("ze_ranks_done", 1)
+        # (the per-rank key FIRST: the counter is what releases rank 0, which then takes the store down with it -- a set() behind
+        #  the add() raced with that and could fail a rank that had finished its work)
         self.store.set(f"ze_rank_done/{self.rank}", "1")
+        self.store.add("ze_ranks_done", 1)
         if self.rank == 0:
             if deadline_s is None:
                 deadline_s = float(os.environ.get("ZE_STEAL_DEADLINE_S", "1800"))
@@ -261,8 +263,8 @@ class TileClaims:
             print(f"[rank {self.rank}] failed with {len(left)} claimed tile(s) possibly unfinished: {left[:8]}"
                   f"{' ...' if len(left) > 8 else ''} -- rerun with --resume", file=sys.stderr, flush=True)
         try:
-            self.store.add("ze_ranks_done", 1)
             self.store.set(f"ze_rank_done/{self.rank}", "1")
+            self.store.add("ze_ranks_done", 1)
         except Exception:
             pass
 
