@@ -44,6 +44,15 @@ if ROUND >= 5:  # round 5: tall one-round tiles for qkv / o, K-steps of 64 in tw
                            qkv="k_gemm_ring<112, 64, 6, 5", o_proj="k_gemm_ring<80, 64, 6, 2")
 
 
+    # second pass of round 5 (tools/profile_round5b.sh): the scheduler's hold raised the line's mean step to ~490 chains; the 410-chain
+    # files stay as sections stream410 / stream410_shared
+    KEYS["wide490"] = {"attention": "k_attn_decode_wave_long<8, 6>", "gate_up": "k_gemm_ring<256, 192, 2, 3",
+                       "down": ("k_gemm_ring<128, 256, 3, 0, 2, 4, true, false", "k_splitk_reduce<128, 256"),
+                       "qkv": "k_gemm_ring<96, 64, 6, 5", "o_proj": "k_gemm_ring<64, 64, 6, 2, 4, 2, false, true", "lm_head": "k_gemm_p8<4, true>"}
+    KEYS["wide490_shared"] = {"attention": "k_attn_decode_wave_long<8, 6>"}
+    SECTION.update(wide490="stream", wide490_shared="stream_shared", wide410="stream410", wide410_shared="stream410_shared")
+
+
 def rows(name, source=None):
     with open(os.path.join(D, f"{P}_{name}")) as fh:
         return [r for r in csv.DictReader(fh) if source is None or r["source"] == source]
