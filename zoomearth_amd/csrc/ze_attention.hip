@@ -40,7 +40,7 @@ __device__ __forceinline__ uint32_t fa_pack_bf16(float lo, float hi) {
 // LDS image of a [64 keys][128 d] bf16 tile with 256-byte rows: byte offset of 16-B chunk ch (0..15) of row `row`.
 // The XOR serves both the ds_read_b128 row reads (K as an MFMA operand) and the ds_read_b64_tr_b16 transposed reads
 // (V^T as an MFMA operand) -- cdna_hip_programming.md T10, image (b).
-__device__ __forceinline__ int fa_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+__device__ __forceinline__ int fa_off(int row, int ch) { return 256 * row + 16 * (ch ^ ze_kv_swz(row)); }
 
 // Flash attention with the SWAPPED product: S^T = K Q^T, O^T = V^T P^T (T12 of the guide).
 //   * a lane of the S^T accumulator holds one query (column fr) and 4 keys per 16-key tile, so the softmax statistics
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q
         for (int g = 0; g < 4; ++g) {
             const int pc = wid_u * 4 + g;
             const int row = 4 * pc + r4;
-            const int ch = pos ^ ((r4 << 2) | (pc & 3));
+            const int ch = pos ^ ze_kv_swz(row);
             const int keyc = min(kt + row, kv_hi - 1);
             const bf16_t* ksrc = k + (size_t)keyc * k_rs + (size_t)kvh * k_hs + ch * 8;
             const bf16_t* vsrc = v + (size_t)keyc * v_rs + (size_t)kvh * v_hs + ch * 8;

@@ -33,7 +33,7 @@ __device__ __forceinline__ void ab_issue(const bf16_t* __restrict__ kb, const bf
     for (int g = 0; g < 4; ++g) {
         const int p = (wid & 1) * 4 + g;
         const int row = 4 * p + r4;
-        const int ch = pos ^ ((r4 << 2) | (p & 3));
+        const int ch = pos ^ ze_kv_swz(row);
         const bf16_t* src = base + (size_t)min(t0r + row, t1 - 1) * 128 + ch * 8;
         unsigned keep;
         asm volatile(
@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AW_VST
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {  // piece pp = rows 4pp .. 4pp + 3; the ad_off swizzle on the source chunk (ab_issue)
             const int row = 4 * pp + r4;
-            const int ch = pos ^ ((r4 << 2) | (pp & 3));
+            const int ch = pos ^ ze_kv_swz(row);
             const int tok = min(tok0 + row, t1 - 1);
             const bf16_t* src = vb + (tok < pfx_rows ? pfx_delta : 0ll) + (size_t)tok * D + ch * 8;
             unsigned keep;
@@ -538,7 +538,7 @@ __device__ __forceinline__ void aw_run_part(const bf16_t* __restrict__ qsrc, con
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
             const int row = 4 * pp + r4;
-            const int ch = pos ^ ((r4 << 2) | (pp & 3));
+            const int ch = pos ^ ze_kv_swz(row);
             const int tok = min(tok0 + row, t1 - 1);
             const bf16_t* src = vb + (tok < pfx_rows ? pfx_delta : 0ll) + (size_t)tok * D + ch * 8;
             unsigned keep;

@@ -29,9 +29,9 @@ typedef short ad_v4s __attribute__((ext_vector_type(4)));
 typedef short ad_v8s __attribute__((ext_vector_type(8)));
 
 // LDS image of a [64 keys][128 d] bf16 tile with 256-byte rows: byte offset of 16-B chunk ch (0..15) of row `row`
-// (the image of the prefill flash kernel, ze_attention.hip: conflict-free for the ds_read_b128 row reads of K as an
-// MFMA operand and for the ds_read_b64_tr_b16 transposed reads of V^T).
-__device__ __forceinline__ int ad_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+// (the image of the prefill flash kernel, ze_attention.hip; the swizzle ze_kv_swz, ze_kernels.h, is conflict-free for the
+// ds_read_b128 row reads of K as an MFMA operand and for the ds_read_b64_tr_b16 transposed reads of V^T).
+__device__ __forceinline__ int ad_off(int row, int ch) { return 256 * row + 16 * (ch ^ ze_kv_swz(row)); }
 // f32 pair -> packed bf16 (round to nearest even: v_cvt_pk_bf16_f32).  Written as a CONVERSION, not as inline asm (round 5): on
 // gfx950 an MFMA that reads a VGPR a VALU instruction wrote needs two wait states in between; hipcc's hazard recogniser inserts
 // them for instructions it knows, but it cannot see a VALU write INSIDE an asm statement -- with `asm("v_cvt_pk_bf16_f32 ...")`
