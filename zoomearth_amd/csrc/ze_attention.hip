@@ -63,7 +63,11 @@ __device__ __forceinline__ int fa_off(int row, int ch) { return 256 * row + 16 *
 // by `global_load_lds_dwordx4` -- the swizzle on the SOURCE chunk, as the decode kernels stage them -- instead of through 32
 // staging registers and a ds_write phase; keys past the end re-read the last valid row (finite; masked out of the softmax).
 template <int D, int CAUSAL, int BKV, int QT = 1, bool DMA = false>
-__global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q, int q_rs, int q_hs,
+// amdgpu_waves_per_eu(2): two workgroups per CU are what hides the S phase of one behind the products of the other; with the two
+// wave-uniform branches below hipcc's own choice was 218 VGPRs + 96 AGPRs (one workgroup per CU) -- held to 256 it allocates 234 plain
+// VGPRs, no AGPR copies around the rescale, no scratch.  (Round 3 saw wrong rows from this attribute on the D = 80 instantiation: that
+// was the asm conversion's hazard, fa_pack_bf16 above; tools/check_mfma_hazards.py and test_attention_every_instantiation hold it now.)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k_flash_attn(const bf16_t* __restrict__ q, int q_rs, int q_hs,
                                                     const bf16_t* __restrict__ k, int k_rs, int k_hs,
                                                     const bf16_t* __restrict__ v, int v_rs, int v_hs,
                                                     bf16_t* __restrict__ o, int o_rs, int o_hs,
@@ -220,17 +224,37 @@ __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q
         for (int u = 0; u < QT; ++u) {
             float p[NKT][4];
             float mx = -INFINITY;
+            // The S phase is what bounds this kernel (11 VALU instructions per MFMA, SQ counters of round 5): a key tile every
+            // query of the wave's tile sees whole -- all but the last one or two of a causal row of tiles, all but the last of a
+            // ViT segment -- skips the two compares and selects per score.  Wave-uniform condition, same values either way
+            // (a visible score is sacc * scale in both branches).  ze_tune-free: -DZE_FA_NO_FAST_PATH builds without it.
+            bool whole = kt + BKV <= kv_hi;
+            if (CAUSAL) whole = whole && (kt + BKV - 1 <= q0 + (wid * QT + u) * 16 + q_pos_offset);
+#ifdef ZE_FA_NO_FAST_PATH
+            whole = false;
+#endif
+            if (__builtin_amdgcn_readfirstlane((int)whole)) {
 #pragma unroll
-            for (int n = 0; n < NKT; ++n)
+                for (int n = 0; n < NKT; ++n)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int kj = kt + n * 16 + fq * 4 + r;
-                    bool ok = kj < kv_hi;
-                    if (CAUSAL) ok = ok && (kj <= qi[u] + q_pos_offset);
-                    const float sv = ok ? sacc[u][n][r] * scale_log2e : -INFINITY;
-                    p[n][r] = sv;
-                    mx = fmaxf(mx, sv);
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const float sv = sacc[u][n][r] * scale_log2e;
+                        p[n][r] = sv;
+                        mx = fmaxf(mx, sv);
+                    }
+            } else {
+#pragma unroll
+                for (int n = 0; n < NKT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kj = kt + n * 16 + fq * 4 + r;
+                        bool ok = kj < kv_hi;
+                        if (CAUSAL) ok = ok && (kj <= qi[u] + q_pos_offset);
+                        const float sv = ok ? sacc[u][n][r] * scale_log2e : -INFINITY;
+                        p[n][r] = sv;
+                        mx = fmaxf(mx, sv);
+                    }
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[u], mx);
@@ -249,12 +273,16 @@ __global__ void __launch_bounds__(256) k_flash_attn(const bf16_t* __restrict__ q
             rs += __shfl_xor(rs, 32, 64);
             l_run[u] = l_run[u] * alpha + rs;
             m_run[u] = m_new;
+            // once a query's running maximum has settled, alpha is exactly 1: the 4 * NV multiplies are skipped when it is for every
+            // lane of the wave (x * 1.0f == x: the same bits)
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                oacc[u][j][0] *= alpha;
-                oacc[u][j][1] *= alpha;
-                oacc[u][j][2] *= alpha;
-                oacc[u][j][3] *= alpha;
+                for (int j = 0; j < NV; ++j) {
+                    oacc[u][j][0] *= alpha;
+                    oacc[u][j][1] *= alpha;
+                    oacc[u][j][2] *= alpha;
+                    oacc[u][j][3] *= alpha;
+                }
             }
 #pragma unroll
             for (int n = 0; n < NKT; ++n) {
