@@ -17,17 +17,31 @@ static inline int ze_cdiv(int a, int b) { return (a + b - 1) / b; }
 // ------------------------------------------------------------------ device numerics
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even, NaN kept a NaN (the integer trick alone turns some NaNs into inf/0)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+// f32 -> bf16, round to nearest even: ONE v_cvt_pk_bf16_f32 per pair (a vector conversion hipcc can see -- never inline asm in front
+// of an MFMA: DESIGN.md 3, asm rule).  Rounds 1-5 did it in integer arithmetic (u + 0x7fff + lsb, NaNs patched): 7 VALU instructions
+// per element, 400 of the 708 of a 64-row slice of the eight-phase GEMM's SwiGLU epilogue.  Same bits for every finite value and
+// infinity; a NaN comes out as the hardware's quiet NaN instead of the input's payload with the quiet bit set.
+// ZE_SOFT_BF16: the integer form (A/B builds).
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+#ifdef ZE_SOFT_BF16
+    auto one = [](float f) -> uint32_t {
+        const uint32_t u = __float_as_uint(f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40;
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    };
+    return one(lo) | (one(hi) << 16);
+#else
+    typedef __attribute__((ext_vector_type(2))) float ze_f32x2_;
+    typedef __attribute__((ext_vector_type(2))) __bf16 ze_bf16x2_;
+    const ze_bf16x2_ b = __builtin_convertvector(ze_f32x2_{lo, hi}, ze_bf16x2_);
+    uint32_t r;
+    __builtin_memcpy(&r, &b, 4);
+    return r;
+#endif
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float bf16_round(float f) { return bf16_to_f32(f32_to_bf16(f)); }
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
-}
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
