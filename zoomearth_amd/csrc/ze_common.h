@@ -45,7 +45,17 @@ __device__ __forceinline__ float bf16_round(float f) { return bf16_to_f32(f32_to
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with v_rcp_f32 (1 ulp) instead of the correctly rounded fp32 division (v_div_scale / v_div_fmas / v_div_fixup + a Newton
+// chain: 10 VALU instructions per quotient, 160 of the 388 of a 64-row slice of the SwiGLU epilogue).  __expf is a 1-ulp v_exp_f32
+// already, and every caller rounds the product to bf16 (8 bits) next: the result differs from the divided one when the exact value
+// lies within ~2 fp32 ulps of a bf16 rounding boundary, about 6 elements in 100,000, by one bf16 ulp.  ZE_EXACT_SILU_DIV: the division.
+__device__ __forceinline__ float silu_f(float x) {
+#ifdef ZE_EXACT_SILU_DIV
+    return x / (1.0f + __expf(-x));
+#else
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+#endif
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
