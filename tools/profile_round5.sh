@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-5 rocprofv3 evidence (run from the repo root through gpurun): kernel statistics of the benchmark workloads, the isolated
 # ViT call / prefill passes, the kernel trace + PMC passes (FETCH_SIZE and WRITE_SIZE in SEPARATE runs, --kernel-trace only beside
-# them) of the decode step's kernels at the line's own chain count (410, live-like contexts) and at 580 chains, and the MFMA-busy table.
+# them) of the decode step's kernels at the line's own chain count (490 since the hold; 410 before, live-like contexts) and at 580 chains, and the MFMA-busy table.
 # usage: tools/profile_round4.sh <tag> [fast]  -> gpurun_out/<tag>_*.csv|json
 set -u
 tag=${1:-r05}
@@ -22,16 +22,16 @@ pmc() {  # counter list, file tag, mode
   ( cd "$root" && rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/p_pmc -- python3 tools/pmc_kernel.py $mode > "$out/${tag}_pmc_${mode}_launches.json" 2> "$out/${tag}_pmc_${mode}_${name}.log" )
   python3 "$root/tools/summarize_prof.py" /tmp/p_pmc "$out/${tag}_pmc_${mode}_${name}.csv" --delete-raw
 }
-# the isolated decode step at the line's mean chain count (410) and in the bucket the stream runs most chain-steps in (580):
+# the isolated decode step at the line's mean chain count (490) and in the bucket the stream runs most chain-steps in (580):
 # kernel trace only (durations reproducible from profiles/), then the PMC passes
-for n in 410 580; do
+for n in 490 580; do
   for m in wide$n wide${n}_shared; do
     rm -rf /tmp/p_kt
     ( cd "$root" && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_kt -- python3 tools/pmc_kernel.py $m > "$out/${tag}_${m}_launches.json" 2> "$out/${tag}_${m}.log" )
     python3 "$root/tools/summarize_prof.py" /tmp/p_kt "$out/${tag}_${m}_kernel_trace.csv" --delete-raw
   done
 done
-for mode in wide410 wide410_shared wide580 wide580_shared batch64 configs1; do
+for mode in wide490 wide490_shared wide580 wide580_shared batch64 configs1; do
   pmc FETCH_SIZE fetch_size $mode
   pmc WRITE_SIZE write_size $mode
 done
