@@ -398,6 +398,9 @@ int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters, float* av
  *   17    1: no shared-prefix hints (every chain reads its own K/V rows: same bits, more HBM traffic)
  *   18    1: round 4's K loop on the 513 .. 768-row decode tiles (K-steps of 32 in four stages; default: 64 in two; same bits)
  *   19    4: the tall qkv / o decode tiles on a plain four-stage ring, one barrier per K-step (default: six stages in groups of two)
+ *   21    1: column walk of the eight-phase GEMM's tile grid (default: 8 x 4 blocks; > 1: R << 8 | C blocks)
+ *   22    1: the prefill's queries rotated in place by the M-RoPE kernel (default at head_dim 128: inside the flash kernel, as it loads
+ *            them; the M-RoPE kernel then writes K and V only; same bits)
  * Changing a knob invalidates captured decode graphs (they are re-captured on the next step). */
 int ze_tune(int knob, int value);
 /* Per-phase device time (ms) accumulated by HIP events since the last reset: [0] front-end, [1] ViT,

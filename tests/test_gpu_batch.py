@@ -615,3 +615,47 @@ def test_batched_mark_seen_and_chain_tokens_equal_the_single_chain_calls(eng):
         assert one[1] == single[0][:4] and e2.chain_tokens_batch([0, 1, 2], 14) == one
     finally:
         e2.close()
+
+
+def test_queries_roped_inside_the_flash_kernel_equal_the_two_launch_form(eng):
+    """Round 5: the prefill flash kernel applies M-RoPE to its Q fragments as it loads them and k_mrope_kv_vec writes K and V only
+    (ze_tune knob 22 = 1: the old form, Q rotated in place first).  Same bf16 arithmetic, so the same bits: last-position logits of
+    a single-chain prefill with distinct positions per M-RoPE axis (a faked image grid: the t / h / w ids differ), of an appended
+    segment behind a cached prefix, and of a cross-chain pass -- plus a decode step each, which reads the K rows the pass wrote."""
+    e = eng
+    prompts = [text_ids(81, 97), text_ids(82, 33), text_ids(83, 150)]
+
+    def positions(n, seed):
+        # three different id rows (as an image span gives them), all inside the table
+        base = np.arange(n, dtype=np.int32)
+        return np.stack([base, base // 2 + (seed % 5), (base * 3) % 61 + 2]).astype(np.int32)
+
+    def run():
+        out = []
+        for s, ids in enumerate(prompts):
+            pos = positions(len(ids), s)
+            e.seq_reset(s)
+            cut = len(ids) // 3
+            e.prefill(s, ids[:cut], None, pos[:, :cut], 0, want_logits=False)
+            lg = e.prefill(s, ids[cut:], None, pos[:, cut:], 0, want_logits=True).cpu().numpy()
+            out.append((lg, e.decode_step(s, 17).cpu().numpy()))
+        for s in range(3):
+            e.seq_reset(s)
+        e.prefill_batch([2, 0, 1], [prompts[2], prompts[0], prompts[1]], [None] * 3,
+                        [positions(len(prompts[s]), s) for s in (2, 0, 1)], [0, 0, 0])
+        for s in range(3):
+            out.append(e.decode_step(s, 23).cpu().numpy())
+        return out
+
+    try:
+        e.lib.ze_tune(22, 1)
+        old = run()
+        e.lib.ze_tune(22, 0)
+        new = run()
+    finally:
+        e.lib.ze_tune(22, 0)
+    for a, b in zip(old[:3], new[:3]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for a, b in zip(old[3:], new[3:]):
+        assert np.array_equal(a, b)
+    assert float(np.abs(new[0][0]).max()) > 0

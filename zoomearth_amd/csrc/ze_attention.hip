@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
                                                     bf16_t* __restrict__ o, int o_rs, int o_hs,
                                                     const int4* __restrict__ tiles, int group, float scale_log2e,
                                                     int q_pos_offset, const int* __restrict__ tile_aux,
-                                                    size_t kv_seq_stride) {
+                                                    size_t kv_seq_stride, ze_fa_rope rope) {
     constexpr int KS = (D + 31) / 32;  // 32-deep steps of the QK^T contraction (D = 80: 3, the third half zero)
     constexpr int DCH = D / 8;         // real 16-B chunks per row
     constexpr int NV = D / 16;         // d-tiles of the output
@@ -105,6 +105,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
             if (qi[t] < q1 && ch < DCH) val = *reinterpret_cast<const uint4*>(q + (size_t)qi[t] * q_rs + (size_t)head * q_hs + ch * 8);
             qf[t][ks] = *reinterpret_cast<const bf16x8*>(&val);
         }
+
+    if constexpr (D == 128) {
+        // M-RoPE of Q here instead of in k_mrope_kv_vec (which then writes K and V only): fragments ks and ks + 2 of a lane are the two
+        // halves of eight rotate_half pairs j = ks * 32 + fq * 8 .. + 7; one position axis per such chunk (ze_mrope_vec_ok)
+        if (rope.cosT) {
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+                if (qi[t] < q1) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int j = ks * 32 + fq * 8;
+                        const int pos = rope.pos3[rope.axis_of[j] * rope.T + qi[t]];
+                        const uint4 c4 = *reinterpret_cast<const uint4*>(rope.cosT + (size_t)pos * 64 + j);
+                        const uint4 s4 = *reinterpret_cast<const uint4*>(rope.sinT + (size_t)pos * 64 + j);
+                        uint4 o1, o2;
+                        rope8(*reinterpret_cast<const uint4*>(&qf[t][ks]), *reinterpret_cast<const uint4*>(&qf[t][ks + 2]), c4, s4, o1, o2);
+                        qf[t][ks] = *reinterpret_cast<const bf16x8*>(&o1);
+                        qf[t][ks + 2] = *reinterpret_cast<const bf16x8*>(&o2);
+                    }
+                }
+        }
+    }
 
     f32x4 oacc[QT][NV];
     float m_run[QT], l_run[QT];
@@ -339,7 +361,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
 void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_rs, int q_hs, const bf16_t* k, int k_rs,
                           int k_hs, const bf16_t* v, int v_rs, int v_hs, bf16_t* o, int o_rs, int o_hs,
                           const int4* tiles, int n_tiles, int heads, int group, float scale, int q_pos_offset,
-                          hipStream_t s, const int* tile_aux, size_t kv_seq_stride, int q_tile, int max_kv) {
+                          hipStream_t s, const int* tile_aux, size_t kv_seq_stride, int q_tile, int max_kv, ze_fa_rope rope) {
     if (n_tiles == 0) return;
     const float sl = scale * 1.4426950408889634f;
     dim3 grid(n_tiles, heads);
@@ -358,7 +380,7 @@ void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_rs, int q_hs
         }                                                                                                         \
         const int lds_ = (max_kv > 0 && max_kv <= BKV_) ? LDS_ / 2 : LDS_;                                        \
         hipLaunchKernelGGL((k_flash_attn<DD, CC, BKV_, QQ, DM>), grid, dim3(256), lds_, s, q, q_rs, q_hs, k, k_rs, k_hs, v, v_rs, \
-                           v_hs, o, o_rs, o_hs, tiles, group, sl, q_pos_offset, tile_aux, kv_seq_stride);          \
+                           v_hs, o, o_rs, o_hs, tiles, group, sl, q_pos_offset, tile_aux, kv_seq_stride, rope);    \
     } while (0)
 #define FA_LAUNCH(DD, CC, QQ) FA_LAUNCH_(DD, CC, QQ, false)
     // D = 128 causal (the prefill: K / V rows are whole 256-byte cache rows, 16-byte aligned): the LDS-DMA staging form;

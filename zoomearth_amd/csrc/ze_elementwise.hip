@@ -389,35 +389,7 @@ void ze_launch_vision_rope(bf16_t* qkv, const float* cosT, const float* sinT, in
 int ze_mrope_vec_ok = 1;  // (process-wide, conservative: any engine with odd M-RoPE sections switches the 16-byte form off)
 #define mrope_vec_ok (ze_mrope_vec_ok != 0)
 
-// eight rotate_half pairs at once: (x1[k], x2[k]) = elements (j + k, j + half + k), cos / sin of the same eight j.  The
-// arithmetic per element is the scalar kernels': bf16(bf16(x1 c) + bf16(-x2 s)), bf16(bf16(x2 c) + bf16(x1 s)).
-__device__ __forceinline__ void rope8(const uint4& a, const uint4& b, const uint4& c4, const uint4& s4, uint4& o1, uint4& o2) {
-    const uint32_t* pa = reinterpret_cast<const uint32_t*>(&a);
-    const uint32_t* pb = reinterpret_cast<const uint32_t*>(&b);
-    const uint32_t* pc = reinterpret_cast<const uint32_t*>(&c4);
-    const uint32_t* ps = reinterpret_cast<const uint32_t*>(&s4);
-    uint32_t r1[4], r2[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        uint32_t lo1, hi1, lo2, hi2;
-        {
-            const float x1 = __uint_as_float(pa[q] << 16), x2 = __uint_as_float(pb[q] << 16);
-            const float c = __uint_as_float(pc[q] << 16), sn = __uint_as_float(ps[q] << 16);
-            lo1 = f32_to_bf16(bf16_round(x1 * c) + bf16_round(-x2 * sn));
-            lo2 = f32_to_bf16(bf16_round(x2 * c) + bf16_round(x1 * sn));
-        }
-        {
-            const float x1 = __uint_as_float(pa[q] & 0xffff0000u), x2 = __uint_as_float(pb[q] & 0xffff0000u);
-            const float c = __uint_as_float(pc[q] & 0xffff0000u), sn = __uint_as_float(ps[q] & 0xffff0000u);
-            hi1 = f32_to_bf16(bf16_round(x1 * c) + bf16_round(-x2 * sn));
-            hi2 = f32_to_bf16(bf16_round(x2 * c) + bf16_round(x1 * sn));
-        }
-        r1[q] = lo1 | (hi1 << 16);
-        r2[q] = lo2 | (hi2 << 16);
-    }
-    o1 = make_uint4(r1[0], r1[1], r1[2], r1[3]);
-    o2 = make_uint4(r2[0], r2[1], r2[2], r2[3]);
-}
+// (rope8: ze_kernels.h -- the prefill flash kernel applies it to its Q fragments)
 
 // ------------------------------------------------------------------ text M-RoPE + KV append (prefill)
 // qkv: [T, (heads + 2*kv_heads) * D] bf16 (q | k | v).  cos/sin tables: bf16 [max_pos, D/2] (already rounded to the
@@ -477,14 +449,15 @@ __global__ void __launch_bounds__(256) k_mrope_kv_vec(bf16_t* __restrict__ qkv, 
                                                       const int* __restrict__ pos3, const int* __restrict__ axis_of,
                                                       bf16_t* __restrict__ kcache, bf16_t* __restrict__ vcache,
                                                       int max_ctx, int past, const int* __restrict__ row_aux,
-                                                      size_t cache_seq_stride) {
+                                                      size_t cache_seq_stride, int q_skip) {
     const int half = D >> 1, hv = half >> 3;
     const int nh = heads + 2 * kv_heads;
+    const int nw = q_skip ? 2 * kv_heads : nh;   // q_skip: the K and V heads only (the flash kernel ropes Q as it loads it)
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)T * nh * hv) return;
+    if (i >= (size_t)T * nw * hv) return;
     const int j = (int)(i % hv) * 8;
-    const int hh = (int)((i / hv) % nh);
-    const int t = (int)(i / ((size_t)hv * nh));
+    const int hh = (int)((i / hv) % nw) + (q_skip ? heads : 0);
+    const int t = (int)(i / ((size_t)hv * nw));
     int cpos = past + t;
     if (row_aux) {
         kcache += (size_t)row_aux[2 * t] * cache_seq_stride;
@@ -510,13 +483,13 @@ __global__ void __launch_bounds__(256) k_mrope_kv_vec(bf16_t* __restrict__ qkv, 
 }
 void ze_launch_mrope_kv(bf16_t* qkv, int T, int heads, int kv_heads, int D, const bf16_t* cosT, const bf16_t* sinT,
                         const int* pos3, const int* axis_of, bf16_t* kcache, bf16_t* vcache, int max_ctx, int past,
-                        const int* row_aux, size_t cache_seq_stride, hipStream_t s) {
+                        const int* row_aux, size_t cache_seq_stride, hipStream_t s, int q_skip) {
     const size_t total = (size_t)T * (heads + 2 * kv_heads) * (D / 2);
     if (total == 0) return;
     if (D % 16 == 0 && mrope_vec_ok) {
-        const size_t tv = total / 8;
+        const size_t tv = (size_t)T * (q_skip ? 2 * kv_heads : heads + 2 * kv_heads) * (D / 2) / 8;
         k_mrope_kv_vec<<<(unsigned)((tv + 255) / 256), 256, 0, s>>>(qkv, T, heads, kv_heads, D, cosT, sinT, pos3, axis_of, kcache,
-                                                                  vcache, max_ctx, past, row_aux, cache_seq_stride);
+                                                                  vcache, max_ctx, past, row_aux, cache_seq_stride, q_skip);
         return;
     }
     k_mrope_kv<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(qkv, T, heads, kv_heads, D, cosT, sinT, pos3,

@@ -618,14 +618,17 @@ static int prefill_impl(ze_engine* e, int seq, const int32_t* input_ids, int len
     const int th = ze_timer_begin(e, 2, s);
     ze_launch_embed_rows(e->tsrc, e->embed, (const bf16_t*)image_embeds, e->th, len, H, s);
     const float scale = 1.0f / sqrtf((float)hd);
+    // the queries' M-RoPE inside the flash kernel (k_mrope_kv_vec then moves K and V only: a fifth of its rows); ze_tune knob 22 = 1:
+    // the two-launch form of rounds 1-5 (the same bits: tests/test_gpu_model.py)
+    const bool q_in_flash = hd == 128 && ze_mrope_vec_ok != 0 && ze_gemv_knobs[22] != 1;
     for (int li = 0; li < c.layers; ++li) {
         const ze_text_layer& L = e->tl[li];
         prefill_norm_gemm(e, L.in_norm, L.qkv, L.qkv.bias, ZE_EPI_NONE, e->tqkv, nqkv, len, nqkv, s);
         ze_launch_mrope_kv(e->tqkv, len, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->tpos, e->axis_of,
-                           e->kc(li, seq), e->vc(li, seq), c.max_ctx, past, nullptr, 0, s);
+                           e->kc(li, seq), e->vc(li, seq), c.max_ctx, past, nullptr, 0, s, q_in_flash ? 1 : 0);
         ze_launch_flash_attn(hd, 1, e->tqkv, nqkv, hd, e->kc(li, seq), hd, c.max_ctx * hd, e->vc(li, seq), hd,
                              c.max_ctx * hd, e->to, nq, hd, e->ttiles, nt, c.heads, c.heads / c.kv_heads, scale, past,
-                             s, nullptr, 0, bq);
+                             s, nullptr, 0, bq, 0, q_in_flash ? ze_fa_rope{e->cosT, e->sinT, e->tpos, e->axis_of, len} : ze_fa_rope{nullptr, nullptr, nullptr, nullptr, 0});
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, len, H, nq, s);
         prefill_norm_gemm(e, L.post_norm, L.gate_up, nullptr, ZE_EPI_SWIGLU, e->ta, e->text_ipad, len, 2 * e->text_ipad, s);
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, nullptr,
@@ -774,14 +777,18 @@ extern "C" int ze_prefill_batch(ze_engine* e, const int32_t* seqs, int n, const 
     ze_launch_embed_rows(e->tsrc, e->embed, (const bf16_t*)image_embeds, e->th, total, H, s);
     const float scale = 1.0f / sqrtf((float)hd);
     const size_t seq_stride = (size_t)c.kv_heads * c.max_ctx * hd;
+    // the queries' M-RoPE inside the flash kernel (k_mrope_kv_vec then moves K and V only: a fifth of its rows); ze_tune knob 22 = 1:
+    // the two-launch form of rounds 1-5 (the same bits: tests/test_gpu_model.py)
+    const bool q_in_flash = hd == 128 && ze_mrope_vec_ok != 0 && ze_gemv_knobs[22] != 1;
     for (int li = 0; li < c.layers; ++li) {
         const ze_text_layer& L = e->tl[li];
         prefill_norm_gemm(e, L.in_norm, L.qkv, L.qkv.bias, ZE_EPI_NONE, e->tqkv, nqkv, total, nqkv, s);
         ze_launch_mrope_kv(e->tqkv, total, c.heads, c.kv_heads, hd, e->cosT, e->sinT, e->tpos, e->axis_of, e->kc(li, 0),
-                           e->vc(li, 0), c.max_ctx, 0, e->trow_aux, seq_stride, s);
+                           e->vc(li, 0), c.max_ctx, 0, e->trow_aux, seq_stride, s, q_in_flash ? 1 : 0);
         ze_launch_flash_attn(hd, 1, e->tqkv, nqkv, hd, e->kc(li, 0), hd, c.max_ctx * hd, e->vc(li, 0), hd,
                              c.max_ctx * hd, e->to, nq, hd, e->ttiles, nt, c.heads, c.heads / c.kv_heads, scale, 0, s,
-                             e->ttile_aux, seq_stride, bq);
+                             e->ttile_aux, seq_stride, bq, 0,
+                             q_in_flash ? ze_fa_rope{e->cosT, e->sinT, e->tpos, e->axis_of, total} : ze_fa_rope{nullptr, nullptr, nullptr, nullptr, 0});
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, total, H, nq, s);
         prefill_norm_gemm(e, L.post_norm, L.gate_up, nullptr, ZE_EPI_SWIGLU, e->ta, e->text_ipad, total, 2 * e->text_ipad, s);
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, nullptr,

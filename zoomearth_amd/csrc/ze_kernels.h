@@ -29,6 +29,39 @@ __device__ __forceinline__ int ze_kv_swz(int row) {
 }
 #endif
 
+#if defined(__HIPCC__)
+// eight rotate_half pairs at once: (x1[k], x2[k]) = elements (j + k, j + half + k), cos / sin of the same eight j.  The
+// arithmetic per element is the scalar kernels': bf16(bf16(x1 c) + bf16(-x2 s)), bf16(bf16(x2 c) + bf16(x1 s)).
+__device__ __forceinline__ void rope8(const uint4& a, const uint4& b, const uint4& c4, const uint4& s4, uint4& o1, uint4& o2) {
+    const uint32_t* pa = reinterpret_cast<const uint32_t*>(&a);
+    const uint32_t* pb = reinterpret_cast<const uint32_t*>(&b);
+    const uint32_t* pc = reinterpret_cast<const uint32_t*>(&c4);
+    const uint32_t* ps = reinterpret_cast<const uint32_t*>(&s4);
+    uint32_t r1[4], r2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t lo1, hi1, lo2, hi2;
+        {
+            const float x1 = __uint_as_float(pa[q] << 16), x2 = __uint_as_float(pb[q] << 16);
+            const float c = __uint_as_float(pc[q] << 16), sn = __uint_as_float(ps[q] << 16);
+            lo1 = f32_to_bf16(bf16_round(x1 * c) + bf16_round(-x2 * sn));
+            lo2 = f32_to_bf16(bf16_round(x2 * c) + bf16_round(x1 * sn));
+        }
+        {
+            const float x1 = __uint_as_float(pa[q] & 0xffff0000u), x2 = __uint_as_float(pb[q] & 0xffff0000u);
+            const float c = __uint_as_float(pc[q] & 0xffff0000u), sn = __uint_as_float(ps[q] & 0xffff0000u);
+            hi1 = f32_to_bf16(bf16_round(x1 * c) + bf16_round(-x2 * sn));
+            hi2 = f32_to_bf16(bf16_round(x2 * c) + bf16_round(x1 * sn));
+        }
+        r1[q] = lo1 | (hi1 << 16);
+        r2[q] = lo2 | (hi2 << 16);
+    }
+    o1 = make_uint4(r1[0], r1[1], r1[2], r1[3]);
+    o2 = make_uint4(r2[0], r2[1], r2[2], r2[3]);
+}
+
+#endif
+
 struct ze_seq_dev {
     int32_t ctx;        // tokens in the KV cache
     int32_t rope_delta; // position of the next token = ctx + rope_delta
@@ -101,7 +134,10 @@ void ze_launch_gather_cast_rows(const float* src, int k, const int* perm, bf16_t
 void ze_launch_vision_rope(bf16_t* qkv, const float* cosT, const float* sinT, int n, int heads, int D, hipStream_t s);
 void ze_launch_mrope_kv(bf16_t* qkv, int T, int heads, int kv_heads, int D, const bf16_t* cosT, const bf16_t* sinT,
                         const int* pos3, const int* axis_of, bf16_t* kcache, bf16_t* vcache, int max_ctx, int past, const int* row_aux, size_t cache_seq_stride,
-                        hipStream_t s);
+                        hipStream_t s, int q_skip = 0);
+// q_skip: Q stays unrotated in qkv -- the prefill flash kernel ropes it as it loads it (ze_fa_rope below; D = 128 and the 16-byte
+// form of the M-RoPE kernel, ze_mrope_vec_ok, only)
+extern int ze_mrope_vec_ok;
 void ze_launch_embed_rows(const int* src, const bf16_t* embed, const bf16_t* image_embeds, bf16_t* out, int T,
                           int hidden, hipStream_t s);
 void ze_launch_scatter_rows(const bf16_t* src, int lds_, const int* dst_idx, bf16_t* dst, int ldd, int rows, int cols,
@@ -197,11 +233,21 @@ void ze_launch_quantize_rows(bf16_t* w, int rows, int cols, int ld, uint8_t* q, 
 
 // ---- attention
 // Varlen flash attention (prefill / ViT). Tiles: host-built list of (q_start, q_end, kv_start, kv_end) int4 rows.
+// M-RoPE of the queries inside the flash kernel (round 5; D = 128 only): the kernel applies rope8 to the Q fragments it has just loaded --
+// a lane holds d = ks * 32 + fq * 8 .. + 7 for ks = 0 .. 3, i.e. both halves of eight rotate_half pairs -- with the arithmetic, tables and
+// position lookup of k_mrope_kv_vec: the same bf16 values that kernel would have written back.  cosT = nullptr: Q is used as it is.
+struct ze_fa_rope {
+    const bf16_t* cosT;
+    const bf16_t* sinT;
+    const int* pos3;     // [3][T] position ids of the pass
+    const int* axis_of;  // [D / 2] M-RoPE axis of every pair
+    int T;
+};
 void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_row_stride, int q_head_stride, const bf16_t* k,
                           int k_row_stride, int k_head_stride, const bf16_t* v, int v_row_stride, int v_head_stride,
                           bf16_t* o, int o_row_stride, int o_head_stride, const int4* tiles, int n_tiles, int heads,
                           int group, float scale, int q_pos_offset, hipStream_t s, const int* tile_aux = nullptr,
-                          size_t kv_seq_stride = 0, int q_tile = 64, int max_kv = 0);
+                          size_t kv_seq_stride = 0, int q_tile = 64, int max_kv = 0, ze_fa_rope rope = ze_fa_rope{nullptr, nullptr, nullptr, nullptr, 0});
 // q_tile: the most query rows a tile of the list spans -- 64 (default) or ZE_FA_BQ_LONG = 128, where every wave holds two
 // 16-query tiles and each K / V^T fragment it reads from LDS feeds two MFMAs (long segments: the prefill, the ViT's
 // full-attention blocks); a row's bits do not depend on the choice
