@@ -106,28 +106,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
             qf[t][ks] = *reinterpret_cast<const bf16x8*>(&val);
         }
 
-    if constexpr (D == 128) {
-        // M-RoPE of Q here instead of in k_mrope_kv_vec (which then writes K and V only): fragments ks and ks + 2 of a lane are the two
-        // halves of eight rotate_half pairs j = ks * 32 + fq * 8 .. + 7; one position axis per such chunk (ze_mrope_vec_ok)
-        if (rope.cosT) {
-#pragma unroll
-            for (int t = 0; t < QT; ++t)
-                if (qi[t] < q1) {
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const int j = ks * 32 + fq * 8;
-                        const int pos = rope.pos3[rope.axis_of[j] * rope.T + qi[t]];
-                        const uint4 c4 = *reinterpret_cast<const uint4*>(rope.cosT + (size_t)pos * 64 + j);
-                        const uint4 s4 = *reinterpret_cast<const uint4*>(rope.sinT + (size_t)pos * 64 + j);
-                        uint4 o1, o2;
-                        rope8(*reinterpret_cast<const uint4*>(&qf[t][ks]), *reinterpret_cast<const uint4*>(&qf[t][ks + 2]), c4, s4, o1, o2);
-                        qf[t][ks] = *reinterpret_cast<const bf16x8*>(&o1);
-                        qf[t][ks + 2] = *reinterpret_cast<const bf16x8*>(&o2);
-                    }
-                }
-        }
-    }
-
     f32x4 oacc[QT][NV];
     float m_run[QT], l_run[QT];
 #pragma unroll
@@ -200,13 +178,36 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
         }
     };
     if (ntile > 0) {
-        if constexpr (DMA) {
-            stage_dma(0, kv0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            stage_load(kv0);
-            stage_write(0, kv0);
+        if constexpr (DMA) stage_dma(0, kv0);
+        else stage_load(kv0);
+    }
+    if constexpr (D == 128) {
+        // (behind the first tile's loads, so that its two dependent lookups -- position, then cos / sin -- ride on their latency)
+        // M-RoPE of Q here instead of in k_mrope_kv_vec (which then writes K and V only): fragments ks and ks + 2 of a lane are the two
+        // halves of eight rotate_half pairs j = ks * 32 + fq * 8 .. + 7; one position axis per such chunk (ze_mrope_vec_ok)
+        if (rope.cosT) {
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+                if (qi[t] < q1) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int j = ks * 32 + fq * 8;
+                        const int axis = j < rope.s0 ? 0 : (j < rope.s01 ? 1 : 2);
+                        const int pos = rope.pos3[axis * rope.T + qi[t]];
+                        const uint4 c4 = *reinterpret_cast<const uint4*>(rope.cosT + (size_t)pos * 64 + j);
+                        const uint4 s4 = *reinterpret_cast<const uint4*>(rope.sinT + (size_t)pos * 64 + j);
+                        uint4 o1, o2;
+                        rope8(*reinterpret_cast<const uint4*>(&qf[t][ks]), *reinterpret_cast<const uint4*>(&qf[t][ks + 2]), c4, s4, o1, o2);
+                        qf[t][ks] = *reinterpret_cast<const bf16x8*>(&o1);
+                        qf[t][ks + 2] = *reinterpret_cast<const bf16x8*>(&o2);
+                    }
+                }
         }
+    }
+
+    if (ntile > 0) {
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else stage_write(0, kv0);
     }
     __syncthreads();
 

@@ -628,7 +628,7 @@ static int prefill_impl(ze_engine* e, int seq, const int32_t* input_ids, int len
                            e->kc(li, seq), e->vc(li, seq), c.max_ctx, past, nullptr, 0, s, q_in_flash ? 1 : 0);
         ze_launch_flash_attn(hd, 1, e->tqkv, nqkv, hd, e->kc(li, seq), hd, c.max_ctx * hd, e->vc(li, seq), hd,
                              c.max_ctx * hd, e->to, nq, hd, e->ttiles, nt, c.heads, c.heads / c.kv_heads, scale, past,
-                             s, nullptr, 0, bq, 0, q_in_flash ? ze_fa_rope{e->cosT, e->sinT, e->tpos, e->axis_of, len} : ze_fa_rope{nullptr, nullptr, nullptr, nullptr, 0});
+                             s, nullptr, 0, bq, 0, q_in_flash ? ze_fa_rope{e->cosT, e->sinT, e->tpos, c.mrope_section[0], c.mrope_section[0] + c.mrope_section[1], len} : ze_fa_rope{nullptr, nullptr, nullptr, 0, 0, 0});
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, len, H, nq, s);
         prefill_norm_gemm(e, L.post_norm, L.gate_up, nullptr, ZE_EPI_SWIGLU, e->ta, e->text_ipad, len, 2 * e->text_ipad, s);
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, nullptr,
@@ -788,7 +788,7 @@ extern "C" int ze_prefill_batch(ze_engine* e, const int32_t* seqs, int n, const 
         ze_launch_flash_attn(hd, 1, e->tqkv, nqkv, hd, e->kc(li, 0), hd, c.max_ctx * hd, e->vc(li, 0), hd,
                              c.max_ctx * hd, e->to, nq, hd, e->ttiles, nt, c.heads, c.heads / c.kv_heads, scale, 0, s,
                              e->ttile_aux, seq_stride, bq, 0,
-                             q_in_flash ? ze_fa_rope{e->cosT, e->sinT, e->tpos, e->axis_of, total} : ze_fa_rope{nullptr, nullptr, nullptr, nullptr, 0});
+                             q_in_flash ? ze_fa_rope{e->cosT, e->sinT, e->tpos, c.mrope_section[0], c.mrope_section[0] + c.mrope_section[1], total} : ze_fa_rope{nullptr, nullptr, nullptr, 0, 0, 0});
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, total, H, nq, s);
         prefill_norm_gemm(e, L.post_norm, L.gate_up, nullptr, ZE_EPI_SWIGLU, e->ta, e->text_ipad, total, 2 * e->text_ipad, s);
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, nullptr,

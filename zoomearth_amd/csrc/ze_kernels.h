@@ -240,14 +240,14 @@ struct ze_fa_rope {
     const bf16_t* cosT;
     const bf16_t* sinT;
     const int* pos3;     // [3][T] position ids of the pass
-    const int* axis_of;  // [D / 2] M-RoPE axis of every pair
+    int s0, s01;         // M-RoPE sections: pairs [0, s0) follow axis 0, [s0, s01) axis 1, the rest axis 2 (no table load in the kernel)
     int T;
 };
 void ze_launch_flash_attn(int D, int causal, const bf16_t* q, int q_row_stride, int q_head_stride, const bf16_t* k,
                           int k_row_stride, int k_head_stride, const bf16_t* v, int v_row_stride, int v_head_stride,
                           bf16_t* o, int o_row_stride, int o_head_stride, const int4* tiles, int n_tiles, int heads,
                           int group, float scale, int q_pos_offset, hipStream_t s, const int* tile_aux = nullptr,
-                          size_t kv_seq_stride = 0, int q_tile = 64, int max_kv = 0, ze_fa_rope rope = ze_fa_rope{nullptr, nullptr, nullptr, nullptr, 0});
+                          size_t kv_seq_stride = 0, int q_tile = 64, int max_kv = 0, ze_fa_rope rope = ze_fa_rope{nullptr, nullptr, nullptr, 0, 0, 0});
 // q_tile: the most query rows a tile of the list spans -- 64 (default) or ZE_FA_BQ_LONG = 128, where every wave holds two
 // 16-query tiles and each K / V^T fragment it reads from LDS feeds two MFMAs (long segments: the prefill, the ViT's
 // full-attention blocks); a row's bits do not depend on the choice
