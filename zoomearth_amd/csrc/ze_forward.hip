@@ -508,7 +508,7 @@ extern "C" int ze_seq_mark_seen(ze_engine* e, int seq, const int32_t* ids, int n
 // ids each always fit), allocated at the first batched call
 static int xfer_reserve(ze_engine* e, int*& host, int*& dev, size_t& cap) {
     if (cap) return ZE_OK;
-    const size_t want = (size_t)e->cfg.max_seqs * (size_t)e->cfg.max_ctx + 2 * (size_t)e->cfg.max_seqs + 8;
+    const size_t want = (size_t)e->cfg.max_seqs * (size_t)e->cfg.max_ctx + 3 * (size_t)e->cfg.max_seqs + 8;  // rows + (n_gen, finished | offsets) + slots
     ZE_HIP(hipHostMalloc((void**)&host, want * sizeof(int)));
     ZE_HIP(hipMalloc((void**)&dev, want * sizeof(int)));
     cap = want;
