@@ -11,6 +11,9 @@ lanes = sorted({r[0] for r in rows})
 by = defaultdict(list)
 passes = defaultdict(list)
 for r in rows:
+    if r[2] == "G":
+        print("scheduler", r[0], "pass enqueued at host +%.3f s; on the GPU it started at +%.3f s and ended at +%.3f s (since the scheduler was created)" % (float(r[3]), float(r[4]), float(r[5])))
+        continue
     if r[2] == "P":
         passes[r[0]].append((float(r[1]), int(r[3]), int(r[4])))
     else:

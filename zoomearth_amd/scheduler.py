@@ -125,6 +125,10 @@ class ChainScheduler:
         self._round = None                 # (todo, needed) of that round: images still to encode / features to keep
         self._ready = []                   # prefilled requests waiting to join the live set
         self._pass_done = []               # (overlap) per entry of _ready: the event behind its prefill pass
+        self._trace_ev = None
+        if os.environ.get("ZE_SCHED_TRACE") and torch.cuda.is_available():   # measurement only: when the first passes really START on the GPU
+            self._trace_ev = dict(base=torch.cuda.Event(enable_timing=True), t0=time.perf_counter(), passes=[])
+            self._trace_ev["base"].record(torch.cuda.current_stream(self.engine.device))
         model._chains.clear()              # the scheduler owns every chain slot while it runs
 
     # ------------------------------------------------------------------ queue
@@ -143,6 +147,12 @@ class ChainScheduler:
     def run(self) -> None:
         while self.busy():
             self.step()
+        tr = self._trace_ev
+        if tr is not None and tr["passes"]:
+            torch.cuda.synchronize()
+            with open(os.environ["ZE_SCHED_TRACE"], "a") as f:
+                for host_s, a, b in tr["passes"]:
+                    f.write(f"{id(self) % 100000} {tr['t0']:.4f} G {host_s:.4f} {tr['base'].elapsed_time(a) / 1e3:.4f} {tr['base'].elapsed_time(b) / 1e3:.4f}\n")
 
     # ------------------------------------------------------------------ one scheduling round
     def step(self) -> None:
@@ -271,7 +281,15 @@ class ChainScheduler:
                 self._encode(OrderedDict(todo), needed)
                 todo.clear()
             n0 = len(self._ready)
-            self._prefill(group)
+            tr = self._trace_ev
+            if tr is not None and len(tr["passes"]) < 4 and self._side is not None:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(self._side)
+                self._prefill(group)
+                b.record(self._side)
+                tr["passes"].append((time.perf_counter() - tr["t0"], a, b))
+            else:
+                self._prefill(group)
             if self._side is not None and len(self._ready) > n0:
                 # the pass's own event: its chains may join the live set as soon as THIS pass is over, whatever else the
                 # admission stream has been given since
