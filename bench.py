@@ -769,8 +769,8 @@ def main():
         torch.cuda.synchronize()
         e2.weights_invalidate()
         engines.append(e2)
-    if len(engines) > 1:
-        e.lib.ze_tune(4, 1)   # engines sharing the GPU: tile-granular prefill GEMM launches (what model.clone_lane() sets)
+    # (several engines on one GPU: the eight-phase prefill GEMM launches one tile per workgroup by itself -- the library counts its
+    #  live engines, zoomearth.h knob 4 -- no process-wide switch is flipped here any more)
 
     def barrier():
         torch.cuda.synchronize()
@@ -1077,10 +1077,13 @@ def main():
             return None, None
 
     def top_kernel_by_gpu_time():
-        """the line's `roofline` names the dominant kernel of the DECODE STEP; the stream's largest consumer of GPU time
-        is another one.  Its name and share come from the latest committed rocprofv3 --kernel-trace --stats summary of this very
+        """the line's `roofline` names the dominant kernel of the DECODE STEP; the stream's largest consumer of GPU
+        time is another one.  Its name and share come from the latest committed rocprofv3 --kernel-trace --stats summary of this very
         command (profiles/rNN_stream_kernel_stats.csv: a profiler cannot run inside this process); its own roofline fraction is
-        measured here, alone on the GPU, at the shape the stream runs it."""
+        measured here, alone on the GPU, per SHAPE (the two pass sizes of the replay: 16 x 802 and 16 x 330 rows -- never a mean over
+        both), in BOTH launch forms (persistent workgroups / one tile per workgroup: what several lanes sharing the GPU run), on the
+        pass's own operands: the layers' weights in rotation and the activation rows the replayed passes left in the workspace
+        (ze_profile_prefill_kernel).  `frac` = the form the stream runs, at the larger pass."""
         import csv
         import glob
         import re as _re
@@ -1098,22 +1101,24 @@ def main():
         obj = {"kernel": top["kernel"].split("(")[0], "share_of_gpu_time": round(float(top["pct_time"]) / 100.0, 4),
                "mean_us_in_stream": round(float(top["mean"]) / 1000.0, 1), "share_source": "profiles/" + os.path.basename(best[1])}
         if "k_gemm_p8<3" in top["kernel"]:  # the prefill / ViT gate-up (SwiGLU epilogue) on the eight-phase 256 x 256 tiles
-            m_rows, n_cols, k_dim = 16 * (L_TEXT_A + 2 + 324 + L_TEXT_B), 2 * cfg.text.intermediate_size, cfg.text.hidden_size
-            a = (torch.randn(m_rows, k_dim, device="cuda") * 0.5).to(torch.bfloat16)
-            w = (torch.randn(n_cols, k_dim, device="cuda") * 0.05).to(torch.bfloat16)
-            for _ in range(2):
-                e.op_linear(a, w, act=4)
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
-            for _ in range(6):
-                e.op_linear(a, w, act=4)
-            ev1.record()
-            torch.cuda.synchronize()
-            us = ev0.elapsed_time(ev1) * 1000.0 / 6
-            tf = 2.0 * m_rows * n_cols * k_dim / (us * 1e-6) / 1e12
-            obj.update(bound="mfma", isolated_us=round(us, 1), achieved_TFLOPs=round(tf, 1), peak_TFLOPs=2500.0, frac=tf / 2500.0,
-                       shape=f"the 16-chain prefill pass: {m_rows} rows x {n_cols} (gate/up interleaved) x {k_dim}, SwiGLU epilogue, random operands")
-            del a, w
+            shapes = {}
+            in_stream = "tile_granular" if len(engines) > 1 else "persistent"
+            for rows_p in (16 * (L_TEXT_A + 2 + 324 + L_TEXT_B), 16 * 330):
+                if rows_p > e.max_prefill_rows:
+                    continue
+                ent = {}
+                for form, knob in (("persistent", 2), ("tile_granular", 1)):
+                    e.lib.ze_tune(4, knob)
+                    us, fl = e.profile_prefill_kernel(2, rows_p, 12)
+                    ent[form] = {"us": round(us, 1), "TFLOPs": round(fl / (us * 1e-6) / 1e12, 1), "frac": round(fl / (us * 1e-6) / 2.5e15, 4)}
+                shapes[str(rows_p)] = ent
+            e.lib.ze_tune(4, 2)
+            big = shapes[max(shapes, key=int)]
+            obj.update(bound="mfma", peak_TFLOPs=2500.0, form_in_stream=in_stream, frac=big[in_stream]["frac"],
+                       achieved_TFLOPs=big[in_stream]["TFLOPs"], isolated_us=big[in_stream]["us"], by_rows=shapes,
+                       shape=(f"gate/up of the replayed prefill passes: rows x {2 * cfg.text.intermediate_size} (gate/up interleaved) x "
+                              f"{cfg.text.hidden_size}, SwiGLU epilogue; operands = the pass's own (post-norm rows of its last layer, the 36 "
+                              "layers' weights in rotation); FLOP = 2 x rows x N x K unpadded; `frac` is the larger pass in the form the stream runs"))
         return obj
 
     def configs1_object(steps, warmup):
@@ -1223,7 +1228,7 @@ def main():
             line["mean_chains_per_step"] = round(st.get("chain_steps", 0) / steps_run, 1)
             line["scheduler"] = st
             if len(engines) > 1:
-                e.lib.ze_tune(4, 0)   # the annexes below run ONE engine alone: persistent launches again
+                e.lib.ze_tune(4, 2)   # the annexes below run ONE engine's kernels alone: the persistent form (restored to 0 = by live-engine count below)
             if args.model == "3b" and not args.fp8:
                 live = int(min(SLOTS, max(1, round(line["mean_chains_per_step"]))))
                 mean_ctx = live_like_contexts(live)
@@ -1300,6 +1305,7 @@ def main():
             line["configs1"] = configs1_object(4, 1)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             line["cpu_baseline"] = measure_cpu_baseline(args.cpu_baseline)
+        e.lib.ze_tune(4, 0)   # (back to the library's own rule: by live-engine count)
         print(json.dumps(line), flush=True)
     for en in engines:
         en.close()

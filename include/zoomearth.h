@@ -369,6 +369,12 @@ int ze_op_kv_read(ze_engine* e, int seq, int layer, int start, int n, void* out_
  * cache); out_bf16 [n, heads x 128] = softmax(q K^T / sqrt(128)) V over rows 0 .. ctx, per head, with the step's own kernel. */
 int ze_op_attn_decode(ze_engine* e, const int32_t* seqs, int n, int layer, const void* qkv_bf16, void* out_bf16, void* stream);
 
+/* The numeric helpers every epilogue shares, alone (device pointers, n elements): out[i] = bf16(x[i]) | bf16(bf16(SiLU(x[i])) * y[i]) << 16
+ * -- HF Qwen2MLP `act_fn(gate_proj(x)) * up_proj(x)` on bf16 modules, transformers/models/qwen2_5_vl/modeling_qwen2_5_vl.py:541-554 --
+ * and out2[i] = the packed pair (bf16(x[i]) | bf16(y[i]) << 16) of the library's f32 -> bf16 store.  Parity ledger: tests hold both
+ * to float64 over every bf16 input. */
+int ze_op_numeric_helpers(ze_engine* e, const float* x, const float* y, uint32_t* out, uint32_t* out2, int n, void* stream);
+
 /* ------------------------------------------------------------------ measurement */
 /* Runs the decode-path weight-streaming kernel `which` (0 qkv, 1 o_proj, 2 gate_up, 3 down, 4 lm_head) `iters`
  * times back to back on `stream`, cycling through the layers' real weights, bracketed by HIP events on that
@@ -380,14 +386,23 @@ int ze_profile_decode_kernel(ze_engine* e, int which, int iters, float* avg_us, 
  * 6 RMSNorm, 7 rope + KV append. */
 int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters, float* avg_us, double* bytes_per_launch,
                             void* stream);
+/* The same for the projections of a PREFILL pass (HF Qwen2_5_VLDecoderLayer: q/k/v_proj, o_proj, gate/up_proj, down_proj,
+ * transformers/models/qwen2_5_vl/modeling_qwen2_5_vl.py:541-554, 692-757) on the pass's own operands: the layers' real weights in
+ * rotation and the activation rows the last ze_prefill_batch left in the workspace, through the launcher the pass uses.
+ * which = 0 qkv, 1 o_proj, 2 gate_up (SwiGLU), 3 down; rows <= max_prefill_rows; outputs go to scratch.  flops_per_launch =
+ * 2 x rows x N x K (unpadded). */
+int ze_profile_prefill_kernel(ze_engine* e, int which, int rows, int iters, float* avg_us, double* flops_per_launch,
+                              void* stream);
 /* Measurement-only kernel-configuration override (A/B of kernels and launch shapes inside one process; value 0 is always
  * the shipped default, every alternative computes the same function -- bit for bit unless noted).  Knobs (0..23; round 4 re-used
  * knobs 3 and 4, which until round 3 switched the removed one-launch-per-layer kernels: an old `3:1` / `4:1` habit now changes GEMM
  * tiling / launch form -- same results, different speed):
  *   0, 1  variants of the single-chain down / gate-up GEMVs          2   grid cap of the GEMV family
  *   3     first row count of the 320 x 192 decode tiles (measurements) 5   1: no fragment / skinny kernels in the batched step
- *   4     1: the eight-phase GEMM launches one tile per workgroup instead of persistent workgroups -- for SEVERAL ENGINES ON
- *         ONE GPU (lanes): the other engine's kernels get CUs at tile boundaries (set by clone_lane; same bits either way)
+ *   4     launch form of the eight-phase GEMM: 0 = by the number of engines alive in this process (one: persistent workgroups;
+ *         several -- lanes sharing the GPU --: one tile per workgroup, so that the other engine's kernels get CUs at tile boundaries;
+ *         the library counts its engines itself, no caller sets this), 1 = always one tile per workgroup, 2 = always persistent
+ *         (same bits in every form)
  *   6, 7  GEMM policy (register-staged vs LDS-DMA ring; forced tile) 8   batched decode attention: 2 = ring kernel,
  *                                                                        1 = 64-key slice kernel (agree within rounding)
  *   9     1: skinny instead of one-shot o projection                 10  1: bf16 fragments on a quantised engine
@@ -401,7 +416,11 @@ int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters, float* av
  *   21    1: column walk of the eight-phase GEMM's tile grid (default: 8 x 4 blocks; > 1: R << 8 | C blocks)
  *   22    1: the prefill's queries rotated in place by the M-RoPE kernel (default at head_dim 128: inside the flash kernel, as it loads
  *            them; the M-RoPE kernel then writes K and V only; same bits)
- * Changing a knob invalidates captured decode graphs (they are re-captured on the next step). */
+ * Changing a knob invalidates captured decode graphs (they are re-captured on the next step).
+ * PROCESS-WIDE, by design: there is no engine argument, every engine of the process sees the value at its next launch, and nothing in
+ * the product path (Engine, scheduler, entry points, clone_lane) calls it -- a knob is for A/B measurements and the bit-equality tests,
+ * which reset it to 0 when they are done.  A library user who wants a per-engine policy has none to set: value 0 is the only supported
+ * production setting. */
 int ze_tune(int knob, int value);
 /* Per-phase device time (ms) accumulated by HIP events since the last reset: [0] front-end, [1] ViT,
  * [2] prefill, [3] decode, [4] sampling.  Only recorded while enabled. */

@@ -16,6 +16,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
+def pytest_sessionfinish(session, exitstatus):
+    import parity_ledger
+    path = parity_ledger.flush()
+    if path:
+        print(f"\nparity ledger: {len(parity_ledger.rows())} rows -> {path}")
+
+
 def sha(a) -> str:
     if isinstance(a, str):
         a = a.encode("utf-8")

@@ -20,6 +20,8 @@ import dataclasses
 
 import numpy as np
 import pytest
+
+import parity_ledger
 import torch
 
 from oracle import frontend, prng
@@ -73,6 +75,7 @@ def test_3b_layer_shape_vit_prefill_decode_vs_oracle():
         err_v = float(np.abs(got_v - v32).max())
         rms_v = float(np.sqrt(np.mean((got_v - v32) ** 2))), float(np.sqrt(np.mean((v16 - v32) ** 2)))
         print(f"3B ViT (1296 patches): max|engine - fp32| = {err_v:.4f} (oracle bf16-vs-fp32 {yard_v:.4f}), rms {rms_v[0]:.5f} ({rms_v[1]:.5f})")
+        parity_ledger.record(err_v, yard_v, "3B ViT, 1296 patches")
         assert err_v <= 2.0 * yard_v and rms_v[0] <= 2.0 * rms_v[1]
 
         # ---- prefill of the benchmark prompt (21 + 1 + 324 + 1 + 455 = 802 tokens) and 6 teacher-forced decode steps
@@ -92,6 +95,7 @@ def test_3b_layer_shape_vit_prefill_decode_vs_oracle():
         worst = [float(np.abs(a - b).max()) for a, b in zip(got, ref32)]
         print(f"3B prefill(802) + 6 decode steps (batch-1 GEMV path): max|engine - fp32| per step = "
               f"{[round(x, 4) for x in worst]}, oracle bf16-vs-fp32 = {yard:.4f}")
+        parity_ledger.record(max(worst), yard, "3B prefill(802) + 6 GEMV decode steps")
         assert max(worst) <= 2.0 * yard
         # greedy token agrees with the fp32 oracle wherever its top-1 / top-2 margin is decidable
         undecidable = 0
@@ -126,6 +130,8 @@ def test_3b_layer_shape_vit_prefill_decode_vs_oracle():
         print(f"3B free-running greedy, {n_free} tokens, penalty {pen}: " +
               (f"identical to the fp32 oracle's ({len(set(ref_toks))} distinct tokens)" if first is None else
                f"first divergence at step {first}, oracle margin there {margins[first]:.4f} (bf16 yardstick {yard:.4f}; first sub-margin step {first_sub})"))
+        parity_ledger.record(0.0 if first is None else margins[first], yard, f"free-running greedy, {n_free} tokens: oracle top-1/top-2 margin at the first "
+                             f"divergence (step {first}; first sub-margin step {first_sub})", sub_margin_steps=int(sum(m <= 4.0 * yard for m in margins)), bar=4.0)
         assert first is None or first >= first_sub, (first, first_sub, margins[:first + 1])
 
         # ---- the same chain through the batched decode step at 1, 33 and 64 chains.  Chain c = the prompt (every
@@ -159,6 +165,7 @@ def test_3b_layer_shape_vit_prefill_decode_vs_oracle():
                 errs = [max(float(np.abs(l1[c] - want[c][0]).max()), float(np.abs(l2[c] - want[c][1]).max())) for c in chains]
                 print(f"3B batched decode, family {regime}, {n} chains: max|engine - fp32| = {max(errs):.4f} "
                       f"(2 x yardstick = {2 * yard:.4f})")
+                parity_ledger.record(max(errs), yard, f"batched decode, regime {regime}, {n} chains")
                 assert max(errs) <= 2.0 * yard, (regime, n, int(np.argmax(errs)), max(errs))
                 # greedy token against the fp32 oracle wherever its margin is decidable
                 for c in chains:
@@ -243,6 +250,7 @@ def test_3b_layer_shape_row_streaming_at_the_headline_chain_counts():
                         undecided += 1
             print(f"3B row-streaming decode at {n} chains: max|engine - fp32| = {max(errs):.4f} (2 x yardstick = {2 * yard:.4f}), "
                   f"greedy token equal on {2 * n - undecided} of {2 * n} decidable steps")
+            parity_ledger.record(max(errs), yard, f"row-streaming decode at {n} chains")
             assert max(errs) <= 2.0 * yard, (n, int(np.argmax(errs)), max(errs), yard)
             for c in (0, 1):
                 if c < n:
@@ -294,6 +302,7 @@ def test_vit_call_on_sixteen_images_equals_the_single_image_calls():
                 got = both[off: off + k].float().cpu().numpy()
                 err, yard = float(np.abs(got - v32).max()), float(np.abs(v16 - v32).max())
                 print(f"image {i} of the 16-image call (grid {g}): max|engine - fp32| = {err:.4f} (oracle bf16-vs-fp32 {yard:.4f})")
+                parity_ledger.record(err, yard, "test_gpu_3b_shape.py:299")
                 assert err <= 2.0 * yard
             off += k
     finally:
@@ -326,6 +335,7 @@ def test_demo_view_1036_px_vit_and_prefill_vs_oracle():
         rms_v = float(np.sqrt(np.mean((got_v - v32) ** 2))), float(np.sqrt(np.mean((v16 - v32) ** 2)))
         print(f"demo view ViT (5476 patches, 100 windows): max|engine - fp32| = {err_v:.4f} (oracle bf16-vs-fp32 {yard_v:.4f}), "
               f"rms {rms_v[0]:.5f} ({rms_v[1]:.5f})")
+        parity_ledger.record(err_v, yard_v, "test_gpu_3b_shape.py:331")
         assert err_v <= 2.0 * yard_v and rms_v[0] <= 2.0 * rms_v[1]
         ids = prng.uniform_ints(51, 21, 10, 3990).tolist() + [VS] + [IMG] * 1369 + [VE] + prng.uniform_ints(52, 455, 10, 3990).tolist()
         forced = [int(t) for t in prng.uniform_ints(53, 3, 10, 3990)]
@@ -338,6 +348,7 @@ def test_demo_view_1036_px_vit_and_prefill_vs_oracle():
         worst = [float(np.abs(a - b).max()) for a, b in zip(got, ref32)]
         print(f"demo view prefill({len(ids)}) + 3 decode steps: max|engine - fp32| = {[round(x, 4) for x in worst]}, "
               f"oracle bf16-vs-fp32 = {yard:.4f}")
+        parity_ledger.record(max(worst), yard, "test_gpu_3b_shape.py:343")
         assert max(worst) <= 2.0 * yard
         for a, b in zip(got, ref32):
             top2 = np.partition(b, -2)[-2:]

@@ -10,6 +10,8 @@ import dataclasses
 
 import numpy as np
 import pytest
+
+import parity_ledger
 import torch
 
 from oracle import prng
@@ -47,6 +49,7 @@ def test_7b_layer_shape_text_path_vs_oracle():
         yard = max(float(np.abs(a - b).max()) for a, b in zip(ref16, ref32))
         worst = max(float(np.abs(a - b).max()) for a, b in zip(got, ref32))
         print(f"7B layer shape: max|engine - fp32 oracle| = {worst:.4f}, oracle bf16-vs-fp32 = {yard:.4f}")
+        parity_ledger.record(worst, yard, "test_gpu_7b_shape.py:50")
         assert worst <= 2.0 * yard
         # batched decode of two chains on this shape agrees with the single-chain path within the same yardstick
         for s in (0, 1):
@@ -57,6 +60,7 @@ def test_7b_layer_shape_text_path_vs_oracle():
             e.seq_reset(s)
             e.prefill(s, ids[: 100 + 30 * s], None, pos[:, : 100 + 30 * s], delta, want_logits=False)
             ls = e.decode_step(s, forced[s]).cpu().numpy()
+            parity_ledger.record(float(np.abs(ls - lb[s]).max()), yard, "test_gpu_7b_shape.py:60")
             assert float(np.abs(ls - lb[s]).max()) <= 2.0 * yard
         toks = e.generate(0, 8, ignore_eos=True)
         assert len(toks) == 8
@@ -94,6 +98,7 @@ def test_7b_shape_through_the_vit():
         o32, o16 = Q.Qwen25VLOracle(oc, w, "fp32"), Q.Qwen25VLOracle(oc, w, "bf16")
         v32, v16 = o32.vit_forward(want_pv, [want_grid]), o16.vit_forward(want_pv, [want_grid])
         assert emb.shape == (196, 3584)
+        parity_ledger.record(float(np.abs(emb.float().cpu().numpy() - v32).max()), float(np.abs(v16 - v32).max()), "7B-shape ViT")
         assert float(np.abs(emb.float().cpu().numpy() - v32).max()) <= 2.0 * float(np.abs(v16 - v32).max())
         ids = prng.uniform_ints(8, 20, 10, 3990).tolist() + [4001] + [4000] * 196 + [4002] + prng.uniform_ints(9, 60, 10, 3990).tolist()
         forced = [int(t) for t in prng.uniform_ints(10, 3, 10, 3990)]
@@ -105,6 +110,7 @@ def test_7b_shape_through_the_vit():
         yard = max(float(np.abs(a - b).max()) for a, b in zip(ref16, ref32))
         worst = max(float(np.abs(a - b).max()) for a, b in zip(got, ref32))
         print(f"7B shape through the ViT: max|engine - fp32 oracle| = {worst:.4f}, oracle bf16-vs-fp32 = {yard:.4f}")
+        parity_ledger.record(worst, yard, "test_gpu_7b_shape.py:108")
         assert worst <= 2.0 * yard
     finally:
         e.close()

@@ -5,6 +5,8 @@ its steps; (2) agreement with the single-chain GEMV path within bf16 rounding of
 chains leaving the batch at their EOS."""
 import numpy as np
 import pytest
+
+import parity_ledger
 import torch
 
 from gpu_util import CHAIN_W, tiny_engine  # noqa: F401
@@ -69,6 +71,7 @@ def test_decode_batch_invariance_and_agreement(eng):
         ref32, ref16 = o32.decode_step(forced[1][step]), o16.decode_step(forced[1][step])
         errs.append(np.abs(batch_logits[step][1] - ref32).max())
         yard.append(np.abs(ref16 - ref32).max())
+    parity_ledger.record(max(errs), max(yard), "test_gpu_batch.py:72")
     assert max(errs) <= 2.0 * max(yard), (errs, yard)
 
 
@@ -324,7 +327,9 @@ def test_follow_up_on_decode_written_rows_matches_the_oracle(eng):
     err_reused, err_fresh = float(np.abs(reused - ref32).max()), float(np.abs(fresh - ref32).max())
     print(f"follow-up on decode-written rows: |reused - fp32| = {err_reused:.4f}, |full prefill - fp32| = {err_fresh:.4f}, "
           f"oracle bf16-vs-fp32 = {yard:.4f}")
+    parity_ledger.record(err_reused, yard, "test_gpu_batch.py:327")
     assert err_reused <= 2.0 * yard and err_fresh <= 2.0 * yard
+    parity_ledger.record(float(np.abs(reused - fresh).max()), yard, "test_gpu_batch.py:328")
     assert float(np.abs(reused - fresh).max()) <= 2.0 * yard
 
 

@@ -6,6 +6,8 @@
   * fp8 decode vs the bf16 GEMV decode of the same (dequantised) weights: same products, another summation order."""
 import numpy as np
 import pytest
+
+import parity_ledger
 import torch
 
 from gpu_util import CHAIN_W
@@ -76,11 +78,13 @@ def test_fp8_model_vs_oracle_on_dequantised_weights(fresh_tiny):
     moved = max(float(np.abs(a - b).max()) for a, b in zip(got, bf16_run))
     print(f"fp8 model: max|engine - fp32 oracle(dq)| = {worst:.4f}, oracle bf16-vs-fp32 = {yard:.4f}, "
           f"fp8 vs unquantised engine = {moved:.4f}")
+    parity_ledger.record(worst, yard, "test_gpu_fp8.py:79")
     assert worst <= 2.0 * yard
     assert moved > 4.0 * yard  # the quantisation is really in effect (it moves the logits far more than bf16 noise)
     # decode stream (fp8 GEMV) vs prefill path (bf16 GEMM on the dequantised copy): one model
     e.seq_reset(1)
     full = e.prefill(1, ids + forced[:1], None, *e.rope_index(ids + forced[:1], [])).cpu().numpy()
+    parity_ledger.record(float(np.abs(full - got[1]).max()), yard, "test_gpu_fp8.py:84")
     assert float(np.abs(full - got[1]).max()) <= 2.0 * yard
     # generation runs (graph path) and batched decode (bf16 GEMM on the dequantised copy) agree with the fp8 GEMV path
     e.seq_reset(0)
@@ -90,6 +94,7 @@ def test_fp8_model_vs_oracle_on_dequantised_weights(fresh_tiny):
     e.seq_reset(1)
     e.prefill(1, ids, None, pos, delta, want_logits=False)
     lb = e.decode_batch([1], [forced[0]]).cpu().numpy()[0]
+    parity_ledger.record(float(np.abs(lb - got[1]).max()), yard, "test_gpu_fp8.py:93")
     assert float(np.abs(lb - got[1]).max()) <= 2.0 * yard
 
 
@@ -199,12 +204,15 @@ def test_fp8_activation_model_vs_oracle_and_across_kernels(fresh_tiny):
     moved = max(float(np.abs(a - b).max()) for a, b in zip(got_gemv, w8a16))
     print(f"fp8 activations: |gemv - fp32 oracle| = {worst_gemv:.4f}, |batched - fp32 oracle| = {worst_batch:.4f}, "
           f"oracle bf16-vs-fp32 = {yard:.4f}, moved vs bf16 activations = {moved:.4f}")
+    parity_ledger.record(worst_gemv, yard, "test_gpu_fp8.py:202")
     assert worst_gemv <= 2.0 * yard and worst_batch <= 2.0 * yard
     assert moved > 0.0                                    # the mode is really in effect
     # prefill of prompt + first forced token == decode of that token (both kernels), within the same yardstick
     e.seq_reset(1)
     full = e.prefill(1, ids + forced[:1], None, *e.rope_index(ids + forced[:1], [])).cpu().numpy()
+    parity_ledger.record(float(np.abs(full - got_gemv[1]).max()), yard, "test_gpu_fp8.py:207")
     assert float(np.abs(full - got_gemv[1]).max()) <= 2.0 * yard
+    parity_ledger.record(float(np.abs(full - got_batch[1]).max()), yard, "test_gpu_fp8.py:208")
     assert float(np.abs(full - got_batch[1]).max()) <= 2.0 * yard
     # switching the mode off returns the W8A16 model exactly
     e.set_fp8_activations(False)

@@ -19,6 +19,8 @@ import zlib
 
 import numpy as np
 import pytest
+
+import parity_ledger
 import torch
 
 from oracle import frontend, prng
@@ -90,6 +92,7 @@ def test_full_depth_vit_prefill_and_every_decode_path_vs_oracle():
         rms = lambda a: float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))  # noqa: E731
         print(f"full-depth ViT (32 blocks, 1296 patches): max|engine - fp32| = {err_v:.4f}, oracle bf16-vs-fp32 = {yard_v:.4f}; "
               f"rms {rms(got_v - v32):.5f} / {rms(v16 - v32):.5f}; scale {float(np.abs(v32).max()):.2f} ({time.time() - t0:.0f}s)")
+        parity_ledger.record(err_v, yard_v, "test_gpu_full_depth.py:93")
         assert err_v <= 2.0 * yard_v and rms(got_v - v32) <= 2.0 * rms(v16 - v32)
 
         # ---- prefill of the benchmark prompt through all 36 layers + 4 teacher-forced steps.  Both oracles take the
@@ -112,6 +115,7 @@ def test_full_depth_vit_prefill_and_every_decode_path_vs_oracle():
             worst_rms = [rms(a - b) for a, b in zip(got, ref32)]
             print(f"full depth, {name}: max|engine - fp32| per step = {[round(x, 4) for x in worst]} (oracle bf16-vs-fp32 "
                   f"{yard:.4f}), rms {[round(x, 5) for x in worst_rms]} ({yard_rms:.5f}); logit scale {float(np.abs(ref32[0]).max()):.2f}")
+            parity_ledger.record(max(worst), yard, "test_gpu_full_depth.py:115")
             assert max(worst) <= 2.0 * yard and max(worst_rms) <= 2.0 * yard_rms, name
             for a, b in zip(got, ref32):  # greedy token wherever the fp32 margin is decidable
                 top2 = np.partition(b, -2)[-2:]

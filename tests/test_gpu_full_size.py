@@ -12,6 +12,8 @@ of SURVEY 8 c.2):
 """
 import numpy as np
 import pytest
+
+import parity_ledger
 import torch
 
 from oracle import prng
@@ -73,6 +75,7 @@ def test_prefill_and_decode_agree_at_full_depth(full):
         rel = float(np.sqrt(np.mean((got - whole).astype(np.float64) ** 2))) / rms
         print(f"full depth, {len(ids)} tokens: |{name} decode - prefill| = {err:.4f} (rms {100 * rel:.2f} % of the logits' rms), "
               f"|gemv - batched| = {yard:.4f}, logit scale {scale:.2f}")
+        parity_ledger.record(err, yard, "test_gpu_full_size.py:76")
         assert np.isfinite(got).all() and err <= 2.0 * yard + 0.02 and rel <= 2.0 * rel_yard + 0.01, (name, err, yard, rel, rel_yard)
         assert int(got.argmax()) == int(whole.argmax()) or float(np.sort(whole)[-1] - np.sort(whole)[-2]) < 2.0 * err
 
@@ -174,6 +177,7 @@ def test_row_streaming_family_prefill_and_decode_agree_at_full_depth(full_wide):
     err = float(np.abs(wide - whole).max())
     rel = float(np.sqrt(np.mean((wide - whole).astype(np.float64) ** 2))) / rms
     print(f"full depth, row-streaming family: |decode - prefill| = {err:.4f} (rms {100 * rel:.2f} %), |gemv - wide| = {yard:.4f}")
+    parity_ledger.record(err, yard, "test_gpu_full_size.py:177")
     assert np.isfinite(wide).all() and err <= 2.0 * yard + 0.02 and rel <= 2.0 * rel_yard + 0.01
     assert int(wide.argmax()) == int(whole.argmax()) or float(np.sort(whole)[-1] - np.sort(whole)[-2]) < 2.0 * err
 

@@ -10,6 +10,8 @@ tests/test_gpu_7b_shape.py and tests/test_gpu_fp8.py):
 import numpy as np
 import pytest
 
+import parity_ledger
+
 from oracle import prng
 
 pytestmark = pytest.mark.gpu
@@ -49,6 +51,7 @@ def check_one_model(tag, whole, gemv, mfma):
     for name, got in (("gemv", gemv), ("batched", mfma)):
         err = float(np.abs(got - whole).max())
         print(f"{tag}: |{name} decode - prefill| = {err:.4f}, |gemv - batched| = {yard:.4f}, logit scale {np.abs(whole).max():.2f}")
+        parity_ledger.record(err, yard, "test_gpu_full_size_7b.py:52")
         assert np.isfinite(got).all() and err <= 2.0 * yard + 0.02, (tag, name, err, yard)
 
 

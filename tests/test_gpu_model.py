@@ -12,6 +12,8 @@ import json
 
 import numpy as np
 import pytest
+
+import parity_ledger
 import torch
 
 from conftest import npz_str
@@ -70,9 +72,11 @@ def test_vit_vs_oracle_and_fixture(tiny_engine, tiny_weights, chain):
     sel = got[:: max(1, got.shape[0] // 16)][:20]
     e_hf = np.abs(z["s1_vit_bf16"] - z["s1_vit_fp32"]).max()
     e_me = np.abs(sel - z["s1_vit_fp32"]).max()
+    parity_ledger.record(e_me, e_hf, "test_gpu_model.py:73", bar=TOL_FACTOR)
     assert e_me <= TOL_FACTOR * e_hf, (e_me, e_hf)
     o = Q.Qwen25VLOracle(Q.tiny_config(), tiny_weights, "bf16")
     want = o.vit_forward(chain["pv_v"].cpu().numpy(), [chain["g_v"]])
+    parity_ledger.record(np.abs(got - want).max(), e_hf, "test_gpu_model.py:76", bar=TOL_FACTOR)
     assert np.abs(got - want).max() <= TOL_FACTOR * e_hf
 
 
@@ -97,7 +101,9 @@ def _check_stage(z, tag, logits, picks, penalty):
     forced = z[f"{tag}_tokens_fp32"].tolist()
     e_hf, rms_hf = np.abs(ref16 - ref32).max(), np.sqrt(np.mean((ref16 - ref32) ** 2))
     e_me, rms_me = np.abs(logits - ref32).max(), np.sqrt(np.mean((logits - ref32) ** 2))
+    parity_ledger.record(e_me, e_hf, "test_gpu_model.py:100", bar=TOL_FACTOR)
     assert e_me <= TOL_FACTOR * e_hf, (tag, e_me, e_hf)
+    parity_ledger.record(rms_me, rms_hf, "test_gpu_model.py:101", bar=TOL_FACTOR)
     assert rms_me <= TOL_FACTOR * rms_hf, (tag, rms_me, rms_hf)
     tol = TOL_FACTOR * e_hf
     sub, mism = 0, 0
@@ -245,6 +251,7 @@ def test_engine_matches_transformers_at_the_3b_head_structure(golden_npz):
         got = emb.float().cpu().numpy()
         sel = got[:: max(1, got.shape[0] // 16)][:20]
         e_hf = np.abs(z["vit_bf16"] - z["vit_fp32"]).max()
+        parity_ledger.record(np.abs(sel - z["vit_fp32"]).max(), e_hf, "test_gpu_model.py:248", bar=TOL_FACTOR)
         assert np.abs(sel - z["vit_fp32"]).max() <= TOL_FACTOR * e_hf, (np.abs(sel - z["vit_fp32"]).max(), e_hf)
         ids, forced, pen = z["ids"].tolist(), z["tokens_fp32"].tolist(), c["repetition_penalty"]
         ref32, ref16 = z["logits_fp32"], z["logits_bf16"]
@@ -253,6 +260,7 @@ def test_engine_matches_transformers_at_the_3b_head_structure(golden_npz):
 
         def check(logits, picks, tag):
             e_me, rms_me = np.abs(logits - ref32).max(), np.sqrt(np.mean((logits - ref32) ** 2))
+            parity_ledger.record(e_me, e_hf, f"3B head structure vs transformers: {tag}", bar=TOL_FACTOR)
             assert e_me <= tol and rms_me <= TOL_FACTOR * rms_hf, (tag, e_me, e_hf, rms_me, rms_hf)
             seen, sub = list(ids), 0
             for step, tok in enumerate(forced):

@@ -10,6 +10,8 @@ import json
 
 import numpy as np
 import pytest
+
+import parity_ledger
 import torch
 
 from conftest import npz_str
@@ -58,9 +60,11 @@ def test_score_vs_reference_and_oracle(tiny_engine, tiny_weights, chain, golden_
     rms_hf, rms_me = np.sqrt(np.mean((ref16 - ref32) ** 2)), np.sqrt(np.mean((got - ref32) ** 2))
     print(f"max|engine-fp32|={e_me:.4f} (HF bf16 {e_hf:.4f}); rms {rms_me:.4f} ({rms_hf:.4f})")
     assert got.shape == (len(ids) - 1,)
+    parity_ledger.record(e_me, e_hf, "test_gpu_score.py:61")
     assert e_me <= 2.0 * e_hf and rms_me <= 2.0 * rms_hf
     o = Q.Qwen25VLOracle(Q.tiny_config(), tiny_weights, "bf16")
     want = o.per_token_logps(ids, torch.cat([chain["pv_v"], chain["pv_c"]]).cpu().numpy(), grids)
+    parity_ledger.record(np.abs(got - want).max(), e_hf, "test_gpu_score.py:64")
     assert np.abs(got - want).max() <= 2.0 * e_hf
 
 

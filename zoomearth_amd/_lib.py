@@ -131,8 +131,10 @@ _SIGS = {
     "ze_op_rope_kv_decode": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.c_int, _P, _P]),
     "ze_op_attn_decode": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.c_int, _P, _P, _P]),
     "ze_op_kv_read": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "ze_op_numeric_helpers": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P]),
     "ze_profile_decode_kernel": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), _P]),
     "ze_profile_batch_kernel": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), _P]),
+    "ze_profile_prefill_kernel": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), _P]),
     "ze_phase_timers": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "ze_tune": (C.c_int, [C.c_int, C.c_int]),
 }

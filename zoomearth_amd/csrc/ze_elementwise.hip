@@ -691,3 +691,18 @@ void ze_launch_kv_copy_prefix(bf16_t* kcache, bf16_t* vcache, size_t layer_strid
     k_kv_copy_prefix<<<dim3(std::max(1, std::min(8, (n_vec + 255) / 256)), layers * kv_heads * 2), 256, 0, s>>>(
         kcache, vcache, layer_stride, seq_stride, head_stride, kv_heads, src, dst, n_vec);
 }
+
+// ------------------------------------------------------------------ the numeric helpers of every epilogue, alone (parity ledger, round 6)
+// out[i] = f32_to_bf16(x[i]) | f32_to_bf16(bf16_round(silu_f(x[i])) * y[i]) << 16  -- the SwiGLU epilogue's arithmetic on one pair --
+// and out2[i] = pack_bf16x2(x[i], y[i]); tests/test_gpu_ops_kernels.py holds both to float64 over a dense grid.
+__global__ void __launch_bounds__(256) k_numeric_helpers(const float* __restrict__ x, const float* __restrict__ y, uint32_t* __restrict__ out,
+                                                         uint32_t* __restrict__ out2, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float a = x[i], b = y[i];
+    out[i] = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(bf16_round(silu_f(a)) * b) << 16);
+    out2[i] = pack_bf16x2(a, b);
+}
+void ze_launch_numeric_helpers(const float* x, const float* y, uint32_t* out, uint32_t* out2, int n, hipStream_t s) {
+    if (n > 0) k_numeric_helpers<<<(n + 255) / 256, 256, 0, s>>>(x, y, out, out2, n);
+}

@@ -182,6 +182,7 @@ struct ze_engine {
 
     // timers
     bool timers_on = false;
+    bool counted = false;  // in ze_live_engines (a create that failed half-way is destroyed uncounted)
     struct ev_pair { int phase; hipEvent_t a, b; };
     std::vector<ev_pair> ev_used;
     std::vector<ev_pair> ev_free;

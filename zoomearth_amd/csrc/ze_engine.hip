@@ -8,6 +8,7 @@
 thread_local std::string ze_global_error;
 extern int ze_mrope_vec_ok;  // ze_elementwise.hip: cleared by an engine whose M-RoPE sections are not multiples of eight pairs
 unsigned ze_tune_epoch = 0;  // bumped whenever captured decode graphs go stale (launch policy or weight streams changed)
+extern int ze_live_engines;  // ze_gemv.hip (read by the launch policy of the eight-phase GEMM: persistent only while ONE engine owns the GPU)
 static int ze_bound_device = -1;  // the launch-policy caches (hipFuncSetAttribute, CU count) are per process: one GPU per process
 
 // Every weight mutation (load, synthetic fill, arena hand-out for a broadcast / RL refresh) invalidates the derived
@@ -407,12 +408,15 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
         ze_engine_destroy(e);
         return r;
     }
+    e->counted = true;
+    __atomic_add_fetch(&ze_live_engines, 1, __ATOMIC_RELAXED);
     *out = e;
     return ZE_OK;
 }
 
 extern "C" int ze_engine_destroy(ze_engine* e) {
     if (!e) return ZE_OK;
+    if (e->counted) __atomic_sub_fetch(&ze_live_engines, 1, __ATOMIC_RELAXED);
     hipSetDevice(e->device);
     hipDeviceSynchronize();
     for (auto g : e->graphs)

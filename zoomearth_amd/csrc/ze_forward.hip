@@ -2227,3 +2227,67 @@ extern "C" int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters
     *bytes_per_launch = bytes;
     return ZE_OK;
 }
+
+// The projections of a PREFILL pass, one kind per call, on the pass's own operands: the engine's layer weights in rotation and the
+// activation rows the last ze_prefill_batch / ze_prefill left in the workspace (normalised hidden rows, attention output, SwiGLU
+// output of its last layer -- rows beyond that pass hold older passes' rows or zeros), through the launcher the pass uses
+// (ze_launch_gemm: k_gemm_p8 from ~1.5 K rows on).  which: 0 qkv, 1 o_proj (+ residual), 2 gate_up (SwiGLU), 3 down (+ residual).
+// Outputs go to scratch rows (the residual stream is read, never written).  flops_per_launch = 2 x rows x N x K of the real shape.
+extern "C" int ze_profile_prefill_kernel(ze_engine* e, int which, int rows, int iters, float* avg_us, double* flops_per_launch,
+                                         void* stream) {
+    if (!e || !avg_us || !flops_per_launch || iters <= 0 || rows <= 0 || rows > e->prefill_rows || which < 0 || which > 3)
+        return ze_fail(e, ZE_ERR_INVALID, "bad argument");
+    const ze_config& c = e->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    const int H = c.hidden, hd = e->head_dim, nq = c.heads * hd, nqkv = nq + 2 * c.kv_heads * hd, ip = e->text_ipad;
+    if (nqkv < H) return ze_fail(e, ZE_ERR_INVALID, "scratch rows too short for this shape");
+    double flops = 0;
+    auto launch = [&](int it) {
+        const ze_text_layer& L = e->tl[it % c.layers];
+        switch (which) {
+            case 0:
+                ze_launch_gemm(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, nullptr, rows, nqkv, H, s);
+                flops = 2.0 * rows * nqkv * H;
+                break;
+            case 1:
+                ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->tqkv, nqkv, nullptr, rows, H, nq, s);
+                flops = 2.0 * rows * H * nq;
+                break;
+            case 2:
+                ze_launch_gemm(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, ip, nullptr, rows, 2 * ip, H, s);
+                flops = 2.0 * rows * 2.0 * c.intermediate * H;
+                break;
+            default:
+                ze_launch_gemm(ZE_EPI_RESIDUAL, e->ta, ip, L.down.w, L.down.ld, nullptr, e->th, H, e->tqkv, nqkv, nullptr, rows, H, ip, s);
+                flops = 2.0 * rows * H * c.intermediate;
+                break;
+        }
+    };
+    hipEvent_t a, b;
+    ZE_HIP(hipEventCreate(&a));
+    ZE_HIP(hipEventCreate(&b));
+    for (int i = 0; i < std::min(iters, 3); ++i) launch(i);  // warm-up
+    ZE_HIP(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) launch(i);
+    ZE_HIP(hipEventRecord(b, s));
+    ZE_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    ZE_HIP(hipEventElapsedTime(&ms, a, b));
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    ZE_KCHECK();
+    *avg_us = ms * 1000.0f / (float)iters;
+    *flops_per_launch = flops;
+    return ZE_OK;
+}
+
+// The numeric helpers every epilogue of the library shares (ze_common.h: f32_to_bf16 / pack_bf16x2 = v_cvt_pk_bf16_f32, silu_f =
+// x * v_rcp_f32(1 + v_exp_f32(-x))), alone: out[i] = bf16(x[i]) | bf16(bf16(silu(x[i])) * y[i]) << 16, out2[i] = pack(x[i], y[i]).
+extern "C" int ze_op_numeric_helpers(ze_engine* e, const float* x, const float* y, uint32_t* out, uint32_t* out2, int n, void* stream) {
+    if (!e || !x || !y || !out || !out2 || n < 0) return ze_fail(e, ZE_ERR_INVALID, "null argument");
+    hipSetDevice(e->device);
+    ze_launch_numeric_helpers(x, y, out, out2, n, (hipStream_t)stream);
+    ZE_KCHECK();
+    return ZE_OK;
+}

@@ -20,6 +20,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define GEMM_BK 64
 
+extern int ze_live_engines;    // ze_gemv.hip: engines alive in this process
 extern int ze_gemv_knobs[24];  // [5]: 1 = no skinny kernel in the weight-streaming launcher; [6]: 0 = shipped policy, 1 = register-staged kernel everywhere, 2 = ring wherever it applies
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -1107,7 +1108,11 @@ static void launch_p8(int epi, const bf16_t* A, int lda, const bf16_t* W, int ld
     // is done, and the other lane's decode kernels wait for all of it (the o projection's 200 workgroups averaged 127 us in the
     // two-lane stream against 16 alone); one tile per workgroup lets them in at tile boundaries: stream 80.5 -> 81.6 questions/s
     // same box, twice.  (knob 7 = 9: the same for A/B runs)
-    const int grid = (ze_gemv_knobs[7] == 9 || ze_gemv_knobs[4] == 1) ? tiles : std::min(tiles, cus);
+    // Round 6: the library knows how many engines are alive (ze_live_engines), so the form follows that by itself -- knob 4 = 0: tile-
+    // granular iff more than one engine exists; 1: always tile-granular; 2: always persistent (measurements).  No caller flips a
+    // process-wide switch on behalf of engines it does not own any more.
+    const bool shared_gpu = ze_gemv_knobs[4] == 1 || (ze_gemv_knobs[4] == 0 && ze_live_engines > 1);
+    const int grid = (ze_gemv_knobs[7] == 9 || shared_gpu) ? tiles : std::min(tiles, cus);
     // the wide-store epilogue (p8_finish_wide: 16-byte row pieces through 4 KB of LDS per wave) wherever rows are 16-byte
     // aligned; knob 7 = 10: the plain two-byte epilogue, for A/B runs and the bit-equality test
     const bool sw = epi == ZE_EPI_SWIGLU;

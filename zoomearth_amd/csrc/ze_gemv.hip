@@ -15,6 +15,7 @@ bool ze_launch_gemv8(int epi, const ze_gemv_args& a, hipStream_t s);
 
 // overrides set through ze_tune(): [0] down variant, [1] gate_up variant, [2] grid cap, [3] fused attention block
 int ze_gemv_knobs[24] = {0};
+int ze_live_engines = 0;  // engines alive in this process (one GPU per process): counted by ze_engine_create / ze_engine_destroy
 
 bool ze_launch_gemv(int epi, const ze_gemv_args& a, hipStream_t s) {
     // shape policy: long-K / few-row matrices split K over the 4 waves of a block (each wave streams its K/4 share

@@ -315,3 +315,4 @@ void ze_launch_mark_seen(uint8_t* seen, const int* ids, int n, hipStream_t s);
 void ze_launch_mark_seen_batch(uint8_t* seen, int vocab, const int* hdr, const int* ids, int n, int max_count, hipStream_t s);
 void ze_launch_gather_chain_tokens(const ze_seq_dev* st, const int* out_tokens, int max_ctx, const int* slots, int n, int cap, int* out,
                                    hipStream_t s);
+void ze_launch_numeric_helpers(const float* x, const float* y, uint32_t* out, uint32_t* out2, int n, hipStream_t s);

@@ -532,6 +532,14 @@ class Engine:
         self._check(self.lib.ze_op_kv_read(self.h, seq, layer, start, n, _ptr(k), _ptr(v), self._stream()))
         return k, v
 
+    def op_numeric_helpers(self, x: torch.Tensor, y: torch.Tensor):
+        """(bf16(x) | bf16(bf16(silu(x)) * y) << 16, pack_bf16x2(x, y)) as two int32 tensors (u32 bit patterns): x, y f32 on the device."""
+        n = x.numel()
+        out = torch.empty(n, dtype=torch.int32, device=self.device)
+        out2 = torch.empty(n, dtype=torch.int32, device=self.device)
+        self._check(self.lib.ze_op_numeric_helpers(self.h, _ptr(x), _ptr(y), _ptr(out), _ptr(out2), n, self._stream()))
+        return out, out2
+
     def op_linear(self, a, w, bias=None, act: int = 0):
         m, k = a.shape
         n = w.shape[0]
@@ -568,6 +576,13 @@ class Engine:
         us, by = C.c_float(), C.c_double()
         self._check(self.lib.ze_profile_batch_kernel(self.h, which, n, iters, C.byref(us), C.byref(by), self._stream()))
         return float(us.value), float(by.value)
+
+    def profile_prefill_kernel(self, which: int, rows: int, iters: int = 12):
+        """(avg us, FLOP) of one projection of a prefill pass (0 qkv, 1 o, 2 gate/up, 3 down) at `rows` rows, on the operands the
+        last pass left in the workspace and the layers' own weights."""
+        us, fl = C.c_float(), C.c_double()
+        self._check(self.lib.ze_profile_prefill_kernel(self.h, which, rows, iters, C.byref(us), C.byref(fl), self._stream()))
+        return float(us.value), float(fl.value)
 
     def phase_timers(self, enable: bool = True, reset: bool = False):
         out = (C.c_float * 5)()

@@ -111,7 +111,6 @@ class ZoomEarthForConditionalGeneration:
             torch.cuda.synchronize(e.device)
             e2.weights_invalidate()
             e2.assert_ready()
-            e.lib.ze_tune(4, 1)   # two engines share the GPU: tile-granular prefill GEMM launches (zoomearth.h, knob 4)
         except Exception:
             e2.close()
             raise
