@@ -270,6 +270,9 @@ class TileFeeder:
         return sum(a.elapsed_time(b) for a, b in self.timed), len(self.timed)
 
 
+REUSE_GENERATED = True   # ChainScheduler.reuse_generated of the streams below (the `reuse_sensitivity` annex runs one stream with it off)
+
+
 def run_stream(engine, table, q0: int, slots: int, stats=None, use_graph=None):
     """The questions `table` = [(question number offset, tile DeviceImage, view key)] through the continuous-batching
     scheduler and the host code of src/eval/infer.py (hostloop: views, crops, prompts); the "parsed" box is scripted,
@@ -282,7 +285,8 @@ def run_stream(engine, table, q0: int, slots: int, stats=None, use_graph=None):
     proc = SynthProcessor(engine.config, engine)
     sched = ChainScheduler(model, proc, do_sample=False, repetition_penalty=PENALTY, ignore_eos=True, burst=int(os.environ.get("ZE_BURST", "8")),
                            use_graph=use_graph, min_admit=int(os.environ.get("ZE_MIN_ADMIT", str(max(1, 3 * slots // 4 if slots > 64 else slots // 2)))), hold_below=int(os.environ.get("ZE_HOLD", str(2 * slots // 3 if slots > 64 else 0))),
-                           max_wait_bursts=int(os.environ.get("ZE_MAX_WAIT", "8" if slots > 64 else "12")), max_batch=slots)
+                           max_wait_bursts=int(os.environ.get("ZE_MAX_WAIT", "8" if slots > 64 else "12")), max_batch=slots,
+                           reuse_generated=REUSE_GENERATED)
     done = {}
     views = {}
     for b, tile, vkey in table:
@@ -691,6 +695,7 @@ def main():
                          "1280-question stream: 1 x 512 slots 57.7, 1 x 1024 60.3, 2 x 256 62.9, 2 x 512 66.2, 2 x 768 67.6, 3 x 512 65.4 questions/s")
     ap.add_argument("--no-batch64", action="store_true", help="skip the batch64 object of the default N = 1 line")
     ap.add_argument("--no-configs1", action="store_true", help="skip the configs1 object of the default N = 1 line")
+    ap.add_argument("--no-reuse-sensitivity", action="store_true", help="skip the two short streams behind `value_without_generated_row_reuse`")
     ap.add_argument("--spawn-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     args.fp8 = args.fp8 or args.fp8_act
@@ -832,6 +837,35 @@ def main():
             dev = {t: DeviceImage(e.tile_upload(host_pool[t % n_pool]), e) for t in my_tiles[:6]}
         n_questions = n_total
         lens_all = bstats.pop("lens")
+        # how much of `value` rests on the synthetic tokenizer's identity round trip.  The stream keeps the K/V
+        # rows the decode steps wrote for a stage-1 output while the re-tokenised ids repeat the generated ones -- with the decimal-word
+        # tokenizer of this bench they always do (191 of 192 rows), with a real BPE they stop at the first re-merged piece.  Two short
+        # streams of the warm-up's size, back to back on the warm engines, one with the reuse on and one with it off (every stage-2
+        # prompt prefilled from the end of the cached stage-1 PROMPT: bit-identical to a full prefill): their ratio scales `value` to
+        # the figure without any generated-row reuse -- the lower bound for any tokenizer.
+        reuse_sens = None
+        if world == 1 and not args.no_reuse_sensitivity and args.warmup > 0:
+            global REUSE_GENERATED
+            n_short = max(4, args.warmup) * Q_STEP
+            short_of = question_table(n_short, seed=3)
+            qps = {}
+            for flag in (True, False):
+                REUSE_GENERATED = flag
+                short = [(i, ("s1" if flag else "s0", t), ("s1" if flag else "s0", t)) for i, t in enumerate(short_of)]
+                st_s = {}
+                torch.cuda.synchronize()
+                ts = time.perf_counter()
+                run_stream_lanes(engines, short, (7_000_000 if flag else 8_000_000), SLOTS, st_s, use_graph=sched_graph, host_pool=host_pool)
+                torch.cuda.synchronize()
+                qps[flag] = (n_short / (time.perf_counter() - ts), st_s.get("prefill_rows", 0) / n_short, st_s.get("reused_generated_rows", 0) / n_short)
+            REUSE_GENERATED = True
+            reuse_sens = {"questions_per_stream": n_short, "with_reuse_qps": round(qps[True][0], 2), "without_reuse_qps": round(qps[False][0], 2),
+                          "ratio": round(qps[False][0] / qps[True][0], 4),
+                          "prefill_rows_per_question": [round(qps[True][1], 1), round(qps[False][1], 1)],
+                          "generated_rows_kept_per_question": [round(qps[True][2], 1), round(qps[False][2], 1)],
+                          "note": ("two short streams back to back on the warm engines (fill and drain weigh more in them than in the timed "
+                                   "stream: compare the ratio, not the absolute figures); without the reuse every stage-2 prompt is prefilled "
+                                   "from the end of the cached stage-1 prompt, bit-identical to a full prefill")}
         lens = (int(np.mean([l[0] for l in lens_all])), int(np.mean([l[2] for l in lens_all])),
                 float(np.mean([l[1] for l in lens_all])), float(np.mean([l[3] for l in lens_all])))
     else:
@@ -1070,6 +1104,12 @@ def main():
             src = (f"profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024 in separate passes, round "
                    f"{tj.get('round')}: {ent['hbm_bytes_per_launch'] / 1e6:.2f} MB per launch = {ent['ratio']:.3f} x algorithmic at "
                    f"{ent.get('chains')} chains)")
+            # a figure from a committed profile goes stale silently when the kernels change after profiling -- the
+            # profile records the hash of the library's sources it ran on, the line says whether this tree still has them
+            from zoomearth_amd._lib import kernel_sources_sha16
+            now, then = kernel_sources_sha16(), tj.get("kernel_sources_sha16")
+            src += (f"; profiled on kernel sources {then}, this tree has {now}: " + ("the same" if then == now else "DIFFERENT -- the counter figure "
+                    "predates later kernel changes") if then else f"; the profile predates the source hash (this tree: {now})")
             if alg_bytes and abs(alg_bytes / ent["algorithmic_bytes_per_launch"] - 1.0) > 0.01:
                 return ent["ratio"] * alg_bytes, src + "; that ratio applied to this launch's algorithmic bytes"
             return ent["hbm_bytes_per_launch"], src
@@ -1227,6 +1267,11 @@ def main():
             line["decode_ms_per_step"] = round(phases["decode"] / steps_run, 3)
             line["mean_chains_per_step"] = round(st.get("chain_steps", 0) / steps_run, 1)
             line["scheduler"] = st
+            offered = max(1, st.get("generated_rows_offered", 0))
+            line["generated_rows_kept_fraction"] = round(st.get("reused_generated_rows", 0) / offered, 4)
+            if reuse_sens is not None:
+                line["reuse_sensitivity"] = reuse_sens
+                line["value_without_generated_row_reuse"] = round(line["value"] * reuse_sens["ratio"], 3)
             if len(engines) > 1:
                 e.lib.ze_tune(4, 2)   # the annexes below run ONE engine's kernels alone: the persistent form (restored to 0 = by live-engine count below)
             if args.model == "3b" and not args.fp8:

@@ -104,11 +104,17 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
     # --resume: keep what an interrupted run of this rank wrote and skip those question_ids (the reference opens the file
     # with "w" and starts over, :167)
     skip = frozenset(done_question_ids_all(exp_name, world)) if resume else frozenset()
+    if resume:
+        # every rank has READ every rank's file before any rank rewrites its own (a peer caught mid-rewrite looked
+        # shorter than it was, and the reader answered again the questions of its tiles that the peer had stolen)
+        accelerator.wait_for_everyone()
     if resume and os.path.exists(out_path):  # drop a torn last line before appending -- also when it is the ONLY line
         with open(out_path, encoding="utf-8") as f:
             good = [ln for ln in f if ln.endswith("\n")]
-        with open(out_path, "w", encoding="utf-8") as f:
+        tmp = out_path + ".resume.tmp"       # (through a temporary file and os.replace: the file is never seen truncated)
+        with open(tmp, "w", encoding="utf-8") as f:
             f.writelines(ln for ln in good if _is_json(ln))
+        os.replace(tmp, out_path)
     fout = open(out_path, "a" if resume else "w", encoding="utf-8")
     model, dl = accelerator.prepare(model, prepare_dataloader(ds_path, collate_fn))
 
@@ -150,10 +156,17 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
         lists = [tile_groups(names_all, shard_by_tile(names_all, r, world)) for r in range(world)]
         assert [n for n, _ in lists[accelerator.process_index]] == [n for n, _ in groups], "the loader's order is the LPT list's"
         claims = TileClaims.connect(accelerator.process_index, world, lists)
-    # test hook: ZE_TEST_SLOW_RANK="<rank>:<seconds>" makes that rank pause before every tile of its own list (tests/test_gpu_infer_e2e.py)
-    slow = os.environ.get("ZE_TEST_SLOW_RANK", "")
-    slow_s = float(slow.split(":")[1]) if slow and int(slow.split(":")[0]) == accelerator.process_index else 0.0
+        # (the straggler of the stealing tests is made by the claims object itself -- TileClaims.connect reads ZE_TEST_SLOW_RANK --
+        #  not by a hook in this loop)
     bar = tqdm(total=len(samples), desc="Evaluating")
+    # which claimed tile every output index belongs to, and how many of its records have not left yet: a tile whose last record
+    # has been written is FINISHED, and an error path names only the others
+    tile_of_idx, tile_left = {}, {}
+    if claims is not None:
+        for g, (_name, items) in enumerate(groups):
+            for idx, _s in items:
+                tile_of_idx[idx] = (accelerator.process_index, g)
+            tile_left[(accelerator.process_index, g)] = len(items)
 
     def flush():  # records leave in the rank's dataset order, whatever order (and on whatever lane) the chains finish
         with lock:
@@ -161,6 +174,11 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
                 sample, r = done.pop(next_out[0])
                 if r is not None:
                     H.record(fout, sample["question"], sample, sample, r["output1"], r["output2"], r["error"])
+                key = tile_of_idx.get(next_out[0])
+                if key is not None:
+                    tile_left[key] -= 1
+                    if tile_left[key] == 0:
+                        claims.mark_finished(*key)
                 next_out[0] += 1
                 bar.update(1)
 
@@ -186,9 +204,6 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
 
         for g, name, items in todo:
             path = tile_path(name)
-            if claims is not None and slow_s > 0:
-                import time
-                time.sleep(slow_s)                     # (test hook ZE_TEST_SLOW_RANK: a straggler for the stealing tests)
             if claims is not None and not claims.claim(accelerator.process_index, g):
                 tiles.skip(path)                       # another rank took this tile off the back of the list: its file has it
                 for idx, sample in items:
@@ -227,12 +242,15 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
                 view = tuple(H.resize_image(tile))
             except Exception as ex:
                 tile, view, err = None, None, ex
+            with lock:
+                tile_left[took] = len(idxs)
             for j in idxs:
                 sample = ds_all[j]
                 with lock:
                     idx = extra_idx[0]
                     extra_idx[0] += 1
                     bar.total += 1
+                    tile_of_idx[idx] = took
                 if tile is None:
                     finish(idx, sample, dict(output1=f"Error: {err}", output2="", error=True))
                 else:
@@ -289,6 +307,9 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
             stats[k] = stats.get(k, 0) + v
     stats["lanes"] = lanes
     stats["stolen_tiles"] = claims.stolen if claims is not None else 0
+    if os.environ.get("ZE_PRINT_STATS") == "1":   # measurement / tests only: the schedulers' counters as one JSON line
+        import json as _json
+        print("[stats] " + _json.dumps({k: v for k, v in stats.items() if isinstance(v, (int, float))}), flush=True)
     if claims is not None:
         print(f"[rank {accelerator.process_index}] tiles run: {len(claims.mine)} ({claims.stolen} of them taken from other ranks' lists)", flush=True)
     return stats

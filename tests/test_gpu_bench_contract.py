@@ -28,6 +28,9 @@ def check_roofline(r, lo=0.05):
     # counter traffic against algorithmic bytes: above 1 where a kernel re-reads, down to ~0.85 where the chains of a tile read their
     # shared prefix from one cache (the stream line's attention: 0.856 x in round 4's PMC passes)
     assert r["traffic"] is None or 0.8 < r["traffic"] / r["bytes_per_launch"] < 1.6
+    if r.get("traffic_source") and "DIFFERENT" in r["traffic_source"]:   # (stale counter figures are named, not hidden)
+        import warnings
+        warnings.warn("profiles/traffic_latest.json was collected on other kernel sources than this tree's: " + r["traffic_source"][-160:])
     if r["traffic"] is not None and "hbm_interface_frac" in r:
         # (avg_us is printed with two decimals)
         assert abs(r["hbm_interface_frac"] - r["traffic"] / (r["avg_us"] * 1e-6) / 1e9 / r["peak"]) < 1e-3 and 0 < r["hbm_interface_frac"] < 1

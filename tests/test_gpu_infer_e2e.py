@@ -40,7 +40,13 @@ def word(i: int, three_number: bool = True) -> str:
     return f'"bbox_2d":[{x},{y},{x + 30 + i % 200},{y + 20 + i % 150}]'
 
 
-def write_tokenizer(path, three_number: bool = True):
+def write_tokenizer(path, three_number: bool = True, kind: str = "word"):
+    if kind == "bpe":   # a trained byte-level BPE: decode -> strip -> re-encode is NOT the identity (tests/tiny_tok.py)
+        from tiny_tok import train_bpe
+        train_bpe(three_number=three_number).save(os.path.join(path, "tokenizer.json"))
+        with open(os.path.join(path, "tokenizer_config.json"), "w") as f:
+            json.dump({"pad_token": "<|endoftext|>"}, f)
+        return
     from tokenizers import AddedToken, Tokenizer
     from tokenizers.models import WordLevel
     from tokenizers.pre_tokenizers import WhitespaceSplit
@@ -71,7 +77,12 @@ def workdir_tiles(tmp_path_factory):
     return build_workdir(tmp_path_factory.mktemp("lrsgro_tiles"), 48, n_tiles=16)
 
 
-def build_workdir(d, n_questions, n_tiles=3):
+@pytest.fixture(scope="module")
+def workdir_bpe(tmp_path_factory):
+    return build_workdir(tmp_path_factory.mktemp("lrsgro_bpe"), 11, tokenizer="bpe")
+
+
+def build_workdir(d, n_questions, n_tiles=3, tokenizer="word"):
     from datasets import Dataset
     from PIL import Image
     ck = d / "ckpt"
@@ -88,7 +99,7 @@ def build_workdir(d, n_questions, n_tiles=3):
     with open(ck / "generation_config.json", "w") as f:
         json.dump({"eos_token_id": [2045, 2043], "pad_token_id": 2043, "repetition_penalty": 1.0}, f)
     checkpoint.write_safetensors(str(ck / "model.safetensors"), Q.synthetic_weights(Q.tiny_config(), **CHAIN_W), bf16=True)
-    write_tokenizer(str(ck))
+    write_tokenizer(str(ck), kind=tokenizer)
     os.makedirs(d / "image")
     sizes = [(700, 640), (900, 520), (300, 280)]  # the last one is smaller than the 512-px view: no downscale
     for t in range(n_tiles):
@@ -121,10 +132,24 @@ def load(path):
         return [json.loads(line) for line in f if line.strip()]
 
 
-def test_infer_entry_point_batched_equals_sequential_then_eval(workdir):
-    d, rows = workdir
+def _stats(out):
+    return json.loads(next(l for l in out.splitlines() if l.startswith("[stats] "))[8:])
+
+
+@pytest.mark.parametrize("which", ["workdir", "workdir_bpe"])
+def test_infer_entry_point_batched_equals_sequential_then_eval(which, request):
+    """`workdir_bpe`: the same run with a trained byte-level BPE, whose decode -> strip -> re-encode round trip is not the
+    identity -- the re-inserted stage-1 output diverges from the generated ids, so the follow-up keeps only the rows up to the first
+    difference (scheduler._reusable) and prefills the rest; the records still do not depend on the batch size."""
+    d, rows = request.getfixturevalue(which)
     base = [sys.executable, "src/infer.py", "--model_name", "ckpt", "--max_new_tokens", "14", "--max_ctx", "2048"]
-    run(base + ["--exp_name", "b8_", "--batch_size", "8"], d)
+    out8 = run(base + ["--exp_name", "b8_", "--batch_size", "8"], d, ZE_PRINT_STATS="1")
+    st = _stats(out8)
+    print(f"{which}: generated rows kept from decode {st.get('reused_generated_rows', 0)} of {st.get('generated_rows_offered', 0)} offered")
+    if which == "workdir_bpe":   # the mismatch branch really ran on the GPU: some rows kept, not all
+        assert 0 < st["reused_generated_rows"] < st["generated_rows_offered"], st
+    else:                        # word-level: the round trip is the identity (up to a special id the model happened to emit)
+        assert 0 < st["reused_generated_rows"] <= st["generated_rows_offered"], st
     run(base + ["--exp_name", "b1_", "--batch_size", "1"], d)
     b8, b1 = load(d / "results" / "b8_0.jsonl"), load(d / "results" / "b1_0.jsonl")
     assert len(b8) == len(rows) == len(b1)
@@ -150,11 +175,12 @@ def test_infer_entry_point_batched_equals_sequential_then_eval(workdir):
     assert "Total Samples: 11" in out and "Overall Accuracy (OA, stage 2)" in out
 
 
-def test_resume_runs_only_the_missing_questions(workdir):
+@pytest.mark.parametrize("which", ["workdir", "workdir_bpe"])
+def test_resume_runs_only_the_missing_questions(which, request):
     """--resume (resume of a partial run; the reference opens its file with "w" and starts over,
     /root/reference/src/eval/infer.py:167): the records an interrupted run left -- a torn last line dropped -- are kept, only
     the missing questions run, and the file ends up equal to an uninterrupted run's."""
-    d, rows = workdir
+    d, rows = request.getfixturevalue(which)
     base = [sys.executable, "src/infer.py", "--model_name", "ckpt", "--max_new_tokens", "14", "--max_ctx", "2048", "--batch_size", "4",
             "--greedy"]
     run(base + ["--exp_name", "full_"], d)

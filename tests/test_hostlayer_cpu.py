@@ -257,6 +257,8 @@ assert claims.claim(rank, 0)
 if rank == 1 and sys.argv[2] == "crash":
     os._exit(3)                                  # dies without a word: rank 0 must not hang
 if rank == 1 and sys.argv[2] == "abandon":
+    assert claims.claim(rank, 1)
+    claims.mark_finished(rank, 0)                # tile 0's last record has left for the file: not "unfinished" (ADVICE r5)
     claims.abandon()                             # the error path of infer.py: says so, names its unfinished tile
     sys.exit(4)
 try:
@@ -286,7 +288,7 @@ def test_tile_claims_finish_does_not_hang_on_a_dead_rank(tmp_path, mode):
         assert procs[1].returncode == 3
     else:
         assert procs[0].returncode == 0 and "FINISHED" in outs[0], outs
-        assert procs[1].returncode == 4 and "t1_0.tif" in outs[1] and "--resume" in outs[1], outs
+        assert procs[1].returncode == 4 and "t1_1.tif" in outs[1] and "t1_0.tif" not in outs[1] and "--resume" in outs[1], outs
 
 
 def test_scorer(tmp_path):

@@ -6,7 +6,7 @@ while [ "${1:0:1}" = "-" ]; do
 done
 for rep in $(seq $reps); do
 for t in "$@"; do
-  env $t python bench.py --steps $steps --warmup 3 --no-cpu-baseline --no-batch64 --no-configs1 2>/dev/null | python -c "
+  env $t python bench.py --steps $steps --warmup 3 --no-cpu-baseline --no-batch64 --no-configs1 --no-reuse-sensitivity 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -2,7 +2,7 @@
 # same-box A/B of the prefill pass budget (rows per pass): tools/ab_prefill_rows.sh ROWS ROWS ...  (26624 = the default 32 x 832)
 mkdir -p gpurun_out/abrows
 for rows in "$@"; do
-  ZE_PREFILL_ROWS=$rows python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-batch64 --no-configs1 > gpurun_out/abrows/$rows.json 2> gpurun_out/abrows/$rows.err
+  ZE_PREFILL_ROWS=$rows python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-batch64 --no-configs1 --no-reuse-sensitivity > gpurun_out/abrows/$rows.json 2> gpurun_out/abrows/$rows.err
   python tools/show_line.py gpurun_out/abrows/$rows.json "prefill rows $rows:" || tail -3 gpurun_out/abrows/$rows.err
   python - <<P
 import json

@@ -1,6 +1,6 @@
 for rep in 1 2; do
 for t in "" "20:1" "20:1,13:4,18:1,15:8"; do
-  ZE_TUNE="$t" python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-batch64 --no-configs1 2>/dev/null | python -c "
+  ZE_TUNE="$t" python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-batch64 --no-configs1 --no-reuse-sensitivity 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

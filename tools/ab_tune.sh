@@ -5,7 +5,7 @@ reps=2
 if [ "$1" = "-r" ]; then reps=$2; shift 2; fi
 for rep in $(seq $reps); do
 for t in "$@"; do
-  ZE_TUNE="$t" python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-batch64 --no-configs1 2>/dev/null | python -c "
+  ZE_TUNE="$t" python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-batch64 --no-configs1 --no-reuse-sensitivity 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

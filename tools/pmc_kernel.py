@@ -30,7 +30,9 @@ else:
     n = {"wide": 220, "wide_shared": 220, "batch64": 64, "configs1": 1}[mode]
 e = Engine(ModelConfig.zoomearth_3b(), max_seqs=slots, max_ctx=2048, max_patches=2048, max_tile_side=1024, max_prefill_rows=16 * 1024)
 e.fill_synthetic(0)
-out = {"mode": mode, "chains": n}
+from zoomearth_amd._lib import kernel_sources_sha16  # noqa: E402
+
+out = {"mode": mode, "chains": n, "kernel_sources_sha16": kernel_sources_sha16()}   # (the tree this profile was taken with)
 if mode == "configs1":
     ids = uniform_ints(100, 1200, 1000, 150000).tolist()
     pos, delta = e.rope_index(ids, [])

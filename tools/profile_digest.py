@@ -74,6 +74,8 @@ for mode, keys in KEYS.items():
     except FileNotFoundError:
         continue
     sec = out.setdefault(SECTION[mode], {})
+    if launches.get("kernel_sources_sha16"):   # round 6: the tree the passes ran on (bench.py compares it with the tree that quotes them)
+        out["kernel_sources_sha16"] = launches["kernel_sources_sha16"]
     for key, sub in keys.items():
         subs = sub if isinstance(sub, tuple) else (sub,)
         parts = [(find(fetch, x), find(write, x)) for x in subs]

@@ -46,6 +46,22 @@ class ZoomEarthError(RuntimeError):
         self.code = code
 
 
+def kernel_sources_sha16() -> str:
+    """sha256 (first 16 hex digits) over the kernel and host sources of the library (csrc/*.hip, *.h, *.cpp, the Makefile, include/
+    zoomearth.h), in name order: what a committed profile records so that a figure quoted from it can be checked against the tree
+    that quotes it (bench.py `roofline.traffic_source`; the .git directory does not travel to the GPU box)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.cpp")) +
+                   [os.path.join(CSRC, "Makefile"), os.path.join(_HERE, "..", "include", "zoomearth.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(force: bool = False, jobs: int = 8) -> str:
     """Compile libzoomearth_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     if force:

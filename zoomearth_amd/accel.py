@@ -200,6 +200,11 @@ class TileClaims:
         self.store, self.rank, self.world, self.lists = store, rank, world, lists
         self.stolen = 0
         self.mine = []       # (owner, pos) of every tile this rank has claimed, in claim order
+        self.finished = set()  # ... and those whose last record has left for the rank's file (mark_finished)
+        # test hook (tests/test_gpu_infer_e2e.py): ZE_TEST_SLOW_RANK="<rank>:<seconds>" makes that rank a straggler -- it pauses
+        # before every claim on its OWN list; kept here, behind the claims-only path, not in the entry point's loop
+        slow = os.environ.get("ZE_TEST_SLOW_RANK", "")
+        self._slow_s = float(slow.split(":")[1]) if slow and int(slow.split(":")[0]) == rank else 0.0
 
     @staticmethod
     def connect(rank: int, world: int, lists, port_offset: int = 17, timeout_s: float = 600.0):
@@ -212,7 +217,13 @@ class TileClaims:
                               wait_for_workers=False)
         return TileClaims(store, rank, world, lists)
 
+    def mark_finished(self, owner: int, pos: int) -> None:
+        self.finished.add((owner, pos))
+
     def claim(self, owner: int, pos: int) -> bool:
+        if self._slow_s > 0 and owner == self.rank:
+            import time
+            time.sleep(self._slow_s)
         won = self.store.add(f"ze_tile/{owner}/{pos}", 1) == 1
         if won:
             self.mine.append((owner, pos))
@@ -258,9 +269,10 @@ class TileClaims:
         """Error path: this rank will claim nothing more.  Prints the tiles it had claimed that are not in `finished` (their
         records are in no file: a --resume run answers them) and counts itself done so that rank 0 does not wait for it."""
         import sys
-        left = [self.lists[o][p][0] for (o, p) in self.mine if (o, p) not in set(finished)]
+        fin = self.finished | set(finished)
+        left = [self.lists[o][p][0] for (o, p) in self.mine if (o, p) not in fin]
         if left:
-            print(f"[rank {self.rank}] failed with {len(left)} claimed tile(s) possibly unfinished: {left[:8]}"
+            print(f"[rank {self.rank}] failed with {len(left)} claimed tile(s) unfinished: {left[:8]}"
                   f"{' ...' if len(left) > 8 else ''} -- rerun with --resume", file=sys.stderr, flush=True)
         try:
             self.store.set(f"ze_rank_done/{self.rank}", "1")

@@ -504,13 +504,30 @@ extern "C" int ze_seq_mark_seen(ze_engine* e, int seq, const int32_t* ids, int n
     return ZE_OK;
 }
 
-// pinned + device scratch of the batched id transfers: max_seqs x max_ctx ints per direction (n distinct chains x at most max_ctx
-// ids each always fit), allocated at the first batched call
-static int xfer_reserve(ze_engine* e, int*& host, int*& dev, size_t& cap) {
-    if (cap) return ZE_OK;
-    const size_t want = (size_t)e->cfg.max_seqs * (size_t)e->cfg.max_ctx + 3 * (size_t)e->cfg.max_seqs + 8;  // rows + (n_gen, finished | offsets) + slots
-    ZE_HIP(hipHostMalloc((void**)&host, want * sizeof(int)));
-    ZE_HIP(hipMalloc((void**)&dev, want * sizeof(int)));
+// pinned + device scratch of the batched id transfers, sized by the REQUEST and grown on demand (max_seqs x max_ctx ints per
+// direction were ~100 MB four times over at 768 slots x 32 K context, for calls that move a few hundred KB): `need` ints, rounded up
+// to the next power of two from 64 Ki ints on.  Growing waits for the work that may still read the old block (the caller's stream and
+// the block's staging event), frees it, and allocates anew; a failed device allocation frees the pinned half it had just obtained.
+static int xfer_reserve(ze_engine* e, int*& host, int*& dev, size_t& cap, size_t need, hipEvent_t staged, hipStream_t s) {
+    if (need <= cap) return ZE_OK;
+    size_t want = (size_t)64 << 10;
+    while (want < need) want <<= 1;
+    if (cap) {
+        if (staged) ZE_HIP(hipEventSynchronize(staged));
+        ZE_HIP(hipStreamSynchronize(s));
+        hipHostFree(host);
+        hipFree(dev);
+        host = dev = nullptr;
+        cap = 0;
+    }
+    int *h = nullptr, *d = nullptr;
+    ZE_HIP(hipHostMalloc((void**)&h, want * sizeof(int)));
+    if (hipMalloc((void**)&d, want * sizeof(int)) != hipSuccess) {
+        hipHostFree(h);
+        return ze_fail(e, ZE_ERR_NOMEM, "hipMalloc of the id transfer scratch failed");
+    }
+    host = h;
+    dev = d;
     cap = want;
     return ZE_OK;
 }
@@ -535,9 +552,10 @@ extern "C" int ze_seq_mark_seen_batch(ze_engine* e, const int32_t* seqs, const i
     if (total == 0) return ZE_OK;
     hipSetDevice(e->device);
     hipStream_t s = (hipStream_t)stream;
-    ZE_TRY(xfer_reserve(e, e->xs_host, e->xs_dev, e->xs_cap));
-    if ((size_t)(2 * n + 1) + total > e->xs_cap) return ze_fail(e, ZE_ERR_NOMEM, "too many ids");
+    // (the event is recorded BEHIND the kernel that reads the device block -- ADVICE r5: behind the copy alone, a second call on
+    //  another stream could have overwritten xs_dev under the first call's kernel; acquire waits for that kernel now)
     ZE_TRY(stage_acquire(e, e->xs_staged));
+    ZE_TRY(xfer_reserve(e, e->xs_host, e->xs_dev, e->xs_cap, (size_t)(2 * n + 1) + total, e->xs_staged, s));
     int* h = e->xs_host;
     h[0] = 0;
     for (int i = 0; i < n; ++i) {
@@ -546,9 +564,9 @@ extern "C" int ze_seq_mark_seen_batch(ze_engine* e, const int32_t* seqs, const i
     }
     memcpy(h + 2 * n + 1, ids, total * sizeof(int));
     ZE_HIP(hipMemcpyAsync(e->xs_dev, h, ((size_t)(2 * n + 1) + total) * sizeof(int), hipMemcpyHostToDevice, s));
-    ZE_TRY(stage_release(e, e->xs_staged, s));
     ze_launch_mark_seen_batch(e->seen, e->cfg.vocab, e->xs_dev, e->xs_dev + 2 * n + 1, n, max_count, s);
     ZE_KCHECK();
+    ZE_TRY(stage_release(e, e->xs_staged, s));
     return ZE_OK;
 }
 
@@ -1143,13 +1161,29 @@ static int ensure_fragments(ze_engine* e, hipStream_t s) {
     for (int li = 0; li < c.layers; ++li) {
         ze_text_layer& L = e->tl[li];
         L.qkv.wf = L.o.wf = L.gate_up.wf = nullptr;
+        L.qkv.wf8 = L.o.wf8 = L.gate_up.wf8 = nullptr;   // (these stayed stale in the row-streaming regime)
         L.qkv.wp = L.qkv.bias_p = nullptr;
     }
     e->lm_head_f = nullptr;
+    e->lm_head8.wf8 = nullptr;
     // Each kernel family gets only the copies it reads: the row-streaming regime the permuted qkv rows (0.38 GB at the
     // 3B shape), the fragment family the fragment-major arena (4.5 GB) -- an engine of 64 slots never runs the first, one of 768
     // never the second.  ze_set_decode_regime clears frag_ready, so a regime change rebuilds what the new family needs.
     const bool wide = e->wide_regime();
+    // ... and the OTHER family's copies are given back (after ze_set_decode_regime the 4.5-GB fragment arena, its FP8 twin
+    // and the permuted qkv rows all stayed allocated).  A regime change is rare and never concurrent with a step: wait for the device.
+    if (wide ? (e->arena_f || e->arena_f8) : (e->arena_p != nullptr)) {
+        ZE_HIP(hipDeviceSynchronize());
+        if (wide) {
+            if (e->arena_f) hipFree(e->arena_f);
+            if (e->arena_f8) hipFree(e->arena_f8);
+            e->arena_f = nullptr;
+            e->arena_f8 = nullptr;
+        } else {
+            hipFree(e->arena_p);
+            e->arena_p = nullptr;
+        }
+    }
     // row-streaming regime: the qkv rows permuted per head, so that M-RoPE + the KV append run as the projection's epilogue
     if (wide && hd == 128 && H % 64 == 0 && H / 64 >= 4 && nqkv % 128 == 0) {
         const size_t per_layer = (size_t)nqkv * H + nqkv;
@@ -1635,9 +1669,8 @@ extern "C" int ze_chain_tokens_batch(ze_engine* e, const int32_t* seqs, int n, i
     cap = std::min(cap, c.max_ctx);
     hipSetDevice(e->device);
     hipStream_t s = (hipStream_t)stream;
-    ZE_TRY(xfer_reserve(e, e->xt_host, e->xt_dev, e->xt_cap));
     const size_t words = 2 * (size_t)n + (size_t)n * cap;
-    if (words + (size_t)n > e->xt_cap) return ze_fail(e, ZE_ERR_NOMEM, "too many tokens");
+    ZE_TRY(xfer_reserve(e, e->xt_host, e->xt_dev, e->xt_cap, words + (size_t)n, nullptr, s));
     // (the call waits for the stream before it returns, so the scratch is free again by the next call)
     int* slots_dev = e->xt_dev + words;
     memcpy(e->xt_host + words, seqs, (size_t)n * sizeof(int));

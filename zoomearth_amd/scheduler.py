@@ -376,6 +376,7 @@ class ChainScheduler:
             while m < len(gen) and n + m < len(ids) - 1 and ids[n + m] == gen[m] and gen[m] not in special:
                 m += 1
             self.stats["reused_generated_rows"] += m
+            self.stats["generated_rows_offered"] = self.stats.get("generated_rows_offered", 0) + max(0, min(len(gen), len(ids) - 1 - n))
             return n + m, len(pkeys)
         return 0, 0
 
