@@ -664,3 +664,47 @@ def test_queries_roped_inside_the_flash_kernel_equal_the_two_launch_form(eng):
     for a, b in zip(old[3:], new[3:]):
         assert np.array_equal(a, b)
     assert float(np.abs(new[0][0]).max()) > 0
+
+
+def test_decode_step_above_768_chains_keeps_a_chains_bits():
+    """Round 6 (the one-lane A/B of VERDICT r5 #1b): an engine with more than 768 chain slots.  Beyond 768 rows the one-pass
+    projections of the decode step take the prefill policy's tiles and the fused qkv + M-RoPE + KV-append a 128 x 128 tile; K in
+    sequence on all of them, so a chain's logits are the same bits alone, among 300 and among 900 chains, and the fused qkv equals
+    the projection + k_rope_kv_batch pair (knob 13 = 2) at 900 rows."""
+    from gpu_util import oracle_cfg_to_model_cfg
+    from zoomearth_amd.engine import Engine
+    n = 900
+    e = Engine(oracle_cfg_to_model_cfg(), device=0, max_seqs=n, max_ctx=96, max_patches=1024, max_tile_side=1024, max_prefill_rows=4096)
+    try:
+        e.fill_synthetic(**CHAIN_W)
+        assert e.set_decode_regime(-1) == 1
+        lens = [5 + (c * 7) % 23 for c in range(n)]
+
+        def fill():
+            for g0 in range(0, n, 100):
+                gs = list(range(g0, min(n, g0 + 100)))
+                ids = [text_ids(9000 + c, lens[c]) for c in gs]
+                pl = [e.rope_index(i, []) for i in ids]
+                for c in gs:
+                    e.seq_reset(c)
+                e.prefill_batch(gs, ids, [None] * len(gs), [p[0] for p in pl], [p[1] for p in pl])
+        toks = [int(t) for t in text_ids(9999, n)]
+        fill()
+        full = e.decode_batch(list(range(n)), toks).cpu().numpy()
+        assert np.isfinite(full).all()
+        fill()
+        part = e.decode_batch(list(range(300)), toks[:300]).cpu().numpy()
+        assert np.array_equal(part, full[:300])
+        fill()
+        for c in (0, 450, 899):
+            one = e.decode_batch([c], [toks[c]]).cpu().numpy()
+            assert np.array_equal(one[0], full[c]), c
+        try:
+            e.lib.ze_tune(13, 2)
+            fill()
+            pair = e.decode_batch(list(range(n)), toks).cpu().numpy()
+        finally:
+            e.lib.ze_tune(13, 0)
+        assert np.array_equal(pair, full)
+    finally:
+        e.close()

@@ -108,7 +108,9 @@ def test_linear_weight_streaming(tiny_engine, m, n, k, bias):
 # of the wide regime -- 65, 128, the 217 live chains of a 256-slot stream's average step, 256, 261 / 300 / 384 (the 384-row
 # instance of the weight-streaming kernel), 385 / 512 (its 512-row instance), 640 (a 512- and a 128-row block) -- plus a
 # drained batch; 513 / 580 / 640: gate/up on 320 x 192 ring tiles with K-steps of 32 (round 4), 768: a 512- and a 256-row block.
-@pytest.mark.parametrize("m", [9, 65, 128, 217, 256, 261, 300, 384, 385, 512, 513, 580, 640, 768])
+# 1152 (round 6): beyond 768 rows -- an engine with more than 768 chain slots, the one-lane A/B of DESIGN 7i -- the one-pass projections
+# take the prefill policy's tile for that row count (same K order: same bits), the down projection stays on its eight slices.
+@pytest.mark.parametrize("m", [9, 65, 128, 217, 256, 261, 300, 384, 385, 512, 513, 580, 640, 768, 1152])
 @pytest.mark.parametrize("n,k,bias,swiglu", [(22016, 2048, False, True), (2048, 11008, False, False),
                                              (2560, 2048, True, False), (4096, 2048, False, False)])
 def test_linear_wide_decode(tiny_engine, m, n, k, bias, swiglu):

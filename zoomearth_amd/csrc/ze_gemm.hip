@@ -2276,6 +2276,12 @@ void ze_launch_gemm_qkv_rope(const bf16_t* A, int lda, const bf16_t* Wp, int ldw
     const long b64 = (long)ze_cdiv(M, 64) * ze_cdiv(N, 64);
     const bf16_t* R = reinterpret_cast<const bf16_t*>(dev_args);
     if (launch_tall<true>(ZE_EPI_QKV_ROPE, A, lda, Wp, ldw, bias_p, R, 0, C, ldc, M, N, K, s)) return;
+    // more than 768 rows (round 6: an engine with more than 768 chain slots -- the one-lane A/B of VERDICT r5 #1b): one round of 128 x 128
+    // tiles, the tile ze_launch_gemm gives a prefill pass of this size (9 x 20 = 180 workgroups at 1152 rows); K in sequence: same bits
+    if (M > 768 && K % GEMM_BK == 0 && K / GEMM_BK >= 4 && (long)ze_cdiv(M, 128) * ze_cdiv(N, 128) <= 256) {
+        launch_ring_variant<128, 128, 4, 2, 4, true, false, true>(ZE_EPI_QKV_ROPE, A, lda, Wp, ldw, bias_p, R, 0, C, ldc, nullptr, M, N, K, s);
+        return;
+    }
     // (two 64-KB workgroups share a CU: up to 512 tiles stay on 64 x 64 -- 16.4 against 20.8 us at 410 rows, 19.9 / 21.0 at 580, 20.9 /
     //  22.7 at 768; knob 13 = 3: 64 x 128 from 257 tiles on, the rule before)
     if (b64 <= (ze_gemv_knobs[13] == 3 ? 256 : 512))
@@ -2357,6 +2363,14 @@ void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int
     // 217 / 256 rows: gate/up 26.6 / 28.1 / 37.9 / 38.0 against 24.3 / 29.7 / 39.9 / 41.3 on the ring tiles, lm_head 168 /
     // 181 / 240 / 245 against 192 / 215 / 226 / 228); knob 15 = 9: ring tiles only, 1: k_gemm_wstream wherever it applies.
     // (the wide-store epilogue of k_gemm_wstream moves whole 16-byte row pieces: aligned rows, N a multiple of 32)
+    // more than 768 rows (round 6, the one-lane A/B of VERDICT r5 #1b: an engine with up to 1536 chain slots): the decode tiles above are
+    // cut for at most 768 rows -- beyond, the row count is a small prefill pass's and its policy serves it best (3B shape at 1152 rows:
+    // qkv 21.7 us, o 21.1, gate/up 101.7 on the prefill policy against 38.1 / 22.3 / 129.9 on two blocks of the decode tiles).  K in
+    // sequence on every tile: the same bits, so the choice may follow the row count.
+    if (M > 768 && epi != ZE_EPI_F32 && ze_gemv_knobs[15] != 9) {
+        ze_launch_gemm(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, nullptr, M, N, K, s);
+        return;
+    }
     const bool ok = K % GEMM_BK == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && (size_t)N * ldw * sizeof(bf16_t) < ((size_t)1 << 31) &&
                     N % 32 == 0 && (ldc % 8) == 0 && ((size_t)A % 16) == 0 && ((size_t)C % 16) == 0;
     const int v = ze_gemv_knobs[15];
