@@ -1149,8 +1149,11 @@ def main():
                 ent = {}
                 for form, knob in (("persistent", 2), ("tile_granular", 1)):
                     e.lib.ze_tune(4, knob)
-                    us, fl = e.profile_prefill_kernel(2, rows_p, 12)
-                    ent[form] = {"us": round(us, 1), "TFLOPs": round(fl / (us * 1e-6) / 1e12, 1), "frac": round(fl / (us * 1e-6) / 2.5e15, 4)}
+                    lay = e.profile_prefill_layer(rows_p, 36)   # the four projections in pass order, each launch between its own events
+                    us, fl = lay["gate_up"]
+                    ent[form] = {"us": round(us, 1), "TFLOPs": round(fl / (us * 1e-6) / 1e12, 1), "frac": round(fl / (us * 1e-6) / 2.5e15, 4),
+                                 "layer_us": {k: round(v[0], 1) for k, v in lay.items()},
+                                 "layer_frac": {k: round(v[1] / (v[0] * 1e-6) / 2.5e15, 4) for k, v in lay.items()}}
                 shapes[str(rows_p)] = ent
             e.lib.ze_tune(4, 2)
             big = shapes[max(shapes, key=int)]
@@ -1158,7 +1161,9 @@ def main():
                        achieved_TFLOPs=big[in_stream]["TFLOPs"], isolated_us=big[in_stream]["us"], by_rows=shapes,
                        shape=(f"gate/up of the replayed prefill passes: rows x {2 * cfg.text.intermediate_size} (gate/up interleaved) x "
                               f"{cfg.text.hidden_size}, SwiGLU epilogue; operands = the pass's own (post-norm rows of its last layer, the 36 "
-                              "layers' weights in rotation); FLOP = 2 x rows x N x K unpadded; `frac` is the larger pass in the form the stream runs"))
+                              "layers' weights in rotation), the layer's four projections issued in pass order with HIP events around every launch "
+                              "(`layer_us`); FLOP = 2 x rows x N x K unpadded; `frac` is gate/up at the larger pass in the form the stream runs; "
+                              "rocprofv3 of the replayed pass: profiles/r06_prefill_by_shape.csv"))
         return obj
 
     def configs1_object(steps, warmup):

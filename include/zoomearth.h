@@ -393,6 +393,10 @@ int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters, float* av
  * 2 x rows x N x K (unpadded). */
 int ze_profile_prefill_kernel(ze_engine* e, int which, int rows, int iters, float* avg_us, double* flops_per_launch,
                               void* stream);
+/* The four projections in PASS ORDER (qkv, o, gate/up, down; `layers_run` layers, the weights in rotation), every launch between its own
+ * pair of HIP events: the per-projection averages a pass sees (clocks and cache state of the neighbouring launches), which the line's
+ * `top_kernel_by_gpu_time` quotes next to the rocprofv3 figure of the replayed pass.  avg_us / flops: [0] qkv [1] o [2] gate/up [3] down. */
+int ze_profile_prefill_layer(ze_engine* e, int rows, int layers_run, float avg_us[4], double flops[4], void* stream);
 /* Measurement-only kernel-configuration override (A/B of kernels and launch shapes inside one process; value 0 is always
  * the shipped default, every alternative computes the same function -- bit for bit unless noted).  Knobs (0..23; round 4 re-used
  * knobs 3 and 4, which until round 3 switched the removed one-launch-per-layer kernels: an old `3:1` / `4:1` habit now changes GEMM

@@ -267,12 +267,19 @@ def test_numeric_helpers_of_every_epilogue_against_float64(tiny_engine):
         # a one-ulp move of the activation moves the product by at most one ulp (+ its own rounding): compare in ulps of the result
         sgn = lambda b: np.where(b & 0x8000, -(b & 0x7FFF).astype(np.int64), (b & 0x7FFF).astype(np.int64))
         d = np.abs(sgn(got) - sgn(want))
+        # g <= -88.7: exp(-g) overflows fp32, so x * rcp(inf) -- and x / inf, the divided form and torch's -- is -0 where float64 has
+        # -|g| e^g < 1e-36: a difference of nothing, but hundreds of bf16 codes apart.  Where the true result is below 2^-100 the check
+        # is "the result is below 2^-99"; the code distance counts everywhere else.
+        tiny = np.abs(act * up) < 2.0 ** -100
+        got_f = (got << 16).astype(np.uint32).view(np.float32)
+        assert (np.abs(got_f[tiny]) < 2.0 ** -99).all()
+        d = np.where(tiny, 0, d)
         worst_ulp = max(worst_ulp, int(d.max()))
         if up == 1.0:
             off_total = int((d > 0).sum())
             print(f"silu_f over all {len(g)} finite bf16 inputs: {off_total} differ from the correctly rounded bf16(silu) "
                   f"({1e5 * off_total / len(g):.1f} per 100,000), worst {int(d.max())} bf16 ulp")
-            parity_ledger.record(float(d.max()), 1.0, f"silu_f (v_rcp_f32) vs float64 over every finite bf16 input: bf16 ulps; {off_total} of {len(g)} inputs off by one",
+            parity_ledger.record(float(d.max()), 1.0, f"silu_f vs float64 over every bf16 input of magnitude >= 2^-100: bf16 ulps of bf16(silu); {off_total} of {len(g)} inputs off by one",
                                  bar=1.0)
             assert d.max() <= 1
         else:

@@ -151,6 +151,7 @@ _SIGS = {
     "ze_profile_decode_kernel": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), _P]),
     "ze_profile_batch_kernel": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), _P]),
     "ze_profile_prefill_kernel": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), _P]),
+    "ze_profile_prefill_layer": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), _P]),
     "ze_phase_timers": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "ze_tune": (C.c_int, [C.c_int, C.c_int]),
 }

@@ -171,6 +171,13 @@ struct ze_engine {
     int gticket_cap = 0;
     ze_gemm_ws gemm_ws() const { return ze_gemm_ws{gslab, gslab_floats, gtickets, gticket_cap}; }
     unsigned* gtickets = nullptr;
+    // split-K workspace of the PREFILL family (round 6: the down projection of a pass in three K slices, ze_gemm.hip ze_prefill_ksplit):
+    // slabs and tickets of its own -- a prefill pass on the admission stream runs beside the decode step, which owns the ones above
+    float* pslab = nullptr;
+    size_t pslab_floats = 0;
+    unsigned* ptickets = nullptr;
+    int pticket_cap = 0;
+    ze_gemm_ws prefill_ws() const { return ze_gemm_ws{pslab, pslab_floats, ptickets, pticket_cap}; }
     // batched decode: activations of its own (rows = chains), so that a decode burst on one HIP stream and a prefill / ViT
     // round on another never share a buffer (the scheduler overlaps them: zoomearth_amd/scheduler.py)
     bf16_t *bh = nullptr, *by = nullptr, *bqkv = nullptr, *bo = nullptr, *ba = nullptr;

@@ -382,6 +382,15 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
         e->gticket_cap = ticket_cap;
     }
     {
+        // prefill split-K slabs: 3 slices x (rows of the largest pass, padded to a 256-row tile) x (hidden, padded to a 256-column tile)
+        // floats -- the same whatever tile a row count selects -- and a ticket per 64 x 64 tile (the smallest)
+        const size_t rows_pad = ((size_t)e->prefill_rows + 255) / 256 * 256, cols_pad = ((size_t)c.hidden + 255) / 256 * 256;
+        e->pslab_floats = 3 * rows_pad * cols_pad;
+        e->pticket_cap = (int)((rows_pad / 64) * (cols_pad / 64)) + 64;
+        chk(dev_alloc(e, &e->pslab, e->pslab_floats, false));
+        chk(dev_alloc(e, &e->ptickets, (size_t)e->pticket_cap, true));
+    }
+    {
         const size_t br = (size_t)(std::max(c.max_seqs, 64) + 63) / 64 * 64;  // rows of the batched step (whole 64-row tiles)
         chk(dev_alloc(e, &e->bh, br * c.hidden));
         chk(dev_alloc(e, &e->by, br * c.hidden));
@@ -435,7 +444,7 @@ extern "C" int ze_engine_destroy(ze_engine* e) {
                    e->st_dev, e->seen, e->out_tokens, e->fe_tmp, e->fe_img, e->fe_coef, e->vx, e->vh, e->vy, e->vqkv,
                    e->vo, e->va, e->vz, e->vz2, e->vcos, e->vsin, e->vperm, e->vinv, e->vtiles_win, e->vtiles_full,
                    e->th, e->ty, e->tqkv, e->to, e->ta, e->tsrc, e->tpos, e->ttiles, e->ttile_aux, e->trow_aux, e->dh, e->dq, e->dattn, e->dact,
-                   e->dlogits, e->dpartial, e->dsample, e->atickets, e->gslab, e->gtickets, e->bh, e->by, e->bqkv, e->bo, e->ba, e->bseq, e->blogits, e->bpartial, e->bsample, e->arena8, e->arena_f, e->arena_f8,
+                   e->dlogits, e->dpartial, e->dsample, e->atickets, e->gslab, e->gtickets, e->pslab, e->ptickets, e->bh, e->by, e->bqkv, e->bo, e->ba, e->bseq, e->blogits, e->bpartial, e->bsample, e->arena8, e->arena_f, e->arena_f8,
                    e->ty8, e->ty8_scale, e->damax, e->ty8p, e->ty8p_scale};
     for (void* p : dev)
         if (p) hipFree(p);

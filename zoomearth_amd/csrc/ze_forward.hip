@@ -583,7 +583,7 @@ static void prefill_norm_gemm(ze_engine* e, const bf16_t* norm_w, const ze_linea
         if (ze_launch_gemm_mx(epi, e->ty8p, H, e->ty8p_scale, lin.w8, lin.ld8, lin.scale8, bias, out, ldo, rows, N, H, s)) return;
     }
     ze_launch_rmsnorm(e->th, H, norm_w, e->ty, H, rows, H, c.rms_eps, s, 0, e->fp8_act ? 1 : 0);
-    ze_launch_gemm(epi, e->ty, H, lin.w, lin.ld, bias, nullptr, 0, out, ldo, nullptr, rows, N, H, s);
+    ze_launch_gemm(epi, e->ty, H, lin.w, lin.ld, bias, nullptr, 0, out, ldo, nullptr, rows, N, H, s, e->prefill_ws());
 }
 
 static int prefill_impl(ze_engine* e, int seq, const int32_t* input_ids, int len, const void* image_embeds,
@@ -647,10 +647,10 @@ static int prefill_impl(ze_engine* e, int seq, const int32_t* input_ids, int len
         ze_launch_flash_attn(hd, 1, e->tqkv, nqkv, hd, e->kc(li, seq), hd, c.max_ctx * hd, e->vc(li, seq), hd,
                              c.max_ctx * hd, e->to, nq, hd, e->ttiles, nt, c.heads, c.heads / c.kv_heads, scale, past,
                              s, nullptr, 0, bq, 0, q_in_flash ? ze_fa_rope{e->cosT, e->sinT, e->tpos, c.mrope_section[0], c.mrope_section[0] + c.mrope_section[1], len} : ze_fa_rope{nullptr, nullptr, nullptr, 0, 0, 0});
-        ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, len, H, nq, s);
+        ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, len, H, nq, s, e->prefill_ws());
         prefill_norm_gemm(e, L.post_norm, L.gate_up, nullptr, ZE_EPI_SWIGLU, e->ta, e->text_ipad, len, 2 * e->text_ipad, s);
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, nullptr,
-                       len, H, e->text_ipad, s);
+                       len, H, e->text_ipad, s, e->prefill_ws());
     }
     // last position: final norm fused into the lm_head stream (logits_to_keep = 1, HF:...:1386-1387) -- the kernel of the
     // batched pass with one chain, so the first token does not depend on how the chain was prefilled
@@ -807,10 +807,10 @@ extern "C" int ze_prefill_batch(ze_engine* e, const int32_t* seqs, int n, const 
                              c.max_ctx * hd, e->to, nq, hd, e->ttiles, nt, c.heads, c.heads / c.kv_heads, scale, 0, s,
                              e->ttile_aux, seq_stride, bq, 0,
                              q_in_flash ? ze_fa_rope{e->cosT, e->sinT, e->tpos, c.mrope_section[0], c.mrope_section[0] + c.mrope_section[1], total} : ze_fa_rope{nullptr, nullptr, nullptr, 0, 0, 0});
-        ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, total, H, nq, s);
+        ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->th, H, nullptr, total, H, nq, s, e->prefill_ws());
         prefill_norm_gemm(e, L.post_norm, L.gate_up, nullptr, ZE_EPI_SWIGLU, e->ta, e->text_ipad, total, 2 * e->text_ipad, s);
         ze_launch_gemm(ZE_EPI_RESIDUAL, e->ta, e->text_ipad, L.down.w, L.down.ld, nullptr, e->th, H, e->th, H, nullptr,
-                       total, H, e->text_ipad, s);
+                       total, H, e->text_ipad, s, e->prefill_ws());
     }
     // last position of every chain: final norm + lm_head, the weight matrix streamed once per EIGHT chains (ze_gemv_logits.hip;
     // per chain the arithmetic -- and the kernel -- of ze_prefill)
@@ -1735,7 +1735,7 @@ extern "C" int ze_op_linear(ze_engine* e, const void* a, const void* w, const vo
     } else if (act == 4) {  // SwiGLU epilogue on interleaved gate/up rows: C is [M, N/2]
         if (N % 32) return ze_fail(e, ZE_ERR_INVALID, "SwiGLU: N = 2 * width with width % 16 == 0");
         ze_launch_gemm(ZE_EPI_SWIGLU, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias, nullptr, 0,
-                       (bf16_t*)cmat, N / 2, nullptr, M, N, K, s);
+                       (bf16_t*)cmat, N / 2, nullptr, M, N, K, s, e->prefill_ws());
     } else if (act == 6 || act == 7) {  // the launcher of the row-streaming decode regime (7: SwiGLU, C is [M, N/2])
         if (act == 7 && N % 32) return ze_fail(e, ZE_ERR_INVALID, "SwiGLU: N = 2 * width with width % 16 == 0");
         ze_launch_gemm_wide(act == 7 ? ZE_EPI_SWIGLU : ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias,
@@ -1747,13 +1747,13 @@ extern "C" int ze_op_linear(ze_engine* e, const void* a, const void* w, const vo
         if (act == 9 && N % 32) return ze_fail(e, ZE_ERR_INVALID, "SwiGLU: N = 2 * width with width % 16 == 0");
         if (K % 64 || K < 64) return ze_fail(e, ZE_ERR_INVALID, "eight-phase kernel: K a multiple of 64");
         ze_launch_gemm_p8(act == 9 ? ZE_EPI_SWIGLU : ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias, nullptr, 0,
-                          (bf16_t*)cmat, act == 9 ? N / 2 : N, nullptr, M, N, K, s);
+                          (bf16_t*)cmat, act == 9 ? N / 2 : N, nullptr, M, N, K, s, e->prefill_ws());
     } else if (act == 2) {  // weight-streaming mode of the batched decode step (rows = chains), for measurements
         ze_launch_gemm_stream(ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias, nullptr, 0,
                               (bf16_t*)cmat, N, M, N, K, e->gemm_ws(), s);
     } else {
         ze_launch_gemm(act ? ZE_EPI_GELU : ZE_EPI_NONE, (const bf16_t*)a, K, (const bf16_t*)w, K, (const bf16_t*)bias,
-                       nullptr, 0, (bf16_t*)cmat, N, nullptr, M, N, K, s);
+                       nullptr, 0, (bf16_t*)cmat, N, nullptr, M, N, K, s, e->prefill_ws());
     }
     ZE_KCHECK();
     return ZE_OK;
@@ -2280,19 +2280,19 @@ extern "C" int ze_profile_prefill_kernel(ze_engine* e, int which, int rows, int 
         const ze_text_layer& L = e->tl[it % c.layers];
         switch (which) {
             case 0:
-                ze_launch_gemm(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, nullptr, rows, nqkv, H, s);
+                ze_launch_gemm(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, nullptr, rows, nqkv, H, s, e->prefill_ws());
                 flops = 2.0 * rows * nqkv * H;
                 break;
             case 1:
-                ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->tqkv, nqkv, nullptr, rows, H, nq, s);
+                ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->tqkv, nqkv, nullptr, rows, H, nq, s, e->prefill_ws());
                 flops = 2.0 * rows * H * nq;
                 break;
             case 2:
-                ze_launch_gemm(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, ip, nullptr, rows, 2 * ip, H, s);
+                ze_launch_gemm(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, ip, nullptr, rows, 2 * ip, H, s, e->prefill_ws());
                 flops = 2.0 * rows * 2.0 * c.intermediate * H;
                 break;
             default:
-                ze_launch_gemm(ZE_EPI_RESIDUAL, e->ta, ip, L.down.w, L.down.ld, nullptr, e->th, H, e->tqkv, nqkv, nullptr, rows, H, ip, s);
+                ze_launch_gemm(ZE_EPI_RESIDUAL, e->ta, ip, L.down.w, L.down.ld, nullptr, e->th, H, e->tqkv, nqkv, nullptr, rows, H, ip, s, e->prefill_ws());
                 flops = 2.0 * rows * H * c.intermediate;
                 break;
         }
@@ -2312,6 +2312,56 @@ extern "C" int ze_profile_prefill_kernel(ze_engine* e, int which, int rows, int 
     ZE_KCHECK();
     *avg_us = ms * 1000.0f / (float)iters;
     *flops_per_launch = flops;
+    return ZE_OK;
+}
+
+// The four projections of a prefill layer in PASS ORDER (qkv, o, gate/up, down; layer after layer, as ze_prefill_batch issues them --
+// minus the norm / rope / attention launches between them), every launch bracketed by its own pair of HIP events: per-projection
+// averages under the clocks and cache state a pass gives them (twelve back-to-back launches of ONE projection run 5-9 % slower than
+// the same kernel inside a pass: rocprofv3 of the replayed pass, profiles/r06_prefill_by_shape.csv).  Operands as
+// ze_profile_prefill_kernel.  avg_us / flops: [0] qkv, [1] o, [2] gate/up, [3] down.
+extern "C" int ze_profile_prefill_layer(ze_engine* e, int rows, int layers_run, float avg_us[4], double flops[4], void* stream) {
+    if (!e || !avg_us || !flops || layers_run <= 0 || layers_run > 256 || rows <= 0 || rows > e->prefill_rows)
+        return ze_fail(e, ZE_ERR_INVALID, "bad argument");
+    const ze_config& c = e->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    hipSetDevice(e->device);
+    const int H = c.hidden, hd = e->head_dim, nq = c.heads * hd, nqkv = nq + 2 * c.kv_heads * hd, ip = e->text_ipad;
+    if (nqkv < H) return ze_fail(e, ZE_ERR_INVALID, "scratch rows too short for this shape");
+    auto launch = [&](int li, int which) {
+        const ze_text_layer& L = e->tl[li % c.layers];
+        switch (which) {
+            case 0: ze_launch_gemm(ZE_EPI_NONE, e->ty, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->tqkv, nqkv, nullptr, rows, nqkv, H, s, e->prefill_ws()); break;
+            case 1: ze_launch_gemm(ZE_EPI_RESIDUAL, e->to, nq, L.o.w, L.o.ld, nullptr, e->th, H, e->tqkv, nqkv, nullptr, rows, H, nq, s, e->prefill_ws()); break;
+            case 2: ze_launch_gemm(ZE_EPI_SWIGLU, e->ty, H, L.gate_up.w, L.gate_up.ld, nullptr, nullptr, 0, e->ta, ip, nullptr, rows, 2 * ip, H, s, e->prefill_ws()); break;
+            default: ze_launch_gemm(ZE_EPI_RESIDUAL, e->ta, ip, L.down.w, L.down.ld, nullptr, e->th, H, e->tqkv, nqkv, nullptr, rows, H, ip, s, e->prefill_ws()); break;
+        }
+    };
+    flops[0] = 2.0 * rows * nqkv * H;
+    flops[1] = 2.0 * rows * H * nq;
+    flops[2] = 2.0 * rows * 2.0 * c.intermediate * H;
+    flops[3] = 2.0 * rows * H * c.intermediate;
+    std::vector<hipEvent_t> ev((size_t)layers_run * 8);
+    for (auto& x : ev) ZE_HIP(hipEventCreate(&x));
+    for (int li = 0; li < 2; ++li)   // warm-up
+        for (int w = 0; w < 4; ++w) launch(li, w);
+    for (int li = 0; li < layers_run; ++li)
+        for (int w = 0; w < 4; ++w) {
+            ZE_HIP(hipEventRecord(ev[(size_t)(li * 4 + w) * 2], s));
+            launch(li, w);
+            ZE_HIP(hipEventRecord(ev[(size_t)(li * 4 + w) * 2 + 1], s));
+        }
+    ZE_HIP(hipStreamSynchronize(s));
+    double sum[4] = {0, 0, 0, 0};
+    for (int li = 0; li < layers_run; ++li)
+        for (int w = 0; w < 4; ++w) {
+            float ms = 0.f;
+            ZE_HIP(hipEventElapsedTime(&ms, ev[(size_t)(li * 4 + w) * 2], ev[(size_t)(li * 4 + w) * 2 + 1]));
+            sum[w] += ms;
+        }
+    for (auto& x : ev) hipEventDestroy(x);
+    ZE_KCHECK();
+    for (int w = 0; w < 4; ++w) avg_us[w] = (float)(sum[w] * 1000.0 / layers_run);
     return ZE_OK;
 }
 

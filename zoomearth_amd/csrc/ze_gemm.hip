@@ -894,11 +894,67 @@ __device__ __forceinline__ void p8_finish_wide(f32x4 (&acc)[8][4], uint8_t* scra
     }
 }
 
+// Split-K tail of k_gemm_p8 (round 6): gemm_finish's protocol on the eight-phase kernel's 512 threads x 32 MFMA tiles -- every slice
+// parks its fp32 accumulators write-through ([MFMA tile][thread] slabs), drains, takes the tile's ticket; the last arriver adds the
+// slices IN SLICE ORDER from zero (whatever order they arrived in) and returns true: it runs the epilogue.  `flag` is LDS the next
+// tile's prefetch does not touch (behind the two K-tile buffers).
+__device__ __forceinline__ bool p8_splitk_reduce(f32x4 (&acc)[8][4], unsigned* flag, int ksplit, int ks, int bid, int nwg,
+                                                 float* __restrict__ slab, unsigned* __restrict__ tickets) {
+    constexpr int NT = 512, T = 32;
+    const int tid = threadIdx.x;
+    const size_t slab_bytes = (size_t)ksplit * nwg * NT * T * 16;
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)min(slab_bytes, (size_t)0x7fffffff), 0x00020000);
+    {
+        const unsigned base = (unsigned)(((size_t)(ks * nwg + bid) * T * NT + tid) * 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u32x4 v;
+                v.x = __float_as_uint(acc[i][j][0]);
+                v.y = __float_as_uint(acc[i][j][1]);
+                v.z = __float_as_uint(acc[i][j][2]);
+                v.w = __float_as_uint(acc[i][j][3]);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, base + (unsigned)(i * 4 + j) * NT * 16, 0, 16 /* sc1 */);
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the ticket
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(&tickets[bid], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned last = (old == (unsigned)ksplit - 1u) ? 1u : 0u;
+        if (last) __hip_atomic_store(&tickets[bid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        *flag = last;
+    }
+    __syncthreads();
+    const unsigned last = *flag;
+    __syncthreads();  // (every wave has read the flag before the epilogue's scratch, which shares its LDS, is written)
+    if (last == 0u) return false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < ksplit; ++q) {
+        const unsigned base = (unsigned)(((size_t)(q * nwg + bid) * T * NT + tid) * 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + (unsigned)(i * 4 + j) * NT * 16, 0, 16);
+                acc[i][j][0] += __uint_as_float(v.x);
+                acc[i][j][1] += __uint_as_float(v.y);
+                acc[i][j][2] += __uint_as_float(v.z);
+                acc[i][j][3] += __uint_as_float(v.w);
+            }
+    }
+    return true;
+}
+
 template <int EPI, bool WIDE = false>
 __global__ void __launch_bounds__(512) k_gemm_p8(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
                                                  const bf16_t* __restrict__ bias, const bf16_t* __restrict__ R, int ldr,
                                                  bf16_t* __restrict__ C, int ldc, const int* __restrict__ c_rows, int M, int N,
-                                                 int K, int blk) {
+                                                 int K, int blk, int ksplit, float* __restrict__ slab, unsigned* __restrict__ tickets) {
     constexpr int BM = 256, BN = 256, HALF = 128 * 128, BUF = 4 * HALF;  // buffer = [A-half 0][A-half 1][W-half 0][W-half 1]
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
@@ -908,7 +964,12 @@ __global__ void __launch_bounds__(512) k_gemm_p8(const bf16_t* __restrict__ A, i
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
     const int fr = lane & 15, fq = lane >> 4;
-    const int nk = K / GEMM_BK;
+    // SPLIT K (round 6: the long-K projection of a prefill pass, ze_prefill_ksplit): a unit of work = (tile, K slice); the slices of a
+    // tile are cut in 64-element K-tiles exactly as k_gemm_ring / k_gemm_tn cut theirs (ceil(nk / ksplit) per slice) and meet in the
+    // fp32 slabs in slice order (p8_splitk_reduce) -- the same sums in the same order whichever kernel serves a row count.
+    const int nk_all = K / GEMM_BK;
+    const int nk_per = (nk_all + ksplit - 1) / ksplit;
+    int ks = 0, kt0 = 0, nk = nk_all;
     const unsigned smem_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem);
 
     // PERSISTENT: workgroup g takes tiles g, g + gridDim.x, ... of the launch order (the XCD-aware remap of k_gemm_ring applied to
@@ -924,7 +985,14 @@ __global__ void __launch_bounds__(512) k_gemm_p8(const bf16_t* __restrict__ A, i
     // inside a block): 32 concurrent tiles = an 8 x 4 block share 8 A tiles and 4 W tiles, and an A tile crosses the fabric once per
     // FOUR columns.  Which workgroup computes which tile never changes a tile's arithmetic: same bits.  blk = 0: the column walk.
     int bm0 = 0, bn0 = 0, bid = 0;
-    auto place = [&](int tile) {
+    auto place = [&](int unit) {
+        // (the slices of a tile are consecutive units: neighbouring workgroups run them side by side, the last arriver waits for no one)
+        const int tile = ksplit > 1 ? unit / ksplit : unit;
+        if (ksplit > 1) {
+            ks = unit - tile * ksplit;
+            kt0 = ks * nk_per;
+            nk = max(0, min(nk_all - kt0, nk_per));
+        }
         const int q = nwg / 8, r = nwg % 8, xcd = tile % 8, idx = tile / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
         if (blk > 0) {
@@ -966,7 +1034,7 @@ __global__ void __launch_bounds__(512) k_gemm_p8(const bf16_t* __restrict__ A, i
     // slot 0..3 = A-half 0, A-half 1, W-half 0, W-half 1
     auto stage = [&](int slot, int t) {
         const unsigned dst = smem_lds + (t & 1) * BUF + slot * HALF + wid * 2048;
-        const bf16_t* base = (slot < 2 ? A : W) + (size_t)t * GEMM_BK;
+        const bf16_t* base = (slot < 2 ? A : W) + (size_t)(kt0 + t) * GEMM_BK;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const unsigned off = slot == 0 ? offA[0][q] : slot == 1 ? offA[1][q] : slot == 2 ? offB[0][q] : offB[1][q];
@@ -1023,8 +1091,9 @@ __global__ void __launch_bounds__(512) k_gemm_p8(const bf16_t* __restrict__ A, i
         __builtin_amdgcn_s_setprio(0);
     };
 
-    int tile = blockIdx.x;
-    if (tile >= nwg) return;
+    const int nunits = nwg * ksplit;
+    int tile = blockIdx.x;   // (the UNIT this workgroup is on: a tile, or a K slice of one)
+    if (tile >= nunits) return;
     place(tile);
     sources();
     prologue();
@@ -1077,13 +1146,20 @@ __global__ void __launch_bounds__(512) k_gemm_p8(const bf16_t* __restrict__ A, i
         if (wr == 0) __builtin_amdgcn_s_barrier();
         // every wave is past its last fragment read (wave row 0: of phase 3, two barriers back; row 1: likewise behind the
         // barrier it just shared): the LDS is free for the next tile's first half-tiles
-        const int done_bid = bid, done_bm0 = bm0, done_bn0 = bn0;
+        const int done_bid = bid, done_bm0 = bm0, done_bn0 = bn0, done_ks = ks;
         tile += gridDim.x;
-        const bool more = tile < nwg;
+        const bool more = tile < nunits;
         if (more) {
             place(tile);
             sources();
             prologue();
+        }
+        bool finish = true;
+        if (ksplit > 1)   // (workgroup-uniform) park this slice; the tile's last arriver adds the slices in slice order and finishes
+            finish = p8_splitk_reduce(acc, reinterpret_cast<unsigned*>(smem + 2 * BUF), ksplit, done_ks, done_bid, nwg, slab, tickets);
+        if (!finish) {
+            if (!more) break;
+            continue;
         }
         if constexpr (WIDE)
             p8_finish_wide<EPI>(acc, smem + 2 * BUF + wid * 4096, bias, R, ldr, C, ldc, c_rows, M, N, done_bm0 + wr * 128, done_bn0 + wc * 64, lane);
@@ -1094,7 +1170,8 @@ __global__ void __launch_bounds__(512) k_gemm_p8(const bf16_t* __restrict__ A, i
 }
 
 static void launch_p8(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R, int ldr,
-                      bf16_t* C, int ldc, const int* c_rows, int M, int N, int K, hipStream_t s) {
+                      bf16_t* C, int ldc, const int* c_rows, int M, int N, int K, hipStream_t s, int ksplit = 1,
+                      const ze_gemm_ws& ws = ze_gemm_ws()) {
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -1112,13 +1189,14 @@ static void launch_p8(int epi, const bf16_t* A, int lda, const bf16_t* W, int ld
     // granular iff more than one engine exists; 1: always tile-granular; 2: always persistent (measurements).  No caller flips a
     // process-wide switch on behalf of engines it does not own any more.
     const bool shared_gpu = ze_gemv_knobs[4] == 1 || (ze_gemv_knobs[4] == 0 && ze_live_engines > 1);
-    const int grid = (ze_gemv_knobs[7] == 9 || shared_gpu) ? tiles : std::min(tiles, cus);
+    const int units = tiles * std::max(1, ksplit);   // (split K: a unit = a K slice of a tile)
+    const int grid = (ze_gemv_knobs[7] == 9 || shared_gpu) ? units : std::min(units, cus);
     // the wide-store epilogue (p8_finish_wide: 16-byte row pieces through 4 KB of LDS per wave) wherever rows are 16-byte
     // aligned; knob 7 = 10: the plain two-byte epilogue, for A/B runs and the bit-equality test
     const bool sw = epi == ZE_EPI_SWIGLU;
     const bool wide = ze_gemv_knobs[7] != 10 && (ldc % 8) == 0 && ((size_t)C % 16) == 0 && ((sw ? N / 2 : N) % 8) == 0 &&
                       (epi != ZE_EPI_RESIDUAL || ((ldr % 8) == 0 && ((size_t)R % 16) == 0));
-    const size_t lds = wide ? (128 + 32) * 1024 : 128 * 1024;
+    const size_t lds = wide ? (128 + 32) * 1024 : (128 + 1) * 1024;   // (+ 1 KB: the split-K flag lives behind the K-tile buffers)
     // the blocked walk of the tile grid (k_gemm_p8: `place`): 8 x 4 blocks; knob 21 = 1: the column walk of rounds 3-4, any other
     // value v > 1: blocks of (v >> 8) x (v & 255)
     const int blk = ze_gemv_knobs[21] == 1 ? 0 : (ze_gemv_knobs[21] > 1 ? ze_gemv_knobs[21] : ((8 << 8) | 4));
@@ -1129,7 +1207,8 @@ static void launch_p8(int epi, const bf16_t* A, int lda, const bf16_t* W, int ld
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_p8<E, WD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr_set = true;                                                                                                   \
         }                                                                                                                      \
-        hipLaunchKernelGGL((k_gemm_p8<E, WD>), dim3(grid), dim3(512), lds, s, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, blk); \
+        hipLaunchKernelGGL((k_gemm_p8<E, WD>), dim3(grid), dim3(512), lds, s, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, blk, \
+                           std::max(1, ksplit), ws.slab, ws.tickets);                                                          \
     } while (0)
     if (wide) {
         switch (epi) {
@@ -1831,6 +1910,29 @@ static void launch_ring_variant(int epi, const bf16_t* A, int lda, const bf16_t*
 #undef ZE_RINGV_LAUNCH
 }
 
+// Round 6: the long-K projection of a prefill pass -- the down projection, K = 11008 (3B) / 18944 (7B) -- is split
+// into THREE K slices on every kernel of the prefill family.  Why: N = hidden is 8 column tiles of 256, so a pass has few, long tiles
+// (408 of ~290 us at 12.8 K rows: 1.6 rounds of workgroups; 168 at 5.3 K rows: two thirds of the chip) -- with three slices the
+// units are a third as long and three times as many (1224 = 4.8 rounds; 504 = 1.97), the last round costs a third as much, and the
+// other lane's decode kernels, which get CUs at unit boundaries (knob 4), wait a third as long.  Why it keeps every invariance: the
+// count is a function of K ALONE -- never of M, of the tile or of the kernel -- the slices are cut at the same K-tiles everywhere
+// (ceil(K / 64 / 3) per slice) and added in slice order from zero, so prefill rows stay independent of their pass (batched = single
+// prefill, stage-2 reuse = fresh prefill: bit-identical, as before).  What it changes: the bits of every prefill AGAINST ROUND 5's
+// (fp32 sums of three partial sums instead of one running sum: the same error bound; every oracle test unchanged).  Needs the
+// engine's prefill slabs (ze_gemm_ws): a caller without them -- a bare unit op -- runs unsplit.  knob 20 = 1: off (A/B).
+static int ze_prefill_ksplit(int K, bool have_slab) {
+    return (have_slab && ze_gemv_knobs[20] != 1 && K > 4096 && K % GEMM_BK == 0 && K / GEMM_BK >= 3 * 8) ? 3 : 1;
+}
+static int ze_prefill_split_dropped(int M, int N, int K, int ksplit) {
+    static bool told = false;
+    if (!told) {
+        told = true;
+        fprintf(stderr, "zoomearth: prefill split-K workspace too small for M=%d N=%d K=%d (ksplit %d -> 1): this call sums K in one run, "
+                        "engine passes in three slices\n", M, N, K, ksplit);
+    }
+    return 1;
+}
+
 template <int BM, int BN>
 static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,
                        const bf16_t* R, int ldr, bf16_t* C, int ldc, const int* c_rows, int M, int N, int K,
@@ -1848,6 +1950,8 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
         const int nk = ze_cdiv(K, GEMM_BK);
         const int tiles_n = ze_cdiv(N, BN);
         while (tiles_n * ksplit < 200 && ksplit < 8 && nk / (ksplit * 2) >= 4) ksplit *= 2;
+    } else {
+        ksplit = ze_prefill_ksplit(K, g_slab != nullptr);   // (round 6) a function of K alone: the same on every tile and kernel
     }
     if (ksplit > 1 && (!g_slab || (size_t)ksplit * nwg * BM * BN > g_slab_floats || nwg > g_ticket_cap)) {
         // never silently: one slice instead of `ksplit` changes the order of every sum of this projection, i.e. a chain's bits
@@ -1856,7 +1960,8 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
         static bool told = false;
         if (g_slab && !told) {
             told = true;
-            fprintf(stderr, "zoomearth: split-K workspace too small for M=%d N=%d K=%d (ksplit %d -> 1): results no longer batch-invariant\n", M, N, K, ksplit);
+            fprintf(stderr, "zoomearth: split-K workspace too small for M=%d N=%d K=%d (ksplit %d -> 1): %s\n", M, N, K, ksplit,
+                    stream_mode ? "results no longer batch-invariant" : "this call sums K in one run, engine passes in three slices");
         }
         ksplit = 1;
     }
@@ -1890,7 +1995,7 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
     //     matrix load (zero-filled operands run 15-20 % faster than random ones: MI355X_MICROARCH.md).
     // All of them accumulate an output element in the same K order: results are bit-identical across the choices.
     // knob 7: 3 = register-staged only, 4 = always 256 x 256, 6 = always 128 x 256.
-    if (BM == 128 && BN == 128 && ksplit == 1 && K % GEMM_BK == 0 && K / GEMM_BK >= 4 && ze_gemv_knobs[7] != 3 &&
+    if (BM == 128 && BN == 128 && (ksplit == 1 || !stream_mode) && K % GEMM_BK == 0 && K / GEMM_BK >= 4 && ze_gemv_knobs[7] != 3 &&
         ze_gemv_knobs[6] == 0) {
         static int cus8 = 0;
         if (!cus8) {
@@ -1907,12 +2012,18 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
         // 0.75 round beat 384 of 128 x 256 = 2 rounds, 215 against 291 us for down at 6144 rows; 128 tiles lose, 210 against 160)
         const int r8 = ze_cdiv(grid4, cus8), ra = ze_cdiv(2 * grid4, cus8);
         const bool p8_wins = 10 * r8 <= 6 * ra;
-        if (p8_ok && (ze_gemv_knobs[7] == 8 || ((ze_gemv_knobs[7] == 0 || ze_gemv_knobs[7] == 9) && p8_wins)))
-            launch_p8(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s);
-        else if (ze_gemv_knobs[7] == 4 || (ze_gemv_knobs[7] != 6 && big))
-            launch_ring_variant<256, 256, 2, 2, 4, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s);
+        // (a split K -- ze_prefill_ksplit -- rides along: the slab holds ksplit x M_pad x N_pad floats whatever the tile; the 256 x 256
+        //  tiles need their own share of the capacity check above, which was made for BM x BN = 128 x 128)
+        const bool fits256 = ksplit == 1 || ((size_t)ksplit * grid4 * 256 * 256 <= g_slab_floats && grid4 <= g_ticket_cap);
+        const bool fits128x256 = ksplit == 1 || ((size_t)ksplit * ze_cdiv(M, 128) * ze_cdiv(N, 256) * 128 * 256 <= g_slab_floats);
+        if (fits256 && p8_ok && (ze_gemv_knobs[7] == 8 || ((ze_gemv_knobs[7] == 0 || ze_gemv_knobs[7] == 9) && p8_wins)))
+            launch_p8(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, ksplit, ws);
+        else if (fits256 && (ze_gemv_knobs[7] == 4 || (ze_gemv_knobs[7] != 6 && big)))
+            launch_ring_variant<256, 256, 2, 2, 4, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, ksplit, ws);
+        else if (fits128x256)
+            launch_ring_variant<128, 256, 3, 2, 4, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, ksplit, ws);
         else
-            launch_ring_variant<128, 256, 3, 2, 4, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s);
+            launch_ring_variant<128, 128, 4, 2, 4, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, ksplit, ws);
         return;
     }
     const bool ring = ze_gemv_knobs[6] == 2 || (ze_gemv_knobs[6] == 0 && (grid <= cus || stream_mode));
@@ -1924,8 +2035,8 @@ static void launch_cfg(int epi, const bf16_t* A, int lda, const bf16_t* W, int l
         // 64 x 128 tiles of a one-round grid: eight waves (2 x 4, 32 x 32 per wave), two per SIMD, hide each other's DMA
         // issue and LDS latency: o 20.4 -> 16.9 us, down 73.4 -> 62.7 (M = 802), 72.7 -> 58.4 (M = 518), ViT proj
         // 15.6 -> 12.4, ViT down 27.3 -> 22.9, merger 37.9 -> 31.4 (1 x 8 waves and the spread refill are 2-8 % behind)
-        if (BM == 64 && BN == 128 && ksplit == 1 && ze_gemv_knobs[7] != 3) {
-            launch_ring_variant<64, 128, 4, 2, 4, false>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s);
+        if (BM == 64 && BN == 128 && (ksplit == 1 || !stream_mode) && ze_gemv_knobs[7] != 3) {
+            launch_ring_variant<64, 128, 4, 2, 4, false>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, ksplit, ws);
             return;
         }
         // the same on 64 x 64 tiles (4 x 2 waves, 16 x 32 per wave: the SwiGLU epilogue pairs two 16-column tiles of a
@@ -2291,9 +2402,12 @@ void ze_launch_gemm_qkv_rope(const bf16_t* A, int lda, const bf16_t* Wp, int ldw
 }
 
 void ze_launch_gemm_p8(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R, int ldr,
-                       bf16_t* C, int ldc, const int* c_rows, int M, int N, int K, hipStream_t s) {
+                       bf16_t* C, int ldc, const int* c_rows, int M, int N, int K, hipStream_t s, const ze_gemm_ws& ws) {
     if (M <= 0 || N <= 0) return;
-    launch_p8(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s);
+    int ks = ze_prefill_ksplit(K, ws.slab != nullptr);   // (as ze_launch_gemm: the direct entry sums like the policy's)
+    const long tiles = (long)ze_cdiv(M, 256) * ze_cdiv(N, 256);
+    if (ks > 1 && ((size_t)ks * tiles * 256 * 256 > ws.slab_floats || tiles > ws.ticket_cap)) ks = ze_prefill_split_dropped(M, N, K, ks);
+    launch_p8(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, ks, ws);
 }
 
 void ze_launch_gemm_stream(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,
@@ -2444,7 +2558,7 @@ void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int
 }
 
 void ze_launch_gemm(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
-                    int ldr, bf16_t* C, int ldc, const int* c_rows, int M, int N, int K, hipStream_t s) {
+                    int ldr, bf16_t* C, int ldc, const int* c_rows, int M, int N, int K, hipStream_t s, const ze_gemm_ws& ws) {
     if (M <= 0 || N <= 0) return;
     // Many tiles: the largest tile (the register-staged kernel hides latency with several workgroups per CU).
     // Otherwise the largest tile whose grid is one round of at least half the CUs, which then runs on the LDS-DMA
@@ -2459,13 +2573,15 @@ void ze_launch_gemm(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw,
     // the unspread 128 x 128 ring).
     if (ringable && K / GEMM_BK >= 4 && b128 < 200 && b128 >= 96 && b64x128 > 256 && ze_gemv_knobs[6] == 0 &&
         ze_gemv_knobs[7] != 3) {
-        launch_ring_variant<128, 128, 4, 2, 4, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s);
+        int ks_ = ze_prefill_ksplit(K, ws.slab != nullptr);
+        if (ks_ > 1 && ((size_t)ks_ * b128 * 128 * 128 > ws.slab_floats || b128 > ws.ticket_cap)) ks_ = ze_prefill_split_dropped(M, N, K, ks_);
+        launch_ring_variant<128, 128, 4, 2, 4, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, ks_, ws);
         return;
     }
     if (b128 >= 200)
-        launch_cfg<128, 128>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, false);
+        launch_cfg<128, 128>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, false, ws);
     else if (b64x128 >= 160 || (ringable && (b64x128 >= 128 || b64 > 256)))
-        launch_cfg<64, 128>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, false);
+        launch_cfg<64, 128>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, false, ws);
     else
-        launch_cfg<64, 64>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, false);
+        launch_cfg<64, 64>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, c_rows, M, N, K, s, false, ws);
 }

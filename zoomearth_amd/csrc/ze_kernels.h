@@ -166,8 +166,10 @@ void ze_launch_gemm_qkv_rope(const bf16_t* A, int lda, const bf16_t* Wp, int ldw
                              bf16_t* C, int ldc, int M, int N, int K, hipStream_t s);
 
 // ---- GEMM (prefill / ViT)
+// `ws` (round 6): the engine's PREFILL split-K workspace -- with it a long-K projection (K > 4096: the down projection) is summed in
+// three K slices on every tile and kernel (ze_gemm.hip: ze_prefill_ksplit); without it (ViT, bare unit ops) K runs in sequence.
 void ze_launch_gemm(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R,
-                    int ldr, bf16_t* C, int ldc, const int* c_rows, int M, int N, int K, hipStream_t s);
+                    int ldr, bf16_t* C, int ldc, const int* c_rows, int M, int N, int K, hipStream_t s, const ze_gemm_ws& ws = ze_gemm_ws());
 
 // Weight-streaming form for batched decode (few rows): 64x64 tiles, deterministic split-K chosen from (N, K) only.
 void ze_launch_gemm_stream(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias,
@@ -183,7 +185,7 @@ void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int
 
 // the eight-phase 256 x 256 kernel directly (ze_launch_gemm picks it for many-round grids); K % 64 == 0, lda / ldw % 8 == 0
 void ze_launch_gemm_p8(int epi, const bf16_t* A, int lda, const bf16_t* W, int ldw, const bf16_t* bias, const bf16_t* R, int ldr,
-                       bf16_t* C, int ldc, const int* c_rows, int M, int N, int K, hipStream_t s);
+                       bf16_t* C, int ldc, const int* c_rows, int M, int N, int K, hipStream_t s, const ze_gemm_ws& ws = ze_gemm_ws());
 
 // ---- decode GEMV family (batch-1 weight streaming)
 struct ze_gemv_args {

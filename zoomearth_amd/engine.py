@@ -584,6 +584,12 @@ class Engine:
         self._check(self.lib.ze_profile_prefill_kernel(self.h, which, rows, iters, C.byref(us), C.byref(fl), self._stream()))
         return float(us.value), float(fl.value)
 
+    def profile_prefill_layer(self, rows: int, layers_run: int = 36):
+        """{projection: (avg us, FLOP)} of a prefill layer's four projections issued in pass order at `rows` rows."""
+        us, fl = (C.c_float * 4)(), (C.c_double * 4)()
+        self._check(self.lib.ze_profile_prefill_layer(self.h, rows, layers_run, us, fl, self._stream()))
+        return {k: (float(us[i]), float(fl[i])) for i, k in enumerate(("qkv", "o", "gate_up", "down"))}
+
     def phase_timers(self, enable: bool = True, reset: bool = False):
         out = (C.c_float * 5)()
         self._check(self.lib.ze_phase_timers(self.h, int(enable), int(reset), out))
