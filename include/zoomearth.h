@@ -417,6 +417,8 @@ int ze_profile_prefill_layer(ze_engine* e, int rows, int layers_run, float avg_u
  *   17    1: no shared-prefix hints (every chain reads its own K/V rows: same bits, more HBM traffic)
  *   18    1: round 4's K loop on the 513 .. 768-row decode tiles (K-steps of 32 in four stages; default: 64 in two; same bits)
  *   19    4: the tall qkv / o decode tiles on a plain four-stage ring, one barrier per K-step (default: six stages in groups of two)
+ *   20    3: the long-K projection of a prefill pass (K > 4096: down) in three K slices on every prefill kernel (round 6: built, slower --
+ *            down 469 -> 725 us at 12.8 K rows, the stream 86.4 -> 82.4 questions/s -- kept for its bit-equality test; other bits than 0)
  *   21    1: column walk of the eight-phase GEMM's tile grid (default: 8 x 4 blocks; > 1: R << 8 | C blocks)
  *   22    1: the prefill's queries rotated in place by the M-RoPE kernel (default at head_dim 128: inside the flash kernel, as it loads
  *            them; the M-RoPE kernel then writes K and V only; same bits)

@@ -674,7 +674,7 @@ def test_decode_step_above_768_chains_keeps_a_chains_bits():
     from gpu_util import oracle_cfg_to_model_cfg
     from zoomearth_amd.engine import Engine
     n = 900
-    e = Engine(oracle_cfg_to_model_cfg(), device=0, max_seqs=n, max_ctx=96, max_patches=1024, max_tile_side=1024, max_prefill_rows=4096)
+    e = Engine(oracle_cfg_to_model_cfg(), device=0, max_seqs=n, max_ctx=1024, max_patches=1024, max_tile_side=1024, max_prefill_rows=4096)
     try:
         e.fill_synthetic(**CHAIN_W)
         assert e.set_decode_regime(-1) == 1

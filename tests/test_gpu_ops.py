@@ -325,3 +325,33 @@ def test_gemm_eight_phase_kernel(tiny_engine, m, n, k, bias, act):
     if act == 0:
         want = a.astype(np.float64) @ w.astype(np.float64).T + (b.astype(np.float64) if bias else 0.0)
         close_bf16(got_t.float().cpu().numpy(), want, scale=0.05 * np.sqrt(k) * 0.05)
+
+
+def test_prefill_split_k_is_one_sum_order_on_every_kernel(tiny_engine):
+    """Round 6 (built, measured slower, off by default -- knob 20 = 3 turns it on): the long-K projection of a prefill pass
+    in three K slices.  What made it admissible at all is that the split is a function of K alone: the eight-phase kernel (its new
+    slab / ticket tail), the 64 x 64 ring tiles the policy picks at this size and the register-staged kernel give the SAME bits, a
+    64-row slice of the rows alone too -- and other bits than the one-run sum, both within one bf16 rounding of float64.  (With the
+    knob on for the whole process the GPU suite was green in round 6: batched = single prefill, stage-2 reuse = fresh prefill.)"""
+    m, n, k = 700, 512, 4160          # 65 K-tiles: slices of 22 / 22 / 21
+    a, w = rnd(51, (m, k)), rnd(52, (n, k), 0.05)
+    da, dw = to_dev_bf16(a), to_dev_bf16(w)
+    e = tiny_engine
+    one_run = e.op_linear(da, dw, None, 8)
+    try:
+        e.lib.ze_tune(20, 3)
+        p8 = e.op_linear(da, dw, None, 8)                      # k_gemm_p8, three slices
+        assert torch.equal(p8, e.op_linear(da, dw, None, 8))   # (tickets reset themselves: repeats are the same bits)
+        policy = e.op_linear(da, dw, None, 0)                  # ze_launch_gemm's own choice at 700 rows: 64 x 64 ring tiles, three slices
+        e.lib.ze_tune(6, 1)
+        staged = e.op_linear(da, dw, None, 0)                  # ... and the register-staged kernel (k_gemm_tn) on the same slices
+        e.lib.ze_tune(6, 0)
+        part = e.op_linear(da[300:364].contiguous(), dw, None, 0)   # 64 rows of it alone
+    finally:
+        e.lib.ze_tune(20, 0)
+        e.lib.ze_tune(6, 0)
+    assert torch.equal(p8, policy) and torch.equal(p8, staged) and torch.equal(part, p8[300:364])
+    assert not torch.equal(p8, one_run)                         # three partial sums are not one running sum
+    want = a.astype(np.float64) @ w.astype(np.float64).T
+    for got in (p8, one_run):
+        close_bf16(got.float().cpu().numpy(), want, scale=0.05 * np.sqrt(k) * 0.05)

@@ -441,3 +441,35 @@ def test_decode_rgb_reads_uncompressed_tiff_strips_directly(tmp_path):
     fp = str(tmp_path / "g.tif")
     Image.fromarray(g).save(fp)
     assert np.array_equal(decode_rgb(fp), np.repeat(g[:, :, None], 3, axis=2))   # not RGB on disk: PIL converts
+
+
+def test_trained_byte_level_bpe_round_trip_is_not_the_identity():
+    """the tokenizer the GPU e2e tests run with (tests/tiny_tok.py: train_bpe) -- specials at the tiny config's ids,
+    prompts of a few hundred tokens, and a decode -> strip -> re-encode round trip that DIVERGES from the generated ids on most random
+    continuations (pieces re-merge, invalid UTF-8 comes back as U+FFFD), while `"bbox_2d":[...]` fragments still parse."""
+    from tiny_tok import SPECIALS, make_bpe_tokenizer
+    from zoomearth_amd import hostloop
+    tok = make_bpe_tokenizer()
+    for name, idx in SPECIALS.items():
+        if name != "<unk>":
+            assert tok.convert_tokens_to_ids(name) == idx
+    p1 = hostloop.stage1_prompt('w3 w6 "bbox_2d":[37,91,98,132]')
+    assert 150 < len(tok.encode(p1)) < 700
+    text = 'w3 "bbox_2d":[37,91,98,132] w9'
+    assert tok.decode(tok.encode(text), skip_special_tokens=True) == text          # text -> ids -> text is exact
+    rng = np.random.default_rng(1)
+    same = boxes = 0
+    prefix = []
+    for _ in range(200):
+        ids = rng.integers(0, 2048, 14).tolist()
+        out = tok.decode(ids, skip_special_tokens=True).strip()
+        back = tok.encode(out)
+        m = 0
+        while m < min(len(back), len(ids)) and back[m] == ids[m]:
+            m += 1
+        prefix.append(m)
+        same += back == ids
+        b = hostloop.extract_bbox(out, 1.0)
+        boxes += bool(b) and len(b[0]) == 4
+    assert same < 100 and 1.0 < np.mean(prefix) < 12.0, (same, np.mean(prefix))       # ids -> text -> ids mostly diverges, after a few ids
+    assert boxes > 60, boxes                                                           # ... and stage 2 still has boxes to zoom into

@@ -374,7 +374,7 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
         // with a fixed 64 MB the 3B shape sat exactly at the limit at 1024 rows and larger shapes would have dropped to one
         // slice above some batch size).  64 MB at least (the unit-op entry points call with shapes of their own).
         const size_t rows_pad = ((size_t)std::max(c.max_seqs, 64) + 255) / 256 * 256;
-        const size_t slab_floats = std::max((size_t)16 << 20, (size_t)400 * 64 * rows_pad);
+        const size_t slab_floats = std::max((size_t)24 << 20, (size_t)400 * 64 * rows_pad);   // (floor: unit ops of up to ~1400 rows x 2048 columns in eight slices)
         const int ticket_cap = std::max(4096, (int)(200 * (rows_pad / 64)) + 64);
         chk(dev_alloc(e, &e->gslab, slab_floats, false));
         chk(dev_alloc(e, &e->gtickets, (size_t)ticket_cap, true));

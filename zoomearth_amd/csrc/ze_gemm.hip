@@ -1910,18 +1910,20 @@ static void launch_ring_variant(int epi, const bf16_t* A, int lda, const bf16_t*
 #undef ZE_RINGV_LAUNCH
 }
 
-// Round 6: the long-K projection of a prefill pass -- the down projection, K = 11008 (3B) / 18944 (7B) -- is split
-// into THREE K slices on every kernel of the prefill family.  Why: N = hidden is 8 column tiles of 256, so a pass has few, long tiles
-// (408 of ~290 us at 12.8 K rows: 1.6 rounds of workgroups; 168 at 5.3 K rows: two thirds of the chip) -- with three slices the
-// units are a third as long and three times as many (1224 = 4.8 rounds; 504 = 1.97), the last round costs a third as much, and the
-// other lane's decode kernels, which get CUs at unit boundaries (knob 4), wait a third as long.  Why it keeps every invariance: the
-// count is a function of K ALONE -- never of M, of the tile or of the kernel -- the slices are cut at the same K-tiles everywhere
-// (ceil(K / 64 / 3) per slice) and added in slice order from zero, so prefill rows stay independent of their pass (batched = single
-// prefill, stage-2 reuse = fresh prefill: bit-identical, as before).  What it changes: the bits of every prefill AGAINST ROUND 5's
-// (fp32 sums of three partial sums instead of one running sum: the same error bound; every oracle test unchanged).  Needs the
-// engine's prefill slabs (ze_gemm_ws): a caller without them -- a bare unit op -- runs unsplit.  knob 20 = 1: off (A/B).
+// Round 6, BUILT, MEASURED, NOT SHIPPED (default off; knob 20 = 3 turns it on for A/B runs and its bit-equality test):
+// the long-K projection of a prefill pass -- the down projection, K = 11008 (3B) / 18944 (7B) -- in THREE K slices on every kernel of
+// the prefill family.  The idea: N = hidden is 8 column tiles of 256, so a pass has few, long tiles (408 of ~290 us at 12.8 K rows: 1.6
+// rounds of workgroups; 168 at 5.3 K rows: two thirds of the chip); with three slices the units are a third as long and three times
+// as many (1224 = 4.8 rounds; 504 = 1.97), and the other lane's decode kernels, which get CUs at unit boundaries, wait a third as long.
+// It keeps every invariance: the count is a function of K ALONE -- never of M, of the tile or of the kernel -- the slices are cut at the
+// same K-tiles everywhere (ceil(K / 64 / 3) per slice) and added in slice order from zero, so prefill rows stay independent of their
+// pass (the whole GPU suite is green with it on).  What it costs: every unit parks 256 KB of fp32 accumulators write-through and the
+// tile's last arriver reads three of them back -- 630 MB of slab traffic for a 12.8 K-row pass whose operands are 330 MB -- behind a
+// drain of the next unit's prefetch.  Measured on the replayed passes (rocprofv3, profiles/r06_prefill_by_shape_splitk.csv against
+// r06_prefill_by_shape.csv): down 469 -> 725 us at 12,832 rows, 217 -> 284 at 5,280; the question stream, same box, two runs each:
+// 86.75 / 86.1 unsplit, 82.2 / 82.6 split.  The grid's idle tail is cheaper than the slabs.  Needs the engine's prefill slabs (ze_gemm_ws).
 static int ze_prefill_ksplit(int K, bool have_slab) {
-    return (have_slab && ze_gemv_knobs[20] != 1 && K > 4096 && K % GEMM_BK == 0 && K / GEMM_BK >= 3 * 8) ? 3 : 1;
+    return (have_slab && ze_gemv_knobs[20] == 3 && K > 4096 && K % GEMM_BK == 0 && K / GEMM_BK >= 3 * 8) ? 3 : 1;
 }
 static int ze_prefill_split_dropped(int M, int N, int K, int ksplit) {
     static bool told = false;
