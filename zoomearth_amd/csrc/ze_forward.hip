@@ -1348,10 +1348,7 @@ static int enqueue_decode_batch(ze_engine* e, int n, float penalty, int ignore_e
         } else {
             // row streaming: projection + M-RoPE + KV append in ONE launch on the permuted rows (same bits as the pair of
             // launches below; knob 13 = 2 keeps the pair, for A/B runs and the bit-equality test)
-            // (beyond 768 rows -- engines with more than 768 chain slots, round 6 -- the pair of launches: a one-round grid of 128-row tiles
-            //  with the wide-store epilogue + k_rope_kv_batch is 26 us at 1152 rows where the fused epilogue's two-byte stores and cache
-            //  scatters on such tiles took 32; the same bits either way)
-            if (tiled && L.qkv.wp && ze_gemv_knobs[13] != 2 && n <= 768) {
+            if (tiled && L.qkv.wp && ze_gemv_knobs[13] != 2) {
                 ze_launch_gemm_qkv_rope(e->by, H, L.qkv.wp, H, L.qkv.bias_p, e->qkv_epi_dev + li, e->bqkv, nqkv, n, nqkv, H, s);
             } else {
                 if (tiled) ze_launch_gemm_wide(ZE_EPI_NONE, e->by, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->bqkv, nqkv, n, nqkv, H, ws, s);
@@ -2201,7 +2198,7 @@ extern "C" int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters
             case 0:
                 if (fr) ze_launch_qkv_rope_oneshot(e->by, L.qkv.wf, L.qkv.bias, e->bqkv, nqkv, n, H, c.heads, c.kv_heads, e->cosT, e->sinT,
                                                    e->st_dev, e->bseq, e->kc(li, 0), e->vc(li, 0), seq_stride, c.max_ctx, s);
-                else if (tiled && L.qkv.wp && ze_gemv_knobs[13] != 2 && n <= 768)
+                else if (tiled && L.qkv.wp && ze_gemv_knobs[13] != 2)
                     ze_launch_gemm_qkv_rope(e->by, H, L.qkv.wp, H, L.qkv.bias_p, e->qkv_epi_dev + li, e->bqkv, nqkv, n, nqkv, H, s);
                 else if (tiled) ze_launch_gemm_wide(ZE_EPI_NONE, e->by, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->bqkv, nqkv, n, nqkv, H, ws, s);
                 else ze_launch_gemm_stream(ZE_EPI_NONE, e->by, H, L.qkv.w, L.qkv.ld, L.qkv.bias, nullptr, 0, e->bqkv, nqkv, n, nqkv, H, ws, s);

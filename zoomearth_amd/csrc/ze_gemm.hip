@@ -2389,6 +2389,12 @@ void ze_launch_gemm_qkv_rope(const bf16_t* A, int lda, const bf16_t* Wp, int ldw
     const long b64 = (long)ze_cdiv(M, 64) * ze_cdiv(N, 64);
     const bf16_t* R = reinterpret_cast<const bf16_t*>(dev_args);
     if (launch_tall<true>(ZE_EPI_QKV_ROPE, A, lda, Wp, ldw, bias_p, R, 0, C, ldc, M, N, K, s)) return;
+    // more than 768 rows (round 6: an engine with more than 768 chain slots -- the one-lane A/B of VERDICT r5 #1b): one round of 128 x 128
+    // tiles, the tile ze_launch_gemm gives a prefill pass of this size (9 x 20 = 180 workgroups at 1152 rows); K in sequence: same bits
+    if (M > 768 && K % GEMM_BK == 0 && K / GEMM_BK >= 4 && (long)ze_cdiv(M, 128) * ze_cdiv(N, 128) <= 256) {
+        launch_ring_variant<128, 128, 4, 2, 4, true, false, true>(ZE_EPI_QKV_ROPE, A, lda, Wp, ldw, bias_p, R, 0, C, ldc, nullptr, M, N, K, s);
+        return;
+    }
     // (two 64-KB workgroups share a CU: up to 512 tiles stay on 64 x 64 -- 16.4 against 20.8 us at 410 rows, 19.9 / 21.0 at 580, 20.9 /
     //  22.7 at 768; knob 13 = 3: 64 x 128 from 257 tiles on, the rule before)
     if (b64 <= (ze_gemv_knobs[13] == 3 ? 256 : 512))
@@ -2460,10 +2466,6 @@ void ze_launch_gemm_wide(int epi, const bf16_t* A, int lda, const bf16_t* W, int
                 if (f == 1 ? launch_splitk_two<384, 128, 4, true, 4, 2, 32>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)
                            : launch_splitk_two<384, 128, 2, false, 4, 2>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
             }
-            // beyond 768 rows (round 6, the one-lane A/B: engines with up to 1536 chain slots): 256 x 256 tiles on the two-stage ring -- four
-            // or five row tiles x 8 column tiles x 8 slices = 256 / 320 workgroups staging 1.4 MB each, where 128 x 256 tiles are 512 / 640
-            // staging 1.06 MB (a third more intake for the same outputs); same slices, same order: same bits.  knob 15 = 10: 128 x 256
-            if (M > 768 && ze_gemv_knobs[15] != 10 && launch_splitk_two<256, 256, 2, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
             // (round 5: 128 x 256 without the spread refill 35.7 against 35.1 us at 399 rows, in two stages 43.8)
             if (M > 256 && launch_splitk_two<128, 256, 3, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
             if (M > 128 && M <= 256 && launch_splitk_two<128, 128, 4, true>(epi, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, ws, s)) return;
