@@ -1293,6 +1293,18 @@ def main():
                     line["roofline"]["top_kernel_by_gpu_time"] = top_kernel_by_gpu_time()
                 except Exception as ex:
                     line["roofline"]["top_kernel_by_gpu_time"] = {"error": f"{type(ex).__name__}: {ex}"}
+                try:   # what a ROW pays for the four projections of a layer, decode step against prefill pass
+                    sk = line["roofline"]["step_kernels"]
+                    dec = sum(sk[k]["us"] for k in ("qkv", "o_proj", "gate_up", "down")) / live
+                    rp = line["roofline_phases"]["decode"]
+                    rp["projections_us_per_row_per_layer"] = round(dec, 4)
+                    rp["projections_note"] = (f"qkv + o + gate/up + down (+ its reducer) of one decode step at {live} chains, alone on the GPU, per chain; "
+                                              "`prefill_pass` = the same four projections of a prefill pass per row (top_kernel_by_gpu_time.by_rows, the form the stream runs)")
+                    tk = line["roofline"]["top_kernel_by_gpu_time"]
+                    rp["prefill_pass_projections_us_per_row_per_layer"] = {
+                        rows: round(sum(ent[tk["form_in_stream"]]["layer_us"].values()) / int(rows), 4) for rows, ent in tk.get("by_rows", {}).items()}
+                except Exception:
+                    pass
         if args.model == "3b" and not args.fp8 and not stream:
             if B == 1:
                 pm = line["phase_ms_per_question"]
