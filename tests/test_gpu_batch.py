@@ -708,3 +708,73 @@ def test_decode_step_above_768_chains_keeps_a_chains_bits():
         assert np.array_equal(pair, full)
     finally:
         e.close()
+
+
+def test_chains_of_a_tile_share_a_workgroup_per_prefix_part_and_keep_their_bits():
+    """Round 6: the decode attention cuts every chain's parts at its split row (the end of its first image block, found
+    where the tokens are prefilled and handed on by ze_seq_copy_prefix), and two chains that read the rows below it from one holder
+    share ONE workgroup per prefix part (the second chain's q heads in the eight MFMA columns that otherwise idle).  Six questions about
+    one 36 x 36 view + one about another + a text-only chain, three steps: the logits with the pairing (default) are the bits of the
+    unpaired run (knob 23 = 2), of the run without hints (knob 17 = 1) and of chains prefilled in full instead of copying the prefix;
+    the round-5 partition (knob 23 = 1: parts of the whole context) agrees within rounding."""
+    from gpu_util import oracle_cfg_to_model_cfg
+    from zoomearth_amd.engine import Engine
+    cfg = Q.tiny_config()
+    e = Engine(oracle_cfg_to_model_cfg(), device=0, max_seqs=8, max_ctx=1024, max_patches=2048, max_tile_side=1024)
+    try:
+        e.fill_synthetic(**CHAIN_W)
+        assert e.set_decode_regime(1) == 1
+        n_img = 324
+        feats = [torch.randn(n_img, cfg.text.hidden_size, device="cuda").to(torch.bfloat16) for _ in range(2)]
+        head = [11, 12, 13, cfg.vision_start_token_id] + [cfg.image_token_id] * n_img + [cfg.vision_end_token_id]
+        split = len(head)
+        tails = [text_ids(1200 + c, 40 + 17 * c) for c in range(6)]
+        other = [21, cfg.vision_start_token_id] + [cfg.image_token_id] * n_img + [cfg.vision_end_token_id] + text_ids(1300, 77)
+        text_only = text_ids(1400, 450)
+        forced = [[int(t) for t in text_ids(1500 + s, 8)] for s in range(3)]
+
+        def fill(copying):
+            for c in range(8):
+                e.seq_reset(c)
+            ids0 = head + tails[0]
+            pos0, d0 = e.rope_index(ids0, [(1, 36, 36)])
+            e.prefill(0, ids0, feats[0], pos0, d0, want_logits=False)
+            for c in range(1, 6):
+                ids = head + tails[c]
+                pos, d = e.rope_index(ids, [(1, 36, 36)])
+                if copying:
+                    e.seq_copy_prefix(c, 0, split)
+                    e.prefill(c, ids[split:], None, pos[:, split:], d, want_logits=False)
+                else:
+                    e.prefill(c, ids, feats[0], pos, d, want_logits=False)
+            pos, d = e.rope_index(other, [(1, 36, 36)])
+            e.prefill(6, other, feats[1], pos, d, want_logits=False)
+            e.prefill(7, text_only, None, *e.rope_index(text_only, []), want_logits=False)
+
+        def steps():
+            return [e.decode_batch(list(range(8)), forced[s]).cpu().numpy() for s in range(3)]
+
+        def run(copying, knob23=0, knob17=0):
+            try:
+                e.lib.ze_tune(23, knob23)
+                e.lib.ze_tune(17, knob17)
+                fill(copying)
+                if copying and knob17 == 0:
+                    assert all(e.seq_prefix_hint(c) == (0, split) for c in range(1, 6))
+                return steps()
+            finally:
+                e.lib.ze_tune(23, 0)
+                e.lib.ze_tune(17, 0)
+        paired = run(True)
+        assert all(np.isfinite(x).all() for x in paired)
+        for other_run in (run(True, knob23=2), run(True, knob17=1), run(False)):
+            for a, b in zip(paired, other_run):
+                assert np.array_equal(a, b)
+        old = run(True, knob23=1)
+        scale = max(float(np.abs(x).max()) for x in paired)
+        diff = max(float(np.abs(a - b).max()) for a, b in zip(paired, old))
+        print(f"split-row partition against the round-5 partition: max |logit difference| {diff:.5f} on logits of scale {scale:.2f}")
+        assert 0 < diff <= 0.02 * scale
+    finally:
+        e.set_decode_regime(-1)
+        e.close()

@@ -285,3 +285,57 @@ def test_numeric_helpers_of_every_epilogue_against_float64(tiny_engine):
         else:
             assert d.max() <= 2, (up, int(d.max()))
     assert worst_ulp <= 2
+
+
+def test_decode_attention_with_a_split_row_against_float64():
+    """Round 6: the pipelined decode attention cuts a chain's parts at its SPLIT ROW -- [0, split) in 384-key pieces, then [split, ctx)
+    in 384-key pieces -- so that a prefix part holds only rows the questions of a tile share (ze_seq_dev::split; here set by hand,
+    `ze_seq_set_split`).  Every combination that moves a boundary: a split inside the first round, on and either side of a part's end,
+    a prefix of two parts, a last own part of one row, no split at all -- against float64 over rows 0 .. ctx; a chain's row is the
+    same bits alone as in the batch."""
+    from zoomearth_amd.config import ModelConfig, TextConfig, VisionConfig
+    from zoomearth_amd.engine import Engine
+    cfg = ModelConfig(vision=VisionConfig(depth=1, hidden_size=160, num_heads=2, intermediate_size=220, out_hidden_size=2048,
+                                          fullatt_block_indexes=(0,)),
+                      text=TextConfig(hidden_size=2048, num_hidden_layers=1, num_attention_heads=16, num_key_value_heads=2,
+                                      intermediate_size=1024, vocab_size=2048, tie_word_embeddings=True),
+                      image_token_id=2005, vision_start_token_id=2002, vision_end_token_id=2003, eos_token_ids=(2045, 2043),
+                      pad_token_id=2043, name="attn-split")
+    cases = [(5, 3), (500, 100), (383, 347), (384, 347), (730, 347), (731, 347), (732, 347), (766, 384), (767, 384), (768, 385),
+             (1000, 500), (1000, 0), (900, 769), (400, 399), (64, 63)]
+    n = len(cases)
+    e = Engine(cfg, device=0, max_seqs=n, max_ctx=1024, max_patches=256, max_tile_side=256)
+    try:
+        e.fill_synthetic(seed=3, std=0.02, matrix_gain=4.0, bias_std=0.5, norm_jitter=0.1)
+        for s_, (L, sp) in enumerate(cases):
+            ids = prng.uniform_ints(700 + s_, L, 10, 1990).tolist()
+            e.seq_reset(s_)
+            e.prefill(s_, ids, None, *e.rope_index(ids, []), want_logits=False)
+            e.seq_set_split(s_, sp)
+        t = cfg.text
+        nq, nkv = t.num_attention_heads * 128, t.num_key_value_heads * 128
+        qkv_host = rnd(901, (n, nq + 2 * nkv), 1.0)
+        seqs = list(range(n))
+        qkv = e.op_rope_kv_decode(seqs, 0, to_dev_bf16(qkv_host))
+        out = e.op_attn_decode(seqs, 0, qkv)
+        got = out.float().cpu().numpy().reshape(n, t.num_attention_heads, 128)
+        q = qkv.float().cpu().numpy()[:, :nq].reshape(n, t.num_attention_heads, 128).astype(np.float64)
+        g = t.num_attention_heads // t.num_key_value_heads
+        worst = 0.0
+        for b, (L, sp) in enumerate(cases):
+            k, v = e.op_kv_read(b, 0, 0, L + 1)
+            k, v = k.float().cpu().numpy().astype(np.float64), v.float().cpu().numpy().astype(np.float64)
+            for h in range(t.num_attention_heads):
+                sc = k[h // g] @ q[b, h] / np.sqrt(128.0)
+                p = np.exp(sc - sc.max())
+                want = (p / p.sum()) @ v[h // g]
+                err = float(np.abs(got[b, h] - want).max())
+                bound = 2.0 ** -7 * float(np.abs(v[h // g]).max())
+                worst = max(worst, err / bound)
+                assert err <= bound, (L, sp, h, err, bound)
+        print(f"split rows: worst error / bound {worst:.3f}")
+        for b in (0, 4, 9, 12):
+            alone = e.op_attn_decode([b], 0, qkv[b:b + 1].contiguous())
+            assert torch.equal(alone[0], out[b]), cases[b]
+    finally:
+        e.close()

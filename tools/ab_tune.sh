@@ -11,6 +11,6 @@ for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l)
         ph = {k: round(v['ms_per_question'], 3) for k, v in d.get('roofline_phases', {}).items() if isinstance(v, dict) and 'ms_per_question' in v}
-        print('tune[$t] value', round(d['value'], 2), 'layer_us', d['roofline'].get('layer_us'), 'phases', ph)
+        print('tune[$t] value', round(d['value'], 2), 'attention_us', d['roofline'].get('avg_us'), 'independent', d['roofline'].get('independent_chains', {}).get('avg_us'), 'layer_us', d['roofline'].get('layer_us'), 'phases', ph)
 "
 done; done

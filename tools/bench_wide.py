@@ -36,9 +36,12 @@ for g0 in range(0, B, 8):
     if rest:
         e.prefill_batch(rest, [ids[s - g0][SHARED:] for s in rest], [None] * len(rest), [pl[s - g0][0][:, SHARED:] for s in rest],
                         [pl[s - g0][1] for s in rest])
+if GROUP > 1:   # (round 6) chains that share an image prefix have their split row at its end
+    for s in range(B):
+        e.seq_set_split(s, SHARED)
 print(f"{B} chain slots, contexts {min(lens)}..{max(lens)} (mean {sum(lens) / B:.0f}); family {e.set_decode_regime(-1)}", flush=True)
 for tune in tunes:
-    for k in range(16):
+    for k in range(24):
         e.lib.ze_tune(k, 0)
     for kv in tune.split(","):
         if ":" in kv:

@@ -22,9 +22,18 @@ def vregs(tok):
 
 
 def parse_blocks(body):
+    """-> {label: [instruction text, ...]}, label order.  An instruction that hipcc emitted itself (outside ;APP ... ;NO_APP) carries
+    the prefix "\x01": its destination registers are the compiler's own business (it waits before it uses them) -- the walker counts
+    such an operation in the FIFO without registers, which keeps the state space of compiler-generated loops (the merges of the tail,
+    two of them since round 6) from multiplying."""
     blocks, order, cur = {"entry": []}, ["entry"], "entry"
+    in_app = False
     for raw in body.split("\n"):
         l = raw.strip()
+        if l.startswith(";APP"):
+            in_app = True
+        elif l.startswith(";NO_APP"):
+            in_app = False
         if not l or l.startswith((";", "//")):
             continue
         m = re.match(r"^(\.LBB\w+):", l)
@@ -35,7 +44,7 @@ def parse_blocks(body):
             continue
         if l.startswith("."):
             continue
-        blocks[cur].append(l.split(";")[0].strip())
+        blocks[cur].append(("" if in_app else "\x01") + l.split(";")[0].strip())
     return blocks, order
 
 
@@ -60,15 +69,20 @@ def check(body, name, limit=400000):
         succ = [nxt[b]]
         stop = False
         for k, l in enumerate(ins):
+            own = l.startswith("\x01")   # emitted by the compiler, not by an asm statement
+            if own:
+                l = l[1:]
             if VMEM.match(l):
                 op = l.split()[0]
                 is_load = "_load_" in op and "_lds_" not in op
-                dest = vregs(l.split(",")[0]) if is_load else set()
+                dest = vregs(l.split(",")[0]) if (is_load and not own) else set()
                 live = set().union(*pending) if pending else set()
                 src = vregs(",".join(l.split(",")[1:])) if is_load else vregs(l)
                 if live & (src | dest):
                     bad[(b, l)] = sorted(live & (src | dest))[:8]
                 pending.append(dest)
+                if len(pending) > 63:   # (vmcnt is a six-bit counter: nothing older can still be counted)
+                    pending.pop(0)
                 n_loads += 1
                 continue
             m = re.search(r"vmcnt\((\d+)\)", l) if l.startswith("s_waitcnt") else None

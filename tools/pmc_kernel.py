@@ -53,6 +53,9 @@ else:
             e.seq_reset(s)
         e.prefill_batch(gs, ids, [None] * len(gs), [p[0] for p in pl], [p[1] for p in pl])
     e.set_decode_regime(1 if mode.startswith("wide") else 0)
+    if live:   # (round 6) the stream's chains are image prompts: their split row is the end of the view's image block, shared or not
+        for s in range(slots):
+            e.seq_set_split(s, 347)
     if mode.endswith("_shared"):
         for s in range(n):
             if s % 10:

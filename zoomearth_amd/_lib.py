@@ -102,6 +102,7 @@ _SIGS = {
     "ze_vit_forward": (C.c_int, [_P, _P, C.POINTER(C.c_int32), C.c_int, _P, _P]),
     "ze_seq_reset": (C.c_int, [_P, C.c_int, _P]),
     "ze_seq_retire": (C.c_int, [_P, C.c_int, _P]),
+    "ze_seq_set_split": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "ze_seq_prefix_hint": (C.c_int, [_P, C.c_int]),
     "ze_seq_set_prefix_hint": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "ze_seq_truncate": (C.c_int, [_P, C.c_int, C.c_int, _P]),

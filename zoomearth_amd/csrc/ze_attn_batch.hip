@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k
     const bf16_t* __restrict__ q, int q_row_stride, const bf16_t* __restrict__ kcache, const bf16_t* __restrict__ vcache,
     size_t cache_seq_stride, const ze_seq_dev* __restrict__ st_base, const int* __restrict__ seq_ids, int heads, int kv_heads,
     int max_ctx, float scale_log2e, float* __restrict__ ws, int max_parts, unsigned* __restrict__ tickets,
-    bf16_t* __restrict__ out, int out_row_stride, int x_rot, const int* __restrict__ prefix) {
+    bf16_t* __restrict__ out, int out_row_stride, int x_rot, const int* __restrict__ prefix, const int* __restrict__ mate, int use_split) {
     constexpr int D = 128, PART = AW_TOK * ROUNDS;
     static_assert(ROUNDS >= 3 && ROUNDS <= 8, "part length");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 4 waves x 3 V stages of 4 KB
@@ -637,10 +637,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k
     const int kvh = xr % kv_heads, part = xr / kv_heads;
     const int seq = seq_ids[bz];
     const int ctx = st_base[seq].ctx + 1;
-    const int nparts = (ctx + PART - 1) / PART;
+    // Round 6: the chain's SPLIT ROW (ze_seq_dev::split: the end of its first image block -- a property of the chain's own tokens,
+    // set when they are prefilled or copied, never of the batch) cuts the parts: [0, split) in PART-key pieces, then [split, ctx) in
+    // PART-key pieces.  The rows below the split are what the questions of a tile share, so a PREFIX part holds no row of the chain's
+    // own -- and two chains that read those rows from one holder (mate[], built by the host per burst) share ONE workgroup for it:
+    // the second chain's q heads take the eight MFMA columns that otherwise repeat head G - 1.  A column's arithmetic does not depend
+    // on what the other columns hold: a chain's partial is the same bits paired or alone, leader or follower.
+    const int sp_ = use_split ? st_base[seq].split : 0;
+    const int split = (sp_ > 0 && sp_ < ctx) ? sp_ : 0;
+    const int np0 = (split + PART - 1) / PART;
+    const int nparts = np0 + (ctx - split + PART - 1) / PART;
     if (part >= nparts) return;  // workgroup-uniform: no part, no ticket
     const int G = heads / kv_heads;
-    const int t0 = part * PART, t1 = min(ctx, t0 + PART);
+    const int t0 = part < np0 ? part * PART : split + (part - np0) * PART;
+    const int t1 = part < np0 ? min(split, t0 + PART) : min(ctx, t0 + PART);
+    int bz2 = bz;                // the chain whose q heads ride in columns G .. 2G - 1 (bz: nobody's)
+    if (part < np0 && mate != nullptr && 2 * G <= 16) {
+        const int m = mate[bz];
+        if (m >= 0) {
+            if (m < bz) return;  // the pair's leader (the lower row of the batch) computes this part for both; it takes this chain's ticket too
+            bz2 = m;
+        }
+    }
+    const bool paired = bz2 != bz;   // workgroup-uniform
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
@@ -652,7 +671,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k
     const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem) +
                               (unsigned)wid * (3 * AW_VSTAGE);
     const uint8_t* ring = smem + wid * (3 * AW_VSTAGE);
-    const bf16_t* qsrc = q + (size_t)bz * q_row_stride + (kvh * G + min(fr, G - 1)) * D + fq * 8;
+    const int qrow = (paired && fr >= G) ? bz2 : bz;
+    const int qhead = (paired && fr >= G) ? min(fr - G, G - 1) : min(fr, G - 1);
+    const bf16_t* qsrc = q + (size_t)qrow * q_row_stride + (kvh * G + qhead) * D + fq * 8;
 
     ad_f32x4 oacc[8];
 #pragma unroll
@@ -716,32 +737,63 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k
     __syncthreads();  // the tail reuses the LDS
 
     float* wsb = ws + (size_t)bz * max_parts * heads * AD_STRIDE;
+    float* wsb2 = ws + (size_t)bz2 * max_parts * heads * AD_STRIDE;   // (the mate's slots; a workgroup-uniform base each: no waterfall)
     if (fr < G) {
         const uint32_t dst = (uint32_t)((part * heads + kvh * G + fr) * AD_STRIDE * 4);
         if (wid == 0 && fq == 0) ad_store16<true>(wsb, dst, m_all, l_all, 0.f, 0.f);
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
             ad_store16<true>(wsb, dst + (uint32_t)((4 + (2 * wid + jj) * 16 + fq * 4) * 4), om[jj][0], om[jj][1], om[jj][2], om[jj][3]);
+    } else if (paired && fr < 2 * G) {
+        const uint32_t dst = (uint32_t)((part * heads + kvh * G + (fr - G)) * AD_STRIDE * 4);
+        if (wid == 0 && fq == 0) ad_store16<true>(wsb2, dst, m_all, l_all, 0.f, 0.f);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+            ad_store16<true>(wsb2, dst + (uint32_t)((4 + (2 * wid + jj) * 16 + fq * 4) * 4), om[jj][0], om[jj][1], om[jj][2], om[jj][3]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     unsigned* flag = reinterpret_cast<unsigned*>(smem + 16 * 1024);
+    int ctx2 = ctx, nparts2 = nparts;
+    if (paired) {   // the mate's own length: its parts beyond the split are its own business, its ticket counts all of them
+        ctx2 = st_base[seq_ids[bz2]].ctx + 1;
+        nparts2 = np0 + (ctx2 - split + PART - 1) / PART;
+    }
     if (threadIdx.x == 0) {
         unsigned* t = tickets + (size_t)bz * kv_heads + kvh;
         const unsigned old = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned last = old == (unsigned)nparts - 1u;
+        unsigned last = old == (unsigned)nparts - 1u ? 1u : 0u;
         if (last) __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (paired) {
+            unsigned* t2 = tickets + (size_t)bz2 * kv_heads + kvh;
+            const unsigned old2 = __hip_atomic_fetch_add(t2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old2 == (unsigned)nparts2 - 1u) {
+                __hip_atomic_store(t2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last |= 2u;
+            }
+        }
         *flag = last;
     }
     __syncthreads();
-    if (*flag == 0u) return;
+    const unsigned last = *flag;
+    if (last == 0u) return;
     __syncthreads();
     float* sW = reinterpret_cast<float*>(smem);
-    if (out_row_stride < 0)
-        attn_merge_group<MB>(sW, sW + AD_GMAX * 64, wsb, ctx, kvh, heads, kv_heads, max_parts, out, -out_row_stride, bz, nparts);
-    else
-        attn_merge_group<MB>(sW, sW + AD_GMAX * 64, wsb, ctx, kvh, heads, kv_heads, max_parts,
-                             out + (size_t)bz * out_row_stride, 0, 0, nparts);
+    if (last & 1u) {
+        if (out_row_stride < 0)
+            attn_merge_group<MB>(sW, sW + AD_GMAX * 64, wsb, ctx, kvh, heads, kv_heads, max_parts, out, -out_row_stride, bz, nparts);
+        else
+            attn_merge_group<MB>(sW, sW + AD_GMAX * 64, wsb, ctx, kvh, heads, kv_heads, max_parts,
+                                 out + (size_t)bz * out_row_stride, 0, 0, nparts);
+    }
+    if (last & 2u) {   // this workgroup also drew the MATE's last ticket: merge that chain too
+        __syncthreads();
+        if (out_row_stride < 0)
+            attn_merge_group<MB>(sW, sW + AD_GMAX * 64, wsb2, ctx2, kvh, heads, kv_heads, max_parts, out, -out_row_stride, bz2, nparts2);
+        else
+            attn_merge_group<MB>(sW, sW + AD_GMAX * 64, wsb2, ctx2, kvh, heads, kv_heads, max_parts,
+                                 out + (size_t)bz2 * out_row_stride, 0, 0, nparts2);
+    }
 }
 
 extern int ze_gemv_knobs[24];
@@ -753,7 +805,7 @@ void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_
                                   size_t cache_seq_stride, bf16_t* out, int out_row_stride, const ze_seq_dev* st,
                                   const int* seq_ids, int n, int heads, int kv_heads, int max_ctx, float scale,
                                   float* ws_partial, int max_parts, unsigned* tickets, hipStream_t s, int chunk, int per_wave,
-                                  const int* prefix) {
+                                  const int* prefix, const int* mate, int long_parts, int use_split) {
     const float sl = scale * 1.4426950408889634f;
     const size_t lds = AB_STAGES * AB_STAGE;
     static bool attr_set = false;
@@ -775,10 +827,14 @@ void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_
         if (ze_gemv_knobs[8] != 4) {
             constexpr int rounds = AW_LONG_ROUNDS;
             const int lparts = (max_ctx + rounds * AW_TOK - 1) / (rounds * AW_TOK);
-            const int lg = plain ? lparts : std::min(lparts, std::max(1, (per_wave * AW_PART + rounds * AW_TOK - 1) / (rounds * AW_TOK)));
+            // (the split adds at most one part to a chain: with it on the grid covers lparts + 1, or the caller's exact count; the
+            //  partial buffer holds wparts = ceil(max_ctx / 192) slots per chain: the split is only honoured when lparts + 1 fit)
+            const int split_on = (use_split && ze_gemv_knobs[23] != 1 && lparts + 1 <= wparts) ? 1 : 0;
+            int lg = plain ? lparts : std::min(lparts, std::max(1, (per_wave * AW_PART + rounds * AW_TOK - 1) / (rounds * AW_TOK)));
+            if (split_on) lg = (plain || long_parts <= 0) ? std::min(lparts + 1, lg + 1) : std::min(lparts + 1, long_parts);
             k_attn_decode_wave_long<8, rounds><<<dim3(kv_heads * lg, n), 256, 4 * 3 * AW_VSTAGE, s>>>(
                 q, q_row_stride, kcache, vcache, cache_seq_stride, st, seq_ids, heads, kv_heads, max_ctx, sl, ws_partial, wparts, tickets, out,
-                out_row_stride, plain ? 0 : xrot_knob(), prefix);
+                out_row_stride, plain ? 0 : xrot_knob(), prefix, (split_on && ze_gemv_knobs[23] != 2) ? mate : nullptr, split_on);
             return;
         }
         k_attn_decode_wave<8><<<dim3(kv_heads * gparts, n), 256, 4 * AW_VSTAGES * AW_VSTAGE, s>>>(

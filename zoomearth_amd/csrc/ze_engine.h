@@ -105,6 +105,9 @@ struct ze_engine {
     uint8_t* seen = nullptr;
     int32_t* out_tokens = nullptr;
     std::vector<int> ctx_host, delta_host;
+    std::vector<int> split_host;   // round 6: the chains' split rows (ze_seq_dev::split), host truth
+    int* bmate = nullptr;          // [max_seqs] per row of the batched step: the row it shares its prefix parts with, or -1 (upload_batch)
+    int live_parts_long = 0;       // 384-key parts of the batch's longest chain under its split (the pipelined attention's grid extent)
     // Shared-prefix hints, (source chain << 16) | P per chain slot.  pfx_host is the truth, kept by whatever call changes it
     // (ze_seq_copy_prefix on the admission stream, ze_seq_retire, ...); the device copy pfx_dev -- what the decode attention
     // reads -- is written by ONE stream only: the stream of the batched decode step, which pushes the words that differ from

@@ -294,6 +294,7 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     chk(dev_alloc(e, &e->pfx_dev, c.max_seqs));
     e->prefix_hints = c.max_seqs < 32768 && c.max_ctx < 65536;  // (ze_tune knob 17 = 1: every chain reads its own rows, for A/B runs)
     e->delta_host.assign(c.max_seqs, 0);
+    e->split_host.assign(c.max_seqs, 0);
     e->graphs.assign(c.max_seqs, nullptr);
     e->graph_penalty.assign(c.max_seqs, 0.f);
     e->graph_ignore_eos.assign(c.max_seqs, 0);
@@ -399,6 +400,7 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
         chk(dev_alloc(e, &e->ba, br * e->text_ipad));
     }
     chk(dev_alloc(e, &e->bseq, c.max_seqs));
+    chk(dev_alloc(e, &e->bmate, c.max_seqs));
     chk(dev_alloc(e, &e->blogits, (size_t)c.max_seqs * c.vocab));
     chk(dev_alloc(e, &e->bpartial, (size_t)c.max_seqs * std::max(e->max_splits, 8) * c.heads * 132));  // >= 8 parts per chain (ze_attn_batch.hip)
     chk(dev_alloc(e, &e->bsample, (size_t)c.max_seqs * 3 * 128 + 8));  // arg-max partials, then chunk sums
@@ -444,7 +446,7 @@ extern "C" int ze_engine_destroy(ze_engine* e) {
                    e->st_dev, e->seen, e->out_tokens, e->fe_tmp, e->fe_img, e->fe_coef, e->vx, e->vh, e->vy, e->vqkv,
                    e->vo, e->va, e->vz, e->vz2, e->vcos, e->vsin, e->vperm, e->vinv, e->vtiles_win, e->vtiles_full,
                    e->th, e->ty, e->tqkv, e->to, e->ta, e->tsrc, e->tpos, e->ttiles, e->ttile_aux, e->trow_aux, e->dh, e->dq, e->dattn, e->dact,
-                   e->dlogits, e->dpartial, e->dsample, e->atickets, e->gslab, e->gtickets, e->pslab, e->ptickets, e->bh, e->by, e->bqkv, e->bo, e->ba, e->bseq, e->blogits, e->bpartial, e->bsample, e->arena8, e->arena_f, e->arena_f8,
+                   e->dlogits, e->dpartial, e->dsample, e->atickets, e->gslab, e->gtickets, e->pslab, e->ptickets, e->bh, e->by, e->bqkv, e->bo, e->ba, e->bseq, e->bmate, e->blogits, e->bpartial, e->bsample, e->arena8, e->arena_f, e->arena_f8,
                    e->ty8, e->ty8_scale, e->damax, e->ty8p, e->ty8p_scale};
     for (void* p : dev)
         if (p) hipFree(p);

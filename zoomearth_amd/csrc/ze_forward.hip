@@ -389,6 +389,7 @@ static int push_state(ze_engine* e, int seq, hipStream_t s, int token, int n_gen
     st.finished = finished;
     st.n_gen = n_gen;
     st.max_gen = e->cfg.max_ctx;
+    st.split = e->split_host[seq];
     static_assert(sizeof(ze_seq_dev) == 8 * sizeof(int), "chain state is eight ints");
     ze_launch_set_ints(reinterpret_cast<int*>(e->st_dev + seq), reinterpret_cast<const int*>(&st), 8, s);
     return ZE_OK;
@@ -400,6 +401,7 @@ extern "C" int ze_seq_reset(ze_engine* e, int seq, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     e->ctx_host[seq] = 0;
     e->delta_host[seq] = 0;
+    e->split_host[seq] = 0;
     prefix_source_gone(e, seq, 0);
     e->pfx_host[seq] = 0;
     ZE_HIP(hipMemsetAsync(e->seen + (size_t)seq * e->cfg.vocab, 0, e->cfg.vocab, s));
@@ -436,6 +438,17 @@ extern "C" int ze_seq_set_prefix_hint(ze_engine* e, int seq, int src_seq, int ro
 }
 
 // (source chain << 16) | rows: where the decode attention reads the first rows of `seq` from; 0 = its own cache
+// Measurement / test entry: declares row `rows` the chain's split row (what prefilling tokens with an image block does by itself,
+// note_split) -- for chains built from text ids that stand in for image prompts (tools/pmc_kernel.py, bench.py's annex, tests).
+extern "C" int ze_seq_set_split(ze_engine* e, int seq, int rows, void* stream) {
+    ZE_TRY(check_seq(e, seq));
+    if (rows < 0 || rows > e->ctx_host[seq] || rows >= 65536) return ze_fail(e, ZE_ERR_INVALID, "split row out of range");
+    hipSetDevice(e->device);
+    e->split_host[seq] = rows;
+    ze_launch_set_ints(&(e->st_dev + seq)->split, &rows, 1, (hipStream_t)stream);
+    return ZE_OK;
+}
+
 extern "C" int ze_seq_prefix_hint(ze_engine* e, int seq) {
     if (check_seq(e, seq) != 0) return ZE_ERR_NOTFOUND;
     return e->pfx_host[seq];
@@ -446,6 +459,7 @@ extern "C" int ze_seq_truncate(ze_engine* e, int seq, int keep_len, void* stream
     if (keep_len < 0 || keep_len > e->ctx_host[seq]) return ze_fail(e, ZE_ERR_INVALID, "keep_len out of range");
     hipSetDevice(e->device);
     e->ctx_host[seq] = keep_len;
+    if (keep_len < e->split_host[seq]) e->split_host[seq] = 0;   // (the image block itself is cut: the rest is a chain without one)
     prefix_source_gone(e, seq, keep_len);   // rows from keep_len on will be rewritten
     if ((e->pfx_host[seq] & 0xffff) > keep_len) e->pfx_host[seq] = 0;
     // the seen-set belongs to the dropped continuation: the caller re-marks the (new) prompt
@@ -467,6 +481,9 @@ extern "C" int ze_seq_copy_prefix(ze_engine* e, int dst_seq, int src_seq, int n_
     ZE_KCHECK();
     e->ctx_host[dst_seq] = n_tokens;
     e->delta_host[dst_seq] = 0;
+    // the split row travels with the rows: the copy holds the source's first image block iff it reaches past its end (the same
+    // tokens, the same split -- however a chain came by its rows)
+    e->split_host[dst_seq] = (e->split_host[src_seq] > 0 && e->split_host[src_seq] <= n_tokens) ? e->split_host[src_seq] : 0;
     prefix_source_gone(e, dst_seq, 0);
     if (!e->pfx_copy_ev[dst_seq]) ZE_HIP(hipEventCreateWithFlags(&e->pfx_copy_ev[dst_seq], hipEventDisableTiming));
     ZE_HIP(hipEventRecord(e->pfx_copy_ev[dst_seq], s));  // (a holder other chains may be pointed at only once this is over)
@@ -571,6 +588,19 @@ extern "C" int ze_seq_mark_seen_batch(ze_engine* e, const int32_t* seqs, const i
 }
 
 // ================================================================== prefill
+// The chain's SPLIT ROW (round 6; ze_seq_dev::split, ze_attn_batch.hip): the row behind its FIRST image block's <|vision_end|> --
+// what the questions about one tile share (system turn + the view's image tokens) ends there.  Found where the tokens are
+// prefilled, whatever pass brings them; a chain that copies the block (ze_seq_copy_prefix) inherits it.  A property of the
+// chain's tokens alone: the decode attention may cut its parts there without a chain's sums depending on the batch.
+static void note_split(ze_engine* e, int seq, const int32_t* ids, int len, int past) {
+    if (e->split_host[seq] != 0 || e->cfg.vision_end_token_id < 0) return;
+    for (int t = 0; t < len; ++t)
+        if (ids[t] == e->cfg.vision_end_token_id) {
+            if (past + t + 1 < 65536) e->split_host[seq] = past + t + 1;
+            return;
+        }
+}
+
 // RMSNorm + the projection behind it, on `rows` prefill rows of e->th.  With FP8 activations on a quantised engine the row
 // goes out as E4M3 bytes + one scale and the product runs on the block-scaled FP8 MFMA against the FP8 weight rows
 // (k_gemm_ring_mx: the values of the fake-quantised bf16 path, another summation order; ze_tune knob 12 = 1 keeps that path).
@@ -616,6 +646,7 @@ static int prefill_impl(ze_engine* e, int seq, const int32_t* input_ids, int len
     if (img != n_image_rows || (img > 0 && !image_embeds))
         return ze_fail(e, ZE_ERR_MISMATCH, "Image features and image tokens do not match, tokens: " +
                                                std::to_string(img) + ", features: " + std::to_string(n_image_rows));
+    note_split(e, seq, input_ids, len, past);
     int nt = 0;
     // query rows per attention tile: 128 -- two query tiles per wave, half the LDS fragment reads per MFMA -- on the LDS-DMA
     // staging form of the kernel (no staging registers: 248 VGPRs, two workgroups per CU; with register staging the same tile
@@ -766,6 +797,7 @@ extern "C" int ze_prefill_batch(ze_engine* e, const int32_t* seqs, int n, const 
             row_aux[2 * (row0 + t)] = seq;
             row_aux[2 * (row0 + t) + 1] = past + t;
         }
+        note_split(e, seq, input_ids + row0, len, past);
         const int want = n_image_rows ? n_image_rows[i] : 0;
         if (img_chain != want || (img_chain > 0 && !image_embeds))
             return ze_fail(e, ZE_ERR_MISMATCH, "Image features and image tokens do not match, tokens: " +
@@ -1265,9 +1297,40 @@ static int ensure_fragments(ze_engine* e, hipStream_t s) {
 
 // the attention grid's extent for the next `steps` decode steps of these chains: the parts of the longest context
 static void set_live_parts(ze_engine* e, const int32_t* seqs, int n, int steps) {
-    int mx = 0;
-    for (int i = 0; i < n; ++i) mx = std::max(mx, e->ctx_host[seqs[i]]);
+    int mx = 0, ml = 0;
+    for (int i = 0; i < n; ++i) {
+        const int c = e->ctx_host[seqs[i]] + std::max(1, steps) + 1, sp = e->split_host[seqs[i]];
+        mx = std::max(mx, e->ctx_host[seqs[i]]);
+        ml = std::max(ml, (sp + 383) / 384 + (c - sp + 383) / 384);   // (the pipelined kernel's 384-key parts under the chain's split)
+    }
     e->live_parts = (mx + std::max(1, steps) + 1 + 191) / 192;
+    e->live_parts_long = ml;
+}
+
+// Round 6: which rows of the step share their PREFIX parts (ze_attn_batch.hip).  Two chains pair when they have the same split row and
+// read the rows below it from the same holder -- the holder itself included -- under the hints this very step uses (sync_prefix ran on
+// this stream just before): first come, first paired, in batch order (the questions of a tile sit next to each other).  Symmetric;
+// -1 = alone.  A pairing changes who computes a partial, never its bits.
+static void upload_mates(ze_engine* e, const int32_t* seqs, int n, hipStream_t s) {
+    std::vector<int> mate(n, -1);
+    if (e->prefix_hints && ze_gemv_knobs[17] != 1) {
+        std::map<long long, int> open;   // (holder, split) -> the row waiting for a partner
+        for (int i = 0; i < n; ++i) {
+            const int q = seqs[i], sp = e->split_host[q];
+            if (sp <= 0) continue;
+            const int h = e->pfx_pushed[q];
+            const int holder = (h != 0 && (h & 0xffff) >= sp) ? (h >> 16) : q;
+            const long long key = ((long long)holder << 20) | (long long)sp;
+            auto it = open.find(key);
+            if (it == open.end()) open[key] = i;
+            else {
+                mate[i] = it->second;
+                mate[it->second] = i;
+                open.erase(it);
+            }
+        }
+    }
+    ze_launch_set_ints(e->bmate, mate.data(), n, s);
 }
 
 static int upload_batch(ze_engine* e, const int32_t* seqs, int n, hipStream_t s) {
@@ -1282,6 +1345,7 @@ static int upload_batch(ze_engine* e, const int32_t* seqs, int n, hipStream_t s)
     }
     ze_launch_set_ints(e->bseq, seqs, n, s);
     sync_prefix(e, seqs, n, s);
+    upload_mates(e, seqs, n, s);
     return ZE_OK;
 }
 
@@ -1312,7 +1376,8 @@ static void launch_batch_attention(ze_engine* e, int li, int n, bool frag_out, h
         const int max_parts = chunk ? (c.max_ctx + chunk - 1) / chunk : 8;           // (at most 8 parts: 128-token floor)
         ze_launch_attn_decode_stream(qb, nqkv, e->kc(li, 0), e->vc(li, 0), seq_stride, ob, frag_out ? -(nq / 32) : nq,
                                      e->st_dev, e->bseq, n, c.heads, c.kv_heads, c.max_ctx, scale, e->bpartial, max_parts,
-                                     e->atickets, s, chunk, per_wave ? (e->live_parts > 0 ? e->live_parts : wparts) : 0, e->pfx_dev);
+                                     e->atickets, s, chunk, per_wave ? (e->live_parts > 0 ? e->live_parts : wparts) : 0, e->pfx_dev,
+                                     q_rows ? nullptr : e->bmate, e->live_parts_long, 1);
     }
 }
 
@@ -1436,7 +1501,7 @@ extern "C" int ze_decode_batch(ze_engine* e, const int32_t* seqs, int n, const i
 // The captured batched decode step for `na` chains (chain ids / positions live in device memory, so one graph per
 // batch size and sampling setting serves every composition); nullptr in *out = run eagerly.
 static int batch_step_graph(ze_engine* e, int na, float pen, int ign, const ze_sample_opts& bso, hipGraphExec_t* out) {
-    auto key = std::make_tuple(na, pen, ign, bso.temperature, bso.seed, e->live_parts);
+    auto key = std::make_tuple(na, pen, ign, bso.temperature, bso.seed, e->live_parts * 64 + e->live_parts_long);
     if (e->bgraph_epoch != ze_tune_epoch) {
         for (auto& kv : e->bgraphs) hipGraphExecDestroy(kv.second);
         e->bgraphs.clear();
@@ -2186,6 +2251,7 @@ extern "C" int ze_profile_batch_kernel(ze_engine* e, int which, int n, int iters
     }
     ze_launch_set_ints(e->bseq, seqs.data(), n, s);
     sync_prefix(e, seqs.data(), n, s);
+    upload_mates(e, seqs.data(), n, s);
     set_live_parts(e, seqs.data(), n, 1);  // (the grid a decode step of these chains would launch)
     double bytes = 0;
     auto launch = [&](int it) {

@@ -70,8 +70,10 @@ struct ze_seq_dev {
     int32_t n_gen;      // tokens written to out_tokens so far
     int32_t max_gen;    // capacity of out_tokens
     int32_t stream;     // sampling stream of this chain: its row in the generate call (0 for single-chain calls)
-    int32_t reserved;   // (was the shared-prefix hint: that word now lives in an array of its own, ze_engine::pfx_dev, written
-                        // by the DECODE stream alone -- chain state is pushed from whatever stream prefills the chain)
+    int32_t split;      // round 6: the chain's split row -- the end of its first image block (0: none) -- a property of the chain's own
+                        // tokens, set when they are prefilled / copied (pushed with the rest of the state, constant while the chain
+                        // decodes); the decode attention cuts its parts there (ze_attn_batch.hip).  (Until round 3 this word held
+                        // the shared-prefix hint, which lives in ze_engine::pfx_dev, written by the decode stream alone.)
 };
 
 // ---- front-end
@@ -273,7 +275,11 @@ void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_
                                   const int* seq_ids, int n, int heads, int kv_heads, int max_ctx, float scale,
                                   float* ws_partial, int max_parts, unsigned* tickets, hipStream_t s, int chunk = 0,
                                   int per_wave = 0,   // per_wave: k_attn_decode_wave (every wave a stream of its own)
-                                  const int* prefix = nullptr);
+                                  const int* prefix = nullptr,
+                                  // round 6 (the pipelined kernel): mate[row of the batch] = the row whose q heads share this row's PREFIX
+                                  // parts (or -1; symmetric; null = nobody pairs), long_parts = the 384-key parts the batch's longest
+                                  // chain has under its split (0: derive from per_wave), use_split = ze_seq_dev::split cuts the parts
+                                  const int* mate = nullptr, int long_parts = 0, int use_split = 0);
 // prefix (per_wave only; per chain SLOT, null = none): (source chain << 16) | P -- rows 0 .. P-1 of the source chain's KV cache
 // hold the same bits as the chain's own (ze_seq_copy_prefix) and are read from the SOURCE, so the questions of one tile stream
 // one copy of their image prefix (Infinity Cache hits)

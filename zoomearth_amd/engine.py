@@ -235,6 +235,10 @@ class Engine:
         """Declares that the first `rows` cached tokens of `seq` equal those of chain `src` (rows = 0 clears)."""
         self._check(self.lib.ze_seq_set_prefix_hint(self.h, seq, src, rows, self._stream()))
 
+    def seq_set_split(self, seq: int, rows: int):
+        """Measurement / tests: declare the chain's split row by hand (prefilling an image block sets it by itself)."""
+        self._check(self.lib.ze_seq_set_split(self.h, int(seq), int(rows), self._stream()))
+
     def seq_prefix_hint(self, seq: int):
         """(source chain, rows): the decode attention reads the first `rows` cached tokens of `seq` from the source's cache
         (the same bits; one copy per tile in flight); (seq, 0) when it reads its own."""
