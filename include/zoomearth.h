@@ -172,9 +172,10 @@ int ze_seq_retire(ze_engine* e, int seq, void* stream);
  * decode attention with the sharing its question stream has. */
 int ze_seq_set_prefix_hint(ze_engine* e, int seq, int src_seq, int rows, void* stream);
 /* Round 6.  A chain's SPLIT ROW is the row behind the <|vision_end|> of its first image block (the rows the questions about one tile
- * share end there); ze_prefill / ze_prefill_batch find it in the ids they are given, ze_seq_copy_prefix hands it on, and the batched
- * decode attention cuts a chain's parts there ([0, split) and [split, ctx) in 384-key pieces) so that two chains reading those rows
- * from one holder share a workgroup per prefix part.  This entry sets it by hand -- measurement / tests on text-only stand-ins. */
+ * share end there); ze_prefill / ze_prefill_batch find it in the ids they are given, ze_seq_copy_prefix hands it on, and -- under ze_tune
+ * knob 23 = 2 / 3 only: the form was measured slower and is not the default -- the batched decode attention cuts a chain's parts there
+ * ([0, split) and [split, ctx) in 384-key pieces) so that two chains reading those rows from one holder can share a workgroup per
+ * prefix part.  This entry sets it by hand -- measurement / tests on text-only stand-ins. */
 int ze_seq_set_split(ze_engine* e, int seq, int rows, void* stream);
 /* (source chain << 16) | rows: whose cache the decode attention reads the first rows of `seq` from; 0 = its own. */
 int ze_seq_prefix_hint(ze_engine* e, int seq);
@@ -427,8 +428,8 @@ int ze_profile_prefill_layer(ze_engine* e, int rows, int layers_run, float avg_u
  *   21    1: column walk of the eight-phase GEMM's tile grid (default: 8 x 4 blocks; > 1: R << 8 | C blocks)
  *   22    1: the prefill's queries rotated in place by the M-RoPE kernel (default at head_dim 128: inside the flash kernel, as it loads
  *            them; the M-RoPE kernel then writes K and V only; same bits)
- *   23    batched decode attention, round 6: 1 = parts of the chain's whole context (no split row: round 5's partition -- other bits,
- *            within rounding), 2 = split on, no pairing of chains on prefix parts (the same bits as 0)
+ *   23    batched decode attention, round 6 (built, measured slower, off): 2 = a chain's parts cut at its split row, 3 = that + two chains
+ *            of a tile per workgroup on the prefix parts (2 and 3: the same bits; against 0 -- parts of the whole context -- within rounding)
  * Changing a knob invalidates captured decode graphs (they are re-captured on the next step).
  * PROCESS-WIDE, by design: there is no engine argument, every engine of the process sees the value at its next launch, and nothing in
  * the product path (Engine, scheduler, entry points, clone_lane) calls it -- a knob is for A/B measurements and the bit-equality tests,

@@ -713,10 +713,11 @@ def test_decode_step_above_768_chains_keeps_a_chains_bits():
 def test_chains_of_a_tile_share_a_workgroup_per_prefix_part_and_keep_their_bits():
     """Round 6: the decode attention cuts every chain's parts at its split row (the end of its first image block, found
     where the tokens are prefilled and handed on by ze_seq_copy_prefix), and two chains that read the rows below it from one holder
-    share ONE workgroup per prefix part (the second chain's q heads in the eight MFMA columns that otherwise idle).  Six questions about
-    one 36 x 36 view + one about another + a text-only chain, three steps: the logits with the pairing (default) are the bits of the
-    unpaired run (knob 23 = 2), of the run without hints (knob 17 = 1) and of chains prefilled in full instead of copying the prefix;
-    the round-5 partition (knob 23 = 1: parts of the whole context) agrees within rounding."""
+    share ONE workgroup per prefix part (the second chain's q heads in the eight MFMA columns that otherwise idle).  Built, measured
+    slower than the shipped form, kept behind ze_tune knob 23 with this test.  Six questions about one 36 x 36 view + one
+    about another + a text-only chain, three steps: the logits with the pairing (knob 23 = 3) are the bits of the unpaired run (knob
+    23 = 2), of the run without hints (knob 17 = 1) and of chains prefilled in full instead of copying the prefix; the shipped partition
+    (knob 23 = 0: parts of the whole context) agrees within rounding."""
     from gpu_util import oracle_cfg_to_model_cfg
     from zoomearth_amd.engine import Engine
     cfg = Q.tiny_config()
@@ -754,7 +755,7 @@ def test_chains_of_a_tile_share_a_workgroup_per_prefix_part_and_keep_their_bits(
         def steps():
             return [e.decode_batch(list(range(8)), forced[s]).cpu().numpy() for s in range(3)]
 
-        def run(copying, knob23=0, knob17=0):
+        def run(copying, knob23=3, knob17=0):
             try:
                 e.lib.ze_tune(23, knob23)
                 e.lib.ze_tune(17, knob17)
@@ -767,10 +768,10 @@ def test_chains_of_a_tile_share_a_workgroup_per_prefix_part_and_keep_their_bits(
                 e.lib.ze_tune(17, 0)
         paired = run(True)
         assert all(np.isfinite(x).all() for x in paired)
-        for other_run in (run(True, knob23=2), run(True, knob17=1), run(False)):
+        for other_run in (run(True, knob23=2), run(True, knob23=3, knob17=1), run(False, knob23=3)):
             for a, b in zip(paired, other_run):
                 assert np.array_equal(a, b)
-        old = run(True, knob23=1)
+        old = run(True, knob23=0)
         scale = max(float(np.abs(x).max()) for x in paired)
         diff = max(float(np.abs(a - b).max()) for a, b in zip(paired, old))
         print(f"split-row partition against the round-5 partition: max |logit difference| {diff:.5f} on logits of scale {scale:.2f}")

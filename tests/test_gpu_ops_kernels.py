@@ -288,9 +288,9 @@ def test_numeric_helpers_of_every_epilogue_against_float64(tiny_engine):
 
 
 def test_decode_attention_with_a_split_row_against_float64():
-    """Round 6: the pipelined decode attention cuts a chain's parts at its SPLIT ROW -- [0, split) in 384-key pieces, then [split, ctx)
-    in 384-key pieces -- so that a prefix part holds only rows the questions of a tile share (ze_seq_dev::split; here set by hand,
-    `ze_seq_set_split`).  Every combination that moves a boundary: a split inside the first round, on and either side of a part's end,
+    """Round 6 (behind ze_tune knob 23 = 2: built, measured slower, not the default): the pipelined decode attention cuts a chain's parts
+    at its SPLIT ROW -- [0, split) in 384-key pieces, then [split, ctx) in 384-key pieces -- so that a prefix part holds only rows the
+    questions of a tile share (ze_seq_dev::split; here set by hand, `ze_seq_set_split`).  Every combination that moves a boundary: a split inside the first round, on and either side of a part's end,
     a prefix of two parts, a last own part of one row, no split at all -- against float64 over rows 0 .. ctx; a chain's row is the
     same bits alone as in the batch."""
     from zoomearth_amd.config import ModelConfig, TextConfig, VisionConfig
@@ -316,6 +316,7 @@ def test_decode_attention_with_a_split_row_against_float64():
         nq, nkv = t.num_attention_heads * 128, t.num_key_value_heads * 128
         qkv_host = rnd(901, (n, nq + 2 * nkv), 1.0)
         seqs = list(range(n))
+        e.lib.ze_tune(23, 2)
         qkv = e.op_rope_kv_decode(seqs, 0, to_dev_bf16(qkv_host))
         out = e.op_attn_decode(seqs, 0, qkv)
         got = out.float().cpu().numpy().reshape(n, t.num_attention_heads, 128)
@@ -337,5 +338,9 @@ def test_decode_attention_with_a_split_row_against_float64():
         for b in (0, 4, 9, 12):
             alone = e.op_attn_decode([b], 0, qkv[b:b + 1].contiguous())
             assert torch.equal(alone[0], out[b]), cases[b]
+        e.lib.ze_tune(23, 0)
+        whole = e.op_attn_decode(seqs, 0, qkv)   # the shipped partition on the same rows: other sums, the same values within rounding
+        assert not torch.equal(whole, out) and float((whole.float() - out.float()).abs().max()) <= 2.0 ** -6 * float(out.float().abs().max())
     finally:
+        e.lib.ze_tune(23, 0)
         e.close()

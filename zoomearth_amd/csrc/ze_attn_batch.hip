@@ -829,12 +829,17 @@ void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_
             const int lparts = (max_ctx + rounds * AW_TOK - 1) / (rounds * AW_TOK);
             // (the split adds at most one part to a chain: with it on the grid covers lparts + 1, or the caller's exact count; the
             //  partial buffer holds wparts = ceil(max_ctx / 192) slots per chain: the split is only honoured when lparts + 1 fit)
-            const int split_on = (use_split && ze_gemv_knobs[23] != 1 && lparts + 1 <= wparts) ? 1 : 0;
+            // Round 6, BUILT, MEASURED, NOT SHIPPED (knob 23 = 2: split rows, 3: split rows + paired prefix parts; 0 = parts of
+            // the whole context as in round 5).  Same box, 490 chains of ten per tile on 800-1440 rows: 95.8 us as shipped, 97.2 with the
+            // split (a chain of 1127 rows has four parts instead of three), 100.5 with the pairing on top -- the prefix rows a pair no longer
+            // loads twice were L2 hits already (0.856 x algorithmic bytes at the HBM interface), while the leader's workgroup now publishes two
+            // sets of partials, draws two tickets and may merge two chains; the stream does not move (85.9-87.0 in every form).
+            const int split_on = (use_split && (ze_gemv_knobs[23] == 2 || ze_gemv_knobs[23] == 3) && lparts + 1 <= wparts) ? 1 : 0;
             int lg = plain ? lparts : std::min(lparts, std::max(1, (per_wave * AW_PART + rounds * AW_TOK - 1) / (rounds * AW_TOK)));
             if (split_on) lg = (plain || long_parts <= 0) ? std::min(lparts + 1, lg + 1) : std::min(lparts + 1, long_parts);
             k_attn_decode_wave_long<8, rounds><<<dim3(kv_heads * lg, n), 256, 4 * 3 * AW_VSTAGE, s>>>(
                 q, q_row_stride, kcache, vcache, cache_seq_stride, st, seq_ids, heads, kv_heads, max_ctx, sl, ws_partial, wparts, tickets, out,
-                out_row_stride, plain ? 0 : xrot_knob(), prefix, (split_on && ze_gemv_knobs[23] != 2) ? mate : nullptr, split_on);
+                out_row_stride, plain ? 0 : xrot_knob(), prefix, (split_on && ze_gemv_knobs[23] == 3) ? mate : nullptr, split_on);
             return;
         }
         k_attn_decode_wave<8><<<dim3(kv_heads * gparts, n), 256, 4 * AW_VSTAGES * AW_VSTAGE, s>>>(
