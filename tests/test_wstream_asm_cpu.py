@@ -64,7 +64,8 @@ def test_no_instruction_touches_an_attention_load_in_flight(lib_asm):
     c = _run("check_attn_asm.py", lib_asm["ze_attn_batch"])
     assert c.returncode == 0, c.stdout[-3000:]
     lines = [ln for ln in c.stdout.splitlines() if "vector-memory operations" in ln]
-    assert len(lines) == 2 and all(" 0 early touches" in ln for ln in lines), c.stdout[-2000:]
+    # (three kernels since round 6: the pipelined kernel has a second instantiation for the split-row / paired form)
+    assert len(lines) == 3 and all(" 0 early touches" in ln for ln in lines), c.stdout[-2000:]
     assert any("wave_long" in ln for ln in lines)
 
 

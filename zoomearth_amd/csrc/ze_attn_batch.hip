@@ -622,7 +622,9 @@ __device__ __forceinline__ void aw_run_part(const bf16_t* __restrict__ qsrc, con
 #undef AW_ISSUE_K
 }
 
-template <int MB, int ROUNDS>
+// SPLIT (round 6, not the shipped form): the split-row partition and the paired prefix parts are an instantiation of their own, so that
+// the shipped kernel is the round-5 code to the instruction (the disabled branches cost it 1-2 % in a same-box A/B: 83.1 -> 85.0 us).
+template <int MB, int ROUNDS, bool SPLIT = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k_attn_decode_wave_long(
     const bf16_t* __restrict__ q, int q_row_stride, const bf16_t* __restrict__ kcache, const bf16_t* __restrict__ vcache,
     size_t cache_seq_stride, const ze_seq_dev* __restrict__ st_base, const int* __restrict__ seq_ids, int heads, int kv_heads,
@@ -643,8 +645,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k
     // own -- and two chains that read those rows from one holder (mate[], built by the host per burst) share ONE workgroup for it:
     // the second chain's q heads take the eight MFMA columns that otherwise repeat head G - 1.  A column's arithmetic does not depend
     // on what the other columns hold: a chain's partial is the same bits paired or alone, leader or follower.
-    const int sp_ = use_split ? st_base[seq].split : 0;
-    const int split = (sp_ > 0 && sp_ < ctx) ? sp_ : 0;
+    const int sp_ = (SPLIT && use_split) ? st_base[seq].split : 0;
+    const int split = (SPLIT && sp_ > 0 && sp_ < ctx) ? sp_ : 0;
     const int np0 = (split + PART - 1) / PART;
     const int nparts = np0 + (ctx - split + PART - 1) / PART;
     if (part >= nparts) return;  // workgroup-uniform: no part, no ticket
@@ -652,14 +654,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k
     const int t0 = part < np0 ? part * PART : split + (part - np0) * PART;
     const int t1 = part < np0 ? min(split, t0 + PART) : min(ctx, t0 + PART);
     int bz2 = bz;                // the chain whose q heads ride in columns G .. 2G - 1 (bz: nobody's)
-    if (part < np0 && mate != nullptr && 2 * G <= 16) {
+    if (SPLIT && part < np0 && mate != nullptr && 2 * G <= 16) {
         const int m = mate[bz];
         if (m >= 0) {
             if (m < bz) return;  // the pair's leader (the lower row of the batch) computes this part for both; it takes this chain's ticket too
             bz2 = m;
         }
     }
-    const bool paired = bz2 != bz;   // workgroup-uniform
+    const bool paired = SPLIT && bz2 != bz;   // workgroup-uniform
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
@@ -837,9 +839,14 @@ void ze_launch_attn_decode_stream(const bf16_t* q, int q_row_stride, const bf16_
             const int split_on = (use_split && (ze_gemv_knobs[23] == 2 || ze_gemv_knobs[23] == 3) && lparts + 1 <= wparts) ? 1 : 0;
             int lg = plain ? lparts : std::min(lparts, std::max(1, (per_wave * AW_PART + rounds * AW_TOK - 1) / (rounds * AW_TOK)));
             if (split_on) lg = (plain || long_parts <= 0) ? std::min(lparts + 1, lg + 1) : std::min(lparts + 1, long_parts);
-            k_attn_decode_wave_long<8, rounds><<<dim3(kv_heads * lg, n), 256, 4 * 3 * AW_VSTAGE, s>>>(
-                q, q_row_stride, kcache, vcache, cache_seq_stride, st, seq_ids, heads, kv_heads, max_ctx, sl, ws_partial, wparts, tickets, out,
-                out_row_stride, plain ? 0 : xrot_knob(), prefix, (split_on && ze_gemv_knobs[23] == 3) ? mate : nullptr, split_on);
+            if (split_on)
+                k_attn_decode_wave_long<8, rounds, true><<<dim3(kv_heads * lg, n), 256, 4 * 3 * AW_VSTAGE, s>>>(
+                    q, q_row_stride, kcache, vcache, cache_seq_stride, st, seq_ids, heads, kv_heads, max_ctx, sl, ws_partial, wparts, tickets, out,
+                    out_row_stride, plain ? 0 : xrot_knob(), prefix, ze_gemv_knobs[23] == 3 ? mate : nullptr, 1);
+            else
+                k_attn_decode_wave_long<8, rounds, false><<<dim3(kv_heads * lg, n), 256, 4 * 3 * AW_VSTAGE, s>>>(
+                    q, q_row_stride, kcache, vcache, cache_seq_stride, st, seq_ids, heads, kv_heads, max_ctx, sl, ws_partial, wparts, tickets, out,
+                    out_row_stride, plain ? 0 : xrot_knob(), prefix, nullptr, 0);
             return;
         }
         k_attn_decode_wave<8><<<dim3(kv_heads * gparts, n), 256, 4 * AW_VSTAGES * AW_VSTAGE, s>>>(
