@@ -48,7 +48,7 @@ BATCH_KERNEL_NAMES_WIDE = {
     2: "k_gemm_ring<192,192 / 256,192 / 320,192 / 384,192,SWIGLU> by row count above 256 chains, k_gemm_wstream<BM,96,SWIGLU> below (row-streaming decode gate/up projection)",
     3: "k_gemm_ring split-K x 8 + k_splitk_reduce (row-streaming decode down projection; 192 x 128 / 128 x 256 / 320 x 128 / 384 x 128 tiles by row count)",
     4: "k_gemm_wstream / k_gemm_ring<256,256,F32> (row-streaming decode lm_head)",
-    5: "k_attn_decode_wave_long<8, 6> (batched decode attention: 384-key parts, every wave streams 16 keys of each 64-key round -- K rows straight into MFMA registers, V rows through its own LDS stages -- three rounds in flight until the part ends)",
+    5: "k_attn_decode_wave_long<8, 6, false> (batched decode attention: 384-key parts, every wave streams 16 keys of each 64-key round -- K rows straight into MFMA registers, V rows through its own LDS stages -- three rounds in flight until the part ends)",
 }
 BATCH_KERNEL_NAMES = {
     0: "k_gemm_oneshot<QKV,4> (batched decode qkv projection + M-RoPE + KV append, sixteen waves per workgroup)",
@@ -56,7 +56,7 @@ BATCH_KERNEL_NAMES = {
     2: "k_gemm_skinny<6,SWIGLU,FRAG,BAL> (batched decode gate/up weight stream, one workgroup per CU)",
     3: "k_gemm_ring<64,64,4,RESIDUAL> split-K (batched decode down projection)",
     4: "k_gemm_skinny<2,F32,FRAG> (batched decode lm_head)",
-    5: "k_attn_decode_wave_long<8, 6> (batched decode attention: 384-key parts, every wave streams 16 keys of each 64-key round -- K rows straight into MFMA registers, V rows through its own LDS stages -- three rounds in flight until the part ends)",
+    5: "k_attn_decode_wave_long<8, 6, false> (batched decode attention: 384-key parts, every wave streams 16 keys of each 64-key round -- K rows straight into MFMA registers, V rows through its own LDS stages -- three rounds in flight until the part ends)",
 }
 
 

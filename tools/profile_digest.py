@@ -27,15 +27,15 @@ SECTION = {"configs1": "configs1", "wide": "stream", "wide_shared": "stream_shar
 if ROUND >= 4:  # round 4: the stream's rows at the line's own mean chain count (410) and every GEMM of the layer; 580 = the bucket
     # (513-640 chains) in which the stream runs most of its chain-steps
     del KEYS["wide"], KEYS["wide_shared"]
-    KEYS["wide410"] = {"attention": "k_attn_decode_wave_long<8, 6>", "gate_up": "k_gemm_wstream<512, 96",
+    KEYS["wide410"] = {"attention": "k_attn_decode_wave_long<8, 6", "gate_up": "k_gemm_wstream<512, 96",
                        "down": ("k_gemm_ring<128, 256, 3, 0, 2, 4, true, false", "k_splitk_reduce<128, 256"),  # (…, true, true: a prefill GEMM of the set-up)
                        "qkv": "k_gemm_ring<64, 64, 4, 5", "o_proj": "k_gemm_ring<64, 64, 4, 2, 4, 2, false, true", "lm_head": "k_gemm_p8<4, true>"}
-    KEYS["wide410_shared"] = {"attention": "k_attn_decode_wave_long<8, 6>"}
-    KEYS["wide580"] = {"attention": "k_attn_decode_wave_long<8, 6>", "gate_up": "k_gemm_ring<320, 192, 4, 3",
+    KEYS["wide410_shared"] = {"attention": "k_attn_decode_wave_long<8, 6"}
+    KEYS["wide580"] = {"attention": "k_attn_decode_wave_long<8, 6", "gate_up": "k_gemm_ring<320, 192, 4, 3",
                        "down": ("k_gemm_ring<320, 128, 4, 0", "k_splitk_reduce<320, 128"),
                        "qkv": "k_gemm_ring<64, 64, 4, 5", "o_proj": "k_gemm_ring<64, 128, 4, 2, 2, 4, false, true", "lm_head": "k_gemm_p8<4, true>"}
-    KEYS["wide580_shared"] = {"attention": "k_attn_decode_wave_long<8, 6>"}
-    KEYS["batch64"]["attention"] = "k_attn_decode_wave_long<8, 6>"
+    KEYS["wide580_shared"] = {"attention": "k_attn_decode_wave_long<8, 6"}
+    KEYS["batch64"]["attention"] = "k_attn_decode_wave_long<8, 6"
     SECTION.update(wide410="stream", wide410_shared="stream_shared", wide580="stream580", wide580_shared="stream580_shared")
 
 if ROUND >= 5:  # round 5: tall one-round tiles for qkv / o, K-steps of 64 in two stages for the 256- / 320-row gate/up and down tiles
@@ -46,10 +46,10 @@ if ROUND >= 5:  # round 5: tall one-round tiles for qkv / o, K-steps of 64 in tw
 
     # second pass of round 5 (tools/profile_round5b.sh): the scheduler's hold raised the line's mean step to ~490 chains; the 410-chain
     # files stay as sections stream410 / stream410_shared
-    KEYS["wide490"] = {"attention": "k_attn_decode_wave_long<8, 6>", "gate_up": "k_gemm_ring<256, 192, 2, 3",
+    KEYS["wide490"] = {"attention": "k_attn_decode_wave_long<8, 6", "gate_up": "k_gemm_ring<256, 192, 2, 3",
                        "down": ("k_gemm_ring<128, 256, 3, 0, 2, 4, true, false", "k_splitk_reduce<128, 256"),
                        "qkv": "k_gemm_ring<96, 64, 6, 5", "o_proj": "k_gemm_ring<64, 64, 6, 2, 4, 2, false, true", "lm_head": "k_gemm_p8<4, true>"}
-    KEYS["wide490_shared"] = {"attention": "k_attn_decode_wave_long<8, 6>"}
+    KEYS["wide490_shared"] = {"attention": "k_attn_decode_wave_long<8, 6"}
     SECTION.update(wide490="stream", wide490_shared="stream_shared", wide410="stream410", wide410_shared="stream410_shared")
 
 
