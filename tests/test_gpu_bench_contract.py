@@ -67,6 +67,21 @@ def test_bench_line_contract():
     assert 0.05 < tk["share_of_gpu_time"] < 0.6 and tk["share_source"].startswith("profiles/r") and tk["kernel"]
     if "frac" in tk:
         assert tk["bound"] == "mfma" and 0.2 < tk["frac"] < 1.0 and abs(tk["frac"] - tk["achieved_TFLOPs"] / 2500.0) < 1e-3
+        # round 6: per pass size, both launch forms, the four projections in pass order -- never a mean over two sizes
+        assert tk["form_in_stream"] in ("tile_granular", "persistent") and len(tk["by_rows"]) >= 2
+        for rows_p, ent in tk["by_rows"].items():
+            for form in ("persistent", "tile_granular"):
+                assert set(ent[form]["layer_us"]) == {"qkv", "o", "gate_up", "down"} and 0.2 < ent[form]["frac"] < 1.0, (rows_p, form, ent[form])
+        big = tk["by_rows"][max(tk["by_rows"], key=int)]
+        assert tk["frac"] == big[tk["form_in_stream"]]["frac"]
+    # round 6: what a row pays for a layer's projections in a decode step and in a prefill pass; what the line
+    # owes to the synthetic tokenizer's identity round trip
+    dec = d["roofline_phases"]["decode"]
+    assert 0.05 < dec["projections_us_per_row_per_layer"] < 1.0
+    assert all(0.02 < v < dec["projections_us_per_row_per_layer"] for v in dec["prefill_pass_projections_us_per_row_per_layer"].values())
+    rs = d["reuse_sensitivity"]
+    assert 0.5 < rs["ratio"] <= 1.02 and abs(d["value_without_generated_row_reuse"] - d["value"] * rs["ratio"]) < 0.01
+    assert rs["generated_rows_kept_per_question"][1] == 0.0 < rs["generated_rows_kept_per_question"][0] and 0 < d["generated_rows_kept_fraction"] <= 1
     # tile uploads are INSIDE the timed region (pinned host -> HBM by each lane's TileFeeder, ahead of the first question)
     assert "INSIDE the timed region" in d["tile_upload_note"] and d["tile_upload_ms"] > 0.3
     # the stream's own whole-question roofline (isolated kernel-time accounting; SURVEY 8d's formula at the measured batch)
