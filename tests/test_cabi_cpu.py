@@ -115,3 +115,35 @@ def test_host_helpers_under_asan_ubsan(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "cabi_san", "run_san.py"), so], capture_output=True, text=True,
                        env=env, timeout=600)
     assert r.returncode == 0 and "sanitized host helpers ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_no_product_path_flips_a_process_wide_tuning_knob():
+    """`ze_tune` has no engine argument -- it is process-wide and measurement-only (include/zoomearth.h says so) -- so
+    nothing a user imports may call it: not the Engine, the scheduler, the model / lane code, the server or the entry points.  (bench.py,
+    tools/ and tests/ are measurement code and do.)"""
+    import glob
+    import re
+    files = glob.glob(os.path.join(ROOT, "zoomearth_amd", "*.py")) + glob.glob(os.path.join(ROOT, "src", "**", "*.py"), recursive=True)
+    assert len(files) > 10
+    offenders = []
+    for f in files:
+        with open(f, encoding="utf-8") as fh:
+            src = fh.read()
+        if os.path.basename(f) == "_lib.py":
+            src = re.sub(r'"ze_tune":.*', "", src)   # (the binding table itself)
+        if re.search(r"\bze_tune\s*\(", src):
+            offenders.append(os.path.relpath(f, ROOT))
+    assert not offenders, offenders
+
+
+def test_the_committed_counter_profile_names_the_kernel_sources_it_was_taken_on():
+    """profiles/traffic_latest.json carries the hash of the library sources the PMC passes ran on; bench.py compares it with
+    the tree that quotes the figure (`roofline.traffic_source`).  The hash function is a pure function of the source files."""
+    import json
+    from zoomearth_amd import _lib
+    a, b = _lib.kernel_sources_sha16(), _lib.kernel_sources_sha16()
+    assert a == b and len(a) == 16 and int(a, 16) >= 0
+    with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
+        tj = json.load(f)
+    assert tj.get("round", 0) >= 6 and len(tj.get("kernel_sources_sha16", "")) == 16
+    assert tj["stream_shared"]["attention"]["ratio"] < tj["stream"]["attention"]["ratio"]
