@@ -180,7 +180,9 @@ struct ze_engine {
     size_t pslab_floats = 0;
     unsigned* ptickets = nullptr;
     int pticket_cap = 0;
-    ze_gemm_ws prefill_ws() const { return ze_gemm_ws{pslab, pslab_floats, ptickets, pticket_cap}; }
+    // (allocated on first use with the split switched on -- ze_tune knob 20 = 3: the form is not shipped, DESIGN 7i c, and 0.7 GB of
+    //  slabs per engine are not reserved for it)
+    ze_gemm_ws prefill_ws();
     // batched decode: activations of its own (rows = chains), so that a decode burst on one HIP stream and a prefill / ViT
     // round on another never share a buffer (the scheduler overlaps them: zoomearth_amd/scheduler.py)
     bf16_t *bh = nullptr, *by = nullptr, *bqkv = nullptr, *bo = nullptr, *ba = nullptr;

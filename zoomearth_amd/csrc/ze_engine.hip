@@ -383,15 +383,6 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
         e->gticket_cap = ticket_cap;
     }
     {
-        // prefill split-K slabs: 3 slices x (rows of the largest pass, padded to a 256-row tile) x (hidden, padded to a 256-column tile)
-        // floats -- the same whatever tile a row count selects -- and a ticket per 64 x 64 tile (the smallest)
-        const size_t rows_pad = ((size_t)e->prefill_rows + 255) / 256 * 256, cols_pad = ((size_t)c.hidden + 255) / 256 * 256;
-        e->pslab_floats = 3 * rows_pad * cols_pad;
-        e->pticket_cap = (int)((rows_pad / 64) * (cols_pad / 64)) + 64;
-        chk(dev_alloc(e, &e->pslab, e->pslab_floats, false));
-        chk(dev_alloc(e, &e->ptickets, (size_t)e->pticket_cap, true));
-    }
-    {
         const size_t br = (size_t)(std::max(c.max_seqs, 64) + 63) / 64 * 64;  // rows of the batched step (whole 64-row tiles)
         chk(dev_alloc(e, &e->bh, br * c.hidden));
         chk(dev_alloc(e, &e->by, br * c.hidden));
@@ -423,6 +414,28 @@ extern "C" int ze_engine_create(const ze_config* cfg, int device_id, ze_engine**
     __atomic_add_fetch(&ze_live_engines, 1, __ATOMIC_RELAXED);
     *out = e;
     return ZE_OK;
+}
+
+extern int ze_gemv_knobs[24];
+// prefill split-K slabs: 3 slices x (rows of the largest pass, padded to a 256-row tile) x (hidden, padded to a 256-column tile) floats --
+// the same whatever tile a row count selects -- and a zeroed ticket per 64 x 64 tile (the smallest).  Only with knob 20 = 3.
+ze_gemm_ws ze_engine::prefill_ws() {
+    if (!pslab && ze_gemv_knobs[20] == 3) {
+        const size_t rows_pad = ((size_t)prefill_rows + 255) / 256 * 256, cols_pad = ((size_t)cfg.hidden + 255) / 256 * 256;
+        const size_t floats = 3 * rows_pad * cols_pad;
+        const int cap = (int)((rows_pad / 64) * (cols_pad / 64)) + 64;
+        float* sl = nullptr;
+        unsigned* tk = nullptr;
+        hipSetDevice(device);
+        if (hipMalloc((void**)&sl, floats * sizeof(float)) == hipSuccess && hipMalloc((void**)&tk, (size_t)cap * sizeof(unsigned)) == hipSuccess &&
+            hipMemset(tk, 0, (size_t)cap * sizeof(unsigned)) == hipSuccess) {
+            pslab = sl, pslab_floats = floats, ptickets = tk, pticket_cap = cap;
+        } else {
+            if (sl) hipFree(sl);
+            if (tk) hipFree(tk);
+        }
+    }
+    return ze_gemm_ws{pslab, pslab_floats, ptickets, pticket_cap};
 }
 
 extern "C" int ze_engine_destroy(ze_engine* e) {
