@@ -286,7 +286,7 @@ def run_stream(engine, table, q0: int, slots: int, stats=None, use_graph=None):
     sched = ChainScheduler(model, proc, do_sample=False, repetition_penalty=PENALTY, ignore_eos=True, burst=int(os.environ.get("ZE_BURST", "8")),
                            use_graph=use_graph, min_admit=int(os.environ.get("ZE_MIN_ADMIT", str(max(1, 3 * slots // 4 if slots > 64 else slots // 2)))), hold_below=int(os.environ.get("ZE_HOLD", str(2 * slots // 3 if slots > 64 else 0))),
                            max_wait_bursts=int(os.environ.get("ZE_MAX_WAIT", "8" if slots > 64 else "12")), max_batch=slots,
-                           reuse_generated=REUSE_GENERATED)
+                           reuse_generated=REUSE_GENERATED, admit_chunk_rows=int(os.environ.get("ZE_ADMIT_ROWS", "0")))
     done = {}
     views = {}
     for b, tile, vkey in table:

@@ -555,3 +555,47 @@ def test_hold_keeps_the_early_members_of_an_admission_round_from_stepping_alone(
     else:
         assert bursts[0] == 2 and "held_steps" not in sched.stats
     assert not sched.live and sorted(sched.free) == list(range(12))
+
+
+def test_admission_in_chunks_gives_the_same_answers_and_enqueues_the_first_pass_early():
+    """Round 6, `admit_chunk_rows`: a long queue is tokenised and planned a pass's worth at a time -- the first pass is enqueued
+    when a FRACTION of the queue has been through the processor, not all of it (the GPU idled 0.4 s behind 640 prompts) -- while
+    (1) the questions of a tile stay in one chunk (their prefix is shared inside it: one pass-A row set per tile, as unchunked),
+    (2) a chunk's last, partial pass waits for the next chunk's items (passes stay full), (3) under `hold_below` nobody decodes
+    until the whole queue is in, and (4) every answer is what the unchunked scheduler gives."""
+    def run(chunk):
+        model = make_model(max_seqs=24, max_prefill_rows=24)
+        model.engine.__class__ = OverlapStub
+        calls = []
+
+        class CountingProc(Proc):
+            def __call__(self, text, images=None, return_tensors="pt", **kw):
+                calls.append(len(model.engine.log))    # how much the engine had been asked to do when this prompt was tokenised
+                return Proc.__call__(self, text, images=images, return_tensors=return_tensors, **kw)
+
+        sched = ChainScheduler(model, CountingProc(), burst=2, hold_below=20, min_shared=3, admit_chunk_rows=chunk)
+        got = {}
+        for q in range(24):                                   # six tiles x four questions: "7t 72 73 <img> q 50"
+            t = q // 4
+            sched.submit(Request(prompt=f"{71 + 2 * t} 72 73 <img> {20 + q} 50", images=[f"view{t}"], max_new_tokens=4,
+                                 on_done=lambda r, toks, text, q=q: got.__setitem__(q, toks)))
+        sched.run()
+        assert not sched.live and sorted(sched.free) == list(range(24)) and not sched._carry
+        return got, model.engine.log, calls, sched.stats
+
+    whole, log0, calls0, st0 = run(0)
+    parts, log1, calls1, st1 = run(24)
+    assert parts == whole == {q: expected(71 + 2 * (q // 4), 4) for q in range(24)}
+    # unchunked: every prompt is tokenised before the engine hears of anything; chunked: the engine is at work from the second chunk on
+    assert max(calls0) == 0 and calls1[-1] > 0 and sum(1 for c in calls1 if c == 0) < 24
+    # the same rows are shared and prefilled, one copy of a tile's prefix per tile
+    assert st1["shared_rows"] == st0["shared_rows"] and st1["prefill_rows"] == st0["prefill_rows"] and st1["admitted"] == 24
+    copies0, copies1 = [x for x in log0 if x[0] == "copy"], [x for x in log1 if x[0] == "copy"]
+    assert len(copies1) == len(copies0) == 18
+    # full passes: pass B never runs with fewer than 0.85 x max_prefill_rows rows while more requests are waiting
+    passes1 = [sum(x[2]) for x in log1 if x[0] == "prefill"]
+    big = [r for r in passes1 if r > 8]
+    assert all(r >= 20 for r in big[:-1]), passes1
+    # the hold: no decode step before at least 20 chains are live
+    first_burst = next(x for x in log1 if x[0] == "burst" and x[2] > 0)
+    assert first_burst[1] >= 20

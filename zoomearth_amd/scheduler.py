@@ -59,7 +59,8 @@ class ChainScheduler:
     def __init__(self, model, processor, do_sample: bool = False, temperature=None, repetition_penalty=None, seed: int = 0,
                  burst: int = 8, max_batch: Optional[int] = None, ignore_eos: bool = False, use_graph: Optional[bool] = None,
                  feature_cache: int = 64, min_admit: int = 1, max_wait_bursts: int = 2, share_prefix: bool = True,
-                 min_shared: int = 64, reuse_generated: bool = True, overlap: Optional[bool] = None, hold_below: int = 0):
+                 min_shared: int = 64, reuse_generated: bool = True, overlap: Optional[bool] = None, hold_below: int = 0,
+                 admit_chunk_rows: int = 0):
         self.model, self.processor, self.engine = model, processor, model.engine
         gc = model.generation_config
         pen = repetition_penalty if repetition_penalty is not None else (getattr(gc, "repetition_penalty", 1.0) or 1.0)
@@ -85,6 +86,13 @@ class ChainScheduler:
         # chains do not decode -- a step costs almost the same at 60 chains as at 400, so the early members of a round wait
         # for the later ones instead of stepping alone beside the passes.  0: never hold (a server's latency setting).
         self.hold_below = max(0, int(hold_below))
+        # Admission in CHUNKS (round 6): with a long queue -- the start of a run: hundreds of prompts at once -- tokenising and planning
+        # every waiting request before the first pass is enqueued leaves the GPU idle for the whole of it (0.4 s for 640 prompts).  With
+        # `admit_chunk_rows` > 0 one call of _admit takes requests off the queue only until that many new rows are planned (a pass's
+        # worth) and the NEXT request is about another first image (the questions of a tile stay together: their shared prefix is
+        # planned within one call), enqueues that pass, and prepares the next chunk while the GPU runs it.  Under `hold_below` the
+        # requests still admissible count as "round in progress": the early chunks' chains wait for the later ones as before.
+        self.admit_chunk_rows = max(0, int(admit_chunk_rows))
         # Shared prompt prefixes: the questions about one tile start with the same system turn and the same view's image
         # tokens (347 of the 802 tokens of a stage-1 prompt).  A fresh chain whose prompt starts like that of a chain that
         # already holds those K/V rows copies them (ze_seq_copy_prefix) and prefills only its own tail; when a round brings
@@ -121,6 +129,7 @@ class ChainScheduler:
             overlap = hasattr(self.engine, "decode_burst_begin") and os.environ.get("ZE_OVERLAP", "1") != "0"
         self.overlap = bool(overlap)
         self._side = torch.cuda.Stream(device=self.engine.device) if (self.overlap and torch.cuda.is_available()) else None
+        self._carry = []                   # (admit_chunk_rows) planned items of a partial pass, waiting for the next chunk's
         self._groups = deque()             # prefill passes of the admission round in progress, one per step
         self._round = None                 # (todo, needed) of that round: images still to encode / features to keep
         self._ready = []                   # prefilled requests waiting to join the live set
@@ -138,11 +147,11 @@ class ChainScheduler:
     def pending_requests(self):
         """Every request the scheduler holds, whatever its state (a caller that gives up on the engine fails them all)."""
         reqs = [l.req for l in self.live.values()] + list(self.waiting) + [r for r, _, _ in self._ready]
-        reqs += [it["req"] for g in self._groups for it in g if it.get("final", True)]
+        reqs += [it["req"] for g in list(self._groups) + [self._carry] for it in g if it.get("final", True)]
         return reqs
 
     def busy(self) -> bool:
-        return bool(self.waiting or self.live or self._groups or self._ready)
+        return bool(self.waiting or self.live or self._groups or self._ready or self._carry)
 
     def run(self) -> None:
         while self.busy():
@@ -162,7 +171,7 @@ class ChainScheduler:
             # what the caller put on ITS stream before submitting (the tile upload, the view's resize) is read by the
             # admission work on the side stream: order the two here, while the caller's stream holds nothing else
             self._side.wait_stream(torch.cuda.current_stream(self.engine.device))
-        hold = bool(self._groups or self._ready) and len(self.live) < self.hold_below
+        hold = self._round_in_progress() and len(self.live) < self.hold_below
         handle = self._burst_begin() if (self.live and self.overlap and not hold) else None
         t1 = tp()
         with self._side_stream():
@@ -177,9 +186,10 @@ class ChainScheduler:
         if handle is not None:
             self._burst_end(handle)
         t4 = tp()
-        self._join_ready(wait=hold and not self._groups)   # (held with nothing left to enqueue: wait for the oldest pass)
+        more = bool(self._carry or (self.admit_chunk_rows and self.waiting and (self.waiting[0].slot >= 0 or self.free)))
+        self._join_ready(wait=hold and not self._groups and not more)   # (held with nothing left to enqueue: wait for the oldest pass)
         if handle is None:   # (nothing was decoding beside the pass: the round may just have begun, or been completed)
-            hold = bool(self._groups or self._ready) and len(self.live) < self.hold_below
+            hold = self._round_in_progress() and len(self.live) < self.hold_below
             if self.live and not hold:
                 self._burst()
         if hold:
@@ -189,6 +199,21 @@ class ChainScheduler:
         for k, v in (("host_s_burst_begin", t1 - t0), ("host_s_admit", t2 - t1), ("host_s_pass", t3 - t2), ("host_s_burst_end", t4 - t3),
                      ("host_s_join", t5 - t4)):
             st[k] = st.get(k, 0.0) + v
+
+    @staticmethod
+    def _first_image_key(req):
+        """What tells two requests about the same view apart from two about different ones, before anything is tokenised: the
+        first image object itself (the entry points hand every question of a tile the same view object), by value where it has one."""
+        if not req.images:
+            return None
+        im = req.images[0]
+        return im if isinstance(im, (str, int, tuple)) else id(im)
+
+    def _round_in_progress(self) -> bool:
+        """Passes still to run, prefilled chains still to join -- or, when admitting in chunks, requests the next call of _admit can take."""
+        if self._groups or self._ready or self._carry:
+            return True
+        return bool(self.admit_chunk_rows and self.waiting and (self.waiting[0].slot >= 0 or self.free))
 
     def _side_stream(self):
         """Admission work (front-end, ViT, prefill, the callbacks' crops) runs on the side stream when overlapping."""
@@ -203,20 +228,23 @@ class ChainScheduler:
                 self._waited += 1
                 return
         self._waited = 0
-        batch = []
+        # tokenise / preprocess each newcomer as it leaves the queue; collect the images whose features are not cached
+        prepared, todo, needed = [], OrderedDict(), set()
+        if self._carry and self._round is not None:   # (items held back from the last chunk keep their images' entries)
+            todo, needed = OrderedDict(self._round[0]), set(self._round[1])
+        rows_planned, last_img = 0, None
         while self.waiting:
             req = self.waiting[0]
+            if self.admit_chunk_rows and rows_planned >= self.admit_chunk_rows and prepared:
+                first = self._first_image_key(req)
+                if first is None or first != last_img:
+                    break                                      # a pass's worth is planned and the next request is about another tile
             if req.slot < 0:
                 if not self.free:
                     break
                 req.slot = self.free.pop()
             self.waiting.popleft()
-            batch.append(req)
-        if not batch:
-            return
-        # tokenise / preprocess each newcomer; collect the images whose features are not cached
-        prepared, todo, needed = [], OrderedDict(), set()
-        for req in batch:
+            last_img = self._first_image_key(req)
             try:
                 inp = self.processor(text=[req.prompt], images=list(req.images) or None, return_tensors="pt")
                 ids = inp["input_ids"][0].tolist()
@@ -240,8 +268,11 @@ class ChainScheduler:
                     needed.add(keys[i])
                 prepared.append(dict(req=req, ids=ids, grids=grids, keys=keys, reuse=reuse, n_reused=n_reused, copy_from=None,
                                      upto=len(ids), final=True))
+                rows_planned += len(ids) - reuse
             except Exception as ex:  # a malformed request must not take the batch down
                 self._fail(req, ex)
+        if not prepared and not self._carry:
+            return
         # The round's prefill passes: rows of several chains share every GEMM, up to max_prefill_rows per pass; pass A (the
         # prefixes that other newcomers of this round will copy) goes first.  One pass runs per step (beside the decode burst
         # when overlapping); each encodes the images it needs that are not cached yet -- ONE multi-resolution ViT call.
@@ -251,11 +282,17 @@ class ChainScheduler:
             self._fail_all([p["req"] for p in prepared if p["req"].slot >= 0], ex)
             return
         self._round = (todo, needed)
-        for items in (anchors, prepared):
+        carried, self._carry = self._carry, []
+        for which, items in (("A", anchors), ("B", carried + prepared)):
             group, rows = [], 0
             for item in items + [None]:
                 if group and (item is None or rows + item["upto"] - item["reuse"] > e.max_prefill_rows):
-                    self._groups.append(group)
+                    # admitting in chunks: the last, partial pass of a chunk waits for the next chunk's items (passes stay full)
+                    if (item is None and which == "B" and self.admit_chunk_rows and rows < 0.85 * e.max_prefill_rows
+                            and self.waiting and (self.waiting[0].slot >= 0 or self.free)):
+                        self._carry = group
+                    else:
+                        self._groups.append(group)
                     group, rows = [], 0
                 if item is not None:
                     group.append(item)
