@@ -186,7 +186,7 @@ class ChainScheduler:
         if handle is not None:
             self._burst_end(handle)
         t4 = tp()
-        more = bool(self._carry or (self.admit_chunk_rows and self.waiting and (self.waiting[0].slot >= 0 or self.free)))
+        more = bool(self._carry or (self.admit_chunk_rows and self.waiting and self.waiting[0].slot < 0 and self.free))
         self._join_ready(wait=hold and not self._groups and not more)   # (held with nothing left to enqueue: wait for the oldest pass)
         if handle is None:   # (nothing was decoding beside the pass: the round may just have begun, or been completed)
             hold = self._round_in_progress() and len(self.live) < self.hold_below
@@ -213,7 +213,8 @@ class ChainScheduler:
         """Passes still to run, prefilled chains still to join -- or, when admitting in chunks, requests the next call of _admit can take."""
         if self._groups or self._ready or self._carry:
             return True
-        return bool(self.admit_chunk_rows and self.waiting and (self.waiting[0].slot >= 0 or self.free))
+        # (FRESH requests only: a follow-up that waits for its pass is the steady state of a running stream, not a round being admitted)
+        return bool(self.admit_chunk_rows and self.waiting and self.waiting[0].slot < 0 and self.free)
 
     def _side_stream(self):
         """Admission work (front-end, ViT, prefill, the callbacks' crops) runs on the side stream when overlapping."""
