@@ -223,7 +223,9 @@ class ChainScheduler:
     # -- admission: waiting requests take free slots (a follow-up keeps the slot its predecessor parked)
     def _admit(self) -> None:
         e = self.engine
-        if self.live and self.min_admit > 1:
+        # (admitting in chunks: the rest of a queue whose first chunks are already in is not "a few newcomers" -- no waiting for more)
+        chunking = bool(self._carry or (self.admit_chunk_rows and self.waiting and self.waiting[0].slot < 0 and self.free))
+        if self.live and self.min_admit > 1 and not chunking:
             ready = sum(1 for r in self.waiting if r.slot >= 0) + min(len(self.free), sum(1 for r in self.waiting if r.slot < 0))
             if 0 < ready < self.min_admit and self._waited < self.max_wait_bursts:
                 self._waited += 1
