@@ -284,9 +284,13 @@ def run_stream(engine, table, q0: int, slots: int, stats=None, use_graph=None):
     model = Model64(engine)
     proc = SynthProcessor(engine.config, engine)
     sched = ChainScheduler(model, proc, do_sample=False, repetition_penalty=PENALTY, ignore_eos=True, burst=int(os.environ.get("ZE_BURST", "8")),
-                           use_graph=use_graph, min_admit=int(os.environ.get("ZE_MIN_ADMIT", str(max(1, 3 * slots // 4 if slots > 64 else slots // 2)))), hold_below=int(os.environ.get("ZE_HOLD", str(2 * slots // 3 if slots > 64 else 0))),
+                           use_graph=use_graph, min_admit=int(os.environ.get("ZE_MIN_ADMIT", str(max(1, 3 * slots // 4 if slots > 64 else slots // 2)))), hold_below=int(os.environ.get("ZE_HOLD", str(3 * slots // 4 if slots > 64 else 0))),
                            max_wait_bursts=int(os.environ.get("ZE_MAX_WAIT", "8" if slots > 64 else "12")), max_batch=slots,
-                           reuse_generated=REUSE_GENERATED, admit_chunk_rows=int(os.environ.get("ZE_ADMIT_ROWS", "0")))
+                           reuse_generated=REUSE_GENERATED,
+                           # round 6: the queue is taken in 1.7 passes' worth of raw prompt rows at a time (the first pass is enqueued ~30 ms
+                           # into the run instead of 0.4 s; with the hold at 3/4 of the slots: 92.2 against 91.0 questions/s, same box, five
+                           # runs each -- profiles/r06_ab_admit_chunks.txt; ZE_ADMIT_ROWS=0 ZE_HOLD=512: round 5's setting)
+                           admit_chunk_rows=int(os.environ.get("ZE_ADMIT_ROWS", str(int(1.7 * engine.max_prefill_rows) if slots > 64 else 0))))
     done = {}
     views = {}
     for b, tile, vkey in table:

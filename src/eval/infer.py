@@ -74,7 +74,7 @@ def done_question_ids_all(exp_name, world):
 
 def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir="./image/", max_new_tokens=1024,
                     batch_size=BATCH_SIZE, max_ctx=4096, do_sample=True, resume=False, decode_workers=3, decode_ahead=6, lanes=1,
-                    steal=False, hold=0):
+                    steal=False, hold=0, admit_rows=0):
     # capacity: the stage-2 prompt holds the stage-1 prompt, its output and a second image (<= ~3200 tokens at the
     # default budgets); prefill passes of up to 16 prompts share their GEMMs
     # one rank per GPU (torchrun / accelerate launch): rank 0 reads the checkpoint, the others receive the packed weight
@@ -189,7 +189,7 @@ def eval_model_lora(model_name, exp_name, ds_path="./LRS_GRO/test", image_dir=".
         # the lane's questions arrive grouped by tile: decode the next tiles while the current one is being questioned
         tiles = TilePrefetcher([tile_path(name) for _, name, _items in todo], m.engine, depth=decode_ahead, workers=decode_workers)
         sched = ChainScheduler(m, proc, do_sample=do_sample, temperature=0.01 if do_sample else None, burst=8,
-                               min_admit=max(1, batch_size // 2), max_wait_bursts=12, hold_below=hold)
+                               min_admit=max(1, batch_size // 2), max_wait_bursts=12, hold_below=hold, admit_chunk_rows=admit_rows)
 
         def finish(idx, sample, r):
             with lock:
@@ -343,6 +343,9 @@ if __name__ == "__main__":
     parser.add_argument("--steal", action="store_true", default=os.environ.get("ZE_STEAL") == "1",
                         help="several ranks: a rank whose own tiles are through takes whole tiles off the back of the other ranks' "
                              "lists (one claim flag per tile in a TCPStore on MASTER_PORT + 17; needs the ranks to run at once)")
+    parser.add_argument("--admit_rows", type=int, default=int(os.environ.get("ZE_ADMIT_ROWS", "0")),
+                        help="throughput setting: take a long queue of waiting questions in chunks of about this many prompt rows (a prefill "
+                             "pass's worth and more) instead of tokenising all of it before the first pass; 0 = the whole queue at once")
     parser.add_argument("--hold", type=int, default=int(os.environ.get("ZE_HOLD", "0")),
                         help="throughput setting: while an admission round still has prefill passes to run and fewer than this many "
                              "chains of a lane are live, the live ones wait for the newcomers instead of stepping alone (a decode step "
@@ -352,4 +355,4 @@ if __name__ == "__main__":
     args = parser.parse_args()
     eval_model_lora(args.model_name, args.exp_name, args.dataset, args.image_dir, args.max_new_tokens, args.batch_size,
                     args.max_ctx, do_sample=not args.greedy, resume=args.resume, decode_workers=args.decode_workers,
-                    decode_ahead=args.decode_ahead, lanes=args.lanes, steal=args.steal, hold=args.hold)
+                    decode_ahead=args.decode_ahead, lanes=args.lanes, steal=args.steal, hold=args.hold, admit_rows=args.admit_rows)
