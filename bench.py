@@ -290,8 +290,7 @@ def run_stream(engine, table, q0: int, slots: int, stats=None, use_graph=None):
                            # round 6: the queue is taken in 1.7 passes' worth of raw prompt rows at a time (the first pass is enqueued ~30 ms
                            # into the run instead of 0.4 s; with the hold at 3/4 of the slots: 92.2 against 91.0 questions/s, same box, five
                            # runs each -- profiles/r06_ab_admit_chunks.txt; ZE_ADMIT_ROWS=0 ZE_HOLD=512: round 5's setting)
-                           admit_chunk_rows=int(os.environ.get("ZE_ADMIT_ROWS", str(int(1.7 * engine.max_prefill_rows) if slots > 64 else 0))),
-                           eager_admit_below=int(os.environ.get("ZE_EAGER_BELOW", "0")))
+                           admit_chunk_rows=int(os.environ.get("ZE_ADMIT_ROWS", str(int(1.7 * engine.max_prefill_rows) if slots > 64 else 0))))
     done = {}
     views = {}
     for b, tile, vkey in table:

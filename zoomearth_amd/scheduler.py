@@ -60,7 +60,7 @@ class ChainScheduler:
                  burst: int = 8, max_batch: Optional[int] = None, ignore_eos: bool = False, use_graph: Optional[bool] = None,
                  feature_cache: int = 64, min_admit: int = 1, max_wait_bursts: int = 2, share_prefix: bool = True,
                  min_shared: int = 64, reuse_generated: bool = True, overlap: Optional[bool] = None, hold_below: int = 0,
-                 admit_chunk_rows: int = 0, eager_admit_below: int = 0):
+                 admit_chunk_rows: int = 0):
         self.model, self.processor, self.engine = model, processor, model.engine
         gc = model.generation_config
         pen = repetition_penalty if repetition_penalty is not None else (getattr(gc, "repetition_penalty", 1.0) or 1.0)
@@ -93,11 +93,6 @@ class ChainScheduler:
         # planned within one call), enqueues that pass, and prepares the next chunk while the GPU runs it.  Under `hold_below` the
         # requests still admissible count as "round in progress": the early chunks' chains wait for the later ones as before.
         self.admit_chunk_rows = max(0, int(admit_chunk_rows))
-        # The admission hysteresis trades a newcomer's latency for a fuller pass -- a good trade while hundreds of chains keep the GPU
-        # busy, a bad one in the DRAIN of a finite job, where the last follow-ups wait `max_wait_bursts` bursts for company that will
-        # never come while their stage 2 is the critical path of the run.  With fewer than `eager_admit_below` chains live, whoever
-        # waits is admitted at once.  0: off.
-        self.eager_admit_below = max(0, int(eager_admit_below))
         # Shared prompt prefixes: the questions about one tile start with the same system turn and the same view's image
         # tokens (347 of the 802 tokens of a stage-1 prompt).  A fresh chain whose prompt starts like that of a chain that
         # already holds those K/V rows copies them (ze_seq_copy_prefix) and prefills only its own tail; when a round brings
@@ -230,7 +225,7 @@ class ChainScheduler:
         e = self.engine
         # (admitting in chunks: the rest of a queue whose first chunks are already in is not "a few newcomers" -- no waiting for more)
         chunking = bool(self._carry or (self.admit_chunk_rows and self.waiting and self.waiting[0].slot < 0 and self.free))
-        if self.live and self.min_admit > 1 and not chunking and len(self.live) >= self.eager_admit_below:
+        if self.live and self.min_admit > 1 and not chunking:
             ready = sum(1 for r in self.waiting if r.slot >= 0) + min(len(self.free), sum(1 for r in self.waiting if r.slot < 0))
             if 0 < ready < self.min_admit and self._waited < self.max_wait_bursts:
                 self._waited += 1
