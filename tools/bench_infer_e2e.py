@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--decode_ahead", type=int, default=6)
     ap.add_argument("--lanes", type=int, default=1)
     ap.add_argument("--hold", type=int, default=0)
+    ap.add_argument("--admit_rows", type=int, default=0)
     ap.add_argument("--workdir", default=None)
     args = ap.parse_args()
     d = args.workdir or tempfile.mkdtemp(prefix="ze_e2e_")
@@ -142,7 +143,7 @@ def main():
         prof = cProfile.Profile()
         prof.enable()
     stats = infer.eval_model_lora("ckpt", "e2e_", "./LRS_GRO/test", "./image/", args.max_new_tokens, args.batch_size, 2048,
-                                  do_sample=False, decode_workers=args.decode_workers, decode_ahead=args.decode_ahead, lanes=args.lanes, hold=args.hold)
+                                  do_sample=False, decode_workers=args.decode_workers, decode_ahead=args.decode_ahead, lanes=args.lanes, hold=args.hold, admit_rows=args.admit_rows)
     if prof is not None:
         import io
         import pstats
@@ -159,7 +160,7 @@ def main():
                 phases[k] = phases.get(k, 0.0) + v
     recs = [json.loads(l) for l in open("results/e2e_0.jsonl")]
     out.update({
-        "entry_point": "src/eval/infer.py eval_model_lora, --batch_size %d --max_new_tokens %d --greedy --lanes %d --hold %d" % (args.batch_size, args.max_new_tokens, args.lanes, args.hold),
+        "entry_point": "src/eval/infer.py eval_model_lora, --batch_size %d --max_new_tokens %d --greedy --lanes %d --hold %d --admit_rows %d" % (args.batch_size, args.max_new_tokens, args.lanes, args.hold, args.admit_rows),
         "model_load_s": round(marks["loaded"] - t0, 2),
         "stream_s": round(t1 - marks["loaded"], 2),
         "questions_per_s": round(len(recs) / (t1 - marks["loaded"]), 2),
